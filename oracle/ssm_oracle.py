@@ -1,0 +1,223 @@
+"""CPU oracle for the Super SloMo frame-pair -> intermediate-frame path.
+
+TEST INFRASTRUCTURE ONLY.  This file is the checker, never the product: only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it.  The product path (`superslomo-videointerpolation-pytorch_amd/`)
+runs hand-written HIP kernels and fails loudly when they are missing.
+
+It is a restatement, in plain PyTorch CPU fp32 ops and explicit index
+arithmetic, of what the reference computes on the hot path.  Each function
+cites the reference file:line it follows (paths relative to the reference
+repository root).  Parity is PINNED: `tests/golden/make_golden.py` imports the
+reference itself (in the build container) and commits its outputs as fixtures;
+`tests/test_oracle_golden.py` holds this file to those fixtures.
+
+Unpinned pieces (stated in DESIGN.md): ConvBLSTM/ConvBGRU bottleneck (source
+absent from the reference tree) and the pretrained-VGG perceptual loss.
+"""
+
+import torch
+import torch.nn.functional as F
+
+LRELU_SLOPE = 0.1  # scripts/models/layers.py:32
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def conv2d(x, w, b):
+    """Plain stride-1 'same' cross-correlation with zero padding and bias.
+    scripts/models/layers.py:22-31 (nn.Conv2d, padding=(k-1)/2, dilation 1);
+    final_conv: scripts/models/flow_computation.py:145-153."""
+    k = w.shape[-1]
+    return F.conv2d(x, w, b, stride=1, padding=(k - 1) // 2)
+
+
+def conv2d_lrelu(x, w, b):
+    """conv + LeakyReLU(0.1).  scripts/models/layers.py:21-33."""
+    y = conv2d(x, w, b)
+    return torch.where(y >= 0, y, y * LRELU_SLOPE)
+
+
+def avg_pool2(x):
+    """2x2 mean, stride 2, no padding.  scripts/models/layers.py:60-63."""
+    B, C, H, W = x.shape
+    v = x.reshape(B, C, H // 2, 2, W // 2, 2)
+    return (v[:, :, :, 0, :, 0] + v[:, :, :, 0, :, 1] + v[:, :, :, 1, :, 0] + v[:, :, :, 1, :, 1]) * 0.25
+
+
+def _up2_axis(x, dim):
+    """Half-pixel (align_corners=False) x2 linear resize along `dim`:
+    out[2i] = .25 x[i-1] + .75 x[i], out[2i+1] = .75 x[i] + .25 x[i+1], edge-clamped."""
+    n = x.shape[dim]
+    idx = torch.arange(n)
+    lo = x.index_select(dim, (idx - 1).clamp(min=0))
+    hi = x.index_select(dim, (idx + 1).clamp(max=n - 1))
+    even = 0.25 * lo + 0.75 * x
+    odd = 0.75 * x + 0.25 * hi
+    out = torch.stack([even, odd], dim=dim + 1)
+    shape = list(x.shape)
+    shape[dim] = 2 * n
+    return out.reshape(shape)
+
+
+def upsample2x_bilinear(x):
+    """F.upsample(x, size=(2h,2w), mode='bilinear') == align_corners=False.
+    scripts/models/flow_computation.py:92-94 (and :103,:113,:124,:135)."""
+    return _up2_axis(_up2_axis(x, 2), 3)
+
+
+def warp(img, flo):
+    """Backward warp: sample img at (x+u, y+v), bilinear, zeros outside.
+    scripts/models/layers.py:73-120.  The reference normalises the sampling
+    grid to [-1,1] (:112-113) and grid_sample(align_corners=True) maps it back;
+    both steps are replayed in fp32 so coordinates round identically."""
+    B, C, H, W = img.shape
+    xx = torch.arange(W, dtype=torch.float32).view(1, 1, W).expand(B, H, W)
+    yy = torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(B, H, W)
+    gx = 2.0 * (xx + flo[:, 0]) / max(W - 1, 1) - 1.0
+    gy = 2.0 * (yy + flo[:, 1]) / max(H - 1, 1) - 1.0
+    ix = ((gx + 1.0) / 2.0) * (W - 1)
+    iy = ((gy + 1.0) / 2.0) * (H - 1)
+    x0 = torch.floor(ix)
+    y0 = torch.floor(iy)
+    x1 = x0 + 1
+    y1 = y0 + 1
+    w_nw = (x1 - ix) * (y1 - iy)
+    w_ne = (ix - x0) * (y1 - iy)
+    w_sw = (x1 - ix) * (iy - y0)
+    w_se = (ix - x0) * (iy - y0)
+    flat = img.reshape(B, C, H * W)
+    out = torch.zeros_like(img)
+    for xs, ys, wt in ((x0, y0, w_nw), (x1, y0, w_ne), (x0, y1, w_sw), (x1, y1, w_se)):
+        inb = (xs >= 0) & (xs <= W - 1) & (ys >= 0) & (ys <= H - 1)
+        lin = (ys.clamp(0, H - 1) * W + xs.clamp(0, W - 1)).long().view(B, 1, H * W).expand(B, C, H * W)
+        val = flat.gather(2, lin).view(B, C, H, W)
+        out = out + val * (wt * inb.to(img.dtype)).unsqueeze(1)
+    return out
+
+
+def flow_interp_inputs(img6, flow4, t):
+    """Stage-2 input tensor.  scripts/models/flow_interpolation.py:338-372.
+    t: [B,1,1,1].  Channel order (ABI): I1, g(I1), Ft1^, Ft0^, g(I0), I0."""
+    f01 = flow4[:, 0:2]
+    f10 = flow4[:, 2:4]
+    ft0 = -(1 - t) * t * f01 + (t ** 2) * f10          # :353
+    ft1 = ((1 - t) ** 2) * f01 - t * (1 - t) * f10     # :356
+    i0 = img6[:, 0:3]
+    i1 = img6[:, 3:6]
+    g1 = warp(i1, ft1)
+    g0 = warp(i0, ft0)
+    return torch.cat([i1, g1, ft1, ft0, g0, i0], dim=1)
+
+
+def synthesize(img6, in16, out5, t):
+    """Visibility-weighted blend of the two warped frames.
+    scripts/models/flow_interpolation.py:374-429."""
+    v1 = torch.sigmoid(out5[:, 0:1])
+    v0 = 1 - v1
+    ft1 = in16[:, 6:8] + out5[:, 1:3]
+    ft0 = in16[:, 8:10] + out5[:, 3:5]
+    i0 = img6[:, 0:3]
+    i1 = img6[:, 3:6]
+    p0 = v0 * warp(i0, ft0)
+    p1 = v1 * warp(i1, ft1)
+    num = (1 - t) * p0 + t * p1
+    den = (1 - t) * v0 + t * v1
+    return num / den
+
+
+# --------------------------------------------------------------------------
+# the two U-Nets (CONV bottleneck)
+# --------------------------------------------------------------------------
+def _cl(p, name, x):
+    return conv2d_lrelu(x, p[name + ".0.weight"], p[name + ".0.bias"])
+
+
+def unet_encoder(p, x):
+    """flow_computation.py:155-204 / flow_interpolation.py:159-208."""
+    c1 = _cl(p, "conv1b", _cl(p, "conv1a", x))
+    c2 = _cl(p, "conv2b", _cl(p, "conv2a", avg_pool2(c1)))
+    c3 = _cl(p, "conv3b", _cl(p, "conv3a", avg_pool2(c2)))
+    c4 = _cl(p, "conv4b", _cl(p, "conv4a", avg_pool2(c3)))
+    c5 = _cl(p, "conv5b", _cl(p, "conv5a", avg_pool2(c4)))
+    return c1, c2, c3, c4, c5, avg_pool2(c5)
+
+
+def unet_bottleneck_conv(p, x):
+    """CONV bottleneck: Sequential(conv, conv).  flow_computation.py:68-71,:213-218."""
+    y = conv2d_lrelu(x, p["conv6.0.0.weight"], p["conv6.0.0.bias"])
+    return conv2d_lrelu(y, p["conv6.1.0.weight"], p["conv6.1.0.bias"])
+
+
+def unet_decoder(p, c6, enc, cross=None):
+    """flow_computation.py:222-289 / flow_interpolation.py:210-281.
+    Skips are concatenated at the LOWER resolution, then the whole concat is
+    upsampled (:244-245)."""
+    c1, c2, c3, c4, c5, _ = enc
+    x = c6 if cross is None else torch.cat([c6, cross], dim=1)
+    x = _cl(p, "conv7b", _cl(p, "conv7a", upsample2x_bilinear(x)))
+    x = _cl(p, "conv8b", _cl(p, "conv8a", upsample2x_bilinear(torch.cat([x, c5], 1))))
+    x = _cl(p, "conv9b", _cl(p, "conv9a", upsample2x_bilinear(torch.cat([x, c4], 1))))
+    x = _cl(p, "conv10b", _cl(p, "conv10a", upsample2x_bilinear(torch.cat([x, c3], 1))))
+    x = _cl(p, "conv11b", _cl(p, "conv11a", upsample2x_bilinear(torch.cat([x, c2], 1))))
+    x = _cl(p, "fuse_conv", torch.cat([x, c1], 1))
+    return conv2d(x, p["final_conv.weight"], p["final_conv.bias"])
+
+
+def stage1(p, img6):
+    """FlowComputationModel on one window: returns (conv6_out, flow4).
+    flow_computation.py:291-325."""
+    enc = unet_encoder(p, img6)
+    c6 = unet_bottleneck_conv(p, enc[-1])
+    return c6, unet_decoder(p, c6, enc)
+
+
+def stage2(p, in16, enc1=None):
+    """FlowInterpolationModel on one window: returns out5.
+    flow_interpolation.py:296-336 (cross-skip cat at :224-231)."""
+    enc = unet_encoder(p, in16)
+    c6 = unet_bottleneck_conv(p, enc[-1])
+    return unet_decoder(p, c6, enc, cross=enc1)
+
+
+# --------------------------------------------------------------------------
+# orchestration
+# --------------------------------------------------------------------------
+def full_model_infer(p1, p2, image_tensor, t_interp, cross_skip=True):
+    """FullModel.forward(inference_mode=True), CONV bottleneck.
+    scripts/models/superslomo_r.py:250-293 (+ :90-106, :152-248).
+    image_tensor [B,N,3,H,W], t_interp [B,N-1,1,1,1].
+    Returns (img_t, (F01, F10, Ft1^, Ft0^, Ft1, Ft0, V0)) of the middle window."""
+    Bn, N = image_tensor.shape[:2]
+    T = N - 1
+    mid = T // 2
+    res = None
+    for k in range(T):
+        img6 = torch.cat([image_tensor[:, k], image_tensor[:, k + 1]], dim=1)
+        c6, flow4 = stage1(p1, img6)
+        t = t_interp[:, k]
+        in16 = flow_interp_inputs(img6, flow4, t)
+        out5 = stage2(p2, in16, c6 if cross_skip else None)
+        img_t = synthesize(img6, in16, out5, t)
+        if k == mid:
+            v0 = 1 - torch.sigmoid(out5[:, 0:1])
+            res = (img_t, (flow4[:, 0:2], flow4[:, 2:4], in16[:, 6:8], in16[:, 8:10],
+                           in16[:, 6:8] + out5[:, 1:3], in16[:, 8:10] + out5[:, 3:5], v0))
+    return res
+
+
+def interpolate_pair(p1, p2, img6, ts, cross_skip=True, hoist=True):
+    """One frame pair -> len(ts) intermediates (the eval loop of
+    scripts/evaluate_interpolation_results.py:213-244).  hoist=False recomputes
+    stage 1 for every t exactly like the reference loop; hoist=True computes it
+    once (same numbers, fewer FLOPs)."""
+    outs = []
+    s1 = stage1(p1, img6) if hoist else None
+    for tv in ts:
+        c6, flow4 = s1 if hoist else stage1(p1, img6)
+        t = torch.full((img6.shape[0], 1, 1, 1), float(tv), dtype=torch.float32)
+        in16 = flow_interp_inputs(img6, flow4, t)
+        out5 = stage2(p2, in16, c6 if cross_skip else None)
+        outs.append(synthesize(img6, in16, out5, t))
+    return outs

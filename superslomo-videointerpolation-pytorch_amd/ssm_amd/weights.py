@@ -1,0 +1,137 @@
+"""Layer table of the two U-Nets and a deterministic, RNG-independent weight fill.
+
+The layer table restates the shapes built by the reference constructors
+(scripts/models/flow_computation.py:27-153, flow_interpolation.py:27-157);
+state-dict keys are the weight ABI (`<name>.0.weight|bias`, `conv6.{0,1}.0.*`,
+`final_conv.*`), tensors are OIHW fp32.
+
+Trained weights are not distributed with the reference (weights/README.org:3),
+so parity fixtures and the benchmark use `synthetic_state_dict`: every value is
+a pure function of (tensor name, flat index), which makes the fill identical in
+the build container (where the reference is imported to produce goldens), on
+the GPU box and across torch versions.  The scale is He-uniform for
+LeakyReLU(0.1) so that activations stay O(1) through all 24 layers and the
+predicted flows are a few pixels - a vanishing network would make end-to-end
+parity vacuous.
+"""
+
+import zlib
+
+import numpy as np
+import torch
+
+# (name, cin, cout, k); stage-2 differences handled in unet_layers()
+_ENC = [
+    ("conv1a", None, 32, 7), ("conv1b", 32, 32, 7),
+    ("conv2a", 32, 64, 5), ("conv2b", 64, 64, 5),
+    ("conv3a", 64, 128, 3), ("conv3b", 128, 128, 3),
+    ("conv4a", 128, 256, 3), ("conv4b", 256, 256, 3),
+    ("conv5a", 256, 512, 3), ("conv5b", 512, 512, 3),
+    ("conv6.0", 512, 512, 3), ("conv6.1", 512, 512, 3),
+]
+_DEC = [
+    ("conv7a", None, 512, 3), ("conv7b", 512, 512, 3),
+    ("conv8a", 1024, 256, 3), ("conv8b", 256, 256, 3),
+    ("conv9a", 512, 128, 3), ("conv9b", 128, 128, 3),
+    ("conv10a", 256, 64, 3), ("conv10b", 64, 64, 3),
+    ("conv11a", 128, 32, 3), ("conv11b", 32, 32, 3),
+    ("fuse_conv", 64, 32, 3),
+    ("final_conv", 32, None, 3),
+]
+
+
+def unet_layers(stage, cross_skip=True):
+    """List of (name, cin, cout, k) for stage 1 (6->4) or stage 2 (16->5)."""
+    assert stage in (1, 2), "Unsupported stage id."
+    cin0, cout_final = (6, 4) if stage == 1 else (16, 5)
+    c7 = 1024 if (stage == 2 and cross_skip) else 512
+    out = []
+    for name, cin, cout, k in _ENC + _DEC:
+        if name == "conv1a":
+            cin = cin0
+        if name == "conv7a":
+            cin = c7
+        if name == "final_conv":
+            cout = cout_final
+        out.append((name, cin, cout, k))
+    return out
+
+
+def param_key(name, what):
+    """State-dict key of a layer's weight/bias (final_conv is a bare Conv2d)."""
+    return "%s.%s" % (name, what) if name == "final_conv" else "%s.0.%s" % (name, what)
+
+
+def _hash_uniform(tag, n):
+    """n floats in [0,1), a pure function of (tag, index): splitmix64 finaliser."""
+    seed = np.uint64(zlib.crc32(tag.encode()) * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + seed
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+def synthetic_state_dict(stage, cross_skip=True, gain=1.0):
+    """Deterministic OIHW fp32 state dict with the reference's keys."""
+    sd = {}
+    for name, cin, cout, k in unet_layers(stage, cross_skip):
+        fan_in = cin * k * k
+        bound = gain * float(np.sqrt(6.0 / (1.01 * fan_in)))
+        if name == "final_conv":
+            bound *= 2.0  # flows of a few px, visibility logits away from 0
+        wkey, bkey = param_key(name, "weight"), param_key(name, "bias")
+        tag = "stage%d/%s" % (stage, name)
+        w = (_hash_uniform(tag + "/w", cout * cin * k * k) * 2.0 - 1.0) * bound
+        b = (_hash_uniform(tag + "/b", cout) * 2.0 - 1.0) * 0.05
+        sd[wkey] = torch.from_numpy(w.astype(np.float32).reshape(cout, cin, k, k).copy())
+        sd[bkey] = torch.from_numpy(b.astype(np.float32).copy())
+    return sd
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)   # configs/superslomo_original.ini:57
+IMAGENET_STD = (0.229, 0.224, 0.225)    # configs/superslomo_original.ini:58
+
+
+def synthetic_frames_u8(n_frames, h, w, seed=42):
+    """Synthetic Adobe240-shaped clip: smooth low-pass texture plus fine grain,
+    translated (3,2) px per frame so the scene has real motion.  uint8 RGB
+    [n_frames, 3, h, w]."""
+    rng = np.random.RandomState(seed)
+    m = 16
+    big = rng.rand(3, h // 8 + 2 * m, w // 8 + 2 * m).astype(np.float32)
+    t = torch.from_numpy(big)[None]
+    t = torch.nn.functional.interpolate(t, scale_factor=8, mode="bicubic", align_corners=False)[0]
+    t = (t - t.min()) / (t.max() - t.min())
+    fine = torch.from_numpy(rng.rand(3, t.shape[1], t.shape[2]).astype(np.float32)) * 0.08
+    t = (t * 0.92 + fine).clamp(0, 1)
+    frames = []
+    for i in range(n_frames):
+        dx, dy = 3 * i, 2 * i
+        crop = t[:, 8 * m - dy: 8 * m - dy + h, 8 * m - dx: 8 * m - dx + w]
+        frames.append(torch.round(crop * 255.0).clamp(0, 255).to(torch.uint8))
+    return torch.stack(frames)
+
+
+def normalize_and_pad(u8, pad_to=32):
+    """Input contract of the path (SURVEY a-0): x/255, ImageNet-normalise
+    (scripts/utils/dataloaders/augmentations.py:141-200), then zero-pad IN
+    NORMALISED SPACE to a multiple of 32, centred
+    (scripts/utils/dataloaders/default_reader.py:266-271).
+    uint8 [N,3,h,w] -> float32 [1,N,3,Hp,Wp]."""
+    n, _, h, w = u8.shape
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32).view(1, 3, 1, 1)
+    x = (u8.to(torch.float32) / 255.0 - mean) / std
+    hp = (h + pad_to - 1) // pad_to * pad_to
+    wp = (w + pad_to - 1) // pad_to * pad_to
+    top, left = (hp - h) // 2, (wp - w) // 2
+    out = torch.zeros(1, n, 3, hp, wp, dtype=torch.float32)
+    out[0, :, :, top: top + h, left: left + w] = x
+    return out
+
+
+def synthetic_frames(n_frames, h, w, seed=42, pad_to=32):
+    """normalize_and_pad(synthetic_frames_u8(...)): float32 [1,n_frames,3,Hp,Wp]."""
+    return normalize_and_pad(synthetic_frames_u8(n_frames, h, w, seed), pad_to)
