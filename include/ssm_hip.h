@@ -1,0 +1,130 @@
+/* ssm_hip.h - C ABI of libssm_hip.so: the MI355X (gfx950) replacement for the
+ * stock-PyTorch operators on the Super SloMo frame-pair -> intermediate-frame
+ * path.  Plain pointers and sizes only; no torch types.  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference
+ * repository root).
+ *
+ * Conventions
+ *  - all tensors are fp32 device memory owned by the caller; the library never
+ *    allocates, frees or keeps a pointer past return;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *    re-entrant, and takes the device from the pointers it is given;
+ *  - return value 0 = ok, negative = SSM_E_* ; ssm_last_error_string() holds a
+ *    message for the calling thread.  Nothing throws or exits.  The Python side
+ *    turns non-zero codes into RuntimeError, mirroring the reference's
+ *    assert/exception convention (scripts/utils/validators.py).
+ *
+ * Tensor views
+ *  A `ssm_view` addresses logical element (b,c,y,x) at
+ *      ptr[b*sb + c*sc + y*sh + x]           (strides in floats, x-stride 1)
+ *  so the same entry points take plain contiguous NCHW (sh=W, sc=H*W,
+ *  sb=C*H*W), channel slices of it, batch-broadcast tensors (sb=0) and the
+ *  library's "padded plane" layout.
+ *
+ * Padded-plane layout (what the convolutions read)
+ *  [B][C][Hp][Wp] with Hp = H + 2*SSM_PADY, Wp = roundup4(W + 2*SSM_PADX),
+ *  the image at rows SSM_PADY.., cols SSM_PADX.. and an all-zero frame around
+ *  it.  `ptr` of such a view points at the first INTERIOR element, is 16-byte
+ *  aligned, and sh/sc/sb are multiples of 4.  The zero frame implements the
+ *  convolution's zero padding (scripts/models/layers.py:22-31) with no bounds
+ *  test in the kernel.  Kernels only ever write interiors, so a buffer zeroed
+ *  once stays valid.  Conv inputs must be readable for SSM_TAIL_SLACK_FLOATS
+ *  past their last element (tile overshoot reads, never used).
+ */
+#ifndef SSM_HIP_H
+#define SSM_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSM_PADX 4
+#define SSM_PADY 3
+#define SSM_TAIL_SLACK_FLOATS (1 << 16)
+
+#define SSM_OK 0
+#define SSM_E_ARG (-1)      /* bad shape / alignment / unsupported size      */
+#define SSM_E_LAUNCH (-2)   /* HIP reported a launch error                   */
+#define SSM_E_UNSUPPORTED (-3)
+
+#define SSM_FLAG_LRELU 1    /* apply LeakyReLU(slope) after bias             */
+
+typedef struct ssm_view {
+    float *ptr;
+    long long sb, sc;   /* batch / channel stride, floats */
+    int sh;             /* row stride, floats             */
+} ssm_view;
+
+int ssm_abi_version(void);
+const char *ssm_last_error_string(void);
+
+/* Padded-plane geometry for an HxW image. */
+void ssm_plane_dims(int H, int W, int *Hp, int *Wp);
+
+/* Strided copy of a [B,C,H,W] block between two views (NCHW <-> padded plane,
+ * channel slices, torch.cat by writing at a channel offset).                */
+int ssm_copy_view(ssm_view src, ssm_view dst, int B, int C, int H, int W, void *stream);
+
+/* Which tile configuration ssm_conv2d_fwd will use for (k, Cout, W):
+ * BN = output-channel block the weights must be packed for, CK = input-channel
+ * chunk (Cin and the first cat source must be multiples of it).             */
+int ssm_conv_config(int k, int Cout, int W, int *BN, int *CK);
+
+/* Number of floats of the packed filter / packed bias for that configuration. */
+size_t ssm_packed_weight_floats(int Cout, int Cin_padded, int k, int BN);
+size_t ssm_packed_bias_floats(int Cout, int BN);
+
+/* OIHW fp32 filter (the reference's state-dict layout) ->
+ * [Cout/BN][Cin_padded][k*k][BN], zero-filled where padded.  Device to device. */
+int ssm_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed,
+                     int Cout, int Cin, int Cin_padded, int k, int BN, void *stream);
+
+/* Replaces layers.conv = Conv2d(stride 1, pad (k-1)/2, bias) [+ LeakyReLU(0.1)]
+ * (scripts/models/layers.py:21-33) and the bare final_conv
+ * (scripts/models/flow_computation.py:145-153).  fp32 implicit GEMM on
+ * v_mfma_f32_32x32x2_f32.  k in {3,5,7}.
+ *   x1,C1 / x2,C2 : input = torch.cat([x1, x2], dim=1) without materialising it
+ *                   (fuse_conv, flow_computation.py:271-272); C2 may be 0.
+ *                   Both padded-plane views with identical sh/sc.
+ *   y             : any view, [B,Cout,H,W]
+ *   pool          : optional (ptr NULL = off) view [B,Cout,H/2,W/2] that
+ *                   receives avg_pool2(y) (scripts/models/layers.py:60-63)
+ *                   fused into the epilogue.                                */
+int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed,
+                   const float *bias_packed, ssm_view y, ssm_view pool, int B, int H, int W,
+                   int Cout, int k, float slope, int flags, void *stream);
+
+/* layers.avg_pool(2) (scripts/models/layers.py:60-63), unfused form. */
+int ssm_avgpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int W, void *stream);
+
+/* y = F.upsample(torch.cat([a, b], 1), size=(2h,2w), mode="bilinear")
+ * (align_corners=False; scripts/models/flow_computation.py:244-245 and the
+ * upsample lambdas :92-137).  Cb may be 0.  y is [B,Ca+Cb,2h,2w].            */
+int ssm_upsample2x_cat_fwd(ssm_view a, int Ca, ssm_view b, int Cb, ssm_view y, int B, int h, int w,
+                           void *stream);
+
+/* layers.warp (scripts/models/layers.py:73-120): backward bilinear warp,
+ * zeros outside, flow = (u,v).  img [B,C,H,W], flow [B,2,H,W], out [B,C,H,W]. */
+int ssm_warp_bilinear_fwd(ssm_view img, ssm_view flow, ssm_view out, int B, int C, int H, int W,
+                          void *stream);
+
+/* FlowInterpolationModel.compute_inputs (scripts/models/flow_interpolation.py:
+ * 338-372), fused: flow approximation + 2 warps + 16-channel concat.
+ * img6 [B,6,H,W] (I0|I1), flow4 [B,4,H,W] (F01|F10), t[B] in (0,1) on device,
+ * out16 [B,16,H,W] in the reference's channel order.                        */
+int ssm_flowinterp_inputs_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_view out16, int B,
+                              int H, int W, void *stream);
+
+/* extract_outputs + compute_output_image (scripts/models/flow_interpolation.py:
+ * 374-429), fused: sigmoid visibility, refined flows, 2 warps, blend.
+ * y3 [B,3,H,W].  aux (ptr NULL = off) [B,5,H,W] receives Ft1(2) | Ft0(2) | V0(1),
+ * the intermediates FullModel returns (scripts/models/superslomo_r.py:142-150). */
+int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, const float *t, ssm_view y3,
+                       ssm_view aux, int B, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSM_HIP_H */

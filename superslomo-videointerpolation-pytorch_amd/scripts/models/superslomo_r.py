@@ -1,0 +1,120 @@
+"""FullModel: frame window -> intermediate frame, MI355X-native.
+
+Interface of the reference's scripts/models/superslomo_r.py:33-293 (ctor from the
+ini `cfg`, `forward(image_tensor, t_interp, target_images, iteration,
+inference_mode)`, attributes `stage1_model`, `stage2_model`, `loss`), so the
+reference's scripts (main.py:130-136, evaluate_interpolation_results.py:227,241,
+visualize_interpolation.py:144) can call it unchanged.
+
+Inference runs on ssm_amd.engine.PairEngine.  `interpolate()` is the hoisted form
+of the evaluators' t-loop: stage 1 once per pair, all t values batched through
+stage 2.
+"""
+import logging
+
+import torch
+import torch.nn as nn
+
+from ssm_amd import hipbind as hb
+from ssm_amd.engine import PairEngine
+
+from . import unetflow as unet
+from .losses import SSMLosses
+
+log = logging.getLogger(__name__)
+
+
+def validate_target_tensor(model_forward_func):
+    def func_wrapper(self, image_tensor, t_interp, target_images=None, iteration=None, inference_mode=True):
+        if not inference_mode:
+            assert target_images is not None, "No target found for loss."
+            assert target_images.shape[1] == self.cfg.getint("TRAIN", "N_FRAMES") - 1, "Insufficient number of targets."
+        return model_forward_func(self, image_tensor, t_interp, target_images, iteration, inference_mode)
+
+    return func_wrapper
+
+
+class FullModel(nn.Module):
+    def __init__(self, cfg, writer=None):
+        super().__init__()
+        self.cfg = cfg
+        self.writer = writer
+        self.load_weights()
+        self.freeze_weights()
+        self.loss = SSMLosses(cfg)
+        self._engine = None
+
+    def load_weights(self):
+        # quirk kept for drop-in behaviour: BOTH paths are gated on STAGE1.LOADPREV (superslomo_r.py:46-52)
+        load = self.cfg.getboolean("STAGE1", "LOADPREV")
+        stage1_weights = self.cfg.get("STAGE1", "WEIGHTS") if load else None
+        stage2_weights = self.cfg.get("STAGE2", "WEIGHTS") if load else None
+        self.cross_skip = self.cfg.getboolean("STAGE2", "CROSS_SKIP")
+        if self.cfg.get("STAGE1", "ENCODER") != "UNET":
+            raise NotImplementedError
+        log.info("STAGE 1 UNET")
+        self.stage1_model = unet.get_model(stage1_weights, 6, 4, self.cross_skip, stage=1, cfg=self.cfg)
+        log.info("STAGE 2 %s", self.cfg.get("STAGE2", "ENCODER"))
+        self.stage2_model = unet.get_model(stage2_weights, 16, 5, self.cross_skip, stage=2, cfg=self.cfg)
+        log.info("Cross stage Skip Connections Present? %s ", self.cross_skip)
+
+    def freeze_weights(self):
+        for name, model in (("STAGE1", self.stage1_model), ("STAGE2", self.stage2_model)):
+            if self.cfg.getboolean(name, "FREEZE"):
+                log.info("Freezing %s model.", name.lower())
+                model.eval()
+                for param in model.parameters():
+                    param.requires_grad = False
+            else:
+                log.info("Training %s model.", name.lower())
+
+    def get_image_pairs(self, img_tensor):
+        """[B,N,3,H,W] -> [B,N-1,6,H,W]: adjacent frames paired on the channel axis."""
+        return torch.cat([img_tensor[:, :-1], img_tensor[:, 1:]], dim=2)
+
+    # ---- engine plumbing ---------------------------------------------------------------
+    def _stamp(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine_for(self, B1, B2, H, W, device):
+        key = (B1, B2, H, W, str(device), self._stamp())
+        if self._engine is None or self._engine[0] != key:
+            sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
+            sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
+            self._engine = (key, PairEngine(sd1, sd2, B1, B2, H, W, device, self.cross_skip))
+        return self._engine[1]
+
+    @torch.no_grad()
+    def interpolate(self, image_pair, t_values):
+        """One pair [1,2,3,H,W] (or [1,6,H,W]) -> [len(t_values),3,H,W]: stage 1 once, every t
+        batched through stage 2 (the loop of evaluate_interpolation_results.py:213-244, hoisted)."""
+        hb.require_device(image_pair, "image pair")
+        img6 = image_pair.reshape(image_pair.shape[0], 6, *image_pair.shape[-2:])
+        assert img6.shape[0] == 1, "interpolate() takes one frame pair"
+        t = torch.as_tensor(t_values, dtype=torch.float32, device=img6.device).reshape(-1)
+        assert bool((t > 0).all() and (t < 1).all()), "Interpolation values out of bounds."
+        eng = self.engine_for(1, t.numel(), img6.shape[2], img6.shape[3], img6.device)
+        return eng.run(img6, t, want_aux=False).clone()
+
+    @validate_target_tensor
+    def forward(self, image_tensor, t_interp, target_images=None, iteration=None, inference_mode=True):
+        """image_tensor [B,N,3,H,W] normalised frames, t_interp [B,N-1,1,1,1] in (0,1).
+        Inference: (I_t [B,3,H,W], (F01, F10, Ft1^, Ft0^, Ft1, Ft0, V0)) of the middle window."""
+        hb.require_device(image_tensor, "image tensor")
+        if not inference_mode:
+            raise NotImplementedError("training step (losses + backward kernels) is the next scope row "
+                                      "(SURVEY 8f-1); only inference_mode=True is built")
+        image_pairs = self.get_image_pairs(image_tensor)
+        B, T = image_pairs.shape[:2]
+        mid_idx = T // 2
+        if iteration == 1:
+            log.info("%s interpolation windows. Mid_idx: %s", T, mid_idx)
+        # CONV bottleneck: windows are independent and only the middle one is returned
+        # (superslomo_r.py:237-238), so only that window is computed.
+        with torch.no_grad():
+            img6 = image_pairs[:, mid_idx]
+            t = t_interp[:, mid_idx].reshape(B).to(torch.float32)
+            eng = self.engine_for(B, B, img6.shape[2], img6.shape[3], img6.device)
+            est_img_t = eng.run(img6, t, want_aux=True).clone()
+            outputs = tuple(x.clone() for x in eng.intermediates())
+        return est_img_t, outputs

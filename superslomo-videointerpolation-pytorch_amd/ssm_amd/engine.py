@@ -1,0 +1,163 @@
+"""Launch plans for the hot path: frame pair -> intermediate frame(s).
+
+A `UNetPlan` is one U-Net (stage 1 = flow computation, stage 2 = arbitrary-time
+flow interpolation) at a fixed (batch, H, W): every activation pre-allocated in
+the padded-plane layout, every filter repacked once, and a fixed sequence of
+C-ABI calls (24 convolutions with fused LeakyReLU / 2x2 mean, 5 concat+bilinear
+upsamples).  Topology restates scripts/models/flow_computation.py:155-289 and
+scripts/models/flow_interpolation.py:159-281 of the reference.
+
+`PairEngine` chains stage 1 -> compute_inputs -> stage 2 -> synthesis
+(scripts/models/superslomo_r.py:250-293).  Stage 1 is t-independent, so for
+several intermediates of one pair it runs ONCE and the t values are batched
+through stage 2 (the reference's eval loop recomputes it per t,
+scripts/evaluate_interpolation_results.py:234-242 - same numbers, fewer FLOPs).
+"""
+import torch
+
+from . import hipbind as hb
+from .weights import param_key, unet_layers
+
+
+class UNetPlan:
+    def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True):
+        if H % 32 or W % 32:
+            raise AssertionError("H and W must be multiples of 32 (got %dx%d): the U-Net pools 5 times "
+                                 "and concatenates skips (unchecked in the reference, fails in torch.cat)" % (H, W))
+        self.stage, self.B, self.H, self.W, self.device = stage, B, H, W, device
+        self.cross = bool(cross_skip) and stage == 2
+        self.layers = {n: (ci, co, k) for n, ci, co, k in unet_layers(stage, cross_skip)}
+        self.pk = {}
+        for name, (ci, co, k) in self.layers.items():
+            w = state_dict[param_key(name, "weight")].to(device=device, dtype=torch.float32)
+            b = state_dict[param_key(name, "bias")].to(device=device, dtype=torch.float32)
+            assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
+            self.pk[name] = hb.PackedConv(w, b, W)
+        P = lambda c, s: hb.Planes(B, c, H // s, W // s, device)  # noqa: E731
+        cin0 = self.layers["conv1a"][0]
+        cfin = self.layers["final_conv"][1]
+        t = self.t = {}
+        t["in"] = P(cin0, 1)
+        t["t1a"], t["c1"], t["p2"] = P(32, 1), P(32, 1), P(32, 2)
+        t["t2a"], t["c2"], t["p3"] = P(64, 2), P(64, 2), P(64, 4)
+        t["t3a"], t["c3"], t["p4"] = P(128, 4), P(128, 4), P(128, 8)
+        t["t4a"], t["c4"], t["p5"] = P(256, 8), P(256, 8), P(256, 16)
+        t["t5a"], t["c5"], t["p6"] = P(512, 16), P(512, 16), P(512, 32)
+        t["t6a"], t["c6"] = P(512, 32), P(512, 32)
+        t["u7"] = P(1024 if self.cross else 512, 16)
+        t["t7a"], t["c7"] = P(512, 16), P(512, 16)
+        t["u8"], t["t8a"], t["c8"] = P(1024, 8), P(256, 8), P(256, 8)
+        t["u9"], t["t9a"], t["c9"] = P(512, 4), P(128, 4), P(128, 4)
+        t["u10"], t["t10a"], t["c10"] = P(256, 2), P(64, 2), P(64, 2)
+        t["u11"], t["t11a"], t["c11"] = P(128, 1), P(32, 1), P(32, 1)
+        t["tf"], t["out"] = P(32, 1), P(cfin, 1)
+
+    def _conv(self, name, src, dst, pool=None, src2=None, lrelu=True):
+        pk = self.pk[name]
+        s = self.t[src]
+        d = self.t[dst]
+        c2 = self.t[src2].C if src2 else 0
+        hb.conv2d(s.view(), s.C, self.t[src2].view() if src2 else None, c2, pk, d.view(),
+                  self.t[pool].view() if pool else None, self.B, s.H, s.W, lrelu=lrelu)
+
+    def _up(self, a, b, dst, b_planes=None, b_broadcast=False):
+        lib = hb.load()
+        A = self.t[a]
+        Bp = b_planes if b_planes is not None else (self.t[b] if b else None)
+        hb.check(lib.ssm_upsample2x_cat_fwd(A.view(), A.C, Bp.view(broadcast=b_broadcast) if Bp else hb.NULL_VIEW,
+                                            Bp.C if Bp else 0, self.t[dst].view(), self.B, A.H, A.W, hb.stream_ptr()))
+
+    def run(self, cross_planes=None, cross_broadcast=False):
+        """Input must already be in self.t['in'].  Returns the Planes of final_conv's output."""
+        c = self._conv
+        c("conv1a", "in", "t1a")
+        c("conv1b", "t1a", "c1", pool="p2")
+        c("conv2a", "p2", "t2a")
+        c("conv2b", "t2a", "c2", pool="p3")
+        c("conv3a", "p3", "t3a")
+        c("conv3b", "t3a", "c3", pool="p4")
+        c("conv4a", "p4", "t4a")
+        c("conv4b", "t4a", "c4", pool="p5")
+        c("conv5a", "p5", "t5a")
+        c("conv5b", "t5a", "c5", pool="p6")
+        c("conv6.0", "p6", "t6a")
+        c("conv6.1", "t6a", "c6")
+        if self.cross:
+            if cross_planes is None:
+                raise RuntimeError("stage 2 was built with CROSS_SKIP but no stage-1 encoding was given")
+            self._up("c6", None, "u7", b_planes=cross_planes, b_broadcast=cross_broadcast)
+        else:
+            self._up("c6", None, "u7")
+        c("conv7a", "u7", "t7a")
+        c("conv7b", "t7a", "c7")
+        self._up("c7", "c5", "u8")
+        c("conv8a", "u8", "t8a")
+        c("conv8b", "t8a", "c8")
+        self._up("c8", "c4", "u9")
+        c("conv9a", "u9", "t9a")
+        c("conv9b", "t9a", "c9")
+        self._up("c9", "c3", "u10")
+        c("conv10a", "u10", "t10a")
+        c("conv10b", "t10a", "c10")
+        self._up("c10", "c2", "u11")
+        c("conv11a", "u11", "t11a")
+        c("conv11b", "t11a", "c11")
+        c("fuse_conv", "c11", "tf", src2="c1")
+        c("final_conv", "tf", "out", lrelu=False)
+        return self.t["out"]
+
+
+class PairEngine:
+    """stage 1 (batch B1) -> compute_inputs -> stage 2 (batch B2) -> synthesis.
+    Either B2 == B1 (one t per sample: FullModel.forward) or B1 == 1 and B2 = number
+    of intermediates of that pair (stage-1 tensors broadcast over the t batch)."""
+
+    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True):
+        assert B2 == B1 or B1 == 1, "stage-2 batch must equal stage-1 batch, or stage-1 batch must be 1"
+        self.B1, self.B2, self.H, self.W, self.device = B1, B2, H, W, device
+        self.cross = bool(cross_skip)
+        self.bcast = (B1 == 1 and B2 > 1)
+        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip)
+        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip)
+        self.t_dev = torch.empty(B2, dtype=torch.float32, device=device)
+        self.img = torch.empty(B2, 3, H, W, dtype=torch.float32, device=device)
+        self.aux = torch.empty(B2, 5, H, W, dtype=torch.float32, device=device)
+
+    def load_pair(self, img6):
+        """img6: [B1,6,H,W] device tensor (I0 | I1 on the channel axis)."""
+        assert tuple(img6.shape) == (self.B1, 6, self.H, self.W), "image pair tensor has shape %s" % (tuple(img6.shape),)
+        self.s1.t["in"].load(img6)
+
+    def run_stage1(self):
+        return self.s1.run()
+
+    def run_stage2(self, t, want_aux=True):
+        """t: [B2] device tensor of interpolation times in (0,1)."""
+        lib = hb.load()
+        st = hb.stream_ptr()
+        self.t_dev.copy_(t.reshape(-1), non_blocking=True)
+        img6, flow4 = self.s1.t["in"], self.s1.t["out"]
+        in16 = self.s2.t["in"]
+        bc = self.bcast
+        hb.check(lib.ssm_flowinterp_inputs_fwd(img6.view(broadcast=bc), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
+                                               in16.view(), self.B2, self.H, self.W, st))
+        out5 = self.s2.run(cross_planes=self.s1.t["c6"] if self.cross else None, cross_broadcast=bc)
+        hb.check(lib.ssm_synthesize_fwd(img6.view(broadcast=bc), in16.view(), out5.view(), self.t_dev.data_ptr(),
+                                        hb.view_of(self.img), hb.view_of(self.aux) if want_aux else hb.NULL_VIEW,
+                                        self.B2, self.H, self.W, st))
+        return self.img
+
+    def run(self, img6, t, want_aux=True):
+        self.load_pair(img6)
+        self.run_stage1()
+        return self.run_stage2(t, want_aux)
+
+    def intermediates(self):
+        """(F01, F10, Ft1^, Ft0^, Ft1, Ft0, V0) as FullModel returns them
+        (scripts/models/superslomo_r.py:108-150); torch views/copies on the device."""
+        flow = self.s1.t["out"].interior
+        if self.bcast:
+            flow = flow.expand(self.B2, -1, -1, -1)
+        in16 = self.s2.t["in"].interior
+        return (flow[:, 0:2], flow[:, 2:4], in16[:, 6:8], in16[:, 8:10], self.aux[:, 0:2], self.aux[:, 2:4],
+                self.aux[:, 4:5])

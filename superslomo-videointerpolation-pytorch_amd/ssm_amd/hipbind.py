@@ -1,0 +1,168 @@
+"""ctypes binding of libssm_hip.so (C ABI: include/ssm_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute
+call goes through the C ABI with raw pointers.  There is NO fallback: if the
+library is missing or a call fails this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libssm_hip.so")
+
+SSM_PADX = 4
+SSM_PADY = 3
+SSM_TAIL_SLACK_FLOATS = 1 << 16
+SSM_FLAG_LRELU = 1
+
+
+class SsmView(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("sb", ctypes.c_longlong), ("sc", ctypes.c_longlong),
+                ("sh", ctypes.c_int)]
+
+
+NULL_VIEW = SsmView(None, 0, 0, 0)
+
+_c_int, _c_float, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); kept in step with include/ssm_hip.h (tests check every symbol)
+SIGNATURES = {
+    "ssm_abi_version": (_c_int, []),
+    "ssm_last_error_string": (ctypes.c_char_p, []),
+    "ssm_plane_dims": (None, [_c_int, _c_int, _ip, _ip]),
+    "ssm_copy_view": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv_config": (_c_int, [_c_int, _c_int, _c_int, _ip, _ip]),
+    "ssm_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "ssm_packed_bias_floats": (_sz, [_c_int, _c_int]),
+    "ssm_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv2d_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int,
+                                _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_avgpool2_fwd": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_upsample2x_cat_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _vp]),
+    "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_flowinterp_inputs_fwd": (_c_int, [SsmView, SsmView, _vp, SsmView, _c_int, _c_int, _c_int, _vp]),
+    "ssm_synthesize_fwd": (_c_int, [SsmView, SsmView, SsmView, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libssm_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C superslomo-videointerpolation-pytorch_amd/csrc`. There is no "
+                "CPU/PyTorch fallback for the hot path." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ssm_last_error_string()
+        raise RuntimeError("libssm_hip: %s (code %d)" % (msg.decode() if msg else "error", rc))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(t, what="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError("%s must be a float32 tensor on the GPU (the HIP path has no CPU fallback); got %s on %s"
+                           % (what, getattr(t, "dtype", type(t)), getattr(t, "device", "?")))
+
+
+def view_of(t):
+    """ssm_view of a 4-D torch tensor [B,C,H,W] whose last stride is 1 (any other strides)."""
+    require_device(t)
+    assert t.dim() == 4 and (t.shape[3] == 1 or t.stride(3) == 1), "need [B,C,H,W] with unit x-stride"
+    return SsmView(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def plane_dims(h, w):
+    return h + 2 * SSM_PADY, (w + 2 * SSM_PADX + 3) // 4 * 4
+
+
+class Planes:
+    """A [B,C,H,W] activation in the padded-plane layout (include/ssm_hip.h): zero frame
+    of SSM_PADY rows / SSM_PADX cols around every plane, rows 16-byte aligned, plus the
+    readable tail slack the convolution's tile overshoot needs.  Zeroed once at
+    allocation; kernels only write interiors."""
+
+    def __init__(self, B, C, H, W, device):
+        self.B, self.C, self.H, self.W = B, C, H, W
+        self.Hp, self.Wp = plane_dims(H, W)
+        n = B * C * self.Hp * self.Wp
+        self.buf = torch.zeros(n + SSM_TAIL_SLACK_FLOATS, dtype=torch.float32, device=device)
+        self.full = self.buf[:n].view(B, C, self.Hp, self.Wp)
+
+    @property
+    def interior(self):
+        """torch view of the logical tensor (non-contiguous)."""
+        return self.full[:, :, SSM_PADY:SSM_PADY + self.H, SSM_PADX:SSM_PADX + self.W]
+
+    def view(self, c0=0, broadcast=False):
+        base = self.buf.data_ptr() + 4 * ((c0 * self.Hp + SSM_PADY) * self.Wp + SSM_PADX)
+        sc = self.Hp * self.Wp
+        return SsmView(base, 0 if broadcast else self.C * sc, sc, self.Wp)
+
+    def load(self, x):
+        """Copy a [B,C,H,W] device tensor into the interior (HIP strided copy)."""
+        x = x if x.stride(3) == 1 else x.contiguous()
+        lib = load()
+        check(lib.ssm_copy_view(view_of(x), self.view(), self.B, self.C, self.H, self.W, stream_ptr()))
+        return self
+
+    def to_nchw(self):
+        out = torch.empty(self.B, self.C, self.H, self.W, dtype=torch.float32, device=self.buf.device)
+        lib = load()
+        check(lib.ssm_copy_view(self.view(), view_of(out), self.B, self.C, self.H, self.W, stream_ptr()))
+        return out
+
+
+def conv_config(k, cout, w):
+    lib = load()
+    bn, ck = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.ssm_conv_config(k, cout, w, ctypes.byref(bn), ctypes.byref(ck)))
+    return bn.value, ck.value
+
+
+class PackedConv:
+    """Filter + bias of one convolution repacked for the tile configuration the
+    library picks for (k, Cout, W).  An explicit handle owned by the Python side
+    (packed-weight caches are created/destroyed by the caller)."""
+
+    def __init__(self, weight, bias, w_hint):
+        require_device(weight, "conv weight")
+        require_device(bias, "conv bias")
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        self.bn, self.ck = conv_config(self.k, self.cout, w_hint)
+        self.cin_p = (self.cin + self.ck - 1) // self.ck * self.ck
+        lib = load()
+        nw = lib.ssm_packed_weight_floats(self.cout, self.cin_p, self.k, self.bn)
+        nb = lib.ssm_packed_bias_floats(self.cout, self.bn)
+        self.w = torch.empty(nw, dtype=torch.float32, device=weight.device)
+        self.b = torch.empty(nb, dtype=torch.float32, device=weight.device)
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        check(lib.ssm_pack_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout,
+                                   self.cin, self.cin_p, self.k, self.bn, stream_ptr()))
+
+
+def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1):
+    lib = load()
+    assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
+    check(lib.ssm_conv2d_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
+                             pool if pool is not None else NULL_VIEW, B, H, W, pk.cout, pk.k, slope,
+                             SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))

@@ -1,0 +1,90 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/ssm_hip.h declares, and its pure-host entry points behave.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ssm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from ssm_amd import hipbind as hb
+    lib = hb.load()
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libssm_hip.so does not export %s" % n
+        assert n in hb.SIGNATURES, "hipbind has no signature for %s" % n
+    assert sorted(hb.SIGNATURES) == names, "binding and header disagree"
+    assert lib.ssm_abi_version() == 1
+
+
+def test_plane_dims_and_conv_config():
+    from ssm_amd import hipbind as hb
+    lib = hb.load()
+    hp, wp = ctypes.c_int(), ctypes.c_int()
+    for h, w in ((736, 1280), (23, 40), (3, 3), (8, 13)):
+        lib.ssm_plane_dims(h, w, ctypes.byref(hp), ctypes.byref(wp))
+        assert (hp.value, wp.value) == hb.plane_dims(h, w)
+        assert wp.value % 4 == 0 and wp.value >= w + 8 and hp.value == h + 6
+    for k, cout, bn in ((7, 32, 32), (5, 64, 64), (3, 32, 32), (3, 5, 32), (3, 64, 64), (3, 128, 128), (3, 512, 128)):
+        b, ck = hb.conv_config(k, cout, 1280)
+        assert b == bn and ck in (2, 4)
+        assert lib.ssm_packed_weight_floats(cout, 8, k, b) == (cout + b - 1) // b * 8 * k * k * b
+    with pytest.raises(RuntimeError, match="unsupported"):
+        hb.conv_config(1, 32, 64)
+
+
+def test_error_convention_bad_arguments():
+    """Bad shapes are refused on the host with a message (no launch, no GPU needed)."""
+    from ssm_amd import hipbind as hb
+    lib = hb.load()
+    v = hb.SsmView(None, 0, 0, 0)
+    rc = lib.ssm_warp_bilinear_fwd(v, v, v, 1, 3, 8, 8, None)
+    assert rc == -1 and b"null" in lib.ssm_last_error_string()
+    rc = lib.ssm_avgpool2_fwd(v, v, 1, 1, 7, 8, None)
+    assert rc == -1
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    from models import layers
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layers.warp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+    m = layers.conv(6, 32, kernel_size=7, padding=3)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(torch.zeros(1, 6, 8, 8))
+
+
+def test_mirror_state_dict_keys_match_reference_abi():
+    """Key names/shapes are the weight ABI: strict load of the synthetic dicts."""
+    from models import unetflow
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_state_dict
+    cfg = load_config("superslomo_original.ini", synthetic_weight_overrides())
+    for stage, cin, cout, nparams in ((1, 6, 4, 18236644), (2, 16, 5, 20611909)):
+        m = unetflow.get_model(None, cin, cout, True, stage=stage, cfg=cfg)
+        m.load_state_dict(synthetic_state_dict(stage, True))          # strict
+        assert sum(p.numel() for p in m.parameters()) == nparams
+        assert len(m.state_dict()) == 48
+
+
+def test_configs_parse_and_gate():
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    cfg = load_config("superslomo_eval.ini", synthetic_weight_overrides())
+    fm = FullModel(cfg)
+    assert fm.cross_skip and not any(p.requires_grad for p in fm.parameters())     # FREEZE=TRUE in the ini
+    with pytest.raises(NotImplementedError):
+        FullModel(load_config("superslomo_recurrent.ini", synthetic_weight_overrides()))   # CLSTM: unpinned
+    x = torch.zeros(2, 4, 3, 8, 8)
+    assert tuple(fm.get_image_pairs(x).shape) == (2, 3, 6, 8, 8)

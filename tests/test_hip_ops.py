@@ -1,0 +1,160 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle
+and the golden fixtures produced by the reference.  Tolerances are written per test; the
+end-to-end bar is 1e-3 max-abs (BASELINE.json), the per-op bars are much tighter."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def report(got, want, what):
+    d = (got - want).abs()
+    i = int(d.argmax())
+    idx = np.unravel_index(i, tuple(d.shape))
+    return "%s: max|diff|=%.3e at %s (got %.6f want %.6f), mean|diff|=%.3e, |want|max=%.3f" % (
+        what, float(d.max()), idx, float(got.flatten()[i]), float(want.flatten()[i]), float(d.mean()),
+        float(want.abs().max()))
+
+
+def test_planes_roundtrip_and_zero_frame(dev):
+    from ssm_amd import hipbind as hb
+    x = torch.randn(2, 5, 12, 20)
+    p = hb.Planes(2, 5, 12, 20, dev).load(x.to(dev))
+    assert torch.equal(p.to_nchw().cpu(), x)
+    full = p.full.cpu().clone()
+    full[:, :, hb.SSM_PADY:hb.SSM_PADY + 12, hb.SSM_PADX:hb.SSM_PADX + 20] = 0
+    assert float(full.abs().max()) == 0.0, "padding frame must stay zero"
+
+
+def test_conv_golden(dev, golden):
+    """layers.conv / bare conv against the reference's own outputs."""
+    from models import layers
+    g = golden("ops")
+    for tag, k, cin, cout in (("conv_k7_c6_n32", 7, 6, 32), ("conv_k5_c32_n64", 5, 32, 64),
+                              ("conv_k3_c64_n32", 3, 64, 32), ("conv_k3_c32_n5", 3, 32, 5)):
+        m = layers.conv(cin, cout, kernel_size=k, padding=(k - 1) // 2)
+        with torch.no_grad():
+            m[0].weight.copy_(T(g[tag + "_w"]))
+            m[0].bias.copy_(T(g[tag + "_b"]))
+        m = m.to(dev)
+        with torch.no_grad():
+            y = m(T(g[tag + "_x"]).to(dev)).cpu()
+            ylin = m[0](T(g[tag + "_x"]).to(dev)).cpu()
+        assert (y - T(g[tag + "_y"])).abs().max() < 2e-5, report(y, T(g[tag + "_y"]), tag)
+        assert (ylin - T(g[tag + "_ylin"])).abs().max() < 2e-5, report(ylin, T(g[tag + "_ylin"]), tag + " (no act)")
+
+
+CONV_CASES = [
+    # k, cin, cout, B, H, W   - every tile configuration, ragged sizes, several cout blocks, batches
+    (7, 6, 32, 1, 16, 64), (7, 16, 32, 2, 24, 72), (7, 32, 32, 1, 37, 100),
+    (5, 32, 64, 1, 16, 64), (5, 64, 64, 2, 19, 40),
+    (3, 128, 32, 1, 16, 64), (3, 32, 32, 2, 9, 33), (3, 64, 32, 1, 8, 130), (3, 32, 4, 1, 16, 64),
+    (3, 256, 64, 1, 16, 64), (3, 64, 64, 2, 11, 70),
+    (3, 64, 128, 1, 8, 64), (3, 128, 256, 1, 12, 128), (3, 512, 512, 1, 4, 64),
+    (3, 512, 512, 1, 23, 40), (3, 256, 512, 2, 6, 16), (3, 1024, 256, 1, 8, 96), (3, 128, 128, 1, 46, 80),
+]
+
+
+@pytest.mark.parametrize("k,cin,cout,B,H,W", CONV_CASES)
+def test_conv_vs_oracle(dev, k, cin, cout, B, H, W):
+    from models import layers
+    from oracle import ssm_oracle as O
+    g = torch.Generator().manual_seed(k * 1000 + cin + cout + H + W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    m = layers.conv(cin, cout, kernel_size=k, padding=(k - 1) // 2)
+    with torch.no_grad():
+        m[0].weight.copy_(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
+        m[0].bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    want = O.conv2d_lrelu(x, m[0].weight.detach(), m[0].bias.detach())
+    with torch.no_grad():
+        got = m.to(dev)(x.to(dev)).cpu()
+    # fp32 MFMA = k-ordered fmaf chain; CPU conv reassociates: a few ulp of sqrt(K)-sized sums
+    assert (got - want).abs().max() < 5e-5, report(got, want, "conv k%d %d->%d %dx%dx%d" % (k, cin, cout, B, H, W))
+
+
+def test_conv_fused_pool_and_cat(dev):
+    """Two-source input (torch.cat on C) + fused 2x2 mean, as fuse_conv / conv1b use them."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 16, 96
+    a, b = torch.randn(B, 32, H, W, generator=g), torch.randn(B, 32, H, W, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24.0
+    bias = torch.randn(32, generator=g) * 0.1
+    want = O.conv2d_lrelu(torch.cat([a, b], 1), w, bias)
+    pa, pb = hb.Planes(B, 32, H, W, dev).load(a.to(dev)), hb.Planes(B, 32, H, W, dev).load(b.to(dev))
+    y, yp = hb.Planes(B, 32, H, W, dev), hb.Planes(B, 32, H // 2, W // 2, dev)
+    pk = hb.PackedConv(w.to(dev), bias.to(dev), W)
+    hb.conv2d(pa.view(), 32, pb.view(), 32, pk, y.view(), yp.view(), B, H, W, lrelu=True)
+    got, gotp = y.to_nchw().cpu(), yp.to_nchw().cpu()
+    assert (got - want).abs().max() < 5e-5, report(got, want, "cat conv")
+    assert (gotp - O.avg_pool2(want)).abs().max() < 5e-5, report(gotp, O.avg_pool2(want), "fused pool")
+
+
+def test_pool_upsample_golden(dev, golden):
+    from models import layers
+    g = golden("ops")
+    y = layers.avg_pool(2, None, 0)(T(g["pool_x"]).to(dev)).cpu()
+    assert (y - T(g["pool_y"])).abs().max() < 1e-6, report(y, T(g["pool_y"]), "avg_pool")
+    up = layers.upsample2x_cat(T(g["up_a"]).to(dev), T(g["up_b"]).to(dev)).cpu()
+    assert (up - T(g["up_y"])).abs().max() < 1e-6, report(up, T(g["up_y"]), "cat+upsample")
+    up1 = layers.upsample2x_cat(T(g["up_a"]).to(dev)).cpu()
+    assert (up1 - T(g["up_y"])[:, :3]).abs().max() < 1e-6
+
+
+def test_warp_golden(dev, golden):
+    from models import layers
+    g = golden("ops")
+    y = layers.warp(T(g["warp_img"]).to(dev), T(g["warp_flo"]).to(dev)).cpu()
+    assert (y - T(g["warp_y"])).abs().max() < 1e-5, report(y, T(g["warp_y"]), "warp")
+
+
+def test_warp_properties_720p(dev):
+    """Full-size properties: zero flow is the identity; an integer shift is an exact shift with zeros
+    shifted in; far-out-of-range flow gives zeros."""
+    from models import layers
+    H, W = 736, 1280
+    img = torch.randn(1, 3, H, W, device=dev)
+    z = torch.zeros(1, 2, H, W, device=dev)
+    assert (layers.warp(img, z) - img).abs().max() < 1e-5
+    f = z.clone()
+    f[:, 0] = 5.0
+    f[:, 1] = -3.0
+    y = layers.warp(img, f)
+    want = torch.zeros_like(img)
+    want[:, :, 3:, :W - 5] = img[:, :, :H - 3, 5:]
+    assert (y - want).abs().max() < 2e-3     # coordinates carry ~1e-4 px of fp32 normalisation error
+    f[:] = 1e6
+    assert float(layers.warp(img, f).abs().max()) == 0.0
+
+
+def test_inputs_and_synthesis_golden(dev, golden):
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from models import unetflow
+    g = golden("ops")
+    s2 = unetflow.get_model(None, 16, 5, True, stage=2, cfg=load_config(overrides=synthetic_weight_overrides()))
+    img6, flow4, out5 = (T(g[n]).to(dev) for n in ("fi_img6", "fi_flow4", "fi_out5"))
+    for i, tv in enumerate((0.125, 0.5, 0.875)):
+        t = torch.full((2, 1, 1, 1), tv, device=dev)
+        in16 = s2.compute_inputs(img6, flow4, t).cpu()
+        assert (in16 - T(g["fi_in16_%d" % i])).abs().max() < 1e-5, report(in16, T(g["fi_in16_%d" % i]), "compute_inputs")
+        img = s2.compute_output_image(img6, T(g["fi_in16_%d" % i]).to(dev), out5, t).cpu()
+        assert (img - T(g["fi_img_%d" % i])).abs().max() < 5e-5, report(img, T(g["fi_img_%d" % i]), "synthesis")
+
+
+def test_cpu_tensor_is_refused():
+    """No silent CPU fallback: the product path raises on CPU tensors."""
+    from models import layers
+    with pytest.raises(RuntimeError):
+        layers.warp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the convolution kernel at the 736x1280 shapes of SURVEY Appendix A.
+usage: python tools/bench_layers.py [B] [H] [W]     (B = batch, e.g. 7 = the stage-2 t batch)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd")
+sys.path[:0] = [ROOT, PKG, os.path.join(PKG, "scripts")]
+import torch  # noqa: E402
+
+from ssm_amd import hipbind as hb  # noqa: E402
+from ssm_amd.weights import unet_layers  # noqa: E402
+
+SCALE = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8,
+         "conv9": 4, "conv10": 2, "conv11": 1, "fuse_": 1, "final": 1}
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 736
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 1280
+    dev = torch.device("cuda:0")
+    tot_t = tot_f = 0.0
+    print("%-10s %5s %5s %2s %9s %9s %8s %8s" % ("layer", "cin", "cout", "k", "hxw", "GFLOP", "ms", "TFLOP/s"))
+    for name, cin, cout, k in unet_layers(2, True):
+        s = [v for p, v in SCALE.items() if name.startswith(p)][0] if not name.startswith("conv1") or name in (
+            "conv1a", "conv1b") else None
+        if s is None:
+            s = 2 if name.startswith("conv10") else 1
+        h, w = H // s, W // s
+        x = hb.Planes(B, cin, h, w, dev)
+        x.interior.normal_()
+        y = hb.Planes(B, cout, h, w, dev)
+        pk = hb.PackedConv(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5,
+                           torch.zeros(cout, device=dev), w)
+        for _ in range(2):
+            hb.conv2d(x.view(), cin, None, 0, pk, y.view(), None, B, h, w)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        e0.record()
+        for _ in range(n):
+            hb.conv2d(x.view(), cin, None, 0, pk, y.view(), None, B, h, w)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        gf = 2.0 * B * h * w * cout * cin * k * k / 1e9
+        tot_t += ms
+        tot_f += gf
+        print("%-10s %5d %5d %2d %4dx%-4d %9.2f %8.3f %8.1f" % (name, cin, cout, k, h, w, gf, ms, gf / ms))
+        del x, y, pk
+    print("TOTAL stage-2 convs: %.1f GFLOP in %.2f ms = %.1f TFLOP/s (fp32 MFMA peak 157.3)" % (tot_f, tot_t, tot_f / tot_t))
+
+
+if __name__ == "__main__":
+    main()
