@@ -1,0 +1,83 @@
+"""Multi-GPU plumbing: one process per GPU, frame pairs sharded with NO data-path collective.
+
+Inference shards naturally: every frame pair is independent, its t values stay on
+the pair's GPU (they share stage 1).  The reference's torch.nn.DataParallel
+(scripts/main.py:74-76, scripts/evaluate_interpolation_results.py:65-67: per-iteration parameter
+broadcast + output gather in one process) is replaced by static round-robin assignment of pair
+indices to ranks with replicated weights.  torch.distributed (backend "nccl" = RCCL on ROCm,
+"gloo" in the CPU tests) is used only for the rendezvous, the timing barrier and the
+max-over-ranks reduction of the elapsed time.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when absent."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def assign_pairs(n_pairs, world, rank):
+    """Static round-robin: pair i -> rank i % world.  Returns this rank's pair indices."""
+    return list(range(rank, n_pairs, world))
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def timed_steps(step_fn, steps, warmup, sync_fn):
+    """The driver's timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
+    barrier + device sync on both sides; returns max-over-ranks elapsed seconds."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    barrier()
+    el = time.perf_counter() - t0
+    return reduce_max(el)
+
+
+def reduce_max(value, device=None):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or _dist_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_frames(frames_by_index, n_pairs):
+    """Collect {pair index: tensor} dicts of all ranks on every rank (host objects; results are
+    written/gathered on the host).  Returns a list ordered by pair index."""
+    if dist.is_initialized():
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, {k: v.cpu() for k, v in frames_by_index.items()})
+    else:
+        parts = [frames_by_index]
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    assert sorted(merged) == list(range(n_pairs)), "some frame pairs were not processed"
+    return [merged[i] for i in range(n_pairs)]
+
+
+def _dist_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")

@@ -19,7 +19,39 @@ from . import hipbind as hb
 from .weights import param_key, unet_layers
 
 
+class KernelTimer:
+    """HIP-event bracket around kernel launches on the stream they are issued on (torch's
+    current stream, which is also what the C ABI receives).  Used by bench.py for the
+    roofline figures; off by default."""
+
+    def __init__(self):
+        self.spans = []      # (family, name, flops, bytes, ev0, ev1)
+
+    def span(self, family, name, flops=0.0, nbytes=0.0):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.spans.append((family, name, flops, nbytes, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        """family -> dict(ms, flops, bytes, launches); call after torch.cuda.synchronize()."""
+        out = {}
+        for fam, name, fl, nb, e0, e1 in self.spans:
+            d = out.setdefault(fam, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "by_name": {}})
+            ms = e0.elapsed_time(e1)
+            d["ms"] += ms
+            d["flops"] += fl
+            d["bytes"] += nb
+            d["launches"] += 1
+            n = d["by_name"].setdefault(name, [0.0, 0.0, 0])
+            n[0] += ms
+            n[1] += fl
+            n[2] += 1
+        return out
+
+
 class UNetPlan:
+    timer = None     # a KernelTimer, or None
+
     def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True):
         if H % 32 or W % 32:
             raise AssertionError("H and W must be multiples of 32 (got %dx%d): the U-Net pools 5 times "
@@ -57,15 +89,28 @@ class UNetPlan:
         s = self.t[src]
         d = self.t[dst]
         c2 = self.t[src2].C if src2 else 0
+        tm = self.timer
+        if tm is not None:
+            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self.B * s.H * s.W * pk.cout * pk.cin * pk.k * pk.k)
+            e0.record()
         hb.conv2d(s.view(), s.C, self.t[src2].view() if src2 else None, c2, pk, d.view(),
                   self.t[pool].view() if pool else None, self.B, s.H, s.W, lrelu=lrelu)
+        if tm is not None:
+            e1.record()
 
     def _up(self, a, b, dst, b_planes=None, b_broadcast=False):
         lib = hb.load()
         A = self.t[a]
         Bp = b_planes if b_planes is not None else (self.t[b] if b else None)
+        tm = self.timer
+        if tm is not None:   # algorithmic bytes: read the sources once, write 4x as many pixels
+            e0, e1 = tm.span("upsample_cat", "s%d.%s" % (self.stage, dst),
+                             nbytes=4.0 * self.B * A.H * A.W * (A.C + (Bp.C if Bp else 0)) * 5)
+            e0.record()
         hb.check(lib.ssm_upsample2x_cat_fwd(A.view(), A.C, Bp.view(broadcast=b_broadcast) if Bp else hb.NULL_VIEW,
                                             Bp.C if Bp else 0, self.t[dst].view(), self.B, A.H, A.W, hb.stream_ptr()))
+        if tm is not None:
+            e1.record()
 
     def run(self, cross_planes=None, cross_broadcast=False):
         """Input must already be in self.t['in'].  Returns the Planes of final_conv's output."""
@@ -139,12 +184,24 @@ class PairEngine:
         img6, flow4 = self.s1.t["in"], self.s1.t["out"]
         in16 = self.s2.t["in"]
         bc = self.bcast
+        tm = UNetPlan.timer
+        px = float(self.B2 * self.H * self.W)
+        if tm is not None:   # 104 B/px (read 10 ch, write 16 ch)
+            e0, e1 = tm.span("warp", "flowinterp_inputs", nbytes=104.0 * px)
+            e0.record()
         hb.check(lib.ssm_flowinterp_inputs_fwd(img6.view(broadcast=bc), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
                                                in16.view(), self.B2, self.H, self.W, st))
+        if tm is not None:
+            e1.record()
         out5 = self.s2.run(cross_planes=self.s1.t["c6"] if self.cross else None, cross_broadcast=bc)
+        if tm is not None:   # 72 B/px (read 6+4+5 ch, write 3 ch)
+            e0, e1 = tm.span("warp", "synthesize", nbytes=72.0 * px)
+            e0.record()
         hb.check(lib.ssm_synthesize_fwd(img6.view(broadcast=bc), in16.view(), out5.view(), self.t_dev.data_ptr(),
                                         hb.view_of(self.img), hb.view_of(self.aux) if want_aux else hb.NULL_VIEW,
                                         self.B2, self.H, self.W, st))
+        if tm is not None:
+            e1.record()
         return self.img
 
     def run(self, img6, t, want_aux=True):

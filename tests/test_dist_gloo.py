@@ -1,0 +1,63 @@
+"""world_size-2 gloo test of the multi-GPU plumbing (ssm_amd.dist): pair sharding covers every pair
+exactly once, the gathered N-rank result equals the 1-rank result, and the bench timing protocol
+(barrier-bracketed, max over ranks) behaves.  CPU only - the per-pair work is a stand-in function;
+the GPU path's per-pair determinism is covered by tests/test_hip_model.py::test_720p_properties."""
+import os
+import socket
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd"))
+
+
+def fake_interpolate(i):
+    g = torch.Generator().manual_seed(100 + i)
+    return torch.randn(7, 3, 4, 6, generator=g)
+
+
+def worker(rank, world, port, n_pairs, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from ssm_amd import dist as sd
+    r, lr, w = sd.init("gloo")
+    assert (r, w) == (rank, world)
+    mine = sd.assign_pairs(n_pairs, world, rank)
+    frames = {i: fake_interpolate(i) for i in mine}
+    allf = sd.gather_frames(frames, n_pairs)
+    ok = all(torch.equal(allf[i], fake_interpolate(i)) for i in range(n_pairs))
+    # timing protocol: rank 1 is slower; every rank must report the max
+    el = sd.timed_steps(lambda: time.sleep(0.01 * (rank + 1)), steps=5, warmup=1, sync_fn=lambda: None)
+    ret[rank] = (mine, ok, el)
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sharding_and_timing():
+    world, n_pairs = 2, 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, free_port(), n_pairs, ret), nprocs=world, join=True)
+    assert sorted(ret[0][0] + ret[1][0]) == list(range(n_pairs))
+    assert set(ret[0][0]).isdisjoint(ret[1][0])
+    assert ret[0][1] and ret[1][1]
+    assert abs(ret[0][2] - ret[1][2]) < 1e-9 and ret[0][2] >= 0.1     # both see rank 1's 5 x 20 ms
+
+
+def test_single_process_defaults():
+    from ssm_amd import dist as sd
+    assert sd.assign_pairs(5, 1, 0) == [0, 1, 2, 3, 4]
+    assert sd.reduce_max(1.5) == 1.5
+    out = sd.gather_frames({0: torch.zeros(1), 1: torch.ones(1)}, 2)
+    assert len(out) == 2

@@ -121,22 +121,42 @@ def test_warp_golden(dev, golden):
 
 
 def test_warp_properties_720p(dev):
-    """Full-size properties: zero flow is the identity; an integer shift is an exact shift with zeros
-    shifted in; far-out-of-range flow gives zeros."""
+    """Full-size (736x1280) properties.  The reference normalises coordinates to [-1,1] and
+    grid_sample maps them back (layers.py:112-119), which costs ~1e-4 px of fp32 rounding at W=1280 -
+    so even a zero flow is not a bit-exact identity in the reference; the tolerances below are that
+    rounding times the image gradient (randn image: |grad| < ~8).
+    (a) zero flow ~ identity, (b) integer shift ~ exact shift with zeros shifted in,
+    (c) far out-of-range flow gives exact zeros, (d) linear in the image."""
     from models import layers
     H, W = 736, 1280
     img = torch.randn(1, 3, H, W, device=dev)
     z = torch.zeros(1, 2, H, W, device=dev)
-    assert (layers.warp(img, z) - img).abs().max() < 1e-5
+    assert (layers.warp(img, z) - img).abs().max() < 2e-3
     f = z.clone()
     f[:, 0] = 5.0
     f[:, 1] = -3.0
     y = layers.warp(img, f)
     want = torch.zeros_like(img)
     want[:, :, 3:, :W - 5] = img[:, :, :H - 3, 5:]
-    assert (y - want).abs().max() < 2e-3     # coordinates carry ~1e-4 px of fp32 normalisation error
+    assert (y - want).abs().max() < 2e-3
     f[:] = 1e6
     assert float(layers.warp(img, f).abs().max()) == 0.0
+    fr = torch.randn(1, 2, H, W, device=dev) * 3
+    img2 = torch.randn(1, 3, H, W, device=dev)
+    lin = layers.warp(img + 2 * img2, fr) - (layers.warp(img, fr) + 2 * layers.warp(img2, fr))
+    assert lin.abs().max() < 1e-4
+
+
+def test_warp_720p_vs_oracle(dev):
+    """Full-size warp against the CPU oracle (same coordinate arithmetic): tight tolerance."""
+    from models import layers
+    from oracle import ssm_oracle as O
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(1, 3, 736, 1280, generator=g)
+    flo = torch.randn(1, 2, 736, 1280, generator=g) * 4
+    got = layers.warp(img.to(dev), flo.to(dev)).cpu()
+    want = O.warp(img, flo)
+    assert (got - want).abs().max() < 1e-5, report(got, want, "warp 720p")
 
 
 def test_inputs_and_synthesis_golden(dev, golden):
