@@ -18,7 +18,7 @@ Extra objects on the JSON line:
   roofline_warp the HBM-bound gather kernels (compute_inputs + synthesis): algorithmic bytes
                 (104 + 72 B/px per t) / their event-timed duration; peak 8 TB/s.
   cpu_baseline  the CPU oracle (torch CPU fp32 ops, pinned to the reference by golden fixtures),
-                timed on this host on a bounded sample: 1 pair x 2 intermediates, reference-style
+                timed on this host on a bounded sample: 1 pair x 1 intermediate, reference-style
                 loop (stage 1 recomputed per t).  A reported baseline, not the target.
   parity        max|HIP - oracle| over those same 2 full-size frames (bar: 1e-3).
 """
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (roofline = null)")
+    ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")
     args = ap.parse_args()
 
     from ssm_amd import dist as sdist
@@ -125,10 +126,16 @@ def main():
         conv = summ["conv"]
         conv_ms_step = conv["ms"] / args.steps
         ach = flops_step / (conv_ms_step * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1b_pmc_traffic_summary.json")
+        if os.path.exists(pmc):        # HBM bytes per step from rocprofv3 --pmc passes (tools/pmc_traffic.sh), not live
+            traffic = json.load(open(pmc)).get("conv_mfma_kernel", {}).get("hbm_bytes_per_step")
         out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32), all %d launches "
                            "of a step" % (conv["launches"] // args.steps), "achieved": round(ach, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": None, "flop_per_step": flops_step, "ms_per_step_in_kernel": round(conv_ms_step, 3)}
+                           "traffic": traffic, "traffic_note": "HBM bytes per step of the conv launches, FETCH_SIZE x2 "
+                           "(gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes: profiles/r1b_pmc_traffic_summary.json",
+                           "flop_per_step": flops_step, "ms_per_step_in_kernel": round(conv_ms_step, 3)}
         wk = summ["warp"]
         wms = wk["ms"] / args.steps
         wach = wk["bytes"] / args.steps / (wms * 1e-3) / 1e9
@@ -136,6 +143,11 @@ def main():
                                 "achieved": round(wach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": round(wach / PEAK_HBM_GBS, 4), "traffic": None,
                                 "bytes_per_step": wk["bytes"] / args.steps, "ms_per_step_in_kernel": round(wms, 3)}
+        if args.detail:
+            det = {fam: {n: {"ms_per_step": v[0] / args.steps, "tflops": (v[1] / v[0] / 1e9 if v[0] > 0 else 0.0)}
+                         for n, v in d["by_name"].items()} for fam, d in summ.items()}
+            with open(args.detail, "w") as f:
+                json.dump(det, f, indent=1)
         up = summ["upsample_cat"]
         out["time_split_ms_per_step"] = {"conv": round(conv_ms_step, 3), "warp_blend": round(wms, 3),
                                          "upsample_cat": round(up["ms"] / args.steps, 3),
@@ -143,7 +155,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ssm_oracle as O
-        ts = [0.125, 0.5]
+        ts = [0.5]
         pair = torch.cat([x[:, 0], x[:, 1]], 1)
         cores = torch.get_num_threads()
         with torch.no_grad():

@@ -67,10 +67,11 @@ void ssm_plane_dims(int H, int W, int *Hp, int *Wp);
  * channel slices, torch.cat by writing at a channel offset).                */
 int ssm_copy_view(ssm_view src, ssm_view dst, int B, int C, int H, int W, void *stream);
 
-/* Which tile configuration ssm_conv2d_fwd will use for (k, Cout, W):
+/* Which tile configuration ssm_conv2d_fwd will use for this problem (kernel size,
+ * output channels, batch, map size, fused pool or not):
  * BN = output-channel block the weights must be packed for, CK = input-channel
  * chunk (Cin and the first cat source must be multiples of it).             */
-int ssm_conv_config(int k, int Cout, int W, int *BN, int *CK);
+int ssm_conv_config(int k, int Cout, int B, int H, int W, int pool, int *BN, int *CK);
 
 /* Number of floats of the packed filter / packed bias for that configuration. */
 size_t ssm_packed_weight_floats(int Cout, int Cin_padded, int k, int BN);

@@ -237,17 +237,31 @@ using CfgK3N32 = Cfg<3, 1, 1, 2, 2, 4, 1, 4>;   //  32    8  64   conv11a/b, fus
 using CfgK3N64 = Cfg<3, 2, 1, 2, 2, 4, 1, 4>;   //  64    8  64   conv10a/b
 using CfgK3N128 = Cfg<3, 2, 2, 2, 2, 2, 1, 4>;  // 128    4  64   conv3..conv9 (wide maps)
 using CfgK3N128S = Cfg<3, 2, 2, 2, 1, 2, 1, 4>;  // 128   4  32   same, maps where 64-wide tiles waste columns
+// small maps (1/16, 1/32 resolution at batch 1): more, smaller workgroups to cover 256 CUs
+using CfgK3N64T = Cfg<3, 1, 2, 2, 1, 2, 1, 4>;   //  64    4  32
+using CfgK3N32T = Cfg<3, 1, 1, 1, 1, 4, 1, 8>;   //  32    4  32   (odd row tile: no fused pool)
 
-enum ConvKind { K7 = 0, K5, K3N32, K3N64, K3N128, K3N128S, NKIND };
+enum ConvKind { K7 = 0, K5, K3N32, K3N64, K3N128, K3N128S, K3N64T, K3N32T, NKIND };
 
-int pick_kind(int k, int Cout, int W) {
+constexpr int kFillBlocks = 256;   // one workgroup per CU
+
+template <class C>
+long long grid_blocks(int B, int H, int W, int Cout) {
+    return (long long)B * ((W + C::TW - 1) / C::TW) * ((H + C::TH - 1) / C::TH) * ((Cout + C::BN - 1) / C::BN);
+}
+
+int pick_kind(int k, int Cout, int B, int H, int W, int pool) {
     if (k == 7) return K7;
     if (k == 5) return K5;
     if (k != 3) return -1;
     if (Cout <= 32) return K3N32;
     if (Cout <= 64) return K3N64;
     const int w64 = (W + 63) / 64 * 64, w32 = (W + 31) / 32 * 32;
-    return (w32 < w64) ? K3N128S : K3N128;
+    const bool narrow = w32 < w64;
+    const long long nb = narrow ? grid_blocks<CfgK3N128S>(B, H, W, Cout) : grid_blocks<CfgK3N128>(B, H, W, Cout);
+    if (nb >= kFillBlocks) return narrow ? K3N128S : K3N128;
+    if (pool || grid_blocks<CfgK3N64T>(B, H, W, Cout) >= kFillBlocks) return K3N64T;
+    return K3N32T;
 }
 
 template <class C>
@@ -297,8 +311,8 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, const float *__
 
 }  // namespace
 
-extern "C" int ssm_conv_config(int k, int Cout, int W, int *BN, int *CK) {
-    const int kind = pick_kind(k, Cout, W);
+extern "C" int ssm_conv_config(int k, int Cout, int B, int H, int W, int pool, int *BN, int *CK) {
+    const int kind = pick_kind(k, Cout, B, H, W, pool);
     switch (kind) {
         case K7: cfg_dims<CfgK7>(BN, CK); break;
         case K5: cfg_dims<CfgK5>(BN, CK); break;
@@ -306,6 +320,8 @@ extern "C" int ssm_conv_config(int k, int Cout, int W, int *BN, int *CK) {
         case K3N64: cfg_dims<CfgK3N64>(BN, CK); break;
         case K3N128: cfg_dims<CfgK3N128>(BN, CK); break;
         case K3N128S: cfg_dims<CfgK3N128S>(BN, CK); break;
+        case K3N64T: cfg_dims<CfgK3N64T>(BN, CK); break;
+        case K3N32T: cfg_dims<CfgK3N32T>(BN, CK); break;
         default:
             ssm::set_error("conv: kernel size %d unsupported (3, 5, 7 are)", k);
             return SSM_E_UNSUPPORTED;
@@ -336,7 +352,7 @@ extern "C" int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const fl
                               const float *bias_packed, ssm_view y, ssm_view pool, int B, int H, int W, int Cout,
                               int k, float slope, int flags, void *stream) {
     int BN = 0, CK = 0;
-    const int rc = ssm_conv_config(k, Cout, W, &BN, &CK);
+    const int rc = ssm_conv_config(k, Cout, B, H, W, pool.ptr ? 1 : 0, &BN, &CK);
     if (rc != SSM_OK) return rc;
     SSM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && C1 > 0 && C2 >= 0, "conv: bad sizes");
     SSM_REQUIRE(x1.ptr && y.ptr && w_packed && bias_packed, "conv: null pointer");
@@ -377,13 +393,15 @@ extern "C" int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const fl
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    switch (pick_kind(k, Cout, W)) {
+    switch (pick_kind(k, Cout, B, H, W, pool.ptr ? 1 : 0)) {
         case K7: return launch<CfgK7>(p, B, st);
         case K5: return launch<CfgK5>(p, B, st);
         case K3N32: return launch<CfgK3N32>(p, B, st);
         case K3N64: return launch<CfgK3N64>(p, B, st);
         case K3N128: return launch<CfgK3N128>(p, B, st);
         case K3N128S: return launch<CfgK3N128S>(p, B, st);
+        case K3N64T: return launch<CfgK3N64T>(p, B, st);
+        case K3N32T: return launch<CfgK3N32T>(p, B, st);
     }
     return SSM_E_UNSUPPORTED;
 }

@@ -147,33 +147,65 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(ssm_view xin, ssm_view yo
 }
 
 // F.upsample(cat[a,b], size=(2h,2w), mode="bilinear"), align_corners=False:
-// scripts/models/flow_computation.py:92-94,:244-245.  One thread per SOURCE pixel
-// writes its 2x2 block.  Index/lambda pairs follow ATen's half-pixel rule:
-// Y=2i -> rows (i-1,i) with (.25,.75) [row 0: (0,0),(1,0)]; Y=2i+1 -> rows (i,i+1) with
-// (.75,.25), the upper row clamped at h-1.   H, W here are the SOURCE dims.
-__global__ __launch_bounds__(256) void upsample2x_cat_kernel(ssm_view a, int Ca, ssm_view bsrc, int Cb, ssm_view yout, int H, int W) {
-    SSM_PIXEL_INDEX();
+// scripts/models/flow_computation.py:92-94,:244-245.  One thread owns TWO adjacent source
+// pixels of one row and writes their 2x4 output block as two 16-byte stores per channel
+// (lanes along x: 1 KiB contiguous per wave-instruction); channels are spread over
+// blockIdx.z so small maps with many channels still fill the chip.  Index/lambda pairs
+// follow ATen's half-pixel rule: Y=2i -> rows (i-1,i) with (.25,.75) [Y=0: row 0 alone];
+// Y=2i+1 -> rows (i,i+1) with (.75,.25), upper row clamped at h-1; same along x.
+// H, W = SOURCE dims.  UP_CPT channels per thread.
+#define UP_CPT 4
+template <bool VEC4>
+__global__ __launch_bounds__(256) void upsample2x_cat_kernel(ssm_view a, int Ca, ssm_view bsrc, int Cb, ssm_view yout, int H, int W, int cgroups) {
+    const int xp = blockIdx.x * 32 + threadIdx.x;      // source pixel pair index
+    const int y = blockIdx.y * 8 + threadIdx.y;
+    const int b = blockIdx.z / cgroups;
+    const int cg = blockIdx.z - b * cgroups;
+    const int x = 2 * xp;
+    if (x >= W || y >= H) return;
     const int ym = y > 0 ? y - 1 : 0, yp = y < H - 1 ? y + 1 : y;
-    const int xm = x > 0 ? x - 1 : 0, xp = x < W - 1 ? x + 1 : x;
-    const float ly0a = y > 0 ? 0.25f : 1.0f, ly0b = y > 0 ? 0.75f : 0.0f;   // output row 2y   : rows (ym, y)
-    const float lx0a = x > 0 ? 0.25f : 1.0f, lx0b = x > 0 ? 0.75f : 0.0f;   // output col 2x   : cols (xm, x)
-    const int ry0 = y > 0 ? ym : 0, ry0b = y > 0 ? y : 0;
-    const int cx0 = x > 0 ? xm : 0, cx0b = x > 0 ? x : 0;
+    const bool pair = x + 1 < W;   // odd W: the last thread of a row owns a single source pixel
+    const int xm = x > 0 ? x - 1 : 0, x1 = pair ? x + 1 : x, x2 = x + 2 < W ? x + 2 : W - 1;
+    const float wyT0 = y > 0 ? 0.25f : 1.0f, wyT1 = y > 0 ? 0.75f : 0.0f;   // Y = 2y   : rows (ym, y)
+    const float wx00 = x > 0 ? 0.25f : 1.0f, wx01 = x > 0 ? 0.75f : 0.0f;   // X = 2x   : cols (xm, x)
     const int C = Ca + Cb;
-    for (int c = 0; c < C; ++c) {
+    const int c0 = cg * UP_CPT;
+#pragma unroll
+    for (int i = 0; i < UP_CPT; ++i) {
+        const int c = c0 + i;
+        if (c >= C) break;
         const ssm_view &s = c < Ca ? a : bsrc;
         const int cc = c < Ca ? c : c - Ca;
-        const float *pT = vp(s, b, cc, ry0), *pTb = vp(s, b, cc, ry0b);   // rows for Y = 2y
-        const float *pM = vp(s, b, cc, y), *pB = vp(s, b, cc, yp);        // rows for Y = 2y+1
-        // Y = 2y
-        const float e00 = ly0a * (lx0a * pT[cx0] + lx0b * pT[cx0b]) + ly0b * (lx0a * pTb[cx0] + lx0b * pTb[cx0b]);
-        const float e01 = ly0a * (0.75f * pT[x] + 0.25f * pT[xp]) + ly0b * (0.75f * pTb[x] + 0.25f * pTb[xp]);
-        // Y = 2y+1
-        const float e10 = 0.75f * (lx0a * pM[cx0] + lx0b * pM[cx0b]) + 0.25f * (lx0a * pB[cx0] + lx0b * pB[cx0b]);
-        const float e11 = 0.75f * (0.75f * pM[x] + 0.25f * pM[xp]) + 0.25f * (0.75f * pB[x] + 0.25f * pB[xp]);
-        float *o0 = vp(yout, b, c, 2 * y) + 2 * x, *o1 = vp(yout, b, c, 2 * y + 1) + 2 * x;
-        *reinterpret_cast<float2 *>(o0) = make_float2(e00, e01);
-        *reinterpret_cast<float2 *>(o1) = make_float2(e10, e11);
+        const float *r0 = vp(s, b, cc, ym), *r1 = vp(s, b, cc, y), *r2 = vp(s, b, cc, yp);
+        float v[3][4];
+        v[0][0] = r0[xm]; v[0][1] = r0[x]; v[0][2] = r0[x1]; v[0][3] = r0[x2];
+        v[1][0] = r1[xm]; v[1][1] = r1[x]; v[1][2] = r1[x1]; v[1][3] = r1[x2];
+        v[2][0] = r2[xm]; v[2][1] = r2[x]; v[2][2] = r2[x1]; v[2][3] = r2[x2];
+        // horizontal pass for the three source rows: X = 2x, 2x+1, 2x+2, 2x+3
+        float h[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            h[r][0] = wx00 * v[r][0] + wx01 * v[r][1];
+            h[r][1] = 0.75f * v[r][1] + 0.25f * v[r][2];
+            h[r][2] = 0.25f * v[r][1] + 0.75f * v[r][2];
+            h[r][3] = 0.75f * v[r][2] + 0.25f * v[r][3];
+        }
+        float4 o0, o1;
+        o0.x = wyT0 * h[0][0] + wyT1 * h[1][0]; o0.y = wyT0 * h[0][1] + wyT1 * h[1][1];
+        o0.z = wyT0 * h[0][2] + wyT1 * h[1][2]; o0.w = wyT0 * h[0][3] + wyT1 * h[1][3];
+        o1.x = 0.75f * h[1][0] + 0.25f * h[2][0]; o1.y = 0.75f * h[1][1] + 0.25f * h[2][1];
+        o1.z = 0.75f * h[1][2] + 0.25f * h[2][2]; o1.w = 0.75f * h[1][3] + 0.25f * h[2][3];
+        float *d0 = vp(yout, b, c, 2 * y) + 2 * x, *d1 = vp(yout, b, c, 2 * y + 1) + 2 * x;
+        if (VEC4 && pair) {
+            *reinterpret_cast<float4 *>(d0) = o0;
+            *reinterpret_cast<float4 *>(d1) = o1;
+        } else if (VEC4) {
+            *reinterpret_cast<float2 *>(d0) = make_float2(o0.x, o0.y);
+            *reinterpret_cast<float2 *>(d1) = make_float2(o1.x, o1.y);
+        } else {   // unaligned destination (plain NCHW with a width that is not a multiple of 4)
+            d0[0] = o0.x; d0[1] = o0.y; d1[0] = o1.x; d1[1] = o1.y;
+            if (pair) { d0[2] = o0.z; d0[3] = o0.w; d1[2] = o1.z; d1[3] = o1.w; }
+        }
     }
 }
 
@@ -204,8 +236,14 @@ extern "C" int ssm_avgpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int
 extern "C" int ssm_upsample2x_cat_fwd(ssm_view a, int Ca, ssm_view b, int Cb, ssm_view y, int B, int H, int W, void *stream) {
     SSM_CHECK_DIMS("upsample2x_cat");
     SSM_REQUIRE(a.ptr && y.ptr && Ca > 0 && Cb >= 0 && (Cb == 0 || b.ptr), "upsample2x_cat: null pointer / channels");
-    SSM_REQUIRE(even_view(y), "upsample2x_cat: output view must be 8-byte aligned with even strides");
-    hipLaunchKernelGGL(upsample2x_cat_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, a, Ca, Cb ? b : a, Cb, y, H, W);
+    const bool vec4 = ssm::aligned16(y.ptr) && y.sh % 4 == 0 && y.sc % 4 == 0 && y.sb % 4 == 0;
+    const int cgroups = (Ca + Cb + UP_CPT - 1) / UP_CPT;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "upsample2x_cat: B*C too large for one launch");
+    const dim3 grid(((W + 1) / 2 + 31) / 32, (H + 7) / 8, B * cgroups);
+    if (vec4)
+        hipLaunchKernelGGL(upsample2x_cat_kernel<true>, grid, dim3(32, 8), 0, (hipStream_t)stream, a, Ca, Cb ? b : a, Cb, y, H, W, cgroups);
+    else
+        hipLaunchKernelGGL(upsample2x_cat_kernel<false>, grid, dim3(32, 8), 0, (hipStream_t)stream, a, Ca, Cb ? b : a, Cb, y, H, W, cgroups);
     return ssm::check_launch("ssm_upsample2x_cat_fwd");
 }
 

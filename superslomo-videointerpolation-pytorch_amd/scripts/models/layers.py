@@ -15,14 +15,16 @@ from ssm_amd import hipbind as hb
 log = logging.getLogger(__name__)
 
 
-def _packed_for(conv_mod, width):
+def _packed_for(conv_mod, B, H, W):
     """Repacked filter of an nn.Conv2d, cached on the module and refreshed when the
-    parameters are replaced or written in place (load_state_dict, optimizer step)."""
+    parameters are replaced or written in place (load_state_dict, optimizer step) or the
+    problem size selects another tile configuration."""
     w, b = conv_mod.weight, conv_mod.bias
-    stamp = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+    stamp = (w.data_ptr(), w._version, b.data_ptr(), b._version,
+             hb.conv_config(w.shape[2], w.shape[0], B, H, W, False))
     cache = conv_mod.__dict__.get("_ssm_packed")
     if cache is None or cache[0] != stamp:
-        cache = (stamp, hb.PackedConv(w, b, width))
+        cache = (stamp, hb.PackedConv(w, b, B, H, W, False))
         conv_mod.__dict__["_ssm_packed"] = cache
     return cache[1]
 
@@ -34,7 +36,7 @@ def conv_forward(conv_mod, x, lrelu, slope=0.1):
         raise NotImplementedError("backward of the HIP convolution is not built yet (SURVEY 8f-1); "
                                   "run under torch.no_grad() / with FREEZE=TRUE")
     B, C, H, W = x.shape
-    pk = _packed_for(conv_mod, W)
+    pk = _packed_for(conv_mod, B, H, W)
     assert C == pk.cin, "conv expects %d input channels, got %d" % (pk.cin, C)
     src = hb.Planes(B, pk.cin_p, H, W, x.device)       # zero frame + channels padded to the chunk size
     lib = hb.load()

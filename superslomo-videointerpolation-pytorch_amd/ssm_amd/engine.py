@@ -49,6 +49,19 @@ class KernelTimer:
         return out
 
 
+POOLED = ("conv1b", "conv2b", "conv3b", "conv4b", "conv5b")      # 2x2 mean fused into these convs
+_SCALE = (("conv10", 2), ("conv11", 1), ("conv1", 1), ("conv2", 2), ("conv3", 4), ("conv4", 8), ("conv5", 16),
+          ("conv6", 32), ("conv7", 16), ("conv8", 8), ("conv9", 4), ("fuse_conv", 1), ("final_conv", 1))
+
+
+def layer_scale(name):
+    """Down-sampling factor of the map a layer runs on."""
+    for prefix, s in _SCALE:
+        if name.startswith(prefix):
+            return s
+    raise KeyError(name)
+
+
 class UNetPlan:
     timer = None     # a KernelTimer, or None
 
@@ -64,7 +77,8 @@ class UNetPlan:
             w = state_dict[param_key(name, "weight")].to(device=device, dtype=torch.float32)
             b = state_dict[param_key(name, "bias")].to(device=device, dtype=torch.float32)
             assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
-            self.pk[name] = hb.PackedConv(w, b, W)
+            s = layer_scale(name)
+            self.pk[name] = hb.PackedConv(w, b, B, H // s, W // s, pool=name in POOLED)
         P = lambda c, s: hb.Planes(B, c, H // s, W // s, device)  # noqa: E731
         cin0 = self.layers["conv1a"][0]
         cfin = self.layers["final_conv"][1]

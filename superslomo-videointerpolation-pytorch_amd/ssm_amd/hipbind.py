@@ -34,7 +34,7 @@ SIGNATURES = {
     "ssm_last_error_string": (ctypes.c_char_p, []),
     "ssm_plane_dims": (None, [_c_int, _c_int, _ip, _ip]),
     "ssm_copy_view": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
-    "ssm_conv_config": (_c_int, [_c_int, _c_int, _c_int, _ip, _ip]),
+    "ssm_conv_config": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip]),
     "ssm_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int, _c_int]),
     "ssm_packed_bias_floats": (_sz, [_c_int, _c_int]),
     "ssm_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -132,23 +132,24 @@ class Planes:
         return out
 
 
-def conv_config(k, cout, w):
+def conv_config(k, cout, B, H, W, pool=False):
     lib = load()
     bn, ck = ctypes.c_int(0), ctypes.c_int(0)
-    check(lib.ssm_conv_config(k, cout, w, ctypes.byref(bn), ctypes.byref(ck)))
+    check(lib.ssm_conv_config(k, cout, B, H, W, 1 if pool else 0, ctypes.byref(bn), ctypes.byref(ck)))
     return bn.value, ck.value
 
 
 class PackedConv:
     """Filter + bias of one convolution repacked for the tile configuration the
-    library picks for (k, Cout, W).  An explicit handle owned by the Python side
-    (packed-weight caches are created/destroyed by the caller)."""
+    library picks for the problem (k, Cout, batch, map size, fused pool).  An explicit
+    handle owned by the Python side (packed-weight caches are
+    created/destroyed by the caller)."""
 
-    def __init__(self, weight, bias, w_hint):
+    def __init__(self, weight, bias, B, H, W, pool=False):
         require_device(weight, "conv weight")
         require_device(bias, "conv bias")
         self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
-        self.bn, self.ck = conv_config(self.k, self.cout, w_hint)
+        self.bn, self.ck = conv_config(self.k, self.cout, B, H, W, pool)
         self.cin_p = (self.cin + self.ck - 1) // self.ck * self.ck
         lib = load()
         nw = lib.ssm_packed_weight_floats(self.cout, self.cin_p, self.k, self.bn)
@@ -163,6 +164,8 @@ class PackedConv:
 def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1):
     lib = load()
     assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
+    assert (pk.bn, pk.ck) == conv_config(pk.k, pk.cout, B, H, W, pool is not None), \
+        "filter was packed for another tile configuration (batch/size/pool changed)"
     check(lib.ssm_conv2d_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                              pool if pool is not None else NULL_VIEW, B, H, W, pk.cout, pk.k, slope,
                              SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))

@@ -37,11 +37,17 @@ def test_plane_dims_and_conv_config():
         assert (hp.value, wp.value) == hb.plane_dims(h, w)
         assert wp.value % 4 == 0 and wp.value >= w + 8 and hp.value == h + 6
     for k, cout, bn in ((7, 32, 32), (5, 64, 64), (3, 32, 32), (3, 5, 32), (3, 64, 64), (3, 128, 128), (3, 512, 128)):
-        b, ck = hb.conv_config(k, cout, 1280)
+        b, ck = hb.conv_config(k, cout, 7, 736, 1280)
         assert b == bn and ck in (2, 4)
         assert lib.ssm_packed_weight_floats(cout, 8, k, b) == (cout + b - 1) // b * 8 * k * k * b
+    # low-parallelism maps get smaller workgroup tiles (more workgroups); fused pool keeps an even row tile
+    assert hb.conv_config(3, 512, 1, 46, 80) == (64, 4)
+    assert hb.conv_config(3, 512, 1, 23, 40) == (32, 8)
+    assert hb.conv_config(3, 512, 1, 4, 4, pool=True) == (64, 4)
+    assert hb.conv_config(3, 512, 7, 23, 40) == (64, 4)
+    assert hb.conv_config(3, 512, 7, 46, 80) == (128, 4)
     with pytest.raises(RuntimeError, match="unsupported"):
-        hb.conv_config(1, 32, 64)
+        hb.conv_config(1, 32, 1, 64, 64)
 
 
 def test_error_convention_bad_arguments():

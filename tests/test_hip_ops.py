@@ -95,7 +95,7 @@ def test_conv_fused_pool_and_cat(dev):
     want = O.conv2d_lrelu(torch.cat([a, b], 1), w, bias)
     pa, pb = hb.Planes(B, 32, H, W, dev).load(a.to(dev)), hb.Planes(B, 32, H, W, dev).load(b.to(dev))
     y, yp = hb.Planes(B, 32, H, W, dev), hb.Planes(B, 32, H // 2, W // 2, dev)
-    pk = hb.PackedConv(w.to(dev), bias.to(dev), W)
+    pk = hb.PackedConv(w.to(dev), bias.to(dev), B, H, W, pool=True)
     hb.conv2d(pa.view(), 32, pb.view(), 32, pk, y.view(), yp.view(), B, H, W, lrelu=True)
     got, gotp = y.to_nchw().cpu(), yp.to_nchw().cpu()
     assert (got - want).abs().max() < 5e-5, report(got, want, "cat conv")
@@ -111,6 +111,19 @@ def test_pool_upsample_golden(dev, golden):
     assert (up - T(g["up_y"])).abs().max() < 1e-6, report(up, T(g["up_y"]), "cat+upsample")
     up1 = layers.upsample2x_cat(T(g["up_a"]).to(dev)).cpu()
     assert (up1 - T(g["up_y"])[:, :3]).abs().max() < 1e-6
+
+
+def test_upsample_odd_and_tiny_sizes(dev):
+    """Source maps with odd width / single row or column (1/32-resolution maps of small frames)."""
+    from models import layers
+    from oracle import ssm_oracle as O
+    g = torch.Generator().manual_seed(9)
+    for shape in ((1, 3, 3, 3), (2, 5, 1, 1), (1, 9, 5, 7), (1, 4, 2, 33), (1, 6, 23, 40)):
+        a = torch.randn(*shape, generator=g)
+        b = torch.randn(shape[0], 2, shape[2], shape[3], generator=g)
+        got = layers.upsample2x_cat(a.to(dev), b.to(dev)).cpu()
+        want = O.upsample2x_bilinear(torch.cat([a, b], 1))
+        assert (got - want).abs().max() < 1e-6, report(got, want, "upsample %s" % (shape,))
 
 
 def test_warp_golden(dev, golden):

@@ -33,7 +33,7 @@ def main():
         x.interior.normal_()
         y = hb.Planes(B, cout, h, w, dev)
         pk = hb.PackedConv(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5,
-                           torch.zeros(cout, device=dev), w)
+                           torch.zeros(cout, device=dev), B, h, w)
         for _ in range(2):
             hb.conv2d(x.view(), cin, None, 0, pk, y.view(), None, B, h, w)
         torch.cuda.synchronize()

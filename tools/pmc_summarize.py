@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Sum FETCH_SIZE / WRITE_SIZE per kernel family from the rocprofv3 --pmc CSVs written by
+tools/pmc_traffic.sh and apply the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact.
+Counter unit: KiB (rocprofv3 derived counter, TCC_EA0_*REQ based)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+res = defaultdict(lambda: defaultdict(float))
+calls = defaultdict(int)
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(os.path.join(out, ctr, "**", "*counter_collection.csv"), recursive=True)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            name = row.get("Kernel_Name", "")
+            if row.get("Counter_Name") != ctr:
+                continue
+            fam = next((k for k in ("conv_mfma_kernel", "upsample2x_cat_kernel", "flowinterp_inputs_kernel",
+                                    "synthesize_kernel", "copy_view_kernel", "pack_weights_kernel", "FillFunctor",
+                                    "copyBuffer") if k in name), "other")
+            res[fam][ctr] += float(row["Counter_Value"])
+            if ctr == "FETCH_SIZE":
+                calls[fam] += 1
+STEPS = 3   # bench.py --steps 2 --warmup 1
+summ = {}
+for fam, d in res.items():
+    rd = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024.0      # gfx950: x2
+    wr = d.get("WRITE_SIZE", 0.0) * 1024.0
+    summ[fam] = {"launches": calls[fam], "hbm_read_bytes_per_step": rd / STEPS, "hbm_write_bytes_per_step": wr / STEPS,
+                 "hbm_bytes_per_step": (rd + wr) / STEPS}
+json.dump(summ, open(os.path.join(out, "pmc_traffic_summary.json"), "w"), indent=1)
+for fam, v in sorted(summ.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:12]:
+    print("%-42s launches %4d  read %8.1f MB  write %8.1f MB per step" % (fam, v["launches"], v["hbm_read_bytes_per_step"] / 1e6, v["hbm_write_bytes_per_step"] / 1e6))
