@@ -38,7 +38,10 @@ import torch  # noqa: E402
 
 H_IN, W_IN, N_T = 720, 1280, 7
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0
+DTYPE_NOTE = {"f32": "f32", "f16": "f16 (f32 accumulate)",
+              "f16x3": "f32 via 3x f16 MFMA on hi/lo-split operands (f32 accumulate)"}
 
 
 def conv_flops_per_pair(h, w, n_t):
@@ -63,6 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (roofline = null)")
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
+                    help="conv arithmetic (default: models.superslomo_r.DEFAULT_PRECISION / $SSM_PRECISION)")
     ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")
     args = ap.parse_args()
 
@@ -85,6 +90,9 @@ def main():
     model.stage1_model.load_state_dict(sd1)
     model.stage2_model.load_state_dict(sd2)
     model = model.to(dev).eval()
+    import models.superslomo_r as ssm_r
+    precision = args.precision or os.environ.get("SSM_PRECISION", ssm_r.DEFAULT_PRECISION)
+    model.precision = precision
 
     x = synthetic_frames(2, H_IN, W_IN, seed=42 + rank)          # [1,2,3,736,1280], normalised, zero-padded
     Hp, Wp = x.shape[-2:]
@@ -114,8 +122,8 @@ def main():
         "metric": "interpolated 1280x720 frames/sec", "value": round(value, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "superslomo_original.ini inference: synthetic 1280x720 pair (padded 736x1280) -> 7 "
+        "vs_baseline": None, "dtype": DTYPE_NOTE[precision], "data": "synthetic",
+        "config": {"precision": precision, "workload": "superslomo_original.ini inference: synthetic 1280x720 pair (padded 736x1280) -> 7 "
                                "intermediates t=i/8, stage 1 once per pair, random-init (deterministic) weights",
                    "pairs_per_step": 1, "frames_per_step": N_T, "parallelism": "pairs sharded, %d rank(s)" % world},
     }
@@ -129,10 +137,17 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r1b_pmc_traffic_summary.json")
         if os.path.exists(pmc):        # HBM bytes per step from rocprofv3 --pmc passes (tools/pmc_traffic.sh), not live
-            traffic = json.load(open(pmc)).get("conv_mfma_kernel", {}).get("hbm_bytes_per_step")
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32), all %d launches "
-                           "of a step" % (conv["launches"] // args.steps), "achieved": round(ach, 2),
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            traffic = json.load(open(pmc)).get("conv_mfma_kernel", {}).get("hbm_bytes_per_step") if precision == "f32" else None
+        if precision == "f32":
+            kname, peak, mfma_per_prod = "conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1
+        else:
+            kname, peak = "conv16_kernel<*> (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
+            mfma_per_prod = 3 if precision == "f16x3" else 1
+        out["roofline"] = {"bound": "mfma", "kernel": kname + ", all %d launches of a step" % (conv["launches"] // args.steps),
+                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "mfma_issue_frac": round(mfma_per_prod * ach / peak, 4),
+                           "note": "achieved = ALGORITHMIC conv FLOP / event-timed kernel time; mfma_issue_frac = issued "
+                                   "MFMA FLOP / peak (%d MFMA per algorithmic product)" % mfma_per_prod,
                            "traffic": traffic, "traffic_note": "HBM bytes per step of the conv launches, FETCH_SIZE x2 "
                            "(gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes: profiles/r1b_pmc_traffic_summary.json",
                            "flop_per_step": flops_step, "ms_per_step_in_kernel": round(conv_ms_step, 3)}

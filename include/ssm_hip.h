@@ -50,12 +50,23 @@ extern "C" {
 #define SSM_E_UNSUPPORTED (-3)
 
 #define SSM_FLAG_LRELU 1    /* apply LeakyReLU(slope) after bias             */
+#define SSM_FLAG_FP16_FAST 2 /* HL8 conv: hi*hi product only (plain fp16 inputs) */
 
 typedef struct ssm_view {
     float *ptr;
     long long sb, sc;   /* batch / channel stride, floats */
     int sh;             /* row stride, floats             */
 } ssm_view;
+
+/* "HL8" activation: every fp32 value x is carried as hi = fp16(x), lo = fp16(x - hi).
+ * [B][C/8][2 = hi|lo][Hp][Wp][8 x fp16]; a pixel's 8 channels of one part are one 16-byte
+ * unit (= one fp16 MFMA operand fragment).  Same zero frame / slack rules as the fp32 padded
+ * planes.  Strides in 16-byte pixels; ptr = first INTERIOR pixel of group 0, hi part.      */
+typedef struct ssm_hview {
+    void *ptr;
+    long long sb, sg, sp;   /* batch stride, channel-group stride, hi->lo stride */
+    int sh;                 /* row stride */
+} ssm_hview;
 
 int ssm_abi_version(void);
 const char *ssm_last_error_string(void);
@@ -96,6 +107,34 @@ int ssm_pack_weights(const float *w_oihw, const float *bias, float *w_packed, fl
 int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed,
                    const float *bias_packed, ssm_view y, ssm_view pool, int B, int H, int W,
                    int Cout, int k, float slope, int flags, void *stream);
+
+/* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------
+ * Same operator as ssm_conv2d_fwd.  Default mode evaluates a*b as a_hi*b_hi + a_hi*b_lo +
+ * a_lo*b_hi with fp32 accumulation (fp32-grade products at 16/3 x the fp32-MFMA rate);
+ * SSM_FLAG_FP16_FAST keeps only a_hi*b_hi (plain fp16 inputs; BASELINE config 5).
+ * Filters are packed once with ssm_pack16_weights (scaled by a power of two `scale`;
+ * pass wscale = 1/scale to the convolution).  Cin is padded to a multiple of 16.
+ * Outputs: y_hl8 (ptr NULL = off) and/or y_f32 (ptr NULL = off), optional fused 2x2 mean
+ * pool_hl8.                                                                               */
+int ssm_conv16_config(int k, int Cout, int W, int *BN, int *KYS);
+size_t ssm_packed16_weight_halves(int Cout, int Cin_padded, int k, int BN);
+int ssm_pack16_weights(const float *w_oihw, const float *bias, void *w_packed, float *bias_packed, int Cout,
+                       int Cin, int Cin_padded, int k, int BN, int KYS, float scale, void *stream);
+int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, const void *w_packed,
+                       const float *bias_packed, float wscale, ssm_hview y_hl8, ssm_view y_f32,
+                       ssm_hview pool_hl8, int B, int H, int W, int Cout, int k, float slope, int flags,
+                       void *stream);
+/* fp32 view [B,C,H,W] <-> HL8 with G >= ceil(C/8) channel groups (extra channels are zeros). */
+int ssm_hl8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream);
+int ssm_hl8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream);
+
+/* HL8 forms of the concat+bilinear-x2 and of compute_inputs (same semantics as the fp32 entry
+ * points below; Ga/Gb = channel groups of 8).  ssm_flowinterp_inputs_hl8_fwd also writes the four
+ * approximated flow channels (Ft1^ u,v | Ft0^ u,v) as fp32 `flows4` for ssm_synthesize_fwd.    */
+int ssm_upsample2x_cat_hl8_fwd(ssm_hview a, int Ga, ssm_hview b, int Gb, ssm_hview y, int B, int h, int w,
+                               void *stream);
+int ssm_flowinterp_inputs_hl8_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_hview out16,
+                                  ssm_view flows4, int B, int H, int W, void *stream);
 
 /* layers.avg_pool(2) (scripts/models/layers.py:60-63), unfused form. */
 int ssm_avgpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int W, void *stream);

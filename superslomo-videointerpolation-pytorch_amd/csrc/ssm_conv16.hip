@@ -1,0 +1,486 @@
+// fp16-MFMA implicit-GEMM convolution (v_mfma_f32_32x32x16_f16) on "HL8" activations.
+//
+// Same operator as ssm_conv.hip (layers.conv / final_conv of the reference,
+// scripts/models/layers.py:21-33, flow_computation.py:145-153) at 16x the matrix-core rate.
+// Every fp32 value x is carried as TWO fp16 numbers  hi = fp16(x), lo = fp16(x - hi)
+// (22-23 significant bits together) and a product is evaluated as
+//        a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (fp32 accumulate)
+// i.e. three MFMAs per 32x32x16 block: 16/3 = 5.3x the fp32-MFMA rate at fp32-grade accuracy
+// (mode SPLIT3).  Mode FAST issues only a_hi*b_hi (plain fp16 inputs, fp32 accumulate): the
+// reduced-precision path for 4K (BASELINE config 5), judged by PSNR instead of 1e-3.
+//
+// HL8 layout (include/ssm_hip.h): [B][C/8][2 = hi|lo][Hp][Wp][8 x fp16], zero frame like the
+// fp32 padded planes.  A pixel's 8 channels are one 16-byte unit = one MFMA operand fragment
+// (lane = pixel, 8 consecutive k = 8 channels), fetched from LDS with ONE conflict-free
+// ds_read_b128; a k-step of 16 = channel groups (2q, 2q+1) on lane halves at one filter tap.
+//
+// Pipeline per workgroup: K loop over 16-channel chunks x filter-row stages.  The activation
+// patch [4 planes][TH+k-1][TW+k-1] x 16 B is double-buffered per chunk, the filter stage
+// [KYS*k taps][2][2][BN] x 16 B per iteration, both by LDS-DMA; the next chunk's patch is
+// fetched in slices spread over the current chunk's iterations.  One barrier per iteration.
+#include "ssm_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct Conv16Params {
+    const char *src1, *src2;   // first interior pixel of group 0, hi plane
+    long long sb1, sb2;        // batch strides (16-byte pixels)
+    long long sg, sp;          // group stride, hi->lo stride (pixels), both sources
+    int sh;                    // row stride (pixels)
+    int C1, Cin;               // channels of source 1 / total (multiples of 16)
+    const char *wpk;
+    const float *bias;
+    float wscale;              // 2^-s: filters are stored multiplied by 2^s
+    char *dh;                  // HL8 destination (or null)
+    long long dhsb, dhsg, dhsp;
+    int dhsh;
+    float *df;                 // fp32 destination view (or null)
+    long long dfsb, dfsc;
+    int dfsh;
+    char *ph;                  // HL8 pooled destination (or null)
+    long long phsb, phsg, phsp;
+    int phsh;
+    int H, W, Cout;
+    int tilesX, tilesY, NB;
+    float slope;
+    int lrelu;
+};
+
+template <int KS_, int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, bool SPLIT3_>
+struct Cfg16 {
+    static constexpr int KS = KS_, KYS = KYS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_;
+    static constexpr bool SPLIT3 = SPLIT3_;
+    static constexpr int PAD = (KS - 1) / 2;
+    static constexpr int NW = WN * WY * WX, NTHREADS = 64 * NW;
+    static constexpr int BN = 32 * NT * WN, TH = MTY * WY, TW = 32 * MTX * WX, MT = MTY * MTX;
+    static constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+    static constexpr int NIT = KS / KYS;                          // iterations (filter-row stages) per chunk
+    static constexpr int PATCH_PIECES = 4 * PH * PW;              // 16-byte pieces
+    static constexpr int PNI = (PATCH_PIECES + 63) / 64;          // 1-KiB DMA instructions per patch
+    static constexpr int PATCH_BYTES = PNI * 1024;
+    static constexpr int WST_PIECES = KYS * KS * 4 * BN;          // [tap][h][part][BN]
+    static constexpr int WNI = WST_PIECES / 64;
+    static constexpr int WST_BYTES = WST_PIECES * 16;
+    static constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * WST_BYTES;
+    static constexpr int PM = (PNI + NW - 1) / NW;                // patch DMA instructions per wave
+    static constexpr int WM = (WNI + NW - 1) / NW;                // filter DMA instructions per wave per stage
+    static_assert(KS % KYS == 0, "filter rows per stage must divide k");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(WST_PIECES % 64 == 0, "filter stage is whole DMA instructions");
+};
+
+#define SSM_GLDS16B(gp, lp)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),       \
+                                     (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
+
+__device__ __forceinline__ void split_store(char *plane_hi, long long sp_bytes, float v0, float v1, float v2, float v3) {
+    h4 hi, lo;
+    hi[0] = (_Float16)v0; hi[1] = (_Float16)v1; hi[2] = (_Float16)v2; hi[3] = (_Float16)v3;
+    lo[0] = (_Float16)(v0 - (float)hi[0]); lo[1] = (_Float16)(v1 - (float)hi[1]);
+    lo[2] = (_Float16)(v2 - (float)hi[2]); lo[3] = (_Float16)(v3 - (float)hi[3]);
+    *reinterpret_cast<h4 *>(plane_hi) = hi;
+    *reinterpret_cast<h4 *>(plane_hi + sp_bytes) = lo;
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 1) void conv16_kernel(const Conv16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KS = C::KS, KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NW = C::NW;
+    char *const pbuf0 = lds;
+    char *const wbuf0 = lds + 2 * C::PATCH_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
+
+    int id = blockIdx.x;
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    const int nchunks = p.Cin / 16;
+    const long long porg = (long long)(y0 - C::PAD) * p.sh + (x0 - C::PAD);     // pixels
+    const char *pbase1 = p.src1 + ((long long)b * p.sb1 + porg) * 16;
+    const char *pbase2 = p.src2 + ((long long)b * p.sb2 + porg) * 16;
+    const char *wbase = p.wpk + (long long)nb * nchunks * C::NIT * C::WST_BYTES;
+
+    // per-lane source byte offsets of this wave's patch DMA instructions (same for every chunk)
+    int poff[C::PM];
+#pragma unroll
+    for (int m = 0; m < C::PM; ++m) {
+        int q = (wid + NW * m) * 64 + lane;
+        if (q >= C::PATCH_PIECES) q = C::PATCH_PIECES - 1;   // tail lanes re-read the last piece into the padding
+        const int pl = q / (PH * PW);
+        const int rem = q - pl * (PH * PW);
+        const int r = rem / PW;
+        const int c = rem - r * PW;
+        poff[m] = (int)(((long long)(pl >> 1) * p.sg + (long long)(pl & 1) * p.sp + (long long)r * p.sh + c) * 16);
+    }
+    const int woff = (wid * 64 + lane) * 16;
+
+    auto patch_src = [&](int ch) -> const char * {
+        const int c0 = ch * 16;
+        return (c0 < p.C1) ? pbase1 + (long long)(c0 >> 3) * p.sg * 16 : pbase2 + (long long)((c0 - p.C1) >> 3) * p.sg * 16;
+    };
+    // slice j (of NIT) of the patch of chunk ch -> pbuf[ch&1]
+    auto issue_patch = [&](int ch, int jlo, int jhi) {
+        const char *ps = patch_src(ch);
+        char *pb = pbuf0 + (ch & 1) * C::PATCH_BYTES;
+#pragma unroll
+        for (int m = 0; m < C::PM; ++m) {
+            const int ii = wid + NW * m;
+            const int j = m % C::NIT;
+            if (ii < C::PNI && j >= jlo && j < jhi) SSM_GLDS16B(ps + poff[m], pb + ii * 1024);
+        }
+    };
+    auto issue_w = [&](int it) {
+        const char *ws = wbase + (long long)it * C::WST_BYTES + woff;
+        char *wb = wbuf0 + (it & 1) * C::WST_BYTES;
+#pragma unroll
+        for (int m = 0; m < C::WM; ++m) {
+            const int ii = wid + NW * m;
+            if (ii < C::WNI) SSM_GLDS16B(ws + m * (NW * 1024), wb + ii * 1024);
+        }
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+
+    // per-lane operand byte offsets inside a patch buffer / filter stage
+    const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
+    const int aOff = (half * 2 * BN + wn * (NT * 32) + l31) * 16;
+    constexpr int B_LO = PH * PW * 16;     // hi -> lo plane inside the patch
+    constexpr int A_LO = BN * 16;          // hi -> lo inside a filter tap
+
+    const int total_it = nchunks * C::NIT;
+    issue_patch(0, 0, C::NIT);
+    issue_w(0);
+    for (int it = 0; it < total_it; ++it) {
+        const int ch = it / C::NIT, j = it - ch * C::NIT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < total_it) issue_w(it + 1);
+        if (ch + 1 < nchunks) issue_patch(ch + 1, j, j + 1);
+
+        const char *sb = pbuf0 + (ch & 1) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
+        const char *sa = wbuf0 + (it & 1) * C::WST_BYTES + aOff;
+#pragma unroll
+        for (int kyy = 0; kyy < KYS; ++kyy) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                h8 ah[NT], al[NT], bh[MT], bl[MT];
+                const int tl = kyy * KS + kx;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    ah[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16);
+                    if (C::SPLIT3) al[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16 + A_LO);
+                }
+#pragma unroll
+                for (int my = 0; my < C::MTY; ++my)
+#pragma unroll
+                    for (int mx = 0; mx < C::MTX; ++mx) {
+                        const int o = ((my + kyy) * PW + mx * 32 + kx) * 16;
+                        bh[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o);
+                        if (C::SPLIT3) bl[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o + B_LO);
+                    }
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bh[m], acc[n][m], 0, 0, 0);
+                        if (C::SPLIT3) {
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bl[m], acc[n][m], 0, 0, 0);
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n], bh[m], acc[n][m], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    // register r of lane (l31, half): cout (r&3) + 8*(r>>2) + 4*half of the 32-cout tile, pixel l31
+    const int xbase = x0 + wx * (C::MTX * 32) + l31;
+    const int ybase = y0 + wy * C::MTY;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ct = nb * BN + (wn * NT + n) * 32;      // first cout of this 32-cout tile
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int co0 = ct + rq * 8 + half * 4;       // this lane's 4 consecutive couts
+            float bias[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[e] = p.bias[co0 + e];
+            float v[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[n][m][rq * 4 + e] * p.wscale + bias[e];
+                    if (p.lrelu) t = t > 0.f ? t : t * p.slope;
+                    v[m][e] = t;
+                }
+#pragma unroll
+            for (int my = 0; my < C::MTY; ++my)
+#pragma unroll
+                for (int mx = 0; mx < C::MTX; ++mx) {
+                    const int m = my * C::MTX + mx;
+                    const int y = ybase + my, x = xbase + mx * 32;
+                    if (y < p.H && x < p.W) {
+                        if (p.dh && co0 < p.Cout) {
+                            char *d = p.dh + (((long long)b * p.dhsb + (long long)(co0 >> 3) * p.dhsg + (long long)y * p.dhsh + x) * 16) + half * 8;
+                            split_store(d, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
+                        }
+                        if (p.df) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (co0 + e < p.Cout) p.df[(long long)b * p.dfsb + (long long)(co0 + e) * p.dfsc + (long long)y * p.dfsh + x] = v[m][e];
+                        }
+                    }
+                }
+            if (p.ph) {
+                if constexpr (C::MTY % 2 == 0) {
+#pragma unroll
+                    for (int my = 0; my < C::MTY; my += 2)
+#pragma unroll
+                        for (int mx = 0; mx < C::MTX; ++mx) {
+                            float s[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float t = v[my * C::MTX + mx][e] + v[(my + 1) * C::MTX + mx][e];
+                                t += __shfl_xor(t, 1);
+                                s[e] = t * 0.25f;
+                            }
+                            const int y = ybase + my, x = xbase + mx * 32;
+                            if (!(l31 & 1) && y < p.H && x < p.W && co0 < p.Cout) {
+                                char *d = p.ph + (((long long)b * p.phsb + (long long)(co0 >> 3) * p.phsg + (long long)(y >> 1) * p.phsh + (x >> 1)) * 16) + half * 8;
+                                split_store(d, p.phsp * 16, s[0], s[1], s[2], s[3]);
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ---- tile configurations --------------------------------------------------------------------------
+//                     KS KYS NT WN MTY MTX WY WX          waves  BN   TH  TW    LDS
+template <bool S> using C16K7 = Cfg16<7, 1, 1, 1, 2, 2, 4, 1, S>;     //   4   32    8  64   154 KB
+template <bool S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, S>;     //   8   64    8  64   145 KB
+template <bool S> using C16K3N32 = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, S>;  //   4   32    8  64   121 KB
+template <bool S> using C16K3N64 = Cfg16<3, 3, 2, 1, 2, 1, 4, 2, S>;  //   8   64    8  64   158 KB
+template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, S>; //   8  128    4  64    99 KB
+template <bool S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, S>; //  4  128    4  32    83 KB
+
+enum Kind16 { H7 = 0, H5, H3N32, H3N64, H3N128, H3N128S };
+
+int pick16(int k, int Cout, int W) {
+    if (k == 7) return H7;
+    if (k == 5) return H5;
+    if (k != 3) return -1;
+    if (Cout <= 32) return H3N32;
+    if (Cout <= 64) return H3N64;
+    const int w64 = (W + 63) / 64 * 64, w32 = (W + 31) / 32 * 32;
+    return w32 < w64 ? H3N128S : H3N128;
+}
+
+template <class C>
+void dims16(int *BN, int *KYS) {
+    *BN = C::BN;
+    *KYS = C::KYS;
+}
+
+template <class C>
+int launch16(Conv16Params &p, int B, hipStream_t st) {
+    p.tilesX = (p.W + C::TW - 1) / C::TW;
+    p.tilesY = (p.H + C::TH - 1) / C::TH;
+    p.NB = (p.Cout + C::BN - 1) / C::BN;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        ssm::set_error("conv16: grid of %lld workgroups out of range", blocks);
+        return SSM_E_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            ssm::set_error("conv16: cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(e));
+            return SSM_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv16_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+    return ssm::check_launch("ssm_conv2d_hl8_fwd");
+}
+
+template <bool S>
+int dispatch16(Conv16Params &p, int B, int k, hipStream_t st) {
+    switch (pick16(k, p.Cout, p.W)) {
+        case H7: return launch16<C16K7<S>>(p, B, st);
+        case H5: return launch16<C16K5<S>>(p, B, st);
+        case H3N32: return launch16<C16K3N32<S>>(p, B, st);
+        case H3N64: return launch16<C16K3N64<S>>(p, B, st);
+        case H3N128: return launch16<C16K3N128<S>>(p, B, st);
+        case H3N128S: return launch16<C16K3N128S<S>>(p, B, st);
+    }
+    return SSM_E_UNSUPPORTED;
+}
+
+// OIHW fp32 -> [nb][chunk16][stage j][tap in stage][h][part][BN][8] fp16, values multiplied by `scale` (2^s)
+__global__ void pack16_kernel(const float *__restrict__ w, const float *__restrict__ bias, _Float16 *__restrict__ wp,
+                              float *__restrict__ bp, int Cout, int Cin, int CinP, int KS, int KYS, int BN, float scale,
+                              long long total, int nbias) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        long long r = i;
+        const int e = (int)(r % 8); r /= 8;
+        const int n = (int)(r % BN); r /= BN;
+        const int part = (int)(r % 2); r /= 2;
+        const int h = (int)(r % 2); r /= 2;
+        const int tl = (int)(r % (KYS * KS)); r /= (KYS * KS);
+        const int j = (int)(r % (KS / KYS)); r /= (KS / KYS);
+        const int ch = (int)(r % (CinP / 16));
+        const int nb = (int)(r / (CinP / 16));
+        const int co = nb * BN + n, ci = ch * 16 + h * 8 + e;
+        const int ky = j * KYS + tl / KS, kx = tl % KS;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[(((long long)co * Cin + ci) * KS + ky) * KS + kx] * scale;
+        const _Float16 hi = (_Float16)v;
+        wp[i] = part ? (_Float16)(v - (float)hi) : hi;
+    }
+    if (i < nbias) bp[i] = (i < Cout) ? bias[i] : 0.f;
+}
+
+// fp32 view [B,C,H,W] -> HL8 (C padded with zero channels up to 8*G), and back
+__global__ __launch_bounds__(256) void to_hl8_kernel(ssm_view src, ssm_hview dst, int C, int G, int H, int W) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;
+    if (x >= W || y >= H) return;
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float v = c < C ? src.ptr[(long long)b * src.sb + (long long)c * src.sc + (long long)y * src.sh + x] : 0.f;
+        hi[e] = (_Float16)v;
+        lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    char *d = (char *)dst.ptr + ((long long)b * dst.sb + (long long)g * dst.sg + (long long)y * dst.sh + x) * 16;
+    *reinterpret_cast<h8 *>(d) = hi;
+    *reinterpret_cast<h8 *>(d + dst.sp * 16) = lo;
+}
+
+__global__ __launch_bounds__(256) void from_hl8_kernel(ssm_hview src, ssm_view dst, int C, int G, int H, int W) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;
+    if (x >= W || y >= H) return;
+    const char *s = (const char *)src.ptr + ((long long)b * src.sb + (long long)g * src.sg + (long long)y * src.sh + x) * 16;
+    const h8 hi = *reinterpret_cast<const h8 *>(s), lo = *reinterpret_cast<const h8 *>(s + src.sp * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        if (c < C) dst.ptr[(long long)b * dst.sb + (long long)c * dst.sc + (long long)y * dst.sh + x] = (float)hi[e] + (float)lo[e];
+    }
+}
+
+}  // namespace
+
+extern "C" int ssm_conv16_config(int k, int Cout, int W, int *BN, int *KYS) {
+    switch (pick16(k, Cout, W)) {
+        case H7: dims16<C16K7<true>>(BN, KYS); break;
+        case H5: dims16<C16K5<true>>(BN, KYS); break;
+        case H3N32: dims16<C16K3N32<true>>(BN, KYS); break;
+        case H3N64: dims16<C16K3N64<true>>(BN, KYS); break;
+        case H3N128: dims16<C16K3N128<true>>(BN, KYS); break;
+        case H3N128S: dims16<C16K3N128S<true>>(BN, KYS); break;
+        default:
+            ssm::set_error("conv16: kernel size %d unsupported (3, 5, 7 are)", k);
+            return SSM_E_UNSUPPORTED;
+    }
+    return SSM_OK;
+}
+
+extern "C" size_t ssm_packed16_weight_halves(int Cout, int CinP, int k, int BN) {
+    return (size_t)((Cout + BN - 1) / BN) * (size_t)(CinP / 16) * k * k * 4 * BN * 8;
+}
+
+extern "C" int ssm_pack16_weights(const float *w, const float *bias, void *wp, float *bp, int Cout, int Cin, int CinP,
+                                  int k, int BN, int KYS, float scale, void *stream) {
+    SSM_REQUIRE(w && bias && wp && bp, "pack16: null pointer");
+    SSM_REQUIRE(Cout > 0 && Cin > 0 && CinP >= Cin && CinP % 16 == 0 && BN % 32 == 0 && k % KYS == 0, "pack16: bad sizes");
+    const long long total = (long long)ssm_packed16_weight_halves(Cout, CinP, k, BN);
+    const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
+    const long long n = total > nbias ? total : nbias;
+    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias,
+                       (_Float16 *)wp, bp, Cout, Cin, CinP, k, KYS, BN, scale, total, nbias);
+    return ssm::check_launch("ssm_pack16_weights");
+}
+
+extern "C" int ssm_hl8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream) {
+    SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && H > 0 && W > 0, "hl8_from_f32: bad arguments");
+    SSM_REQUIRE((long long)B * G <= 65535, "hl8_from_f32: B*G too large");
+    hipLaunchKernelGGL(to_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    return ssm::check_launch("ssm_hl8_from_f32");
+}
+
+extern "C" int ssm_hl8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream) {
+    SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && H > 0 && W > 0, "hl8_to_f32: bad arguments");
+    SSM_REQUIRE((long long)B * G <= 65535, "hl8_to_f32: B*G too large");
+    hipLaunchKernelGGL(from_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    return ssm::check_launch("ssm_hl8_to_f32");
+}
+
+extern "C" int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, const void *w_packed, const float *bias_packed,
+                                  float wscale, ssm_hview y_hl8, ssm_view y_f32, ssm_hview pool_hl8, int B, int H, int W,
+                                  int Cout, int k, float slope, int flags, void *stream) {
+    SSM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && C1 > 0 && C2 >= 0, "conv16: bad sizes");
+    SSM_REQUIRE(x1.ptr && w_packed && bias_packed && (y_hl8.ptr || y_f32.ptr), "conv16: null pointer");
+    SSM_REQUIRE(C1 % 16 == 0 && C2 % 16 == 0, "conv16: channel counts (%d,%d) must be multiples of 16", C1, C2);
+    SSM_REQUIRE(ssm::aligned16(x1.ptr) && ssm::aligned16(w_packed), "conv16: 16-byte alignment");
+    SSM_REQUIRE(x1.sh >= W + 2 * SSM_PADX, "conv16: input row stride %d leaves no zero frame for W=%d", x1.sh, W);
+    if (C2 > 0) SSM_REQUIRE(x2.ptr && x2.sh == x1.sh && x2.sg == x1.sg && x2.sp == x1.sp, "conv16: cat sources must share strides");
+    if (y_hl8.ptr) SSM_REQUIRE(Cout % 8 == 0, "conv16: HL8 output needs Cout %% 8 == 0 (got %d)", Cout);
+    if (pool_hl8.ptr) SSM_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cout % 8 == 0, "conv16: fused pool needs even H, W and Cout %% 8 == 0");
+    SSM_REQUIRE(x1.sg * 32 < 0x7fffffffLL, "conv16: plane too large for 32-bit piece offsets");
+    if (pick16(k, Cout, W) < 0) {
+        ssm::set_error("conv16: kernel size %d unsupported", k);
+        return SSM_E_UNSUPPORTED;
+    }
+    Conv16Params p;
+    p.src1 = (const char *)x1.ptr;
+    p.src2 = C2 > 0 ? (const char *)x2.ptr : (const char *)x1.ptr;
+    p.sb1 = x1.sb;
+    p.sb2 = C2 > 0 ? x2.sb : 0;
+    p.sg = x1.sg;
+    p.sp = x1.sp;
+    p.sh = x1.sh;
+    p.C1 = C1;
+    p.Cin = C1 + C2;
+    p.wpk = (const char *)w_packed;
+    p.bias = bias_packed;
+    p.wscale = wscale;
+    p.dh = (char *)y_hl8.ptr;
+    p.dhsb = y_hl8.sb; p.dhsg = y_hl8.sg; p.dhsp = y_hl8.sp; p.dhsh = y_hl8.sh;
+    p.df = y_f32.ptr;
+    p.dfsb = y_f32.sb; p.dfsc = y_f32.sc; p.dfsh = y_f32.sh;
+    p.ph = (char *)pool_hl8.ptr;
+    p.phsb = pool_hl8.sb; p.phsg = pool_hl8.sg; p.phsp = pool_hl8.sp; p.phsh = pool_hl8.sh;
+    p.H = H; p.W = W; p.Cout = Cout;
+    p.slope = slope;
+    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & SSM_FLAG_FP16_FAST) return dispatch16<false>(p, B, k, st);
+    return dispatch16<true>(p, B, k, st);
+}

@@ -209,6 +209,107 @@ __global__ __launch_bounds__(256) void upsample2x_cat_kernel(ssm_view a, int Ca,
     }
 }
 
+// ---- HL8 (fp16 hi/lo, 8-channel groups) variants ------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ const char *hp(const ssm_hview &v, int b, int g, int y, int x) {
+    return (const char *)v.ptr + ((long long)b * v.sb + (long long)g * v.sg + (long long)y * v.sh + x) * 16;
+}
+
+__device__ __forceinline__ void hl8_load(const ssm_hview &v, int b, int g, int y, int x, float (&o)[8]) {
+    const char *s = hp(v, b, g, y, x);
+    const h8 hi = *reinterpret_cast<const h8 *>(s), lo = *reinterpret_cast<const h8 *>(s + v.sp * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)hi[e] + (float)lo[e];
+}
+
+__device__ __forceinline__ void hl8_store(const ssm_hview &v, int b, int g, int y, int x, const float (&o)[8]) {
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (_Float16)o[e];
+        lo[e] = (_Float16)(o[e] - (float)hi[e]);
+    }
+    char *d = const_cast<char *>(hp(v, b, g, y, x));
+    *reinterpret_cast<h8 *>(d) = hi;
+    *reinterpret_cast<h8 *>(d + v.sp * 16) = lo;
+}
+
+// concat + bilinear x2 on HL8 tensors: one thread = one SOURCE pixel of one 8-channel group -> its 2x2
+// output block (each output pixel is one 16-byte hi store + one 16-byte lo store).  Same half-pixel
+// index/lambda rule as upsample2x_cat_kernel above.  H, W = source dims; Ga/Gb channel groups.
+__global__ __launch_bounds__(256) void upsample2x_cat_hl8_kernel(ssm_hview a, int Ga, ssm_hview bsrc, int Gb, ssm_hview yout, int H, int W) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int G = Ga + Gb;
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;
+    if (x >= W || y >= H) return;
+    const ssm_hview &s = g < Ga ? a : bsrc;
+    const int gg = g < Ga ? g : g - Ga;
+    const int ym = y > 0 ? y - 1 : 0, yp = y < H - 1 ? y + 1 : y;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < W - 1 ? x + 1 : x;
+    const float wy0 = y > 0 ? 0.25f : 1.0f, wy1 = y > 0 ? 0.75f : 0.0f;     // Y = 2y   : rows (ym, y)
+    const float wx0 = x > 0 ? 0.25f : 1.0f, wx1 = x > 0 ? 0.75f : 0.0f;     // X = 2x   : cols (xm, x)
+    float v[3][3][8];
+    const int ys[3] = {ym, y, yp}, xs[3] = {xm, x, xp};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hl8_load(s, b, gg, ys[r], xs[c], v[r][c]);
+    float o00[8], o01[8], o10[8], o11[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float h0[3], h1[3];      // horizontal pass: X = 2x and X = 2x+1, for the three rows
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            h0[r] = wx0 * v[r][0][e] + wx1 * v[r][1][e];
+            h1[r] = 0.75f * v[r][1][e] + 0.25f * v[r][2][e];
+        }
+        o00[e] = wy0 * h0[0] + wy1 * h0[1];
+        o01[e] = wy0 * h1[0] + wy1 * h1[1];
+        o10[e] = 0.75f * h0[1] + 0.25f * h0[2];
+        o11[e] = 0.75f * h1[1] + 0.25f * h1[2];
+    }
+    hl8_store(yout, b, g, 2 * y, 2 * x, o00);
+    hl8_store(yout, b, g, 2 * y, 2 * x + 1, o01);
+    hl8_store(yout, b, g, 2 * y + 1, 2 * x, o10);
+    hl8_store(yout, b, g, 2 * y + 1, 2 * x + 1, o11);
+}
+
+// compute_inputs writing the 16-channel tensor straight into HL8 (two groups) plus the four approximated
+// flow channels (Ft1^ u,v | Ft0^ u,v) as fp32 planes for the synthesis kernel.
+__global__ __launch_bounds__(256) void flowinterp_inputs_hl8_kernel(ssm_view img6, ssm_view flow4, const float *__restrict__ tarr,
+                                                                    ssm_hview out16, ssm_view flows, int H, int W) {
+    SSM_PIXEL_INDEX();
+    const float t = tarr[b];
+    const float omt = 1.0f - t;
+    const float f01u = vp(flow4, b, 0, y)[x], f01v = vp(flow4, b, 1, y)[x];
+    const float f10u = vp(flow4, b, 2, y)[x], f10v = vp(flow4, b, 3, y)[x];
+    const float c00 = (-omt) * t, c01 = t * t;
+    const float c10 = omt * omt, c11 = t * omt;
+    const float ft0u = c00 * f01u + c01 * f10u, ft0v = c00 * f01v + c01 * f10v;
+    const float ft1u = c10 * f01u - c11 * f10u, ft1v = c10 * f01v - c11 * f10v;
+    const Taps t1 = make_taps(x, y, ft1u, ft1v, H, W, img6.sh);
+    const Taps t0 = make_taps(x, y, ft0u, ft0v, H, W, img6.sh);
+    float ga[8], gb[8];     // channels 0..7 and 8..15 (order: I1, g(I1), Ft1, Ft0, g(I0), I0)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ga[c] = vp(img6, b, 3 + c, y)[x];
+        ga[3 + c] = sample(vp(img6, b, 3 + c, 0), t1);
+        gb[2 + c] = sample(vp(img6, b, c, 0), t0);
+        gb[5 + c] = vp(img6, b, c, y)[x];
+    }
+    ga[6] = ft1u;
+    ga[7] = ft1v;
+    gb[0] = ft0u;
+    gb[1] = ft0v;
+    hl8_store(out16, b, 0, y, x, ga);
+    hl8_store(out16, b, 1, y, x, gb);
+    vp(flows, b, 0, y)[x] = ft1u;
+    vp(flows, b, 1, y)[x] = ft1v;
+    vp(flows, b, 2, y)[x] = ft0u;
+    vp(flows, b, 3, y)[x] = ft0v;
+}
+
 inline dim3 pix_grid(int B, int H, int W) { return dim3((W + 63) / 64, (H + 3) / 4, B); }
 inline bool even_view(const ssm_view &v) { return ((reinterpret_cast<size_t>(v.ptr) & 7) == 0) && v.sh % 2 == 0 && v.sc % 2 == 0 && v.sb % 2 == 0; }
 
@@ -269,4 +370,21 @@ extern "C" int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, c
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "synthesize: plane too large");
     hipLaunchKernelGGL(synthesize_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, in16, out5, t, y3, aux, H, W);
     return ssm::check_launch("ssm_synthesize_fwd");
+}
+
+extern "C" int ssm_upsample2x_cat_hl8_fwd(ssm_hview a, int Ga, ssm_hview b, int Gb, ssm_hview y, int B, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("upsample2x_cat_hl8");
+    SSM_REQUIRE(a.ptr && y.ptr && Ga > 0 && Gb >= 0 && (Gb == 0 || b.ptr), "upsample2x_cat_hl8: null pointer / groups");
+    SSM_REQUIRE((long long)B * (Ga + Gb) <= 65535, "upsample2x_cat_hl8: B*G too large for one launch");
+    hipLaunchKernelGGL(upsample2x_cat_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * (Ga + Gb)), dim3(64, 4), 0,
+                       (hipStream_t)stream, a, Ga, Gb ? b : a, Gb, y, H, W);
+    return ssm::check_launch("ssm_upsample2x_cat_hl8_fwd");
+}
+
+extern "C" int ssm_flowinterp_inputs_hl8_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_hview out16, ssm_view flows, int B, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("flowinterp_inputs_hl8");
+    SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && flows.ptr && t, "flowinterp_inputs_hl8: null pointer");
+    SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_hl8: plane too large");
+    hipLaunchKernelGGL(flowinterp_inputs_hl8_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
+    return ssm::check_launch("ssm_flowinterp_inputs_hl8_fwd");
 }

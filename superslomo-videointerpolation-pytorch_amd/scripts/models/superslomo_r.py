@@ -11,12 +11,18 @@ of the evaluators' t-loop: stage 1 once per pair, all t values batched through
 stage 2.
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
 
 from ssm_amd import hipbind as hb
 from ssm_amd.engine import PairEngine
+
+# Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f16x3" evaluates every fp32
+# product as three fp16 MFMAs on hi/lo-split operands with fp32 accumulation (fp32-grade results, held to the
+# same 1e-3 bar by the tests); "f32" is the plain fp32-MFMA kernel; "f16" is reduced precision.
+DEFAULT_PRECISION = "f32"
 
 from . import unetflow as unet
 from .losses import SSMLosses
@@ -76,12 +82,16 @@ class FullModel(nn.Module):
     def _stamp(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    precision = None    # "f32" | "f16x3" | "f16"; None -> $SSM_PRECISION or the default below
+
     def engine_for(self, B1, B2, H, W, device):
-        key = (B1, B2, H, W, str(device), self._stamp())
+        mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)
+        key = (B1, B2, H, W, str(device), mode, self._stamp())
         if self._engine is None or self._engine[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
             sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
-            self._engine = (key, PairEngine(sd1, sd2, B1, B2, H, W, device, self.cross_skip))
+            self._engine = None      # free the old plan's activations before allocating the new one
+            self._engine = (key, PairEngine(sd1, sd2, B1, B2, H, W, device, self.cross_skip, mode))
         return self._engine[1]
 
     @torch.no_grad()

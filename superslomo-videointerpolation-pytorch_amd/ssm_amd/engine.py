@@ -49,6 +49,10 @@ class KernelTimer:
         return out
 
 
+MODES = ("f32", "f16x3", "f16")
+# f32   : fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 padded planes
+# f16x3 : fp16 MFMA on hi/lo-split operands, 3 MFMAs per product, fp32 accumulate (fp32-grade results)
+# f16   : fp16 MFMA, hi*hi only (reduced precision; 4K / config 5)
 POOLED = ("conv1b", "conv2b", "conv3b", "conv4b", "conv5b")      # 2x2 mean fused into these convs
 _SCALE = (("conv10", 2), ("conv11", 1), ("conv1", 1), ("conv2", 2), ("conv3", 4), ("conv4", 8), ("conv5", 16),
           ("conv6", 32), ("conv7", 16), ("conv8", 8), ("conv9", 4), ("fuse_conv", 1), ("final_conv", 1))
@@ -65,7 +69,9 @@ def layer_scale(name):
 class UNetPlan:
     timer = None     # a KernelTimer, or None
 
-    def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True):
+    def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32"):
+        assert mode in MODES, "precision mode must be one of %s" % (MODES,)
+        self.mode, self.hl8 = mode, mode != "f32"
         if H % 32 or W % 32:
             raise AssertionError("H and W must be multiples of 32 (got %dx%d): the U-Net pools 5 times "
                                  "and concatenates skips (unchecked in the reference, fails in torch.cat)" % (H, W))
@@ -78,12 +84,18 @@ class UNetPlan:
             b = state_dict[param_key(name, "bias")].to(device=device, dtype=torch.float32)
             assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
             s = layer_scale(name)
-            self.pk[name] = hb.PackedConv(w, b, B, H // s, W // s, pool=name in POOLED)
-        P = lambda c, s: hb.Planes(B, c, H // s, W // s, device)  # noqa: E731
+            if self.hl8:
+                self.pk[name] = hb.PackedConv16(w, b, W // s)
+            else:
+                self.pk[name] = hb.PackedConv(w, b, B, H // s, W // s, pool=name in POOLED)
+        if self.hl8:
+            P = lambda c, s: hb.HPlanes(B, c, H // s, W // s, device)  # noqa: E731
+        else:
+            P = lambda c, s: hb.Planes(B, c, H // s, W // s, device)  # noqa: E731
         cin0 = self.layers["conv1a"][0]
         cfin = self.layers["final_conv"][1]
         t = self.t = {}
-        t["in"] = P(cin0, 1)
+        t["in"] = hb.HPlanes(B, cin0, H, W, device, groups=self.pk["conv1a"].cin_p // 8) if self.hl8 else P(cin0, 1)
         t["t1a"], t["c1"], t["p2"] = P(32, 1), P(32, 1), P(32, 2)
         t["t2a"], t["c2"], t["p3"] = P(64, 2), P(64, 2), P(64, 4)
         t["t3a"], t["c3"], t["p4"] = P(128, 4), P(128, 4), P(128, 8)
@@ -96,7 +108,8 @@ class UNetPlan:
         t["u9"], t["t9a"], t["c9"] = P(512, 4), P(128, 4), P(128, 4)
         t["u10"], t["t10a"], t["c10"] = P(256, 2), P(64, 2), P(64, 2)
         t["u11"], t["t11a"], t["c11"] = P(128, 1), P(32, 1), P(32, 1)
-        t["tf"], t["out"] = P(32, 1), P(cfin, 1)
+        t["tf"] = P(32, 1)
+        t["out"] = hb.Planes(B, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
 
     def _conv(self, name, src, dst, pool=None, src2=None, lrelu=True):
         pk = self.pk[name]
@@ -107,8 +120,14 @@ class UNetPlan:
         if tm is not None:
             e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self.B * s.H * s.W * pk.cout * pk.cin * pk.k * pk.k)
             e0.record()
-        hb.conv2d(s.view(), s.C, self.t[src2].view() if src2 else None, c2, pk, d.view(),
-                  self.t[pool].view() if pool else None, self.B, s.H, s.W, lrelu=lrelu)
+        if self.hl8:
+            final = name == "final_conv"
+            hb.conv2d_hl8(s.view(), s.G * 8, self.t[src2].view() if src2 else None, c2, pk, None if final else d.view(),
+                          d.view() if final else None, self.t[pool].view() if pool else None, self.B, s.H, s.W,
+                          lrelu=lrelu, fast=self.mode == "f16")
+        else:
+            hb.conv2d(s.view(), s.C, self.t[src2].view() if src2 else None, c2, pk, d.view(),
+                      self.t[pool].view() if pool else None, self.B, s.H, s.W, lrelu=lrelu)
         if tm is not None:
             e1.record()
 
@@ -121,8 +140,14 @@ class UNetPlan:
             e0, e1 = tm.span("upsample_cat", "s%d.%s" % (self.stage, dst),
                              nbytes=4.0 * self.B * A.H * A.W * (A.C + (Bp.C if Bp else 0)) * 5)
             e0.record()
-        hb.check(lib.ssm_upsample2x_cat_fwd(A.view(), A.C, Bp.view(broadcast=b_broadcast) if Bp else hb.NULL_VIEW,
-                                            Bp.C if Bp else 0, self.t[dst].view(), self.B, A.H, A.W, hb.stream_ptr()))
+        if self.hl8:
+            hb.check(lib.ssm_upsample2x_cat_hl8_fwd(A.view(), A.G, Bp.view(broadcast=b_broadcast) if Bp else hb.NULL_HVIEW,
+                                                    Bp.G if Bp else 0, self.t[dst].view(), self.B, A.H, A.W,
+                                                    hb.stream_ptr()))
+        else:
+            hb.check(lib.ssm_upsample2x_cat_fwd(A.view(), A.C, Bp.view(broadcast=b_broadcast) if Bp else hb.NULL_VIEW,
+                                                Bp.C if Bp else 0, self.t[dst].view(), self.B, A.H, A.W,
+                                                hb.stream_ptr()))
         if tm is not None:
             e1.record()
 
@@ -171,31 +196,41 @@ class PairEngine:
     Either B2 == B1 (one t per sample: FullModel.forward) or B1 == 1 and B2 = number
     of intermediates of that pair (stage-1 tensors broadcast over the t batch)."""
 
-    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True):
+    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32"):
         assert B2 == B1 or B1 == 1, "stage-2 batch must equal stage-1 batch, or stage-1 batch must be 1"
         self.B1, self.B2, self.H, self.W, self.device = B1, B2, H, W, device
         self.cross = bool(cross_skip)
+        self.mode, self.hl8 = mode, mode != "f32"
         self.bcast = (B1 == 1 and B2 > 1)
-        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip)
-        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip)
+        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode)
+        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode)
         self.t_dev = torch.empty(B2, dtype=torch.float32, device=device)
         self.img = torch.empty(B2, 3, H, W, dtype=torch.float32, device=device)
         self.aux = torch.empty(B2, 5, H, W, dtype=torch.float32, device=device)
+        self.img6 = None        # the caller's [B1,6,H,W] pair, read in place by the two gather kernels
+        self.est = torch.empty(B2, 4, H, W, dtype=torch.float32, device=device) if self.hl8 else None   # Ft1^ | Ft0^
 
     def load_pair(self, img6):
         """img6: [B1,6,H,W] device tensor (I0 | I1 on the channel axis)."""
         assert tuple(img6.shape) == (self.B1, 6, self.H, self.W), "image pair tensor has shape %s" % (tuple(img6.shape),)
-        self.s1.t["in"].load(img6)
+        self.img6 = img6.contiguous()
+        self.s1.t["in"].load(self.img6)
 
     def run_stage1(self):
         return self.s1.run()
+
+    def _img6_view(self):
+        v = hb.view_of(self.img6)
+        if self.bcast:
+            v.sb = 0
+        return v
 
     def run_stage2(self, t, want_aux=True):
         """t: [B2] device tensor of interpolation times in (0,1)."""
         lib = hb.load()
         st = hb.stream_ptr()
         self.t_dev.copy_(t.reshape(-1), non_blocking=True)
-        img6, flow4 = self.s1.t["in"], self.s1.t["out"]
+        flow4 = self.s1.t["out"]
         in16 = self.s2.t["in"]
         bc = self.bcast
         tm = UNetPlan.timer
@@ -203,15 +238,24 @@ class PairEngine:
         if tm is not None:   # 104 B/px (read 10 ch, write 16 ch)
             e0, e1 = tm.span("warp", "flowinterp_inputs", nbytes=104.0 * px)
             e0.record()
-        hb.check(lib.ssm_flowinterp_inputs_fwd(img6.view(broadcast=bc), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
-                                               in16.view(), self.B2, self.H, self.W, st))
+        if self.hl8:
+            hb.check(lib.ssm_flowinterp_inputs_hl8_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
+                                                       in16.view(), hb.view_of(self.est), self.B2, self.H, self.W, st))
+        else:
+            hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
+                                                   in16.view(), self.B2, self.H, self.W, st))
         if tm is not None:
             e1.record()
         out5 = self.s2.run(cross_planes=self.s1.t["c6"] if self.cross else None, cross_broadcast=bc)
+        if self.hl8:    # the kernel reads channels 6..9 of its `in16` argument: alias them onto the 4 est-flow planes
+            ev = hb.view_of(self.est)
+            in16_view = hb.SsmView(ev.ptr - 4 * 6 * ev.sc, ev.sb, ev.sc, ev.sh)
+        else:
+            in16_view = in16.view()
         if tm is not None:   # 72 B/px (read 6+4+5 ch, write 3 ch)
             e0, e1 = tm.span("warp", "synthesize", nbytes=72.0 * px)
             e0.record()
-        hb.check(lib.ssm_synthesize_fwd(img6.view(broadcast=bc), in16.view(), out5.view(), self.t_dev.data_ptr(),
+        hb.check(lib.ssm_synthesize_fwd(self._img6_view(), in16_view, out5.view(), self.t_dev.data_ptr(),
                                         hb.view_of(self.img), hb.view_of(self.aux) if want_aux else hb.NULL_VIEW,
                                         self.B2, self.H, self.W, st))
         if tm is not None:
@@ -229,6 +273,9 @@ class PairEngine:
         flow = self.s1.t["out"].interior
         if self.bcast:
             flow = flow.expand(self.B2, -1, -1, -1)
-        in16 = self.s2.t["in"].interior
-        return (flow[:, 0:2], flow[:, 2:4], in16[:, 6:8], in16[:, 8:10], self.aux[:, 0:2], self.aux[:, 2:4],
-                self.aux[:, 4:5])
+        if self.hl8:
+            e1, e0 = self.est[:, 0:2], self.est[:, 2:4]
+        else:
+            in16 = self.s2.t["in"].interior
+            e1, e0 = in16[:, 6:8], in16[:, 8:10]
+        return (flow[:, 0:2], flow[:, 2:4], e1, e0, self.aux[:, 0:2], self.aux[:, 2:4], self.aux[:, 4:5])

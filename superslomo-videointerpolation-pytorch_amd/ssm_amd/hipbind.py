@@ -25,6 +25,15 @@ class SsmView(ctypes.Structure):
 
 NULL_VIEW = SsmView(None, 0, 0, 0)
 
+
+class SsmHView(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("sb", ctypes.c_longlong), ("sg", ctypes.c_longlong),
+                ("sp", ctypes.c_longlong), ("sh", ctypes.c_int)]
+
+
+NULL_HVIEW = SsmHView(None, 0, 0, 0, 0)
+SSM_FLAG_FP16_FAST = 2
+
 _c_int, _c_float, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 _ip = ctypes.POINTER(ctypes.c_int)
 
@@ -40,6 +49,15 @@ SIGNATURES = {
     "ssm_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int,
                                 _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_conv16_config": (_c_int, [_c_int, _c_int, _c_int, _ip, _ip]),
+    "ssm_packed16_weight_halves": (_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "ssm_pack16_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _vp]),
+    "ssm_conv2d_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, _c_float, SsmHView, SsmView, SsmHView,
+                                    _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_hl8_from_f32": (_c_int, [SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_hl8_to_f32": (_c_int, [SsmHView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_upsample2x_cat_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, SsmHView, _c_int, _c_int, _c_int, _vp]),
+    "ssm_flowinterp_inputs_hl8_fwd": (_c_int, [SsmView, SsmView, _vp, SsmHView, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_avgpool2_fwd": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -169,3 +187,64 @@ def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1):
     check(lib.ssm_conv2d_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                              pool if pool is not None else NULL_VIEW, B, H, W, pk.cout, pk.k, slope,
                              SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
+# ---- HL8 (fp16 hi/lo) tensors and the fp16-MFMA convolution ------------------------------------
+class HPlanes:
+    """A [B,C,H,W] activation in the HL8 layout (include/ssm_hip.h): [B][G][hi|lo][Hp][Wp][8 x fp16],
+    G = ceil(C/8) channel groups (optionally more: zero channels), zero frame, tail slack."""
+
+    def __init__(self, B, C, H, W, device, groups=None):
+        self.B, self.C, self.H, self.W = B, C, H, W
+        self.G = groups if groups is not None else (C + 7) // 8
+        self.Hp, self.Wp = plane_dims(H, W)
+        n = B * self.G * 2 * self.Hp * self.Wp * 8
+        self.buf = torch.zeros(n + 2 * SSM_TAIL_SLACK_FLOATS, dtype=torch.float16, device=device)
+
+    def view(self, g0=0, broadcast=False):
+        pix = self.Hp * self.Wp
+        base = self.buf.data_ptr() + 16 * (g0 * 2 * pix + SSM_PADY * self.Wp + SSM_PADX)
+        return SsmHView(base, 0 if broadcast else self.G * 2 * pix, 2 * pix, pix, self.Wp)
+
+    def load(self, x):
+        x = x if x.stride(3) == 1 else x.contiguous()
+        check(load().ssm_hl8_from_f32(view_of(x), self.view(), self.B, self.C, self.G, self.H, self.W, stream_ptr()))
+        return self
+
+    def to_nchw(self):
+        out = torch.empty(self.B, self.C, self.H, self.W, dtype=torch.float32, device=self.buf.device)
+        check(load().ssm_hl8_to_f32(self.view(), view_of(out), self.B, self.C, self.G, self.H, self.W, stream_ptr()))
+        return out
+
+
+class PackedConv16:
+    """Filter split into fp16 hi/lo parts, scaled by a power of two so both parts sit in fp16's
+    normal range, repacked for the fp16-MFMA kernel's tile configuration."""
+
+    def __init__(self, weight, bias, W):
+        require_device(weight, "conv weight")
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        lib = load()
+        bn, kys = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib.ssm_conv16_config(self.k, self.cout, W, ctypes.byref(bn), ctypes.byref(kys)))
+        self.bn, self.kys = bn.value, kys.value
+        self.cin_p = (self.cin + 15) // 16 * 16
+        wmax = float(weight.detach().abs().max())
+        import math
+        self.scale = 2.0 ** (3 - math.ceil(math.log2(wmax))) if wmax > 0 else 1.0     # max|w|*scale in (4, 8]
+        nh = lib.ssm_packed16_weight_halves(self.cout, self.cin_p, self.k, self.bn)
+        nb = lib.ssm_packed_bias_floats(self.cout, self.bn)
+        self.w = torch.empty(nh, dtype=torch.float16, device=weight.device)
+        self.b = torch.empty(nb, dtype=torch.float32, device=weight.device)
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        check(lib.ssm_pack16_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout,
+                                     self.cin, self.cin_p, self.k, self.bn, self.kys, self.scale, stream_ptr()))
+
+
+def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slope=0.1, fast=False):
+    assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
+    flags = (SSM_FLAG_LRELU if lrelu else 0) | (SSM_FLAG_FP16_FAST if fast else 0)
+    check(load().ssm_conv2d_hl8_fwd(x1, c1, x2 if x2 is not None else NULL_HVIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(),
+                                    1.0 / pk.scale, y_hl8 if y_hl8 is not None else NULL_HVIEW,
+                                    y_f32 if y_f32 is not None else NULL_VIEW, pool if pool is not None else NULL_HVIEW,
+                                    B, H, W, pk.cout, pk.k, slope, flags, stream_ptr()))

@@ -1,0 +1,109 @@
+"""GPU parity of the fp16-MFMA pipeline (HL8 activations).  Precision mode "f16x3" (three fp16 MFMAs per
+fp32 product, fp32 accumulate) is held to the SAME bars as the fp32 path: 1e-3 max-abs on the frame, 2e-4 on raw
+flows.  Mode "f16" (plain fp16 inputs) is the reduced-precision path of BASELINE config 5 and is judged by PSNR."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_FRAME = 1e-3
+TOL_STAGE = 2e-4
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def build(dev, precision):
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_state_dict
+    m = FullModel(load_config("superslomo_original.ini", synthetic_weight_overrides()))
+    m.stage1_model.load_state_dict(synthetic_state_dict(1, True))
+    m.stage2_model.load_state_dict(synthetic_state_dict(2, True))
+    m.precision = precision
+    return m.to(dev).eval()
+
+
+@pytest.fixture(scope="module")
+def model_x3(dev):
+    return build(dev, "f16x3")
+
+
+def maxdiff(a, b):
+    return float((a.cpu() - T(b)).abs().max())
+
+
+def test_f16x3_full_model_golden(dev, golden, model_x3):
+    from ssm_amd.weights import normalize_and_pad
+    g = golden("fullmodel_small")
+    x = normalize_and_pad(T(g["a_u8"])).to(dev)
+    names = ("F01", "F10", "Ft1e", "Ft0e", "Ft1", "Ft0", "V0")
+    img, inter = model_x3(x, torch.full((1, 1, 1, 1, 1), 3 / 8.0, device=dev), inference_mode=True)
+    assert maxdiff(img, g["a_img_t3"]) < TOL_FRAME
+    for n, v in zip(names, inter):
+        assert maxdiff(v, g["a_%s_t3" % n]) < TOL_STAGE, n
+    imgs = model_x3.interpolate(x, [i / 8.0 for i in range(1, 8)])
+    worst = max(maxdiff(imgs[i - 1:i], g["a_img_t%d" % i]) for i in range(1, 8))
+    print("f16x3 64x64 worst frame error vs reference: %.3e" % worst)
+    assert worst < TOL_FRAME
+    u8b = T(g["b_u8"])
+    xb = torch.cat([normalize_and_pad(u8b[0]), normalize_and_pad(u8b[1])], 0).to(dev)
+    img, _ = model_x3(xb, T(g["b_t"]).to(dev), inference_mode=True)
+    assert maxdiff(img, g["b_img"]) < TOL_FRAME
+    xc = normalize_and_pad(T(g["c_u8"])).to(dev)
+    imgs = model_x3.interpolate(xc, [1 / 8.0, 4 / 8.0, 7 / 8.0])
+    for j, i in enumerate((1, 4, 7)):
+        assert maxdiff(imgs[j:j + 1], g["c_img_t%d" % i]) < TOL_FRAME
+
+
+def test_f16x3_config1_256_golden(dev, golden, model_x3):
+    from ssm_amd.weights import normalize_and_pad
+    g = golden("config1_256")
+    x = normalize_and_pad(T(g["u8"])).to(dev)
+    img, inter = model_x3(x, torch.full((1, 1, 1, 1, 1), 0.5, device=dev), inference_mode=True)
+    e1, e2 = maxdiff(img[:, :, ::4, ::4], g["img_sub4"]), maxdiff(inter[0][:, :, ::4, ::4], g["F01_sub4"])
+    print("f16x3 256x256: frame err %.3e, flow err %.3e px" % (e1, e2))
+    assert e1 < TOL_FRAME and e2 < TOL_STAGE
+    assert maxdiff(img[:, :, 96:160, 96:160], g["img_center64"]) < TOL_FRAME
+
+
+def test_f16x3_vs_f32_path_720p(dev, model_x3):
+    """Full size: the split-fp16 pipeline against the fp32-MFMA pipeline on the same pair, all 7 t."""
+    from ssm_amd.weights import synthetic_frames
+    x = synthetic_frames(2, 720, 1280, seed=42).to(dev)
+    ts = [i / 8.0 for i in range(1, 8)]
+    a = model_x3.interpolate(x, ts)
+    assert torch.isfinite(a).all() and torch.equal(a, model_x3.interpolate(x, ts))
+    a = a.cpu()
+    m32 = build(dev, "f32")
+    b = m32.interpolate(x, ts).cpu()
+    err = float((a - b).abs().max())
+    print("720p f16x3 vs f32 path: max|diff| = %.3e" % err)
+    assert err < TOL_FRAME
+
+
+def test_f16_fast_psnr(dev):
+    """Reduced-precision mode: PSNR against the CPU oracle on a 96x160 pair (config-5 style judgement)."""
+    from oracle import ssm_oracle as O
+    from ssm_amd.weights import IMAGENET_STD, synthetic_frames, synthetic_state_dict
+    m = build(dev, "f16")
+    x = synthetic_frames(2, 96, 160, seed=11)
+    ts = [0.25, 0.5, 0.75]
+    got = m.interpolate(x.to(dev), ts).cpu()
+    pair = torch.cat([x[:, 0], x[:, 1]], 1)
+    want = torch.cat(O.interpolate_pair(synthetic_state_dict(1), synthetic_state_dict(2), pair, ts), 0)
+    std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    mse = float((((got - want) * std * 255.0) ** 2).mean())         # in 8-bit grey levels
+    psnr = 10 * math.log10(255.0 ** 2 / max(mse, 1e-12))
+    print("f16 fast mode PSNR vs fp32 oracle: %.1f dB (max abs %.3e)" % (psnr, float((got - want).abs().max())))
+    assert psnr > 45.0

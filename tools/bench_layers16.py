@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the fp16-MFMA convolution (HL8 layout) at the 736x1280 shapes.
+usage: python tools/bench_layers16.py [B] [fast(0/1)]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd")
+sys.path[:0] = [ROOT, PKG, os.path.join(PKG, "scripts")]
+import torch  # noqa: E402
+
+from ssm_amd import hipbind as hb  # noqa: E402
+from ssm_amd.engine import layer_scale  # noqa: E402
+from ssm_amd.weights import unet_layers  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    fast = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+    H, W = 736, 1280
+    dev = torch.device("cuda:0")
+    tot_t = tot_f = 0.0
+    print("mode: %s   B=%d" % ("fp16 fast (1 MFMA)" if fast else "fp16 split (3 MFMA, fp32-grade)", B))
+    print("%-10s %5s %5s %2s %9s %9s %8s %8s" % ("layer", "cin", "cout", "k", "hxw", "GFLOP", "ms", "TFLOP/s"))
+    for name, cin, cout, k in unet_layers(2, True):
+        s = layer_scale(name)
+        h, w = H // s, W // s
+        pk = hb.PackedConv16(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5,
+                             torch.zeros(cout, device=dev), w)
+        x = hb.HPlanes(B, cin, h, w, dev, groups=pk.cin_p // 8)
+        x.buf.normal_()
+        y = hb.HPlanes(B, cout, h, w, dev) if cout % 8 == 0 else None
+        y32 = torch.empty(B, cout, h, w, device=dev) if y is None else None
+        args = (x.view(), pk.cin_p, None, 0, pk, y.view() if y else None, hb.view_of(y32) if y32 is not None else None,
+                None, B, h, w)
+        for _ in range(2):
+            hb.conv2d_hl8(*args, fast=fast)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        e0.record()
+        for _ in range(n):
+            hb.conv2d_hl8(*args, fast=fast)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        gf = 2.0 * B * h * w * cout * cin * k * k / 1e9
+        tot_t += ms
+        tot_f += gf
+        print("%-10s %5d %5d %2d %4dx%-4d %9.2f %8.3f %8.1f" % (name, cin, cout, k, h, w, gf, ms, gf / ms))
+        del x, y, pk
+    print("TOTAL stage-2 convs: %.1f GFLOP in %.2f ms = %.1f TFLOP/s (algorithmic)" % (tot_f, tot_t, tot_f / tot_t))
+
+
+if __name__ == "__main__":
+    main()
