@@ -22,7 +22,7 @@ from ssm_amd.engine import PairEngine
 # Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f16x3" evaluates every fp32
 # product as three fp16 MFMAs on hi/lo-split operands with fp32 accumulation (fp32-grade results, held to the
 # same 1e-3 bar by the tests); "f32" is the plain fp32-MFMA kernel; "f16" is reduced precision.
-DEFAULT_PRECISION = "f32"
+DEFAULT_PRECISION = "f16x3"
 
 from . import unetflow as unet
 from .losses import SSMLosses
