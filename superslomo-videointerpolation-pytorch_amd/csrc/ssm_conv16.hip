@@ -20,6 +20,10 @@
 // fetched in slices spread over the current chunk's iterations.  One barrier per iteration.
 #include "ssm_common.h"
 
+#ifndef SSM_C16_SCHED
+#define SSM_C16_SCHED 1
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,9 +54,11 @@ struct Conv16Params {
     int lrelu;
 };
 
-template <int KS_, int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, bool SPLIT3_>
+template <int KS_, int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int PBUFS_, bool SPLIT3_>
 struct Cfg16 {
     static constexpr int KS = KS_, KYS = KYS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_;
+    static constexpr int PBUFS = PBUFS_;      // 2: patch double-buffered in the workgroup (1 workgroup / CU);
+                                              // 1: single patch buffer, latency hidden by a 2nd workgroup on the CU
     static constexpr bool SPLIT3 = SPLIT3_;
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int NW = WN * WY * WX, NTHREADS = 64 * NW;
@@ -65,7 +71,8 @@ struct Cfg16 {
     static constexpr int WST_PIECES = KYS * KS * 4 * BN;          // [tap][h][part][BN]
     static constexpr int WNI = WST_PIECES / 64;
     static constexpr int WST_BYTES = WST_PIECES * 16;
-    static constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * WST_BYTES;
+    static constexpr int LDS_BYTES = PBUFS * PATCH_BYTES + 2 * WST_BYTES;
+    static constexpr int BLOCKS_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && NW <= 4) ? 2 : 1;
     static constexpr int PM = (PNI + NW - 1) / NW;                // patch DMA instructions per wave
     static constexpr int WM = (WNI + NW - 1) / NW;                // filter DMA instructions per wave per stage
     static_assert(KS % KYS == 0, "filter rows per stage must divide k");
@@ -87,11 +94,11 @@ __device__ __forceinline__ void split_store(char *plane_hi, long long sp_bytes, 
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS, 1) void conv16_kernel(const Conv16Params p) {
+__global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void conv16_kernel(const Conv16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int KS = C::KS, KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NW = C::NW;
     char *const pbuf0 = lds;
-    char *const wbuf0 = lds + 2 * C::PATCH_BYTES;
+    char *const wbuf0 = lds + C::PBUFS * C::PATCH_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_kernel(const Conv16Para
     // slice j (of NIT) of the patch of chunk ch -> pbuf[ch&1]
     auto issue_patch = [&](int ch, int jlo, int jhi) {
         const char *ps = patch_src(ch);
-        char *pb = pbuf0 + (ch & 1) * C::PATCH_BYTES;
+        char *pb = pbuf0 + (C::PBUFS == 2 ? (ch & 1) : 0) * C::PATCH_BYTES;
 #pragma unroll
         for (int m = 0; m < C::PM; ++m) {
             const int ii = wid + NW * m;
@@ -171,43 +178,56 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_kernel(const Conv16Para
     issue_w(0);
     for (int it = 0; it < total_it; ++it) {
         const int ch = it / C::NIT, j = it - ch * C::NIT;
+        if (C::PBUFS == 1 && j == 0 && ch > 0) {
+            __syncthreads();                      // every wave is done reading the previous chunk's patch
+            issue_patch(ch, 0, C::NIT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (it + 1 < total_it) issue_w(it + 1);
-        if (ch + 1 < nchunks) issue_patch(ch + 1, j, j + 1);
+        if (C::PBUFS == 2 && ch + 1 < nchunks) issue_patch(ch + 1, j, j + 1);
 
-        const char *sb = pbuf0 + (ch & 1) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
+        const char *sb = pbuf0 + (C::PBUFS == 2 ? (ch & 1) : 0) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
         const char *sa = wbuf0 + (it & 1) * C::WST_BYTES + aOff;
+        // operand fragments of tap tl (software-pipelined one tap ahead of the MFMAs that consume them)
+        auto fetch = [&](int tl, h8 (&ah)[NT], h8 (&al)[NT], h8 (&bh)[MT], h8 (&bl)[MT]) {
+            const int kyy = tl / KS, kx = tl - kyy * KS;
 #pragma unroll
-        for (int kyy = 0; kyy < KYS; ++kyy) {
-#pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                h8 ah[NT], al[NT], bh[MT], bl[MT];
-                const int tl = kyy * KS + kx;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    ah[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16);
-                    if (C::SPLIT3) al[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16 + A_LO);
-                }
-#pragma unroll
-                for (int my = 0; my < C::MTY; ++my)
-#pragma unroll
-                    for (int mx = 0; mx < C::MTX; ++mx) {
-                        const int o = ((my + kyy) * PW + mx * 32 + kx) * 16;
-                        bh[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o);
-                        if (C::SPLIT3) bl[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o + B_LO);
-                    }
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bh[m], acc[n][m], 0, 0, 0);
-                        if (C::SPLIT3) {
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[n], bl[m], acc[n][m], 0, 0, 0);
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[n], bh[m], acc[n][m], 0, 0, 0);
-                        }
-                    }
+            for (int n = 0; n < NT; ++n) {
+                ah[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16);
+                if (C::SPLIT3) al[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16 + A_LO);
             }
+#pragma unroll
+            for (int my = 0; my < C::MTY; ++my)
+#pragma unroll
+                for (int mx = 0; mx < C::MTX; ++mx) {
+                    const int o = ((my + kyy) * PW + mx * 32 + kx) * 16;
+                    bh[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o);
+                    if (C::SPLIT3) bl[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o + B_LO);
+                }
+        };
+        h8 ah[2][NT], al[2][NT], bh[2][MT], bl[2][MT];
+        fetch(0, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+        for (int tl = 0; tl < KYS * KS; ++tl) {
+            const int cur = tl & 1;
+            if (tl + 1 < KYS * KS) fetch(tl + 1, ah[cur ^ 1], al[cur ^ 1], bh[cur ^ 1], bl[cur ^ 1]);
+#if SSM_C16_SCHED
+            __builtin_amdgcn_sched_barrier(0);      // keep the next tap's LDS reads ahead of this tap's MFMAs
+#endif
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
+                    if (C::SPLIT3) {
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][n], bl[cur][m], acc[n][m], 0, 0, 0);
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
+                    }
+                }
+#if SSM_C16_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
 
@@ -277,13 +297,13 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_kernel(const Conv16Para
 }
 
 // ---- tile configurations --------------------------------------------------------------------------
-//                     KS KYS NT WN MTY MTX WY WX          waves  BN   TH  TW    LDS
-template <bool S> using C16K7 = Cfg16<7, 1, 1, 1, 2, 2, 4, 1, S>;     //   4   32    8  64   154 KB
-template <bool S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, S>;     //   8   64    8  64   145 KB
-template <bool S> using C16K3N32 = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, S>;  //   4   32    8  64   121 KB
-template <bool S> using C16K3N64 = Cfg16<3, 3, 2, 1, 2, 1, 4, 2, S>;  //   8   64    8  64   158 KB
-template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, S>; //   8  128    4  64    99 KB
-template <bool S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, S>; //  4  128    4  32    83 KB
+//                     KS KYS NT WN MTY MTX WY WX PBUFS        waves  BN   TH  TW    LDS     workgroups/CU
+template <bool S> using C16K7 = Cfg16<7, 1, 1, 1, 2, 1, 4, 1, 1, S>;       //  4   32    8  32    63 KB   2
+template <bool S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, 2, S>;       //  8   64    8  64   145 KB   1
+template <bool S> using C16K3N32 = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, 1, S>;    //  4   32    8  64    80 KB   2
+template <bool S> using C16K3N64 = Cfg16<3, 3, 2, 1, 2, 1, 4, 2, 2, S>;    //  8   64    8  64   158 KB   1
+template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8  128    4  64    99 KB   1
+template <bool S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, 2, S>;  //  4  128    4  32    83 KB   1
 
 enum Kind16 { H7 = 0, H5, H3N32, H3N64, H3N128, H3N128S };
 

@@ -106,6 +106,29 @@ class FullModel(nn.Module):
         eng = self.engine_for(1, t.numel(), img6.shape[2], img6.shape[3], img6.device)
         return eng.run(img6, t, want_aux=False).clone()
 
+    @torch.no_grad()
+    def interpolate_many(self, pairs, t_values, n_streams=2):
+        """Throughput form of interpolate(): a list of pairs ([1,2,3,H,W] each, same size) -> list of
+        [len(t_values),3,H,W] tensors.  Pairs are dealt round-robin to `n_streams` engines on separate HIP
+        streams (ssm_amd.engine.PairPipeline) so HBM-bound and MFMA-bound kernels of different pairs overlap."""
+        from ssm_amd.engine import PairPipeline
+        first = pairs[0]
+        hb.require_device(first, "image pair")
+        H, W = first.shape[-2:]
+        t = torch.as_tensor(t_values, dtype=torch.float32, device=first.device).reshape(-1)
+        assert bool((t > 0).all() and (t < 1).all()), "Interpolation values out of bounds."
+        mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)
+        key = ("pipe", n_streams, t.numel(), H, W, str(first.device), mode, self._stamp())
+        if getattr(self, "_pipe", None) is None or self._pipe[0] != key:
+            sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
+            sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
+            self._pipe = None
+            self._pipe = (key, PairPipeline(sd1, sd2, t.numel(), H, W, first.device, self.cross_skip, mode, n_streams))
+        pipe = self._pipe[1]
+        outs = [pipe.submit(pr.reshape(1, 6, H, W), t, clone=True) for pr in pairs]
+        pipe.sync()
+        return outs
+
     @validate_target_tensor
     def forward(self, image_tensor, t_interp, target_images=None, iteration=None, inference_mode=True):
         """image_tensor [B,N,3,H,W] normalised frames, t_interp [B,N-1,1,1,1] in (0,1).

@@ -279,3 +279,37 @@ class PairEngine:
             in16 = self.s2.t["in"].interior
             e1, e0 = in16[:, 6:8], in16[:, 8:10]
         return (flow[:, 0:2], flow[:, 2:4], e1, e0, self.aux[:, 0:2], self.aux[:, 2:4], self.aux[:, 4:5])
+
+
+class PairPipeline:
+    """Throughput mode: N PairEngines on N HIP streams, frame pairs dealt round-robin.
+
+    Pairs are independent, so while one stream is in an HBM-bound kernel (concat+upsample, the gather
+    kernels) or an under-filled one (stage 1 at batch 1 on the 1/16 and 1/32 maps) the other stream's
+    MFMA-bound convolutions use the idle matrix cores / CUs.  Each engine owns its activations; the input
+    pair is read in place.  Results of `submit` stay valid until that slot is reused (N pairs later)."""
+
+    def __init__(self, sd1, sd2, n_t, H, W, device, cross_skip=True, mode="f16x3", n_streams=2):
+        self.engines = [PairEngine(sd1, sd2, 1, n_t, H, W, device, cross_skip, mode) for _ in range(n_streams)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        self.n = n_streams
+        self._i = 0
+
+    def submit(self, img6, t, want_aux=False, clone=False):
+        """Queue one pair [1,6,H,W] with its t vector on the next stream.  Returns the [n_t,3,H,W] frames:
+        the slot's own output buffer (valid until the slot is reused, N pairs later) or, with clone=True, a
+        private copy made on the slot's stream.  Filled asynchronously: call sync() before reading."""
+        k = self._i % self.n
+        self._i += 1
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream())        # inputs produced on the caller's stream
+        with torch.cuda.stream(st):
+            out = self.engines[k].run(img6, t, want_aux)
+            if clone:
+                out = out.clone()
+                out.record_stream(torch.cuda.current_stream())
+        return out
+
+    def sync(self):
+        for st in self.streams:
+            torch.cuda.current_stream().wait_stream(st)
