@@ -154,9 +154,11 @@ def main():
         conv_ms_step = conv["ms"] / args.steps
         ach = flops_step / (conv_ms_step * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1b_pmc_traffic_summary.json")
-        if os.path.exists(pmc):        # HBM bytes per step from rocprofv3 --pmc passes (tools/pmc_traffic.sh), not live
-            traffic = json.load(open(pmc)).get("conv_mfma_kernel", {}).get("hbm_bytes_per_step") if precision == "f32" else None
+        pmc_file, pmc_key = {"f32": ("r1b_pmc_traffic_summary.json", "conv_mfma_kernel"),
+                             "f16x3": ("r1c_pmc_traffic_summary.json", "conv16_kernel")}.get(precision, (None, None))
+        pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
+        if pmc and os.path.exists(pmc):   # HBM bytes per step from rocprofv3 --pmc passes (tools/pmc_traffic.sh), not live
+            traffic = json.load(open(pmc)).get(pmc_key, {}).get("hbm_bytes_per_step")
         if precision == "f32":
             kname, peak, mfma_per_prod = "conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1
         else:
@@ -170,7 +172,7 @@ def main():
                            "note": "achieved = ALGORITHMIC conv FLOP / event-timed kernel time; mfma_issue_frac = issued "
                                    "MFMA FLOP / peak (%d MFMA per algorithmic product)" % mfma_per_prod,
                            "traffic": traffic, "traffic_note": "HBM bytes per step of the conv launches, FETCH_SIZE x2 "
-                           "(gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes: profiles/r1b_pmc_traffic_summary.json",
+                           "(gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/%s" % pmc_file,
                            "flop_per_step": flops_step, "ms_per_step_in_kernel": round(conv_ms_step, 3)}
         wk = summ["warp"]
         wms = wk["ms"] / args.steps

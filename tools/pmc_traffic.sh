@@ -5,7 +5,7 @@ set -e
 OUT=$(realpath ${1:-gpurun_out/pmc}); mkdir -p $OUT
 REPO=$(pwd); cd /tmp; export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -o pmc -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers > $OUT/$C.log 2>&1 || echo "pmc pass $C failed"
+  rocprofv3 --pmc $C --output-format csv -d $OUT/$C -o pmc -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers --streams 1 > $OUT/$C.log 2>&1 || echo "pmc pass $C failed"
 done
 cd $REPO
 python3 tools/pmc_summarize.py $OUT
