@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
                     help="conv arithmetic (default: models.superslomo_r.DEFAULT_PRECISION / $SSM_PRECISION)")
+    ap.add_argument("--size", default="720p", choices=["720p", "4k"],
+                    help="720p = BASELINE configs[1] (the headline); 4k = configs[4] shape (3840x2160, use --precision f16)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (= frame pairs in flight) per GPU")
     ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")
     args = ap.parse_args()
@@ -95,7 +97,8 @@ def main():
     precision = args.precision or os.environ.get("SSM_PRECISION", ssm_r.DEFAULT_PRECISION)
     model.precision = precision
 
-    x = synthetic_frames(2, H_IN, W_IN, seed=42 + rank)          # [1,2,3,736,1280], normalised, zero-padded
+    h_in, w_in = (H_IN, W_IN) if args.size == "720p" else (2160, 3840)
+    x = synthetic_frames(2, h_in, w_in, seed=42 + rank)          # [1,2,3,736,1280], normalised, zero-padded
     Hp, Wp = x.shape[-2:]
     img6 = x.reshape(1, 6, Hp, Wp).to(dev)
     t_dev = torch.tensor([i / 8.0 for i in range(1, N_T + 1)], dtype=torch.float32, device=dev)
@@ -136,12 +139,13 @@ def main():
     frames = N_T * args.steps * world
     value = frames / elapsed
     out = {
-        "metric": "interpolated 1280x720 frames/sec", "value": round(value, 3), "unit": "frames/s",
+        "metric": "interpolated 1280x720 frames/sec" if args.size == "720p" else "interpolated 3840x2160 frames/sec", "value": round(value, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE_NOTE[precision], "data": "synthetic",
-        "config": {"precision": precision, "workload": "superslomo_original.ini inference: synthetic 1280x720 pair (padded 736x1280) -> 7 "
-                               "intermediates t=i/8, stage 1 once per pair, random-init (deterministic) weights",
+        "config": {"precision": precision, "workload": "superslomo_original.ini inference: synthetic %dx%d pair (padded %dx%d) -> 7 "
+                               "intermediates t=i/8, stage 1 once per pair, random-init (deterministic) weights"
+                               % (w_in, h_in, Wp, Hp),
                    "pairs_per_step": 1, "frames_per_step": N_T, "streams_per_gpu": args.streams,
                    "parallelism": "pairs sharded, %d rank(s); %d pair(s) in flight per GPU on separate HIP streams"
                                   % (world, args.streams)},

@@ -164,6 +164,21 @@ int ssm_flowinterp_inputs_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm
 int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, const float *t, ssm_view y3,
                        ssm_view aux, int B, int H, int W, void *stream);
 
+/* ---- frame formats either side of the path (uint8 HWC RGB on the device) ----------------
+ * ssm_frames_from_u8_fwd: [N,H,W,3] uint8 -> normalised fp32 [N,3,Hp,Wp], image at (top,left),
+ *   fusing ToTensor + Normalize + EvalPad (scripts/utils/dataloaders/augmentations.py:141-200;
+ *   pad_before_norm=0: pad value 0 in normalised space) or the visualiser's load_batch +
+ *   normalize_tensor (scripts/visualize_interpolation.py:61-88,257-262; pad_before_norm=1).
+ *   mean3/std3 are HOST pointers to 3 floats (MODEL.PIXEL_MEAN / PIXEL_STD).
+ * ssm_frames_to_u8_fwd: normalised fp32 [N,3,*,*] -> cropped [N,H,W,3] uint8: get_crop +
+ *   denormalize + *255 + astype(uint8) (scripts/evaluate_interpolation_results.py:143-163,
+ *   192-202).  mode 0 = the reference's cast (truncate, wrap mod 256); 1 = round + saturate. */
+int ssm_frames_from_u8_fwd(const unsigned char *frames_hwc, ssm_view out, int N, int H, int W, int Hp, int Wp,
+                           int top, int left, const float *mean3, const float *std3, int pad_before_norm,
+                           void *stream);
+int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int N, int H, int W, int top, int left,
+                         const float *mean3, const float *std3, int mode, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

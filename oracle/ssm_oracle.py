@@ -221,3 +221,37 @@ def interpolate_pair(p1, p2, img6, ts, cross_skip=True, hoist=True):
         out5 = stage2(p2, in16, c6 if cross_skip else None)
         outs.append(synthesize(img6, in16, out5, t))
     return outs
+
+
+# --------------------------------------------------------------------------
+# frame formats either side of the path (uint8 <-> normalised padded tensors)
+# --------------------------------------------------------------------------
+def frames_from_u8(frames_u8, mean, std, pad_before_norm=False, multiple=32):
+    """[N,H,W,3] uint8 -> [N,3,Hp,Wp] fp32.  pad_before_norm=False: ToTensor + Normalize + EvalPad
+    (scripts/utils/dataloaders/augmentations.py:141-200, zero pad in normalised space);
+    True: load_batch pads the 0-255 frames with 0, then normalize_tensor
+    (scripts/visualize_interpolation.py:61-88,257-262)."""
+    x = frames_u8.permute(0, 3, 1, 2).float()
+    n, _, h, w = x.shape
+    hp, wp = -(-h // multiple) * multiple, -(-w // multiple) * multiple
+    top, left = (hp - h) // 2, (wp - w) // 2
+    pad = [left, wp - w - left, top, hp - h - top]
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    if pad_before_norm:
+        return (F.pad(x, pad, mode="constant", value=0) / 255.0 - m) / s
+    return F.pad((x / 255.0 - m) / s, pad, mode="constant", value=0)
+
+
+def frames_to_u8(x, h, w, mean, std):
+    """get_crop + denormalize + *255 + numpy astype(uint8)
+    (scripts/evaluate_interpolation_results.py:143-163,192-202).  The numpy cast truncates toward zero and
+    wraps modulo 256; it is reproduced through an explicit int64 step so the result does not depend on the
+    platform's out-of-range float->uint8 behaviour."""
+    n, _, hp, wp = x.shape
+    top, left = (hp - h) // 2, (wp - w) // 2
+    b = x.permute(0, 2, 3, 1)[:, top:top + h, left:left + w, :]
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 1, 1, 3)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 1, 1, 3)
+    b = (b * s + m) * 255.0
+    return (torch.trunc(b).to(torch.int64) & 255).to(torch.uint8)

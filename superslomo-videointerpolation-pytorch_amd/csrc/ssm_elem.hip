@@ -310,6 +310,56 @@ __global__ __launch_bounds__(256) void flowinterp_inputs_hl8_kernel(ssm_view img
     vp(flows, b, 3, y)[x] = ft0v;
 }
 
+// ---- frame formats either side of the path ---------------------------------------------------------
+// uint8 HWC RGB frames -> normalised, zero-padded fp32 NCHW: fuses the evaluator's ToTensor + Normalize +
+// EvalPad (scripts/utils/dataloaders/augmentations.py:141-200: pad value 0 AFTER normalisation) or the
+// visualiser's load_batch + normalize_tensor (scripts/visualize_interpolation.py:61-88,257-262: zero pixels
+// padded BEFORE normalisation -> pad value (0/255-mean)/std).  out [N,3,Hp,Wp]; (top,left) = pad offsets.
+__global__ __launch_bounds__(256) void frames_from_u8_kernel(const unsigned char *__restrict__ in, ssm_view out, int H, int W,
+                                                             int Hp, int Wp, int top, int left, float m0, float m1, float m2,
+                                                             float s0, float s1, float s2, int pad_before_norm) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (x >= Wp || y >= Hp) return;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    const int sy = y - top, sx = x - left;
+    const bool inside = sy >= 0 && sy < H && sx >= 0 && sx < W;
+    const unsigned char *px = in + (((long long)b * H + (inside ? sy : 0)) * W + (inside ? sx : 0)) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v;
+        if (inside) v = ((float)px[c] / 255.0f - mean[c]) / sd[c];
+        else v = pad_before_norm ? (0.0f / 255.0f - mean[c]) / sd[c] : 0.0f;
+        vp(out, b, c, y)[x] = v;
+    }
+}
+
+// normalised fp32 NCHW -> cropped uint8 HWC: get_crop + denormalize + *255 + astype(uint8)
+// (scripts/evaluate_interpolation_results.py:143-163,192-202; scripts/visualize_interpolation.py:223-237,264-268).
+// mode 0 = numpy's float->uint8 cast as the reference performs it (truncate toward zero, wrap modulo 256);
+// mode 1 = round to nearest and saturate (what a video writer wants).
+__global__ __launch_bounds__(256) void frames_to_u8_kernel(ssm_view in, unsigned char *__restrict__ out, int H, int W, int top,
+                                                           int left, float m0, float m1, float m2, float s0, float s1, float s2,
+                                                           int mode) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    unsigned char *px = out + (((long long)b * H + y) * W + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = vp(in, b, c, y + top)[x + left] * sd[c] + mean[c];
+        v = v * 255.0f;
+        int q;
+        if (mode == 0) {
+            const float t = truncf(v);
+            q = (t >= -2147483648.0f && t < 2147483648.0f) ? ((int)t & 255) : 0;
+        } else {
+            const float r = rintf(v);
+            q = r < 0.f ? 0 : (r > 255.f ? 255 : (int)r);
+        }
+        px[c] = (unsigned char)q;
+    }
+}
+
 inline dim3 pix_grid(int B, int H, int W) { return dim3((W + 63) / 64, (H + 3) / 4, B); }
 inline bool even_view(const ssm_view &v) { return ((reinterpret_cast<size_t>(v.ptr) & 7) == 0) && v.sh % 2 == 0 && v.sc % 2 == 0 && v.sb % 2 == 0; }
 
@@ -387,4 +437,23 @@ extern "C" int ssm_flowinterp_inputs_hl8_fwd(ssm_view img6, ssm_view flow4, cons
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_hl8: plane too large");
     hipLaunchKernelGGL(flowinterp_inputs_hl8_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
     return ssm::check_launch("ssm_flowinterp_inputs_hl8_fwd");
+}
+
+extern "C" int ssm_frames_from_u8_fwd(const unsigned char *frames_hwc, ssm_view out, int N, int H, int W, int Hp, int Wp, int top,
+                                      int left, const float *mean3, const float *std3, int pad_before_norm, void *stream) {
+    SSM_REQUIRE(frames_hwc && out.ptr && mean3 && std3, "frames_from_u8: null pointer");
+    SSM_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0 && Hp >= H + top && Wp >= W + left && top >= 0 && left >= 0,
+                "frames_from_u8: bad geometry %dx%d -> %dx%d at (%d,%d)", H, W, Hp, Wp, top, left);
+    hipLaunchKernelGGL(frames_from_u8_kernel, pix_grid(N, Hp, Wp), dim3(64, 4), 0, (hipStream_t)stream, frames_hwc, out, H, W, Hp,
+                       Wp, top, left, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], pad_before_norm);
+    return ssm::check_launch("ssm_frames_from_u8_fwd");
+}
+
+extern "C" int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int N, int H, int W, int top, int left,
+                                    const float *mean3, const float *std3, int mode, void *stream) {
+    SSM_REQUIRE(frames_hwc && in.ptr && mean3 && std3, "frames_to_u8: null pointer");
+    SSM_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0 && top >= 0 && left >= 0 && (mode == 0 || mode == 1), "frames_to_u8: bad arguments");
+    hipLaunchKernelGGL(frames_to_u8_kernel, pix_grid(N, H, W), dim3(64, 4), 0, (hipStream_t)stream, in, frames_hwc, H, W, top, left,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], mode);
+    return ssm::check_launch("ssm_frames_to_u8_fwd");
 }

@@ -58,6 +58,10 @@ SIGNATURES = {
     "ssm_hl8_to_f32": (_c_int, [SsmHView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, SsmHView, _c_int, _c_int, _c_int, _vp]),
     "ssm_flowinterp_inputs_hl8_fwd": (_c_int, [SsmView, SsmView, _vp, SsmHView, SsmView, _c_int, _c_int, _c_int, _vp]),
+    "ssm_frames_from_u8_fwd": (_c_int, [_vp, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                        ctypes.POINTER(_c_float), ctypes.POINTER(_c_float), _c_int, _vp]),
+    "ssm_frames_to_u8_fwd": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_float),
+                                      ctypes.POINTER(_c_float), _c_int, _vp]),
     "ssm_avgpool2_fwd": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),

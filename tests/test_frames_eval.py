@@ -1,0 +1,94 @@
+"""Frame-format kernels (bit-exact vs the oracle) and the evaluator/visualiser host logic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ssm_oracle as O
+from ssm_amd.weights import IMAGENET_MEAN, IMAGENET_STD
+
+
+def test_sliding_window_matches_reference_semantics():
+    from ssm_amd.evaluation import sliding_window, t_values
+    assert list(sliding_window(4, 2)) == [[0, 1], [1, 2], [2, 3]]
+    # N_FRAMES=4: window centred on the pair, clamped at both ends (visualize_interpolation.py:277-286)
+    assert list(sliding_window(4, 4)) == [[0, 0, 1, 2], [0, 1, 2, 3], [1, 2, 3, 3]]
+    assert list(sliding_window(17, 2, is_fps_240=True)) == [[0, 8], [8, 16]]
+    assert t_values(8) == [i / 8.0 for i in range(1, 8)]
+
+
+def test_metrics_known_answers():
+    from ssm_amd.evaluation import eval_single_image, interpolation_error, psnr, ssim
+    rng = np.random.RandomState(0)
+    a = rng.randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    assert psnr(a, a) == float("inf") and interpolation_error(a, a) == 0.0 and abs(ssim(a, a) - 1.0) < 1e-12
+    b = a.copy()
+    b[..., 0] = np.clip(a[..., 0].astype(int) + 4, 0, 255)     # +4 on red where not saturated
+    d = a.astype(float) - b.astype(float)
+    assert abs(psnr(a, b) - 10 * np.log10(255 ** 2 / np.mean(d ** 2))) < 1e-9
+    assert abs(interpolation_error(a, b) - np.mean(np.abs(d[..., 0]))) < 1e-9
+    p, s, ie = eval_single_image(a, b)
+    assert 30 < p < 50 and 0.9 < s < 1.0 and 0 < ie <= 4
+    # SSIM decreases with distortion and is symmetric
+    c = np.clip(a.astype(int) + rng.randint(-40, 41, a.shape), 0, 255).astype(np.uint8)
+    assert ssim(a, c) < ssim(a, b) and abs(ssim(a, c) - ssim(c, a)) < 1e-12
+
+
+def test_oracle_frame_formats_roundtrip():
+    rng = np.random.RandomState(1)
+    u8 = torch.from_numpy(rng.randint(0, 256, (2, 45, 70, 3)).astype(np.uint8))
+    for pbn in (False, True):
+        x = O.frames_from_u8(u8, IMAGENET_MEAN, IMAGENET_STD, pad_before_norm=pbn)
+        assert tuple(x.shape) == (2, 3, 64, 96)
+        back = O.frames_to_u8(x, 45, 70, IMAGENET_MEAN, IMAGENET_STD)
+        assert (back.int() - u8.int()).abs().max() <= 1          # truncation may lose one grey level
+    assert float(O.frames_from_u8(u8, IMAGENET_MEAN, IMAGENET_STD)[0, :, 0, 0].abs().max()) == 0.0
+    want = (0.0 - IMAGENET_MEAN[0]) / IMAGENET_STD[0]
+    assert abs(float(O.frames_from_u8(u8, IMAGENET_MEAN, IMAGENET_STD, True)[0, 0, 0, 0]) - want) < 1e-6
+
+
+@pytest.mark.gpu
+def test_frame_kernels_bit_exact_vs_oracle():
+    from ssm_amd import frames as F
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(2)
+    for (n, h, w) in ((2, 45, 70), (1, 720, 1280), (3, 64, 64)):
+        u8 = torch.from_numpy(rng.randint(0, 256, (n, h, w, 3)).astype(np.uint8))
+        for pbn in (False, True):
+            got = F.frames_from_u8(u8.to(dev), None, pad_before_norm=pbn).cpu()
+            want = O.frames_from_u8(u8, IMAGENET_MEAN, IMAGENET_STD, pad_before_norm=pbn)
+            assert torch.equal(got, want), "ingest %s pad_before_norm=%s" % ((n, h, w), pbn)
+        # egress: values inside and far outside [0,255] (the reference's cast wraps), NaN-free
+        x = torch.randn(n, 3, -(-h // 32) * 32, -(-w // 32) * 32) * 1.5
+        got = F.frames_to_u8(x.to(dev), h, w).cpu()
+        want = O.frames_to_u8(x, h, w, IMAGENET_MEAN, IMAGENET_STD)
+        assert torch.equal(got, want), "egress %s" % ((n, h, w),)
+        sat = F.frames_to_u8(x.to(dev), h, w, saturate=True).cpu()
+        assert int(sat.max()) <= 255 and (sat.int() - want.int()).abs().float().mean() < 64
+
+
+@pytest.mark.gpu
+def test_interpolate_clip_end_to_end():
+    """uint8 clip in -> uint8 intermediates out (ingest kernel, 2-stream pipeline, egress kernel); checked
+    against the CPU oracle pipeline on the same clip; PSNR between consecutive outputs is finite."""
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.evaluation import interpolate_clip, psnr
+    from ssm_amd.weights import synthetic_frames_u8, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    m = FullModel(load_config("superslomo_original.ini", synthetic_weight_overrides()))
+    sd1, sd2 = synthetic_state_dict(1), synthetic_state_dict(2)
+    m.stage1_model.load_state_dict(sd1)
+    m.stage2_model.load_state_dict(sd2)
+    m = m.to(dev).eval()
+    clip = synthetic_frames_u8(3, 60, 90, seed=5).permute(0, 2, 3, 1).contiguous()      # [3,60,90,3]
+    out = interpolate_clip(m, clip.to(dev), upsample_rate=4, saturate=True).cpu()
+    assert tuple(out.shape) == (2, 3, 60, 90, 3) and out.dtype == torch.uint8
+    x = O.frames_from_u8(clip, IMAGENET_MEAN, IMAGENET_STD, pad_before_norm=True)
+    for p in range(2):
+        pair = torch.cat([x[p], x[p + 1]])[None]
+        want = O.interpolate_pair(sd1, sd2, pair, [0.25, 0.5, 0.75])
+        for k in range(3):
+            ref = torch.round((want[k].permute(0, 2, 3, 1)[0, 2:62, 3:93] * torch.tensor(IMAGENET_STD)
+                               + torch.tensor(IMAGENET_MEAN)) * 255.0).clamp(0, 255)
+            assert (out[p, k].float() - ref).abs().max() <= 1.0        # <= one grey level
+    assert np.isfinite(psnr(out[0, 0].numpy(), out[0, 1].numpy()))

@@ -107,3 +107,25 @@ def test_f16_fast_psnr(dev):
     psnr = 10 * math.log10(255.0 ** 2 / max(mse, 1e-12))
     print("f16 fast mode PSNR vs fp32 oracle: %.1f dB (max abs %.3e)" % (psnr, float((got - want).abs().max())))
     assert psnr > 45.0
+
+
+def test_config5_4k_fp16_psnr(dev):
+    """BASELINE config 5: 3840x2160 (padded 2176x3840) pair on the fp16-MFMA path, 3 intermediates, untiled
+    (a 3-t plan is ~80 GB of the 288 GB HBM).  There is no CPU run at this size: the reduced-precision frames are
+    judged by PSNR against the fp32-grade split mode on the same inputs (PSNR instead of 1e-3)."""
+    from ssm_amd.weights import IMAGENET_STD, synthetic_frames
+    x = synthetic_frames(2, 2160, 3840, seed=7).to(dev)
+    assert tuple(x.shape) == (1, 2, 3, 2176, 3840)
+    ts = [0.25, 0.5, 0.75]
+    m = build(dev, "f16")
+    fast = m.interpolate(x, ts).cpu()
+    m.precision = "f16x3"
+    ref = m.interpolate(x, ts).cpu()
+    assert torch.isfinite(fast).all() and torch.isfinite(ref).all()
+    std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    mse = float((((fast - ref) * std * 255.0) ** 2).mean())
+    psnr = 10 * math.log10(255.0 ** 2 / max(mse, 1e-12))
+    print("4K f16 vs f16x3: PSNR %.1f dB, max abs %.3e" % (psnr, float((fast - ref).abs().max())))
+    assert psnr > 45.0
+    del m
+    torch.cuda.empty_cache()
