@@ -92,3 +92,31 @@ def test_interpolate_clip_end_to_end():
                                + torch.tensor(IMAGENET_MEAN)) * 255.0).clamp(0, 255)
             assert (out[p, k].float() - ref).abs().max() <= 1.0        # <= one grey level
     assert np.isfinite(psnr(out[0, 0].numpy(), out[0, 1].numpy()))
+
+
+@pytest.mark.gpu
+def test_visualize_cli_writes_interleaved_pngs(tmp_path):
+    """The visualiser entry point (reference flags) on 3 PNG frames, rate 4: 3 originals + 2x3 intermediates, in order."""
+    from PIL import Image
+    import visualize_interpolation as V
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import CONFIG_DIR, load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_frames_u8, synthetic_state_dict
+    import os
+    clip = synthetic_frames_u8(3, 60, 90, seed=5).permute(0, 2, 3, 1).numpy()
+    src = tmp_path / "in"
+    src.mkdir()
+    for i in range(3):
+        Image.fromarray(clip[i]).save(src / ("f_%03d.png" % i))
+    m = FullModel(load_config("superslomo_original.ini", synthetic_weight_overrides()))
+    m.stage1_model.load_state_dict(synthetic_state_dict(1))
+    m.stage2_model.load_state_dict(synthetic_state_dict(2))
+    # the shipped ini has LOADPREV=TRUE (no weights are distributed) -> hand the CLI a ready model
+    n = V.main(["-c", os.path.join(CONFIG_DIR, "superslomo_original.ini"), "--expt", "t", "--log", str(tmp_path / "l.log"),
+                "--input_dir", str(src), "--img_type", "png", "--upsample_rate", "4", "--output_dir", str(tmp_path / "out")],
+               model=m)
+    files = sorted(os.listdir(tmp_path / "out" / "t" / "images"))
+    assert n == 9 and files == ["img_%05d.png" % i for i in range(9)]
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "out" / "t" / "images" / "img_00004.png")), clip[1])
+    mid = np.asarray(Image.open(tmp_path / "out" / "t" / "images" / "img_00002.png"))
+    assert mid.shape == (60, 90, 3) and mid.std() > 1.0
