@@ -190,7 +190,7 @@ def main():
                          for n, v in d["by_name"].items()} for fam, d in summ.items()}
             with open(args.detail, "w") as f:
                 json.dump(det, f, indent=1)
-        up = summ["upsample_cat"]
+        up = summ.get("upsample_cat", {"ms": 0.0})
         out["time_split_ms_per_step"] = {"conv": round(conv_ms_step, 3), "warp_blend": round(wms, 3),
                                          "upsample_cat": round(up["ms"] / args.steps, 3),
                                          "wall_single_stream": round(solo_ms, 3),

@@ -124,6 +124,15 @@ int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, const void *w
                        const float *bias_packed, float wscale, ssm_hview y_hl8, ssm_view y_f32,
                        ssm_hview pool_hl8, int B, int H, int W, int Cout, int k, float slope, int flags,
                        void *stream);
+/* Fused  conv3x3( F.upsample(torch.cat([a, b], 1), size=(2h,2w), mode="bilinear") )  - the decoder step of
+ * scripts/models/flow_computation.py:244-247 (and :103-137) - on LOW-res HL8 inputs a [B,C1,H/2,W/2] and
+ * b [B,C2,H/2,W/2] (C2 may be 0; b may be batch-broadcast).  H, W = OUTPUT size.  The concatenated, upsampled
+ * tensor is never materialised: expander waves rebuild it tile by tile in LDS under the matrix waves' MFMAs.
+ * Filters: the ssm_pack16_weights packing for (k=3, Cout) (independent of KYS).                              */
+int ssm_conv16_ups_config(int Cout, int W, int *BN, int *KYS);
+int ssm_conv2d_ups_hl8_fwd(ssm_hview a, int C1, ssm_hview b, int C2, const void *w_packed,
+                           const float *bias_packed, float wscale, ssm_hview y_hl8, ssm_view y_f32, int B, int H,
+                           int W, int Cout, float slope, int flags, void *stream);
 /* fp32 view [B,C,H,W] <-> HL8 with G >= ceil(C/8) channel groups (extra channels are zeros). */
 int ssm_hl8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream);
 int ssm_hl8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream);

@@ -93,10 +93,130 @@ __device__ __forceinline__ void split_store(char *plane_hi, long long sp_bytes, 
     *reinterpret_cast<h4 *>(plane_hi + sp_bytes) = lo;
 }
 
+// One pipeline iteration of a wave: KYS*KS filter taps x (NT x MT) 32x32 tiles.  sb / sa = this lane's base
+// addresses in the activation patch / filter stage (LDS).  Operand fragments are fetched one tap ahead of the
+// MFMAs that consume them.
+template <class C>
+__device__ __forceinline__ void conv16_compute(f32x16 (&acc)[C::NT][C::MT], const char *sb, const char *sa) {
+    constexpr int KS = C::KS, KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT;
+    constexpr int B_LO = PH * PW * 16;     // hi -> lo plane inside the patch
+    constexpr int A_LO = BN * 16;          // hi -> lo inside a filter tap
+    // operand fragments of tap tl (software-pipelined one tap ahead of the MFMAs that consume them)
+    auto fetch = [&](int tl, h8 (&ah)[NT], h8 (&al)[NT], h8 (&bh)[MT], h8 (&bl)[MT]) {
+        const int kyy = tl / KS, kx = tl - kyy * KS;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            ah[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16);
+            if (C::SPLIT3) al[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16 + A_LO);
+        }
+#pragma unroll
+        for (int my = 0; my < C::MTY; ++my)
+#pragma unroll
+            for (int mx = 0; mx < C::MTX; ++mx) {
+                const int o = ((my + kyy) * PW + mx * 32 + kx) * 16;
+                bh[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o);
+                if (C::SPLIT3) bl[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o + B_LO);
+            }
+    };
+    h8 ah[2][NT], al[2][NT], bh[2][MT], bl[2][MT];
+    fetch(0, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+    for (int tl = 0; tl < KYS * KS; ++tl) {
+        const int cur = tl & 1;
+        if (tl + 1 < KYS * KS) fetch(tl + 1, ah[cur ^ 1], al[cur ^ 1], bh[cur ^ 1], bl[cur ^ 1]);
+#if SSM_C16_SCHED
+        __builtin_amdgcn_sched_barrier(0);      // keep the next tap's LDS reads ahead of this tap's MFMAs
+#endif
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
+                if (C::SPLIT3) {
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][n], bl[cur][m], acc[n][m], 0, 0, 0);
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
+                }
+            }
+#if SSM_C16_SCHED
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+// bias, LeakyReLU, hi/lo split, stores (HL8 and/or fp32 planes), fused 2x2 mean.
+template <class C>
+__device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&acc)[C::NT][C::MT], int nb, int b, int x0, int y0,
+                                                int wn, int wy, int wx, int l31, int half) {
+    constexpr int BN = C::BN, NT = C::NT, MT = C::MT;
+    // ---- epilogue ---------------------------------------------------------------------------
+    // register r of lane (l31, half): cout (r&3) + 8*(r>>2) + 4*half of the 32-cout tile, pixel l31
+    const int xbase = x0 + wx * (C::MTX * 32) + l31;
+    const int ybase = y0 + wy * C::MTY;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ct = nb * BN + (wn * NT + n) * 32;      // first cout of this 32-cout tile
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int co0 = ct + rq * 8 + half * 4;       // this lane's 4 consecutive couts
+            float bias[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[e] = p.bias[co0 + e];
+            float v[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[n][m][rq * 4 + e] * p.wscale + bias[e];
+                    if (p.lrelu) t = t > 0.f ? t : t * p.slope;
+                    v[m][e] = t;
+                }
+#pragma unroll
+            for (int my = 0; my < C::MTY; ++my)
+#pragma unroll
+                for (int mx = 0; mx < C::MTX; ++mx) {
+                    const int m = my * C::MTX + mx;
+                    const int y = ybase + my, x = xbase + mx * 32;
+                    if (y < p.H && x < p.W) {
+                        if (p.dh && co0 < p.Cout) {
+                            char *d = p.dh + (((long long)b * p.dhsb + (long long)(co0 >> 3) * p.dhsg + (long long)y * p.dhsh + x) * 16) + half * 8;
+                            split_store(d, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
+                        }
+                        if (p.df) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (co0 + e < p.Cout) p.df[(long long)b * p.dfsb + (long long)(co0 + e) * p.dfsc + (long long)y * p.dfsh + x] = v[m][e];
+                        }
+                    }
+                }
+            if (p.ph) {
+                if constexpr (C::MTY % 2 == 0) {
+#pragma unroll
+                    for (int my = 0; my < C::MTY; my += 2)
+#pragma unroll
+                        for (int mx = 0; mx < C::MTX; ++mx) {
+                            float s[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float t = v[my * C::MTX + mx][e] + v[(my + 1) * C::MTX + mx][e];
+                                t += __shfl_xor(t, 1);
+                                s[e] = t * 0.25f;
+                            }
+                            const int y = ybase + my, x = xbase + mx * 32;
+                            if (!(l31 & 1) && y < p.H && x < p.W && co0 < p.Cout) {
+                                char *d = p.ph + (((long long)b * p.phsb + (long long)(co0 >> 3) * p.phsg + (long long)(y >> 1) * p.phsh + (x >> 1)) * 16) + half * 8;
+                                split_store(d, p.phsp * 16, s[0], s[1], s[2], s[3]);
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void conv16_kernel(const Conv16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int KS = C::KS, KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NW = C::NW;
+    constexpr int KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NW = C::NW;
     char *const pbuf0 = lds;
     char *const wbuf0 = lds + C::PBUFS * C::PATCH_BYTES;
 
@@ -170,8 +290,6 @@ __global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void con
     // per-lane operand byte offsets inside a patch buffer / filter stage
     const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
     const int aOff = (half * 2 * BN + wn * (NT * 32) + l31) * 16;
-    constexpr int B_LO = PH * PW * 16;     // hi -> lo plane inside the patch
-    constexpr int A_LO = BN * 16;          // hi -> lo inside a filter tap
 
     const int total_it = nchunks * C::NIT;
     issue_patch(0, 0, C::NIT);
@@ -189,109 +307,249 @@ __global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void con
 
         const char *sb = pbuf0 + (C::PBUFS == 2 ? (ch & 1) : 0) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
         const char *sa = wbuf0 + (it & 1) * C::WST_BYTES + aOff;
-        // operand fragments of tap tl (software-pipelined one tap ahead of the MFMAs that consume them)
-        auto fetch = [&](int tl, h8 (&ah)[NT], h8 (&al)[NT], h8 (&bh)[MT], h8 (&bl)[MT]) {
-            const int kyy = tl / KS, kx = tl - kyy * KS;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                ah[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16);
-                if (C::SPLIT3) al[n] = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16 + A_LO);
-            }
-#pragma unroll
-            for (int my = 0; my < C::MTY; ++my)
-#pragma unroll
-                for (int mx = 0; mx < C::MTX; ++mx) {
-                    const int o = ((my + kyy) * PW + mx * 32 + kx) * 16;
-                    bh[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o);
-                    if (C::SPLIT3) bl[my * C::MTX + mx] = *reinterpret_cast<const h8 *>(sb + o + B_LO);
-                }
-        };
-        h8 ah[2][NT], al[2][NT], bh[2][MT], bl[2][MT];
-        fetch(0, ah[0], al[0], bh[0], bl[0]);
-#pragma unroll
-        for (int tl = 0; tl < KYS * KS; ++tl) {
-            const int cur = tl & 1;
-            if (tl + 1 < KYS * KS) fetch(tl + 1, ah[cur ^ 1], al[cur ^ 1], bh[cur ^ 1], bl[cur ^ 1]);
-#if SSM_C16_SCHED
-            __builtin_amdgcn_sched_barrier(0);      // keep the next tap's LDS reads ahead of this tap's MFMAs
-#endif
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
-                    if (C::SPLIT3) {
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][n], bl[cur][m], acc[n][m], 0, 0, 0);
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
-                    }
-                }
-#if SSM_C16_SCHED
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
+        conv16_compute<C>(acc, sb, sa);
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------
-    // register r of lane (l31, half): cout (r&3) + 8*(r>>2) + 4*half of the 32-cout tile, pixel l31
-    const int xbase = x0 + wx * (C::MTX * 32) + l31;
-    const int ybase = y0 + wy * C::MTY;
+    conv16_epilogue<C>(p, acc, nb, b, x0, y0, wn, wy, wx, l31, half);
+}
+
+// =====================================================================================================
+// Fused  conv3x3( F.upsample(torch.cat([a, b], 1), x2, bilinear) )   (scripts/models/flow_computation.py:
+// 244-247 and the four sites like it): the concatenated, upsampled tensor is never written to HBM.
+//
+// Wave-specialised workgroup: NWM "matrix" waves run exactly the pipeline iteration of conv16_kernel on a
+// hi-res activation patch in LDS; NWE "expander" waves (a) issue ALL LDS-DMA of the workgroup - the LOW-res raw
+// patch [4 planes][TH/2+2][TW/2+2] of the next-but-one chunk and the filter stages - and (b) bilinearly expand
+// the next chunk's raw patch into the other hi-res patch buffer (hi+lo -> fp32, ATen's half-pixel rule with
+// edge clamping, zero outside the image = the convolution's zero padding, re-split to hi/lo).  VALU expansion
+// and MFMA run on different pipes of the same CU, so the expansion hides under the matrix work; the conv
+// reads 4x fewer activation bytes than from a materialised upsampled tensor.  One barrier per iteration.
+template <int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int NWE_, bool SPLIT3_>
+struct CfgUps {
+    static constexpr int KS = 3, KYS = KYS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_;
+    static constexpr bool SPLIT3 = SPLIT3_;
+    static constexpr int PAD = 1;
+    static constexpr int NWM = WN * WY * WX, NWE = NWE_, NTHREADS = 64 * (NWM + NWE);
+    static constexpr int BN = 32 * NT * WN, TH = MTY * WY, TW = 32 * MTX * WX, MT = MTY * MTX;
+    static constexpr int PH = TH + 2, PW = TW + 2;                 // hi-res patch
+    static constexpr int RH = TH / 2 + 2, RW = TW / 2 + 2;         // low-res raw patch
+    static constexpr int NIT = KS / KYS;
+    static constexpr int PATCH_BYTES = (4 * PH * PW * 16 + 1023) / 1024 * 1024;
+    static constexpr int RAW_PIECES = 4 * RH * RW;
+    static constexpr int RNI = (RAW_PIECES + 63) / 64;
+    static constexpr int RAW_BYTES = RNI * 1024;
+    static constexpr int WST_PIECES = KYS * KS * 4 * BN;
+    static constexpr int WNI = WST_PIECES / 64;
+    static constexpr int WST_BYTES = WST_PIECES * 16;
+    static constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * RAW_BYTES + 2 * WST_BYTES;
+    static constexpr int RM = (RNI + NWE - 1) / NWE, WM = (WNI + NWE - 1) / NWE;
+    static constexpr int PH2 = PH / 2, PW2 = PW / 2, NUNITS = 2 * PH2 * PW2;     // 2x2 output blocks x 2 channel groups
+    static_assert(TH % 2 == 0 && TW % 2 == 0, "even tile");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(WST_PIECES % 64 == 0, "filter stage is whole DMA instructions");
+};
+
+__device__ __forceinline__ void h8_to_f32(const char *hi_ptr, int lo_off, float (&o)[8]) {
+    const h8 hi = *reinterpret_cast<const h8 *>(hi_ptr), lo = *reinterpret_cast<const h8 *>(hi_ptr + lo_off);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int ct = nb * BN + (wn * NT + n) * 32;      // first cout of this 32-cout tile
+    for (int e = 0; e < 8; ++e) o[e] = (float)hi[e] + (float)lo[e];
+}
+
+__device__ __forceinline__ void f32_to_h8(char *hi_ptr, int lo_off, const float (&v)[8], bool zero) {
+    h8 hi, lo;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int co0 = ct + rq * 8 + half * 4;       // this lane's 4 consecutive couts
-            float bias[4];
+    for (int e = 0; e < 8; ++e) {
+        const float x = zero ? 0.f : v[e];
+        hi[e] = (_Float16)x;
+        lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+    *reinterpret_cast<h8 *>(hi_ptr) = hi;
+    *reinterpret_cast<h8 *>(hi_ptr + lo_off) = lo;
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, RH = C::RH, RW = C::RW;
+    char *const pbuf0 = lds;
+    char *const rbuf0 = lds + 2 * C::PATCH_BYTES;
+    char *const wbuf0 = rbuf0 + 2 * C::RAW_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_mfma = wid < C::NWM;
+    const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = (wid / (C::WN * C::WY)) % C::WX;   // matrix waves
+    const int ew = wid - C::NWM, etid = tid - C::NWM * 64;                                            // expander waves
+
+    int id = blockIdx.x;
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * C::TW, y0 = ty * C::TH;          // hi-res tile origin (even)
+    const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;        // low-res origin of the raw patch (may be -1: zero frame)
+    const int lh = p.H / 2, lw = p.W / 2;                // low-res image size
+
+    const int nchunks = p.Cin / 16;
+    const int total_it = nchunks * C::NIT;
+
+    // ---- expander-side state ---------------------------------------------------------------------------
+    const long long rorg = (long long)ly0 * p.sh + lx0;                       // pixels, relative to the interior origin
+    const char *rbase1 = p.src1 + ((long long)b * p.sb1 + rorg) * 16;
+    const char *rbase2 = p.src2 + ((long long)b * p.sb2 + rorg) * 16;
+    const char *wbase = p.wpk + (long long)nb * nchunks * C::NIT * C::WST_BYTES;
+    int roff[C::RM];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bias[e] = p.bias[co0 + e];
-            float v[MT][4];
+    for (int m = 0; m < C::RM; ++m) {
+        int q = ((ew < 0 ? 0 : ew) + C::NWE * m) * 64 + lane;
+        if (q >= C::RAW_PIECES) q = C::RAW_PIECES - 1;
+        const int pl = q / (RH * RW);
+        const int rem = q - pl * (RH * RW);
+        const int r = rem / RW;
+        const int c = rem - r * RW;
+        roff[m] = (int)(((long long)(pl >> 1) * p.sg + (long long)(pl & 1) * p.sp + (long long)r * p.sh + c) * 16);
+    }
+    auto issue_raw = [&](int ch) {
+        const int c0 = ch * 16;
+        const char *rs = (c0 < p.C1) ? rbase1 + (long long)(c0 >> 3) * p.sg * 16 : rbase2 + (long long)((c0 - p.C1) >> 3) * p.sg * 16;
+        char *rb = rbuf0 + (ch & 1) * C::RAW_BYTES;
+#pragma unroll
+        for (int m = 0; m < C::RM; ++m) {
+            const int ii = ew + C::NWE * m;
+            if (ii < C::RNI) SSM_GLDS16B(rs + roff[m], rb + ii * 1024);
+        }
+    };
+    auto issue_w = [&](int it) {
+        const char *ws = wbase + (long long)it * C::WST_BYTES + (ew * 64 + lane) * 16;
+        char *wb = wbuf0 + (it & 1) * C::WST_BYTES;
+#pragma unroll
+        for (int m = 0; m < C::WM; ++m) {
+            const int ii = ew + C::NWE * m;
+            if (ii < C::WNI) SSM_GLDS16B(ws + m * (C::NWE * 1024), wb + ii * 1024);
+        }
+    };
+    // Bilinear x2 of chunk ch: raw[ch&1] -> patch[ch&1].  Work unit = one 2x2 output block of 4 channels (half a
+    // group), so every expander lane is busy even on the small tiles; the units are processed in rounds of
+    // NWE*64, round r in pipeline iteration r % nsl (all rounds when nsl == 1).
+    auto expand = [&](int ch, int j, int nsl) {
+        const char *rb = rbuf0 + (ch & 1) * C::RAW_BYTES;
+        char *pb = pbuf0 + (ch & 1) * C::PATCH_BYTES;
+        constexpr int R_LO = RH * RW * 16, P_LO = PH * PW * 16;
+        constexpr int NHU = 2 * C::NUNITS;                          // half-units
+        constexpr int ROUNDS = (NHU + C::NWE * 64 - 1) / (C::NWE * 64);
+#pragma unroll 1
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r % nsl != j) continue;
+            const int u = r * (C::NWE * 64) + etid;
+            if (u >= NHU) continue;
+            const int hs = u & 1;                                   // which 4 of the group's 8 channels
+            const int uu = u >> 1;
+            const int g = uu / (C::PH2 * C::PW2);
+            const int rem = uu - g * (C::PH2 * C::PW2);
+            const int by = rem / C::PW2, bx = rem - by * C::PW2;
+            // low-res rows i, i+1 and columns jx, jx+1 (image coordinates), clamped like ATen clamps its source index
+            const int i = ly0 + by, jx = lx0 + bx;
+            const int r0 = min(max(i, 0), lh - 1) - ly0, r1 = min(max(i + 1, 0), lh - 1) - ly0;
+            const int c0 = min(max(jx, 0), lw - 1) - lx0, c1 = min(max(jx + 1, 0), lw - 1) - lx0;
+            const char *rg = rb + (g * 2 * RH * RW) * 16 + hs * 8;
+            auto ld = [&](int rr, int cc, float (&o)[4]) {
+                const h4 hi = *reinterpret_cast<const h4 *>(rg + (rr * RW + cc) * 16);
+                const h4 lo = *reinterpret_cast<const h4 *>(rg + (rr * RW + cc) * 16 + R_LO);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (float)hi[e] + (float)lo[e];
+            };
+            // horizontal pass first (rows i and i+1); X = 2j+1: cols (j,j+1) x (.75,.25), X = 2j+2: (.25,.75)
+            float t0[4], t1[4], u0[4], u1[4];
+            {
+                float a[4], bb[4];
+                ld(r0, c0, a);
+                ld(r0, c1, bb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t0[e] = 0.75f * a[e] + 0.25f * bb[e];
+                    t1[e] = 0.25f * a[e] + 0.75f * bb[e];
+                }
+                ld(r1, c0, a);
+                ld(r1, c1, bb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u0[e] = 0.75f * a[e] + 0.25f * bb[e];
+                    u1[e] = 0.25f * a[e] + 0.75f * bb[e];
+                }
+            }
+            // hi-res coordinates of the block; positions outside the image are the convolution's zero padding
+            const int Y = 2 * i + 1, X = 2 * jx + 1;
+            const bool zy0 = Y < 0 || Y >= p.H, zy1 = Y + 1 < 0 || Y + 1 >= p.H;
+            const bool zx0 = X < 0 || X >= p.W, zx1 = X + 1 < 0 || X + 1 >= p.W;
+            char *pg = pb + (g * 2 * PH * PW) * 16 + ((2 * by) * PW + 2 * bx) * 16 + hs * 8;
+            auto st = [&](char *d, float wa, float wb, const float (&ta)[4], const float (&ua)[4], bool zero) {
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = zero ? 0.f : wa * ta[e] + wb * ua[e];
+                    hi[e] = (_Float16)x;
+                    lo[e] = (_Float16)(x - (float)hi[e]);
+                }
+                *reinterpret_cast<h4 *>(d) = hi;
+                *reinterpret_cast<h4 *>(d + P_LO) = lo;
+            };
+            // vertical pass: Y = 2i+1: rows (i, i+1) x (.75, .25); Y = 2i+2: (.25, .75)
+            st(pg, 0.75f, 0.25f, t0, u0, zy0 || zx0);
+            st(pg + 16, 0.75f, 0.25f, t1, u1, zy0 || zx1);
+            st(pg + PW * 16, 0.25f, 0.75f, t0, u0, zy1 || zx0);
+            st(pg + PW * 16 + 16, 0.25f, 0.75f, t1, u1, zy1 || zx1);
+        }
+    };
+
+    // ---- matrix-side operand bases ---------------------------------------------------------------------
+    const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
+    const int aOff = (half * 2 * BN + wn * (NT * 32) + l31) * 16;
+
+    // ---- prologue: raw(0), raw(1), filter stage 0; expand chunk 0 -----------------------------------------
+    if (!is_mfma) {
+        issue_raw(0);
+        if (nchunks > 1) issue_raw(1);
+        issue_w(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!is_mfma) expand(0, 0, 1);
+    __syncthreads();
+
+    // Two role-specific loops with the same barrier count (registers: max of the roles, not their sum).
+    if (is_mfma) {
+        f32x16 acc[NT][MT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[n][m][rq * 4 + e] * p.wscale + bias[e];
-                    if (p.lrelu) t = t > 0.f ? t : t * p.slope;
-                    v[m][e] = t;
-                }
-#pragma unroll
-            for (int my = 0; my < C::MTY; ++my)
-#pragma unroll
-                for (int mx = 0; mx < C::MTX; ++mx) {
-                    const int m = my * C::MTX + mx;
-                    const int y = ybase + my, x = xbase + mx * 32;
-                    if (y < p.H && x < p.W) {
-                        if (p.dh && co0 < p.Cout) {
-                            char *d = p.dh + (((long long)b * p.dhsb + (long long)(co0 >> 3) * p.dhsg + (long long)y * p.dhsh + x) * 16) + half * 8;
-                            split_store(d, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
-                        }
-                        if (p.df) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (co0 + e < p.Cout) p.df[(long long)b * p.dfsb + (long long)(co0 + e) * p.dfsc + (long long)y * p.dfsh + x] = v[m][e];
-                        }
-                    }
-                }
-            if (p.ph) {
-                if constexpr (C::MTY % 2 == 0) {
-#pragma unroll
-                    for (int my = 0; my < C::MTY; my += 2)
-#pragma unroll
-                        for (int mx = 0; mx < C::MTX; ++mx) {
-                            float s[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float t = v[my * C::MTX + mx][e] + v[(my + 1) * C::MTX + mx][e];
-                                t += __shfl_xor(t, 1);
-                                s[e] = t * 0.25f;
-                            }
-                            const int y = ybase + my, x = xbase + mx * 32;
-                            if (!(l31 & 1) && y < p.H && x < p.W && co0 < p.Cout) {
-                                char *d = p.ph + (((long long)b * p.phsb + (long long)(co0 >> 3) * p.phsg + (long long)(y >> 1) * p.phsh + (x >> 1)) * 16) + half * 8;
-                                split_store(d, p.phsp * 16, s[0], s[1], s[2], s[3]);
-                            }
-                        }
-                }
-            }
+                for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+        for (int it = 0; it < total_it; ++it) {
+            const int ch = it / C::NIT, j = it - ch * C::NIT;
+            const char *sb = pbuf0 + (ch & 1) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
+            const char *sa = wbuf0 + (it & 1) * C::WST_BYTES + aOff;
+            conv16_compute<C>(acc, sb, sa);
+            __syncthreads();
+        }
+        conv16_epilogue<C>(p, acc, nb, b, x0, y0, wn, wy, wx, l31, half);
+    } else {
+        for (int it = 0; it < total_it; ++it) {
+            const int ch = it / C::NIT, j = it - ch * C::NIT;
+            // Buffers: raw(c) -> raw[c&1], expanded into patch[c&1], consumed by the matrix waves during chunk c.
+            // Every wave has passed the barrier that ended iteration it-1, so
+            //  - filter stage (it+1)&1 is free (its readers were iteration it-1),
+            //  - at j == 0: raw[ch&1] is free (chunk ch was expanded while chunk ch-1 ran, or in the prologue) and
+            //    patch[(ch+1)&1] is free (its readers were chunk ch-1),
+            //  - raw(ch+1) has landed (issued one chunk ago, waited for below).
+            if (it + 1 < total_it) issue_w(it + 1);
+            if (j == 0 && ch + 2 < nchunks) issue_raw(ch + 2);
+            if (ch + 1 < nchunks) expand(ch + 1, j, C::NIT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
     }
 }
@@ -300,18 +558,25 @@ __global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void con
 //                     KS KYS NT WN MTY MTX WY WX PBUFS        waves  BN   TH  TW    LDS     workgroups/CU
 template <bool S> using C16K7 = Cfg16<7, 1, 1, 1, 2, 1, 4, 1, 1, S>;       //  4   32    8  32    63 KB   2
 template <bool S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, 2, S>;       //  8   64    8  64   145 KB   1
-template <bool S> using C16K3N32 = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, 1, S>;    //  4   32    8  64    80 KB   2
+template <bool S> using C16K3N32 = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, 1, S>;    //  4   32    8  64    80 KB   2   (short K)
+template <bool S> using C16K3N32D = Cfg16<3, 3, 1, 1, 2, 1, 4, 2, 2, S>;   //  8   32    8  64   121 KB   1   (Cin >= 64)
 template <bool S> using C16K3N64 = Cfg16<3, 3, 2, 1, 2, 1, 4, 2, 2, S>;    //  8   64    8  64   158 KB   1
 template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8  128    4  64    99 KB   1
 template <bool S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, 2, S>;  //  4  128    4  32    83 KB   1
 
-enum Kind16 { H7 = 0, H5, H3N32, H3N64, H3N128, H3N128S };
+//                        KYS NT WN MTY MTX WY WX NWE           matrix+expander waves  BN  TH  TW   LDS
+template <bool S> using U3N32 = CfgUps<3, 1, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4   32   8  64  146 KB   conv11a
+template <bool S> using U3N64 = CfgUps<1, 2, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4   64   8  64  134 KB   conv10a
+template <bool S> using U3N128 = CfgUps<1, 2, 2, 2, 1, 2, 2, 4, S>;   //  8 + 4  128   4  64  116 KB   conv9a
+template <bool S> using U3N128S = CfgUps<1, 2, 2, 2, 1, 2, 1, 4, S>;  //  4 + 4  128   4  32   84 KB   conv7a, conv8a
 
-int pick16(int k, int Cout, int W) {
+enum Kind16 { H7 = 0, H5, H3N32, H3N32D, H3N64, H3N128, H3N128S };
+
+int pick16(int k, int Cout, int W, int Cin = 0) {
     if (k == 7) return H7;
     if (k == 5) return H5;
     if (k != 3) return -1;
-    if (Cout <= 32) return H3N32;
+    if (Cout <= 32) return Cin >= 128 ? H3N32D : H3N32;      // same BN / KYS: the packed filter does not depend on it
     if (Cout <= 64) return H3N64;
     const int w64 = (W + 63) / 64 * 64, w32 = (W + 31) / 32 * 32;
     return w32 < w64 ? H3N128S : H3N128;
@@ -346,12 +611,48 @@ int launch16(Conv16Params &p, int B, hipStream_t st) {
     return ssm::check_launch("ssm_conv2d_hl8_fwd");
 }
 
+template <class C>
+int launch16_ups(Conv16Params &p, int B, hipStream_t st) {
+    p.tilesX = (p.W + C::TW - 1) / C::TW;
+    p.tilesY = (p.H + C::TH - 1) / C::TH;
+    p.NB = (p.Cout + C::BN - 1) / C::BN;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        ssm::set_error("conv16_ups: grid of %lld workgroups out of range", blocks);
+        return SSM_E_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)conv16_ups_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) {
+            ssm::set_error("conv16_ups: cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(e));
+            return SSM_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv16_ups_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+    return ssm::check_launch("ssm_conv2d_ups_hl8_fwd");
+}
+
+template <bool S>
+int dispatch16_ups(Conv16Params &p, int B, hipStream_t st) {
+    switch (pick16(3, p.Cout, p.W, p.Cin)) {
+        case H3N32:
+        case H3N32D: return launch16_ups<U3N32<S>>(p, B, st);
+        case H3N64: return launch16_ups<U3N64<S>>(p, B, st);
+        case H3N128: return launch16_ups<U3N128<S>>(p, B, st);
+        case H3N128S: return launch16_ups<U3N128S<S>>(p, B, st);
+    }
+    return SSM_E_UNSUPPORTED;
+}
+
 template <bool S>
 int dispatch16(Conv16Params &p, int B, int k, hipStream_t st) {
-    switch (pick16(k, p.Cout, p.W)) {
+    switch (pick16(k, p.Cout, p.W, p.Cin)) {
         case H7: return launch16<C16K7<S>>(p, B, st);
         case H5: return launch16<C16K5<S>>(p, B, st);
         case H3N32: return launch16<C16K3N32<S>>(p, B, st);
+        case H3N32D: return launch16<C16K3N32D<S>>(p, B, st);
         case H3N64: return launch16<C16K3N64<S>>(p, B, st);
         case H3N128: return launch16<C16K3N128<S>>(p, B, st);
         case H3N128S: return launch16<C16K3N128S<S>>(p, B, st);
@@ -421,7 +722,8 @@ extern "C" int ssm_conv16_config(int k, int Cout, int W, int *BN, int *KYS) {
     switch (pick16(k, Cout, W)) {
         case H7: dims16<C16K7<true>>(BN, KYS); break;
         case H5: dims16<C16K5<true>>(BN, KYS); break;
-        case H3N32: dims16<C16K3N32<true>>(BN, KYS); break;
+        case H3N32:
+        case H3N32D: dims16<C16K3N32<true>>(BN, KYS); break;
         case H3N64: dims16<C16K3N64<true>>(BN, KYS); break;
         case H3N128: dims16<C16K3N128<true>>(BN, KYS); break;
         case H3N128S: dims16<C16K3N128S<true>>(BN, KYS); break;
@@ -503,4 +805,54 @@ extern "C" int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, co
     hipStream_t st = (hipStream_t)stream;
     if (flags & SSM_FLAG_FP16_FAST) return dispatch16<false>(p, B, k, st);
     return dispatch16<true>(p, B, k, st);
+}
+
+// conv3x3(upsample2x(cat[a, b])) with a, b LOW-res HL8 tensors [B,C1|C2,H/2,W/2]; H, W = output (hi-res) size.
+// Uses the filter packing of ssm_conv16_config(3, Cout, W) with KYS taken from ssm_conv16_ups_config.
+extern "C" int ssm_conv16_ups_config(int Cout, int W, int *BN, int *KYS) {
+    switch (pick16(3, Cout, W, 0)) {
+        case H3N32:
+        case H3N32D: *BN = U3N32<true>::BN; *KYS = U3N32<true>::KYS; break;
+        case H3N64: *BN = U3N64<true>::BN; *KYS = U3N64<true>::KYS; break;
+        case H3N128: *BN = U3N128<true>::BN; *KYS = U3N128<true>::KYS; break;
+        case H3N128S: *BN = U3N128S<true>::BN; *KYS = U3N128S<true>::KYS; break;
+        default: return SSM_E_UNSUPPORTED;
+    }
+    return SSM_OK;
+}
+
+extern "C" int ssm_conv2d_ups_hl8_fwd(ssm_hview a, int C1, ssm_hview b, int C2, const void *w_packed, const float *bias_packed,
+                                      float wscale, ssm_hview y_hl8, ssm_view y_f32, int B, int H, int W, int Cout, float slope,
+                                      int flags, void *stream) {
+    SSM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout > 0 && C1 > 0 && C2 >= 0, "conv16_ups: bad sizes");
+    SSM_REQUIRE(a.ptr && w_packed && bias_packed && (y_hl8.ptr || y_f32.ptr), "conv16_ups: null pointer");
+    SSM_REQUIRE(C1 % 16 == 0 && C2 % 16 == 0, "conv16_ups: channel counts (%d,%d) must be multiples of 16", C1, C2);
+    SSM_REQUIRE(ssm::aligned16(a.ptr) && ssm::aligned16(w_packed), "conv16_ups: 16-byte alignment");
+    SSM_REQUIRE(a.sh >= W / 2 + 2 * SSM_PADX, "conv16_ups: source row stride %d leaves no frame for w=%d", a.sh, W / 2);
+    if (C2 > 0) SSM_REQUIRE(b.ptr && b.sh == a.sh && b.sg == a.sg && b.sp == a.sp, "conv16_ups: cat sources must share strides");
+    if (y_hl8.ptr) SSM_REQUIRE(Cout % 8 == 0, "conv16_ups: HL8 output needs Cout %% 8 == 0 (got %d)", Cout);
+    SSM_REQUIRE(a.sg * 32 < 0x7fffffffLL, "conv16_ups: plane too large for 32-bit piece offsets");
+    Conv16Params p;
+    p.src1 = (const char *)a.ptr;
+    p.src2 = C2 > 0 ? (const char *)b.ptr : (const char *)a.ptr;
+    p.sb1 = a.sb;
+    p.sb2 = C2 > 0 ? b.sb : 0;
+    p.sg = a.sg; p.sp = a.sp; p.sh = a.sh;
+    p.C1 = C1;
+    p.Cin = C1 + C2;
+    p.wpk = (const char *)w_packed;
+    p.bias = bias_packed;
+    p.wscale = wscale;
+    p.dh = (char *)y_hl8.ptr;
+    p.dhsb = y_hl8.sb; p.dhsg = y_hl8.sg; p.dhsp = y_hl8.sp; p.dhsh = y_hl8.sh;
+    p.df = y_f32.ptr;
+    p.dfsb = y_f32.sb; p.dfsc = y_f32.sc; p.dfsh = y_f32.sh;
+    p.ph = nullptr;
+    p.phsb = p.phsg = p.phsp = 0; p.phsh = 0;
+    p.H = H; p.W = W; p.Cout = Cout;
+    p.slope = slope;
+    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (flags & SSM_FLAG_FP16_FAST) return dispatch16_ups<false>(p, B, st);
+    return dispatch16_ups<true>(p, B, st);
 }

@@ -69,9 +69,10 @@ def layer_scale(name):
 class UNetPlan:
     timer = None     # a KernelTimer, or None
 
-    def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32"):
+    def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True):
         assert mode in MODES, "precision mode must be one of %s" % (MODES,)
         self.mode, self.hl8 = mode, mode != "f32"
+        self.fuse_up = bool(fuse_upsample) and self.hl8      # concat+upsample fused into the consumer conv's loader
         if H % 32 or W % 32:
             raise AssertionError("H and W must be multiples of 32 (got %dx%d): the U-Net pools 5 times "
                                  "and concatenates skips (unchecked in the reference, fails in torch.cat)" % (H, W))
@@ -102,12 +103,14 @@ class UNetPlan:
         t["t4a"], t["c4"], t["p5"] = P(256, 8), P(256, 8), P(256, 16)
         t["t5a"], t["c5"], t["p6"] = P(512, 16), P(512, 16), P(512, 32)
         t["t6a"], t["c6"] = P(512, 32), P(512, 32)
-        t["u7"] = P(1024 if self.cross else 512, 16)
+        if not self.fuse_up:        # materialised concat+upsample tensors (the largest activations of the net)
+            t["u7"] = P(1024 if self.cross else 512, 16)
+            t["u8"], t["u9"], t["u10"], t["u11"] = P(1024, 8), P(512, 4), P(256, 2), P(128, 1)
         t["t7a"], t["c7"] = P(512, 16), P(512, 16)
-        t["u8"], t["t8a"], t["c8"] = P(1024, 8), P(256, 8), P(256, 8)
-        t["u9"], t["t9a"], t["c9"] = P(512, 4), P(128, 4), P(128, 4)
-        t["u10"], t["t10a"], t["c10"] = P(256, 2), P(64, 2), P(64, 2)
-        t["u11"], t["t11a"], t["c11"] = P(128, 1), P(32, 1), P(32, 1)
+        t["t8a"], t["c8"] = P(256, 8), P(256, 8)
+        t["t9a"], t["c9"] = P(128, 4), P(128, 4)
+        t["t10a"], t["c10"] = P(64, 2), P(64, 2)
+        t["t11a"], t["c11"] = P(32, 1), P(32, 1)
         t["tf"] = P(32, 1)
         t["out"] = hb.Planes(B, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
 
@@ -128,6 +131,24 @@ class UNetPlan:
         else:
             hb.conv2d(s.view(), s.C, self.t[src2].view() if src2 else None, c2, pk, d.view(),
                       self.t[pool].view() if pool else None, self.B, s.H, s.W, lrelu=lrelu)
+        if tm is not None:
+            e1.record()
+
+    def _up_conv(self, name, a, b, u, dst, b_planes=None, b_broadcast=False):
+        """dst = conv(name)( upsample2x(cat[a, b]) ): fused in one kernel, or via the materialised tensor `u`."""
+        if not self.fuse_up:
+            self._up(a, b, u, b_planes=b_planes, b_broadcast=b_broadcast)
+            return self._conv(name, u, dst)
+        pk = self.pk[name]
+        A = self.t[a]
+        Bp = b_planes if b_planes is not None else (self.t[b] if b else None)
+        d = self.t[dst]
+        tm = self.timer
+        if tm is not None:
+            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self.B * d.H * d.W * pk.cout * pk.cin * 9)
+            e0.record()
+        hb.conv2d_ups_hl8(A.view(), A.G * 8, Bp.view(broadcast=b_broadcast) if Bp else None, Bp.G * 8 if Bp else 0, pk,
+                          d.view(), None, self.B, d.H, d.W, lrelu=True, fast=self.mode == "f16")
         if tm is not None:
             e1.record()
 
@@ -166,25 +187,21 @@ class UNetPlan:
         c("conv5b", "t5a", "c5", pool="p6")
         c("conv6.0", "p6", "t6a")
         c("conv6.1", "t6a", "c6")
+        uc = self._up_conv
         if self.cross:
             if cross_planes is None:
                 raise RuntimeError("stage 2 was built with CROSS_SKIP but no stage-1 encoding was given")
-            self._up("c6", None, "u7", b_planes=cross_planes, b_broadcast=cross_broadcast)
+            uc("conv7a", "c6", None, "u7", "t7a", b_planes=cross_planes, b_broadcast=cross_broadcast)
         else:
-            self._up("c6", None, "u7")
-        c("conv7a", "u7", "t7a")
+            uc("conv7a", "c6", None, "u7", "t7a")
         c("conv7b", "t7a", "c7")
-        self._up("c7", "c5", "u8")
-        c("conv8a", "u8", "t8a")
+        uc("conv8a", "c7", "c5", "u8", "t8a")
         c("conv8b", "t8a", "c8")
-        self._up("c8", "c4", "u9")
-        c("conv9a", "u9", "t9a")
+        uc("conv9a", "c8", "c4", "u9", "t9a")
         c("conv9b", "t9a", "c9")
-        self._up("c9", "c3", "u10")
-        c("conv10a", "u10", "t10a")
+        uc("conv10a", "c9", "c3", "u10", "t10a")
         c("conv10b", "t10a", "c10")
-        self._up("c10", "c2", "u11")
-        c("conv11a", "u11", "t11a")
+        uc("conv11a", "c10", "c2", "u11", "t11a")
         c("conv11b", "t11a", "c11")
         c("fuse_conv", "c11", "tf", src2="c1")
         c("final_conv", "tf", "out", lrelu=False)

@@ -54,6 +54,9 @@ SIGNATURES = {
     "ssm_pack16_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _vp]),
     "ssm_conv2d_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, _c_float, SsmHView, SsmView, SsmHView,
                                     _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_conv16_ups_config": (_c_int, [_c_int, _c_int, _ip, _ip]),
+    "ssm_conv2d_ups_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, _c_float, SsmHView, SsmView,
+                                        _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_hl8_from_f32": (_c_int, [SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_hl8_to_f32": (_c_int, [SsmHView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, SsmHView, _c_int, _c_int, _c_int, _vp]),
@@ -252,3 +255,13 @@ def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slop
                                     1.0 / pk.scale, y_hl8 if y_hl8 is not None else NULL_HVIEW,
                                     y_f32 if y_f32 is not None else NULL_VIEW, pool if pool is not None else NULL_HVIEW,
                                     B, H, W, pk.cout, pk.k, slope, flags, stream_ptr()))
+
+
+def conv2d_ups_hl8(a, c1, b, c2, pk, y_hl8, y_f32, B, H, W, lrelu=True, slope=0.1, fast=False):
+    """conv3x3(upsample2x(cat[a, b])): a, b LOW-res HL8 views, H, W the OUTPUT size."""
+    assert pk.k == 3 and pk.cin_p == c1 + c2, "packed 3x3 filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
+    flags = (SSM_FLAG_LRELU if lrelu else 0) | (SSM_FLAG_FP16_FAST if fast else 0)
+    check(load().ssm_conv2d_ups_hl8_fwd(a, c1, b if b is not None else NULL_HVIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(),
+                                        1.0 / pk.scale, y_hl8 if y_hl8 is not None else NULL_HVIEW,
+                                        y_f32 if y_f32 is not None else NULL_VIEW, B, H, W, pk.cout, slope, flags,
+                                        stream_ptr()))

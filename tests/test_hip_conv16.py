@@ -74,3 +74,42 @@ def test_conv16_fused_pool_and_cat(dev):
     hb.conv2d_hl8(pa.view(), 32, pb.view(), 32, pk, y.view(), None, yp.view(), B, H, W, lrelu=True)
     assert float((y.to_nchw().cpu() - want).abs().max()) < 5e-5
     assert float((yp.to_nchw().cpu() - O.avg_pool2(want)).abs().max()) < 5e-5
+
+
+UPS_CASES = [
+    # c1, c2, cout, B, h (low), w (low)      -> every fused tile configuration, image borders, ragged tiles, 1 source
+    (32, 32, 32, 1, 8, 32), (64, 64, 32, 2, 12, 36), (128, 0, 32, 1, 4, 32),
+    (128, 128, 64, 1, 8, 32), (64, 64, 64, 2, 5, 40),
+    (256, 256, 128, 1, 6, 64), (64, 64, 128, 1, 10, 32),
+    (512, 512, 256, 1, 6, 16), (128, 128, 512, 2, 3, 8), (16, 16, 128, 1, 2, 2),
+]
+
+
+@pytest.mark.parametrize("c1,c2,cout,B,h,w", UPS_CASES)
+def test_conv16_fused_upsample_vs_oracle(dev, c1, c2, cout, B, h, w):
+    """conv3x3(upsample2x(cat[a,b])) in ONE kernel (expander waves + matrix waves) against the oracle's
+    upsample followed by conv; also with the second source batch-broadcast (the cross-skip case)."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(c1 + c2 + cout + h + w)
+    a = torch.randn(B, c1, h, w, generator=g)
+    b = torch.randn(1, c2, h, w, generator=g) if c2 else None          # broadcast over the batch
+    cin = c1 + c2
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    cat = a if b is None else torch.cat([a, b.expand(B, -1, -1, -1)], 1)
+    want = O.conv2d_lrelu(O.upsample2x_bilinear(cat), wt, bias)
+    H, W = 2 * h, 2 * w
+    pk = hb.PackedConv16(wt.to(dev), bias.to(dev), W)
+    pa = hb.HPlanes(B, c1, h, w, dev).load(a.to(dev))
+    pb = hb.HPlanes(1, c2, h, w, dev).load(b.to(dev)) if c2 else None
+    y32 = torch.empty(B, cout, H, W, device=dev)
+    dst = hb.HPlanes(B, cout, H, W, dev)
+    hb.conv2d_ups_hl8(pa.view(), c1, pb.view(broadcast=True) if pb else None, c2, pk, dst.view(), hb.view_of(y32), B, H, W)
+    got = y32.cpu()
+    err = float((got - want).abs().max())
+    assert err < 5e-5, "fused upsample conv %d+%d->%d %dx%dx%d: max err %.3e" % (c1, c2, cout, B, h, w, err)
+    assert float((dst.to_nchw().cpu() - got).abs().max()) < 1e-5
+    full = dst.buf[:B * dst.G * 2 * dst.Hp * dst.Wp * 8].view(B, dst.G, 2, dst.Hp, dst.Wp, 8).float().cpu().clone()
+    full[:, :, :, hb.SSM_PADY:hb.SSM_PADY + H, hb.SSM_PADX:hb.SSM_PADX + W] = 0
+    assert float(full.abs().max()) == 0.0, "zero frame of the output was written"
