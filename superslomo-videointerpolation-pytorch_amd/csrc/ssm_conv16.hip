@@ -565,7 +565,7 @@ template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8
 template <bool S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, 2, S>;  //  4  128    4  32    83 KB   1
 
 //                        KYS NT WN MTY MTX WY WX NWE           matrix+expander waves  BN  TH  TW   LDS
-template <bool S> using U3N32 = CfgUps<3, 1, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4   32   8  64  146 KB   conv11a
+template <bool S> using U3N32 = CfgUps<3, 1, 1, 2, 1, 4, 2, 8, S>;    //  8 + 8   32   8  64  146 KB   conv11a (expansion-heaviest: 8 expander waves, measured 1.90 -> 1.72 ms)
 template <bool S> using U3N64 = CfgUps<1, 2, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4   64   8  64  134 KB   conv10a
 template <bool S> using U3N128 = CfgUps<1, 2, 2, 2, 1, 2, 2, 4, S>;   //  8 + 4  128   4  64  116 KB   conv9a
 template <bool S> using U3N128S = CfgUps<1, 2, 2, 2, 1, 2, 1, 4, S>;  //  4 + 4  128   4  32   84 KB   conv7a, conv8a
