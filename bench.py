@@ -159,14 +159,15 @@ def main():
         ach = flops_step / (conv_ms_step * 1e-3) / 1e12
         traffic = None
         pmc_file, pmc_key = {"f32": ("r1b_pmc_traffic_summary.json", "conv_mfma_kernel"),
-                             "f16x3": ("r1c_pmc_traffic_summary.json", "conv16_kernel")}.get(precision, (None, None))
+                             "f16x3": ("r1d_pmc_traffic_summary.json", "conv16_kernel")}.get(precision, (None, None))
         pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
         if pmc and os.path.exists(pmc):   # HBM bytes per step from rocprofv3 --pmc passes (tools/pmc_traffic.sh), not live
-            traffic = json.load(open(pmc)).get(pmc_key, {}).get("hbm_bytes_per_step")
+            pj = json.load(open(pmc))
+            traffic = pj.get(pmc_key, {}).get("hbm_bytes_per_step", 0.0) + pj.get("conv16_ups_kernel", {}).get("hbm_bytes_per_step", 0.0)
         if precision == "f32":
             kname, peak, mfma_per_prod = "conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1
         else:
-            kname, peak = "conv16_kernel<*> (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
+            kname, peak = "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
             mfma_per_prod = 3 if precision == "f16x3" else 1
         out["roofline"] = {"bound": "mfma", "kernel": kname + ", all %d launches of a step" % (conv["launches"] // args.steps),
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
