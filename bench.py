@@ -215,7 +215,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

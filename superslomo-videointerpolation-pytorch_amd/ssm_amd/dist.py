@@ -22,10 +22,17 @@ def env_world():
 
 
 def init(backend):
+    """Join the process group when launched by torch.distributed.run (RANK/WORLD_SIZE/MASTER_* in the environment),
+    also at world size 1 so the same barrier / all-reduce path runs everywhere.  A plain `python bench.py` stays
+    single-process with no rendezvous."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if launched and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
@@ -36,7 +43,10 @@ def assign_pairs(n_pairs, world, rank):
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def timed_steps(step_fn, steps, warmup, sync_fn):
