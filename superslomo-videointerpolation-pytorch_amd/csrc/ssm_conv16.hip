@@ -20,6 +20,10 @@
 // fetched in slices spread over the current chunk's iterations.  One barrier per iteration.
 #include "ssm_common.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #ifndef SSM_C16_SCHED
 #define SSM_C16_SCHED 1
 #endif
@@ -582,6 +586,23 @@ int pick16(int k, int Cout, int W, int Cin = 0) {
     return w32 < w64 ? H3N128S : H3N128;
 }
 
+// Kernels here use up to 158 KB of dynamic LDS: opt in once per (kernel, device); re-entrant.
+bool reserve_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        ssm::set_error("conv16: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(e));
+        return false;
+    }
+    done.insert({kernel, dev});
+    return true;
+}
+
 template <class C>
 void dims16(int *BN, int *KYS) {
     *BN = C::BN;
@@ -598,15 +619,7 @@ int launch16(Conv16Params &p, int B, hipStream_t st) {
         ssm::set_error("conv16: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv16_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) {
-            ssm::set_error("conv16: cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(e));
-            return SSM_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if (!reserve_lds((const void *)conv16_kernel<C>, C::LDS_BYTES)) return SSM_E_LAUNCH;
     hipLaunchKernelGGL(conv16_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
     return ssm::check_launch("ssm_conv2d_hl8_fwd");
 }
@@ -621,15 +634,7 @@ int launch16_ups(Conv16Params &p, int B, hipStream_t st) {
         ssm::set_error("conv16_ups: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)conv16_ups_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) {
-            ssm::set_error("conv16_ups: cannot reserve %d bytes of LDS: %s", C::LDS_BYTES, hipGetErrorString(e));
-            return SSM_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if (!reserve_lds((const void *)conv16_ups_kernel<C>, C::LDS_BYTES)) return SSM_E_LAUNCH;
     hipLaunchKernelGGL(conv16_ups_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
     return ssm::check_launch("ssm_conv2d_ups_hl8_fwd");
 }

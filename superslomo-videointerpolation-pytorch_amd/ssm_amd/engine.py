@@ -1,10 +1,11 @@
 """Launch plans for the hot path: frame pair -> intermediate frame(s).
 
 A `UNetPlan` is one U-Net (stage 1 = flow computation, stage 2 = arbitrary-time
-flow interpolation) at a fixed (batch, H, W): every activation pre-allocated in
-the padded-plane layout, every filter repacked once, and a fixed sequence of
-C-ABI calls (24 convolutions with fused LeakyReLU / 2x2 mean, 5 concat+bilinear
-upsamples).  Topology restates scripts/models/flow_computation.py:155-289 and
+flow interpolation) at a fixed (batch, H, W) and precision mode: every activation
+pre-allocated (HL8 hi/lo-fp16 planes by default, fp32 padded planes in mode f32),
+every filter repacked once, and a fixed sequence of C-ABI calls: 24 convolutions
+with fused LeakyReLU / 2x2 mean / two-source concat, the five decoder "a"
+convolutions with the concat + bilinear x2 upsample fused into their loader.  Topology restates scripts/models/flow_computation.py:155-289 and
 scripts/models/flow_interpolation.py:159-281 of the reference.
 
 `PairEngine` chains stage 1 -> compute_inputs -> stage 2 -> synthesis

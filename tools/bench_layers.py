@@ -12,8 +12,7 @@ import torch  # noqa: E402
 from ssm_amd import hipbind as hb  # noqa: E402
 from ssm_amd.weights import unet_layers  # noqa: E402
 
-SCALE = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8,
-         "conv9": 4, "conv10": 2, "conv11": 1, "fuse_": 1, "final": 1}
+from ssm_amd.engine import layer_scale  # noqa: E402
 
 
 def main():
@@ -24,10 +23,7 @@ def main():
     tot_t = tot_f = 0.0
     print("%-10s %5s %5s %2s %9s %9s %8s %8s" % ("layer", "cin", "cout", "k", "hxw", "GFLOP", "ms", "TFLOP/s"))
     for name, cin, cout, k in unet_layers(2, True):
-        s = [v for p, v in SCALE.items() if name.startswith(p)][0] if not name.startswith("conv1") or name in (
-            "conv1a", "conv1b") else None
-        if s is None:
-            s = 2 if name.startswith("conv10") else 1
+        s = layer_scale(name)
         h, w = H // s, W // s
         x = hb.Planes(B, cin, h, w, dev)
         x.interior.normal_()
