@@ -27,6 +27,9 @@
 #ifndef SSM_C16_SCHED
 #define SSM_C16_SCHED 1
 #endif
+#ifndef SSM_C16_PRIO
+#define SSM_C16_PRIO 0
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -131,6 +134,9 @@ __device__ __forceinline__ void conv16_compute(f32x16 (&acc)[C::NT][C::MT], cons
 #if SSM_C16_SCHED
         __builtin_amdgcn_sched_barrier(0);      // keep the next tap's LDS reads ahead of this tap's MFMAs
 #endif
+#if SSM_C16_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -141,6 +147,9 @@ __device__ __forceinline__ void conv16_compute(f32x16 (&acc)[C::NT][C::MT], cons
                     acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
                 }
             }
+#if SSM_C16_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if SSM_C16_SCHED
         __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -129,14 +129,37 @@ class FullModel(nn.Module):
         pipe.sync()
         return outs
 
+    def _forward_with_losses(self, image_tensor, t_interp, target_images):
+        """inference_mode=False (superslomo_r.py:204-243): every window is interpolated, the losses of all windows
+        are averaged, the middle window's frame is returned.  Forward values only: with trainable parameters and
+        autograd enabled this raises, because the backward kernels are not built yet."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("training through the HIP path needs the backward kernels (SURVEY 8f-1, next "
+                                      "scope row); the loss VALUES are available under torch.no_grad()")
+        image_pairs = self.get_image_pairs(image_tensor)
+        B, T = image_pairs.shape[:2]
+        losses = torch.zeros(B, 4, device=image_tensor.device)
+        est_img_t = None
+        with torch.no_grad():
+            for k in range(T):
+                img6 = image_pairs[:, k].contiguous()
+                eng = self.engine_for(B, B, img6.shape[2], img6.shape[3], img6.device)
+                pred = eng.run(img6, t_interp[:, k].reshape(B).to(torch.float32), want_aux=True)
+                f01, f10, e1, e0, _, _, _ = eng.intermediates()
+                out5 = eng.s2.t["out"].interior
+                losses = losses + self.loss.losses_from_parts(img6, torch.cat([f01, f10], 1), e1, e0, out5, pred,
+                                                              target_images[:, k])
+                if k == T // 2:
+                    est_img_t = pred.clone()
+        return est_img_t, losses / T
+
     @validate_target_tensor
     def forward(self, image_tensor, t_interp, target_images=None, iteration=None, inference_mode=True):
         """image_tensor [B,N,3,H,W] normalised frames, t_interp [B,N-1,1,1,1] in (0,1).
         Inference: (I_t [B,3,H,W], (F01, F10, Ft1^, Ft0^, Ft1, Ft0, V0)) of the middle window."""
         hb.require_device(image_tensor, "image tensor")
         if not inference_mode:
-            raise NotImplementedError("training step (losses + backward kernels) is the next scope row "
-                                      "(SURVEY 8f-1); only inference_mode=True is built")
+            return self._forward_with_losses(image_tensor, t_interp, target_images)
         image_pairs = self.get_image_pairs(image_tensor)
         B, T = image_pairs.shape[:2]
         mid_idx = T // 2

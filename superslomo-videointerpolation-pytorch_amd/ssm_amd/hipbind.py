@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libssm_hip.so")
+LIB_PATH = os.environ.get("SSM_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libssm_hip.so")
 
 SSM_PADX = 4
 SSM_PADY = 3

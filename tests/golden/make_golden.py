@@ -186,6 +186,25 @@ def main():
     c1["flow_absmax"] = np.float32(max(inter[0].abs().max().item(), inter[1].abs().max().item()))
     np.savez_compressed(os.path.join(HERE, "config1_256.npz"), **c1)
 
+    # ---------------- training-mode forward: [B,4] losses (a-13), FREEZE=FALSE so every warp term is on ------
+    # The perceptual term runs on the torchvision STUB (identity features), i.e. lambda_p * MSE(pred, target);
+    # the HIP-side test reproduces it with an identity feature extractor.  Forward values only (no backward).
+    cfgT = make_cfg(True)
+    cfgT.set("STAGE1", "FREEZE", "FALSE")
+    cfgT.set("STAGE2", "FREEZE", "FALSE")
+    fmT = ssm.FullModel(cfgT)
+    fmT.stage1_model.load_state_dict(synthetic_state_dict(1, True))
+    fmT.stage2_model.load_state_dict(synthetic_state_dict(2, True))
+    u8t = torch.stack([synthetic_frames_u8(3, 64, 64, seed=60), synthetic_frames_u8(3, 64, 64, seed=61)])   # [2,3,3,64,64]
+    clip = torch.cat([normalize_and_pad(u8t[0]), normalize_and_pad(u8t[1])], 0)                           # [2,3,3,64,64]
+    xin = clip[:, [0, 2]]                         # frames 0 and 2 are the inputs, frame 1 is the target
+    tgt = clip[:, 1:2]
+    tt = torch.tensor([0.5, 0.5]).view(2, 1, 1, 1, 1)
+    img, losses = fmT(xin, tt, tgt, None, False)
+    np.savez_compressed(os.path.join(HERE, "train_forward_64.npz"), u8=u8t.numpy(), t=npy(tt), img=npy(img),
+                        losses=npy(losses))
+    print("training-mode losses [B,4]:", losses)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
