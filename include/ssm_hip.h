@@ -188,6 +188,29 @@ int ssm_frames_from_u8_fwd(const unsigned char *frames_hwc, ssm_view out, int N,
 int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int N, int H, int W, int top, int left,
                          const float *mean3, const float *std3, int mode, void *stream);
 
+/* ---- backward kernels of the training step (fp32 planes; BASELINE config 3) ------------------------------
+ * The data gradient of a convolution is ssm_conv2d_fwd on the transposed, spatially flipped filter.
+ * ssm_lrelu_bwd           dz = (dy + 1/4 dpool[y/2][x/2]) * (y > 0 ? 1 : slope)   (dy or dpool may be NULL views;
+ *                         has_act = 0 for the bare final_conv)  - LeakyReLU' + adjoint of the fused 2x2 mean
+ * ssm_bias_grad           db[c] = sum dz
+ * ssm_conv2d_wgrad        dw (OIHW fp32, overwritten) = sum_{b,y,x} dz * x(shifted); x is a padded-plane view
+ * ssm_upsample2x_cat_bwd  adjoint of ssm_upsample2x_cat_fwd; acc_a/acc_b: add into da/db instead of overwriting
+ * ssm_synthesize_bwd      adjoint of ssm_synthesize_fwd fused with d(L1 reconstruction) and, if stage2_terms, the two
+ *                         refined-flow warp-loss terms (scripts/models/losses.py:160-161,217); c_rec[b], c_warp[b] =
+ *                         lambda * upstream gradient / (3*H*W) per sample (device arrays); est4 = Ft1^ | Ft0^
+ * ssm_flowinterp_inputs_bwd  adjoint of ssm_flowinterp_inputs_fwd wrt the stage-1 flows, fused with the two stage-1
+ *                         warp-loss terms (losses.py:152-154) if stage1_terms                                   */
+int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, int B, int C, int H, int W, float slope, int has_act,
+                  void *stream);
+int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream);
+int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, void *stream);
+int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int h, int w, int acc_a, int acc_b,
+                           void *stream);
+int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,
+                       const float *c_warp, ssm_view dout5, ssm_view dest4, int B, int H, int W, int stage2_terms, void *stream);
+int ssm_flowinterp_inputs_bwd(ssm_view img6, ssm_view flow4, ssm_view din16, ssm_view dest4, const float *t, const float *c_warp,
+                              ssm_view dflow4, int B, int H, int W, int stage1_terms, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,364 @@
+// Backward kernels of the training step (BASELINE config 3), fp32 planes.
+//
+// The reference trains through autograd over the stock ops of scripts/models/*; these are the hand-written
+// adjoints of the forward kernels of this library.  What is NOT here is the data-gradient of the convolution:
+// dX = conv(dZ, W^T flipped) is the forward kernel (ssm_conv2d_fwd) on a repacked filter.
+//
+//   lrelu_bwd       dZ = (dY + 1/4 dP[y/2][x/2]) * (Y > 0 ? 1 : slope)        LeakyReLU' and the fused 2x2-mean adjoint
+//   bias_grad       db[c] = sum_{b,y,x} dZ
+//   wgrad           dW[co][ci][ky][kx] = sum_{b,y,x} dZ[b,co,y,x] * X[b,ci,y+ky-p,x+kx-p]      (VALU, LDS-tiled)
+//   upsample_cat_bwd  adjoint of cat + bilinear x2 (F.upsample align_corners=False, edge clamp folded in)
+//   synth_bwd       adjoint of extract_outputs + compute_output_image, fused with the gradients of the L1
+//                   reconstruction loss and of the two stage-2 warp-loss terms (losses.py:113-170,217)
+//   inputs_bwd      adjoint of compute_inputs (flow approximation + the two warps wrt their flows), fused with the
+//                   two stage-1 warp-loss terms
+#include "ssm_common.h"
+
+namespace {
+
+__device__ __forceinline__ float *vp(const ssm_view &v, int b, int c, int y) {
+    return v.ptr + (long long)b * v.sb + (long long)c * v.sc + (long long)y * v.sh;
+}
+
+#define SSM_PIXEL_INDEX()                                     \
+    const int x = blockIdx.x * 64 + threadIdx.x;              \
+    const int y = blockIdx.y * 4 + threadIdx.y;               \
+    const int b = blockIdx.z;                                 \
+    if (x >= W || y >= H) return;
+
+inline dim3 pix_grid(int B, int H, int W) { return dim3((W + 63) / 64, (H + 3) / 4, B); }
+
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(ssm_view dy, ssm_view dpool, ssm_view yv, ssm_view dz, int C, int H, int W,
+                                                        float slope, int has_act) {
+    SSM_PIXEL_INDEX();
+    for (int c = 0; c < C; ++c) {
+        float g = dy.ptr ? vp(dy, b, c, y)[x] : 0.f;
+        if (dpool.ptr) g += 0.25f * vp(dpool, b, c, y >> 1)[x >> 1];
+        if (has_act) g *= (vp(yv, b, c, y)[x] > 0.f) ? 1.0f : slope;
+        vp(dz, b, c, y)[x] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__restrict__ db, int B, int H, int W) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    const int n = B * H * W;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int xx = i % W, r = i / W;
+        const int yy = r % H, bb = r / H;
+        s += vp(dz, bb, c, yy)[xx];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] = red[0];
+}
+
+// dW tile of 16 couts x 16 cins per workgroup (thread = one (co, ci) pair, all k*k taps in registers); the
+// workgroup walks image rows (b, y) strided by gridDim.z and adds its partial sums with fp32 atomics.
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout, int H,
+                                                    int W) {
+    constexpr int PAD = (KS - 1) / 2, MAXW = 64;
+    __shared__ float sdz[16][MAXW + 1];
+    __shared__ float sx[16][KS][MAXW + 2 * PAD + 1];
+    const int tid = threadIdx.x;
+    const int tci = tid & 15, tco = tid >> 4;
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+    float acc[KS][KS];
+#pragma unroll
+    for (int a = 0; a < KS; ++a)
+#pragma unroll
+        for (int c = 0; c < KS; ++c) acc[a][c] = 0.f;
+    const int rows = B * H;
+    for (int r = blockIdx.z; r < rows; r += gridDim.z) {
+        const int b = r / H, y = r - b * H;
+        for (int xs = 0; xs < W; xs += MAXW) {
+            const int wseg = min(MAXW, W - xs);
+            __syncthreads();
+            for (int i = tid; i < 16 * MAXW; i += 256) {
+                const int c = i / MAXW, xx = i - c * MAXW;
+                sdz[c][xx] = (co0 + c < Cout && xx < wseg) ? vp(dz, b, co0 + c, y)[xs + xx] : 0.f;
+            }
+            // X rows y-PAD..y+PAD, columns xs-PAD .. xs+wseg+PAD-1: the padded-plane frame supplies the zeros
+            for (int i = tid; i < 16 * KS * (MAXW + 2 * PAD); i += 256) {
+                const int c = i / (KS * (MAXW + 2 * PAD));
+                const int rem = i - c * (KS * (MAXW + 2 * PAD));
+                const int ky = rem / (MAXW + 2 * PAD), xx = rem - ky * (MAXW + 2 * PAD);
+                float v = 0.f;
+                if (ci0 + c < Cin && xx < wseg + 2 * PAD) v = vp(x, b, ci0 + c, y + ky - PAD)[xs + xx - PAD];
+                sx[c][ky][xx] = v;
+            }
+            __syncthreads();
+            for (int xx = 0; xx < wseg; ++xx) {
+                const float g = sdz[tco][xx];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) acc[ky][kx] += g * sx[tci][ky][xx + kx];
+            }
+        }
+    }
+    if (co0 + tco < Cout && ci0 + tci < Cin) {
+        float *d = dw + ((long long)(co0 + tco) * Cin + (ci0 + tci)) * (KS * KS);
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) atomicAdd(d + ky * KS + kx, acc[ky][kx]);
+    }
+}
+
+// adjoint of  U = upsample2x(cat[a, b])  (see upsample2x_cat_kernel): one thread per LOW-res pixel and channel
+// gathers its 4x4 hi-res neighbourhood.  1-D weights of x[i] in U(Y): Y=2i: .75 (1 at i=0); Y=2i+1: .75 (1 at
+// i=h-1); Y=2i+2: .25 if i+1<h; Y=2i-1: .25 if i>0.
+__global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(ssm_view du, ssm_view da, int Ca, ssm_view dbv, int Cb, int H, int W,
+                                                               int acc_a, int acc_b) {
+    SSM_PIXEL_INDEX();          // H, W = LOW-res dims
+    float wy[4], wx[4];
+    wy[0] = y > 0 ? 0.25f : 0.f;
+    wy[1] = y > 0 ? 0.75f : 1.0f;
+    wy[2] = y < H - 1 ? 0.75f : 1.0f;
+    wy[3] = y < H - 1 ? 0.25f : 0.f;
+    wx[0] = x > 0 ? 0.25f : 0.f;
+    wx[1] = x > 0 ? 0.75f : 1.0f;
+    wx[2] = x < W - 1 ? 0.75f : 1.0f;
+    wx[3] = x < W - 1 ? 0.25f : 0.f;
+    const int C = Ca + Cb;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int Y = 2 * y - 1 + j;
+            if (wy[j] == 0.f) continue;
+            const float *row = vp(du, b, c, Y);
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (wx[i] != 0.f) t += wx[i] * row[2 * x - 1 + i];
+            s += wy[j] * t;
+        }
+        if (c < Ca) {
+            float *d = vp(da, b, c, y) + x;
+            *d = acc_a ? *d + s : s;
+        } else {
+            float *d = vp(dbv, b, c - Ca, y) + x;
+            *d = acc_b ? *d + s : s;
+        }
+    }
+}
+
+// ---- bilinear sampler with derivatives --------------------------------------------------------------------
+struct TapsD {
+    int o00, o01, o10, o11;
+    float fx, fy;                // ix - x0, iy - y0
+};
+
+__device__ __forceinline__ TapsD make_taps_d(int x, int y, float u, float v, int H, int W, int sh) {
+    const float wd = (float)(W - 1 > 1 ? W - 1 : 1), hd = (float)(H - 1 > 1 ? H - 1 : 1);
+    const float gx = 2.0f * ((float)x + u) / wd - 1.0f, gy = 2.0f * ((float)y + v) / hd - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    const float wm = (float)(W - 1), hm = (float)(H - 1);
+    const bool bx0 = x0 >= 0.f && x0 <= wm, bx1 = x1 >= 0.f && x1 <= wm;
+    const bool by0 = y0 >= 0.f && y0 <= hm, by1 = y1 >= 0.f && y1 <= hm;
+    const int xi0 = bx0 ? (int)x0 : 0, xi1 = bx1 ? (int)x1 : 0, yi0 = by0 ? (int)y0 : 0, yi1 = by1 ? (int)y1 : 0;
+    TapsD t;
+    t.o00 = (bx0 && by0) ? yi0 * sh + xi0 : -1;
+    t.o01 = (bx1 && by0) ? yi0 * sh + xi1 : -1;
+    t.o10 = (bx0 && by1) ? yi1 * sh + xi0 : -1;
+    t.o11 = (bx1 && by1) ? yi1 * sh + xi1 : -1;
+    t.fx = ix - x0;
+    t.fy = iy - y0;
+    return t;
+}
+
+// value and d/d(ix), d/d(iy) of the zero-padded bilinear sample (d ix / d u = 1: the reference's normalise /
+// un-normalise pair is the identity map)
+__device__ __forceinline__ void sample_d(const float *__restrict__ plane, const TapsD &t, float &val, float &dvx, float &dvy) {
+    const float a = t.o00 >= 0 ? plane[t.o00] : 0.f, b = t.o01 >= 0 ? plane[t.o01] : 0.f;
+    const float c = t.o10 >= 0 ? plane[t.o10] : 0.f, d = t.o11 >= 0 ? plane[t.o11] : 0.f;
+    const float gx = 1.0f - t.fx, gy = 1.0f - t.fy;
+    val = a * gx * gy + b * t.fx * gy + c * gx * t.fy + d * t.fx * t.fy;
+    dvx = (b - a) * gy + (d - c) * t.fy;
+    dvy = (c - a) * gx + (d - b) * t.fx;
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// Loss + synthesis adjoint.  cr[b], cw[b] = per-sample coefficients of d(L1 recon mean) and d(L1 warp mean)
+// (lambda * upstream / (3*H*W)); stage2_terms = 0 when STAGE2.FREEZE drops the two refined-flow warp terms.
+// Outputs: dout5 [B,5,H,W] and dest [B,4,H,W] (gradient wrt the approximated flows Ft1^(u,v) | Ft0^(u,v)).
+__global__ __launch_bounds__(256) void synth_bwd_kernel(ssm_view img6, ssm_view est, ssm_view out5, ssm_view target,
+                                                        const float *__restrict__ tarr, const float *__restrict__ cr,
+                                                        const float *__restrict__ cw, ssm_view dout5, ssm_view dest, int H, int W,
+                                                        int stage2_terms) {
+    SSM_PIXEL_INDEX();
+    const float t = tarr[b], omt = 1.0f - t;
+    const float v1 = 1.0f / (1.0f + expf(-vp(out5, b, 0, y)[x])), v0 = 1.0f - v1;
+    const float ft1u = vp(est, b, 0, y)[x] + vp(out5, b, 1, y)[x], ft1v = vp(est, b, 1, y)[x] + vp(out5, b, 2, y)[x];
+    const float ft0u = vp(est, b, 2, y)[x] + vp(out5, b, 3, y)[x], ft0v = vp(est, b, 3, y)[x] + vp(out5, b, 4, y)[x];
+    const TapsD t0 = make_taps_d(x, y, ft0u, ft0v, H, W, img6.sh), t1 = make_taps_d(x, y, ft1u, ft1v, H, W, img6.sh);
+    const float den = omt * v0 + t * v1;
+    float dv0 = 0.f, dv1 = 0.f, dden = 0.f, d0x = 0.f, d0y = 0.f, d1x = 0.f, d1y = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float w0, w0x, w0y, w1, w1x, w1y;
+        sample_d(vp(img6, b, c, 0), t0, w0, w0x, w0y);
+        sample_d(vp(img6, b, 3 + c, 0), t1, w1, w1x, w1y);
+        const float tg = vp(target, b, c, y)[x];
+        const float num = omt * v0 * w0 + t * v1 * w1;
+        const float pred = num / den;
+        const float dpred = cr[b] * sgn(pred - tg);
+        const float dnum = dpred / den;
+        dden -= dpred * pred / den;
+        float dw0 = dnum * omt * v0, dw1 = dnum * t * v1;
+        dv0 += dnum * omt * w0;
+        dv1 += dnum * t * w1;
+        if (stage2_terms) {        // |g(I0,Ft0) - I_t| + |g(I1,Ft1) - I_t|
+            dw0 += cw[b] * sgn(w0 - tg);
+            dw1 += cw[b] * sgn(w1 - tg);
+        }
+        d0x += dw0 * w0x;
+        d0y += dw0 * w0y;
+        d1x += dw1 * w1x;
+        d1y += dw1 * w1y;
+    }
+    dv0 += dden * omt;
+    dv1 += dden * t;
+    vp(dout5, b, 0, y)[x] = (dv1 - dv0) * v1 * v0;
+    vp(dout5, b, 1, y)[x] = d1x;
+    vp(dout5, b, 2, y)[x] = d1y;
+    vp(dout5, b, 3, y)[x] = d0x;
+    vp(dout5, b, 4, y)[x] = d0y;
+    vp(dest, b, 0, y)[x] = d1x;
+    vp(dest, b, 1, y)[x] = d1y;
+    vp(dest, b, 2, y)[x] = d0x;
+    vp(dest, b, 3, y)[x] = d0y;
+}
+
+// compute_inputs adjoint: din16 [B,16,H,W] (gradient of the stage-2 input) and dest (from synth_bwd) -> dflow4
+// (gradient wrt stage 1's F01 | F10), plus the two stage-1 warp-loss terms |g(I1,F01)-I0| + |g(I0,F10)-I1|.
+__global__ __launch_bounds__(256) void inputs_bwd_kernel(ssm_view img6, ssm_view flow4, ssm_view din16, ssm_view dest,
+                                                         const float *__restrict__ tarr, const float *__restrict__ cw,
+                                                         ssm_view dflow4, int H, int W, int stage1_terms) {
+    SSM_PIXEL_INDEX();
+    const float t = tarr[b], omt = 1.0f - t;
+    const float f01u = vp(flow4, b, 0, y)[x], f01v = vp(flow4, b, 1, y)[x];
+    const float f10u = vp(flow4, b, 2, y)[x], f10v = vp(flow4, b, 3, y)[x];
+    const float c00 = (-omt) * t, c01 = t * t, c10 = omt * omt, c11 = t * omt;
+    const float ft0u = c00 * f01u + c01 * f10u, ft0v = c00 * f01v + c01 * f10v;
+    const float ft1u = c10 * f01u - c11 * f10u, ft1v = c10 * f01v - c11 * f10v;
+    const TapsD t1 = make_taps_d(x, y, ft1u, ft1v, H, W, img6.sh), t0 = make_taps_d(x, y, ft0u, ft0v, H, W, img6.sh);
+    // in16 = [I1(0:3), g(I1,Ft1)(3:6), Ft1(6:8), Ft0(8:10), g(I0,Ft0)(10:13), I0(13:16)]
+    float d1u = vp(din16, b, 6, y)[x] + vp(dest, b, 0, y)[x], d1v = vp(din16, b, 7, y)[x] + vp(dest, b, 1, y)[x];
+    float d0u = vp(din16, b, 8, y)[x] + vp(dest, b, 2, y)[x], d0v = vp(din16, b, 9, y)[x] + vp(dest, b, 3, y)[x];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float val, gx, gy;
+        sample_d(vp(img6, b, 3 + c, 0), t1, val, gx, gy);
+        const float g1 = vp(din16, b, 3 + c, y)[x];
+        d1u += g1 * gx;
+        d1v += g1 * gy;
+        sample_d(vp(img6, b, c, 0), t0, val, gx, gy);
+        const float g0 = vp(din16, b, 10 + c, y)[x];
+        d0u += g0 * gx;
+        d0v += g0 * gy;
+    }
+    float dF01u = c10 * d1u + c00 * d0u, dF01v = c10 * d1v + c00 * d0v;
+    float dF10u = -c11 * d1u + c01 * d0u, dF10v = -c11 * d1v + c01 * d0v;
+    if (stage1_terms) {
+        const TapsD a = make_taps_d(x, y, f01u, f01v, H, W, img6.sh), bq = make_taps_d(x, y, f10u, f10v, H, W, img6.sh);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float val, gx, gy;
+            sample_d(vp(img6, b, 3 + c, 0), a, val, gx, gy);           // g(I1, F01) vs I0
+            float s = cw[b] * sgn(val - vp(img6, b, c, y)[x]);
+            dF01u += s * gx;
+            dF01v += s * gy;
+            sample_d(vp(img6, b, c, 0), bq, val, gx, gy);              // g(I0, F10) vs I1
+            s = cw[b] * sgn(val - vp(img6, b, 3 + c, y)[x]);
+            dF10u += s * gx;
+            dF10v += s * gy;
+        }
+    }
+    vp(dflow4, b, 0, y)[x] = dF01u;
+    vp(dflow4, b, 1, y)[x] = dF01v;
+    vp(dflow4, b, 2, y)[x] = dF10u;
+    vp(dflow4, b, 3, y)[x] = dF10v;
+}
+
+}  // namespace
+
+#define SSM_CHECK_DIMS(name)                                                                         \
+    SSM_REQUIRE(B > 0 && H > 0 && W > 0 && B <= 65535 && (H + 3) / 4 <= 65535, name ": bad sizes B=%d H=%d W=%d", B, H, W)
+
+extern "C" int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, int B, int C, int H, int W, float slope,
+                             int has_act, void *stream) {
+    SSM_CHECK_DIMS("lrelu_bwd");
+    SSM_REQUIRE(dz.ptr && (dy.ptr || dpool.ptr) && (!has_act || y.ptr) && C > 0, "lrelu_bwd: null pointer / C");
+    hipLaunchKernelGGL(lrelu_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act);
+    return ssm::check_launch("ssm_lrelu_bwd");
+}
+
+extern "C" int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream) {
+    SSM_REQUIRE(dz.ptr && db && B > 0 && C > 0 && H > 0 && W > 0, "bias_grad: bad arguments");
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dz, db, B, H, W);
+    return ssm::check_launch("ssm_bias_grad");
+}
+
+extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, void *stream) {
+    SSM_REQUIRE(x.ptr && dz.ptr && dw_oihw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad: bad arguments");
+    SSM_REQUIRE(x.sh >= W + 2 * SSM_PADX, "wgrad: x must be a padded-plane view (zero frame)");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, st);
+    if (e != hipSuccess) {
+        ssm::set_error("wgrad: memset failed: %s", hipGetErrorString(e));
+        return SSM_E_LAUNCH;
+    }
+    const int tiles = ((Cin + 15) / 16) * ((Cout + 15) / 16);
+    int split = (2048 + tiles - 1) / tiles;          // aim for >= 2048 workgroups
+    const int rows = B * H;
+    if (split > rows) split = rows;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    const dim3 grid((Cin + 15) / 16, (Cout + 15) / 16, split);
+    switch (k) {
+        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W); break;
+        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W); break;
+        case 7: hipLaunchKernelGGL(wgrad_kernel<7>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W); break;
+        default: ssm::set_error("wgrad: kernel size %d unsupported", k); return SSM_E_UNSUPPORTED;
+    }
+    return ssm::check_launch("ssm_conv2d_wgrad");
+}
+
+extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int H, int W, int acc_a, int acc_b,
+                                      void *stream) {
+    SSM_CHECK_DIMS("upsample2x_cat_bwd");
+    SSM_REQUIRE(du.ptr && da.ptr && Ca > 0 && Cb >= 0 && (Cb == 0 || db.ptr), "upsample2x_cat_bwd: null pointer / channels");
+    hipLaunchKernelGGL(upsample_cat_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, du, da, Ca, Cb ? db : da, Cb, H,
+                       W, acc_a, acc_b);
+    return ssm::check_launch("ssm_upsample2x_cat_bwd");
+}
+
+extern "C" int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,
+                                  const float *c_warp, ssm_view dout5, ssm_view dest4, int B, int H, int W, int stage2_terms,
+                                  void *stream) {
+    SSM_CHECK_DIMS("synthesize_bwd");
+    SSM_REQUIRE(img6.ptr && est4.ptr && out5.ptr && target.ptr && t && c_rec && c_warp && dout5.ptr && dest4.ptr, "synthesize_bwd: null pointer");
+    hipLaunchKernelGGL(synth_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, est4, out5, target, t, c_rec,
+                       c_warp, dout5, dest4, H, W, stage2_terms);
+    return ssm::check_launch("ssm_synthesize_bwd");
+}
+
+extern "C" int ssm_flowinterp_inputs_bwd(ssm_view img6, ssm_view flow4, ssm_view din16, ssm_view dest4, const float *t, const float *c_warp,
+                                         ssm_view dflow4, int B, int H, int W, int stage1_terms, void *stream) {
+    SSM_CHECK_DIMS("flowinterp_inputs_bwd");
+    SSM_REQUIRE(img6.ptr && flow4.ptr && din16.ptr && dest4.ptr && t && c_warp && dflow4.ptr, "flowinterp_inputs_bwd: null pointer");
+    hipLaunchKernelGGL(inputs_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, din16, dest4, t, c_warp,
+                       dflow4, H, W, stage1_terms);
+    return ssm::check_launch("ssm_flowinterp_inputs_bwd");
+}

@@ -65,6 +65,14 @@ SIGNATURES = {
                                         ctypes.POINTER(_c_float), ctypes.POINTER(_c_float), _c_int, _vp]),
     "ssm_frames_to_u8_fwd": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_float),
                                       ctypes.POINTER(_c_float), _c_int, _vp]),
+    "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_upsample2x_cat_bwd": (_c_int, [SsmView, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_synthesize_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int,
+                                    _c_int, _vp]),
+    "ssm_flowinterp_inputs_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int,
+                                           _vp]),
     "ssm_avgpool2_fwd": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),

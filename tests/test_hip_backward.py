@@ -1,0 +1,143 @@
+"""GPU parity of the backward kernels against CPU autograd of the oracle (which is written in differentiable
+torch ops).  Tolerances are relative to the largest gradient entry (fp32 sums in different orders; wgrad
+accumulates with fp32 atomics)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rel_err(got, want):
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("k,cin,cout,B,H,W,act", [(7, 6, 32, 2, 16, 40, True), (5, 32, 64, 1, 12, 32, True),
+                                                   (3, 64, 32, 2, 9, 33, True), (3, 32, 5, 1, 16, 64, False),
+                                                   (3, 128, 256, 1, 8, 16, True), (3, 64, 32, 1, 70, 130, True)])
+def test_conv_backward(dev, k, cin, cout, B, H, W, act):
+    """dX (forward kernel on the transposed filter), dW (wgrad), db, through LeakyReLU', vs autograd."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import backward as Bk
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(k + cin + cout + H)
+    x = torch.randn(B, cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_()
+    bias = (torch.randn(cout, generator=g) * 0.1).requires_grad_()
+    r = torch.randn(B, cout, H, W, generator=g)
+    y = O.conv2d_lrelu(x, w, bias) if act else O.conv2d(x, w, bias)
+    (y * r).sum().backward()
+    yp = hb.Planes(B, cout, H, W, dev).load(y.detach().to(dev))
+    dyp = hb.Planes(B, cout, H, W, dev).load(r.to(dev))
+    # dZ with the channel count padded to the data-gradient conv's chunk size
+    wt = Bk.transposed_filter(w).to(dev)
+    pk = hb.PackedConv(wt, torch.zeros(cin, device=dev), B, H, W)
+    dzp = hb.Planes(B, pk.cin_p, H, W, dev)
+    Bk.lrelu_bwd(dyp, None, yp, _sub(dzp, cout), has_act=act)
+    dx = torch.empty(B, cin, H, W, device=dev)
+    hb.conv2d(dzp.view(), pk.cin_p, None, 0, pk, hb.view_of(dx), None, B, H, W, lrelu=False)
+    xp = hb.Planes(B, cin, H, W, dev).load(x.detach().to(dev))
+    dw = Bk.wgrad(xp, _sub(dzp, cout), torch.empty(cout, cin, k, k, device=dev), k)
+    db = Bk.bias_grad(_sub(dzp, cout), torch.empty(cout, device=dev))
+    assert rel_err(dx.cpu(), x.grad) < 2e-4, "dX"
+    assert rel_err(dw.cpu(), w.grad) < 2e-4, "dW"
+    assert rel_err(db.cpu(), bias.grad) < 2e-4, "db"
+
+
+def _sub(planes, c):
+    """The first c channels of a Planes buffer as a Planes-like object (same storage, same batch stride)."""
+    from ssm_amd import hipbind as hb
+
+    class Sub:
+        pass
+    s = Sub()
+    s.B, s.C, s.H, s.W = planes.B, c, planes.H, planes.W
+    s.view = lambda c0=0, broadcast=False: planes.view(c0, broadcast)
+    return s
+
+
+def test_pool_adjoint_fused_in_lrelu_bwd(dev):
+    from oracle import ssm_oracle as O
+    from ssm_amd import backward as Bk
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(3)
+    pre = torch.randn(2, 8, 12, 20, generator=g, requires_grad=True)
+    y = torch.where(pre >= 0, pre, pre * 0.1)
+    p = O.avg_pool2(y)
+    r1, r2 = torch.randn(y.shape, generator=g), torch.randn(p.shape, generator=g)
+    ((y * r1).sum() + (p * r2).sum()).backward()
+    dz = hb.Planes(2, 8, 12, 20, dev)
+    Bk.lrelu_bwd(hb.Planes(2, 8, 12, 20, dev).load(r1.to(dev)), hb.Planes(2, 8, 6, 10, dev).load(r2.to(dev)),
+                 hb.Planes(2, 8, 12, 20, dev).load(y.detach().to(dev)), dz)
+    assert rel_err(dz.to_nchw().cpu(), pre.grad) < 1e-6
+
+
+def test_upsample_cat_adjoint(dev):
+    from oracle import ssm_oracle as O
+    from ssm_amd import backward as Bk
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(4)
+    for (B, ca, cb, h, w) in ((2, 3, 2, 6, 10), (1, 4, 0, 1, 1), (1, 2, 2, 5, 3), (1, 8, 8, 23, 40)):
+        a = torch.randn(B, ca, h, w, generator=g, requires_grad=True)
+        b = torch.randn(B, cb, h, w, generator=g, requires_grad=True) if cb else None
+        u = O.upsample2x_bilinear(a if b is None else torch.cat([a, b], 1))
+        r = torch.randn(u.shape, generator=g)
+        (u * r).sum().backward()
+        da = hb.Planes(B, ca, h, w, dev)
+        dbp = hb.Planes(B, cb, h, w, dev) if cb else None
+        Bk.upsample_cat_bwd(hb.Planes(B, ca + cb, 2 * h, 2 * w, dev).load(r.to(dev)), da, dbp)
+        assert rel_err(da.to_nchw().cpu(), a.grad) < 1e-5, (B, ca, cb, h, w)
+        if cb:
+            assert rel_err(dbp.to_nchw().cpu(), b.grad) < 1e-5
+    # accumulate flag
+    Bk.upsample_cat_bwd(hb.Planes(B, ca + cb, 2 * h, 2 * w, dev).load(r.to(dev)), da, dbp, acc_a=True)
+    assert rel_err(da.to_nchw().cpu(), 2 * a.grad) < 1e-5
+
+
+@pytest.mark.parametrize("s1_terms,s2_terms", [(True, True), (False, True), (True, False)])
+def test_synthesis_and_inputs_adjoints_with_losses(dev, s1_terms, s2_terms):
+    """Gradients wrt stage 2's output (5 ch) and stage 1's flows (4 ch) of
+    sum_b [ c_rec * |pred - I_t|_1 + c_warp * (stage-2 warp terms + stage-1 warp terms) ] + <in16, R16>."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 20, 28
+    img6 = torch.randn(B, 6, H, W, generator=g)
+    flow4 = (torch.randn(B, 4, H, W, generator=g) * 2).requires_grad_()
+    out5 = (torch.randn(B, 5, H, W, generator=g) * 1.5).requires_grad_()
+    target = torch.randn(B, 3, H, W, generator=g)
+    r16 = torch.randn(B, 16, H, W, generator=g) * 0.01
+    t = torch.tensor([0.25, 0.625]).view(B, 1, 1, 1)
+    cr, cw = torch.tensor([0.7, 1.3]), torch.tensor([0.4, 0.9])
+    in16 = O.flow_interp_inputs(img6, flow4, t)
+    pred = O.synthesize(img6, in16, out5, t)
+    i0, i1 = img6[:, 0:3], img6[:, 3:6]
+    per = lambda z: z.abs().flatten(1).sum(1)     # noqa: E731
+    loss = (cr * per(pred - target)).sum() + (in16 * r16).sum()
+    if s2_terms:
+        ft1, ft0 = in16[:, 6:8] + out5[:, 1:3], in16[:, 8:10] + out5[:, 3:5]
+        loss = loss + (cw * (per(O.warp(i0, ft0) - target) + per(O.warp(i1, ft1) - target))).sum()
+    if s1_terms:
+        loss = loss + (cw * (per(O.warp(i1, flow4[:, 0:2]) - i0) + per(O.warp(i0, flow4[:, 2:4]) - i1))).sum()
+    loss.backward()
+    lib = hb.load()
+    d = lambda z: z.detach().to(dev).contiguous()     # noqa: E731
+    img6d, flow4d, out5d, tgtd, in16d, r16d = d(img6), d(flow4), d(out5), d(target), d(in16), d(r16)
+    est = in16d[:, 6:10].contiguous()
+    td, crd, cwd = d(t.reshape(B)), d(cr), d(cw)
+    dout5, dest, dflow4 = (torch.empty(B, 5, H, W, device=dev), torch.empty(B, 4, H, W, device=dev),
+                           torch.empty(B, 4, H, W, device=dev))
+    hb.check(lib.ssm_synthesize_bwd(hb.view_of(img6d), hb.view_of(est), hb.view_of(out5d), hb.view_of(tgtd), td.data_ptr(),
+                                    crd.data_ptr(), cwd.data_ptr(), hb.view_of(dout5), hb.view_of(dest), B, H, W,
+                                    1 if s2_terms else 0, hb.stream_ptr()))
+    hb.check(lib.ssm_flowinterp_inputs_bwd(hb.view_of(img6d), hb.view_of(flow4d), hb.view_of(r16d), hb.view_of(dest),
+                                           td.data_ptr(), cwd.data_ptr(), hb.view_of(dflow4), B, H, W, 1 if s1_terms else 0,
+                                           hb.stream_ptr()))
+    assert rel_err(dout5.cpu(), out5.grad) < 2e-4, "d out5"
+    assert rel_err(dflow4.cpu(), flow4.grad) < 2e-4, "d flow4"
