@@ -193,7 +193,8 @@ int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int N, int H, i
  * ssm_lrelu_bwd           dz = (dy + 1/4 dpool[y/2][x/2]) * (y > 0 ? 1 : slope)   (dy or dpool may be NULL views;
  *                         has_act = 0 for the bare final_conv)  - LeakyReLU' + adjoint of the fused 2x2 mean
  * ssm_bias_grad           db[c] = sum dz
- * ssm_conv2d_wgrad        dw (OIHW fp32, overwritten) = sum_{b,y,x} dz * x(shifted); x is a padded-plane view
+ * ssm_conv2d_wgrad        dw[:, ci_offset:ci_offset+Cin] of an OIHW fp32 filter with cin_total inputs (zeroed first if
+ *                         zero_first; two-source convs call it once per source) += sum_{b,y,x} dz * x(shifted); x padded planes
  * ssm_upsample2x_cat_bwd  adjoint of ssm_upsample2x_cat_fwd; acc_a/acc_b: add into da/db instead of overwriting
  * ssm_synthesize_bwd      adjoint of ssm_synthesize_fwd fused with d(L1 reconstruction) and, if stage2_terms, the two
  *                         refined-flow warp-loss terms (scripts/models/losses.py:160-161,217); c_rec[b], c_warp[b] =
@@ -203,7 +204,8 @@ int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int N, int H, i
 int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, int B, int C, int H, int W, float slope, int has_act,
                   void *stream);
 int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream);
-int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, void *stream);
+int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
+                     int ci_offset, int zero_first, void *stream);
 int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int h, int w, int acc_a, int acc_b,
                            void *stream);
 int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__re
 // workgroup walks image rows (b, y) strided by gridDim.z and adds its partial sums with fp32 atomics.
 template <int KS>
 __global__ __launch_bounds__(256) void wgrad_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout, int H,
-                                                    int W) {
+                                                    int W, int cin_total, int ci_offset) {
     constexpr int PAD = (KS - 1) / 2, MAXW = 64;
     __shared__ float sdz[16][MAXW + 1];
     __shared__ float sx[16][KS][MAXW + 2 * PAD + 1];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(ssm_view x, ssm_view dz, flo
         }
     }
     if (co0 + tco < Cout && ci0 + tci < Cin) {
-        float *d = dw + ((long long)(co0 + tco) * Cin + (ci0 + tci)) * (KS * KS);
+        float *d = dw + ((long long)(co0 + tco) * cin_total + (ci_offset + ci0 + tci)) * (KS * KS);
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
@@ -310,14 +310,19 @@ extern "C" int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W,
     return ssm::check_launch("ssm_bias_grad");
 }
 
-extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, void *stream) {
+extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
+                                int ci_offset, int zero_first, void *stream) {
     SSM_REQUIRE(x.ptr && dz.ptr && dw_oihw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad: bad arguments");
+    SSM_REQUIRE(ci_offset >= 0 && ci_offset + Cin <= cin_total, "wgrad: channel range [%d,%d) outside the filter's %d inputs", ci_offset,
+                ci_offset + Cin, cin_total);
     SSM_REQUIRE(x.sh >= W + 2 * SSM_PADX, "wgrad: x must be a padded-plane view (zero frame)");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)Cout * Cin * k * k, st);
-    if (e != hipSuccess) {
-        ssm::set_error("wgrad: memset failed: %s", hipGetErrorString(e));
-        return SSM_E_LAUNCH;
+    if (zero_first) {
+        hipError_t e = hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)Cout * cin_total * k * k, st);
+        if (e != hipSuccess) {
+            ssm::set_error("wgrad: memset failed: %s", hipGetErrorString(e));
+            return SSM_E_LAUNCH;
+        }
     }
     const int tiles = ((Cin + 15) / 16) * ((Cout + 15) / 16);
     int split = (2048 + tiles - 1) / tiles;          // aim for >= 2048 workgroups
@@ -327,9 +332,9 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
     if (split > 65535) split = 65535;
     const dim3 grid((Cin + 15) / 16, (Cout + 15) / 16, split);
     switch (k) {
-        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W); break;
-        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W); break;
-        case 7: hipLaunchKernelGGL(wgrad_kernel<7>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W); break;
+        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total, ci_offset); break;
+        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total, ci_offset); break;
+        case 7: hipLaunchKernelGGL(wgrad_kernel<7>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total, ci_offset); break;
         default: ssm::set_error("wgrad: kernel size %d unsupported", k); return SSM_E_UNSUPPORTED;
     }
     return ssm::check_launch("ssm_conv2d_wgrad");

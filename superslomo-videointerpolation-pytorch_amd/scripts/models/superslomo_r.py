@@ -40,6 +40,40 @@ def validate_target_tensor(model_forward_func):
     return func_wrapper
 
 
+class _TrainStep(torch.autograd.Function):
+    """forward = the HIP forward of one window + the [B,4] losses; backward = ssm_amd.backward.PairGrad.
+    The parameters are inputs of the Function so autograd delivers their gradients to `.grad`."""
+
+    @staticmethod
+    def forward(ctx, model, img6, t, target, *params):
+        B, _, H, W = img6.shape
+        eng, pg = model._train_engine(B, H, W, img6.device)
+        sd1 = {k: v.detach() for k, v in model.stage1_model.state_dict().items()}
+        sd2 = {k: v.detach() for k, v in model.stage2_model.state_dict().items()}
+        eng.s1.refresh_weights(sd1)
+        eng.s2.refresh_weights(sd2)
+        pred = eng.run(img6, t, want_aux=True).clone()
+        f01, f10, e1, e0, _, _, _ = eng.intermediates()
+        losses = model.loss.losses_from_parts(img6, torch.cat([f01, f10], 1), e1, e0, eng.s2.t["out"].interior, pred, target)
+        ctx.model, ctx.pg, ctx.sd, ctx.target = model, pg, (sd1, sd2), target
+        ctx.mark_non_differentiable(pred)
+        return pred, losses
+
+    @staticmethod
+    def backward(ctx, d_pred, d_losses):
+        model = ctx.model
+        lambda_r, _, lambda_w = model.loss.loss_weights
+        train_s1 = not model.cfg.getboolean("STAGE1", "FREEZE")
+        train_s2 = not model.cfg.getboolean("STAGE2", "FREEZE")
+        grads = ctx.pg.backward(ctx.sd[0], ctx.sd[1], ctx.target, d_losses.contiguous(), lambda_r, lambda_w, train_s1, train_s2)
+        out = []
+        for stage, mod in (("stage1.", model.stage1_model), ("stage2.", model.stage2_model)):
+            for name, p in mod.named_parameters():
+                g = grads.get(stage + name)
+                out.append(g.clone() if (g is not None and p.requires_grad) else None)
+        return (None, None, None, None) + tuple(out)
+
+
 class FullModel(nn.Module):
     def __init__(self, cfg, writer=None):
         super().__init__()
@@ -129,15 +163,33 @@ class FullModel(nn.Module):
         pipe.sync()
         return outs
 
+    # ---- training step ------------------------------------------------------------------------------------------
+    def _train_engine(self, B, H, W, device):
+        """fp32 plan with materialised upsample tensors (what the hand-written backward walks) + its PairGrad."""
+        from ssm_amd.backward import PairGrad
+        key = (B, H, W, str(device))
+        if getattr(self, "_train", None) is None or self._train[0] != key:
+            sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
+            sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
+            self._train = None
+            eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, "f32", fuse_upsample=False)
+            self._train = (key, eng, PairGrad(eng))
+        return self._train[1], self._train[2]
+
     def _forward_with_losses(self, image_tensor, t_interp, target_images):
         """inference_mode=False (superslomo_r.py:204-243): every window is interpolated, the losses of all windows
-        are averaged, the middle window's frame is returned.  Forward values only: with trainable parameters and
-        autograd enabled this raises, because the backward kernels are not built yet."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("training through the HIP path needs the backward kernels (SURVEY 8f-1, next "
-                                      "scope row); the loss VALUES are available under torch.no_grad()")
+        are averaged, the middle window's frame is returned.  With trainable parameters and autograd enabled the
+        returned loss tensor carries the hand-written backward (ssm_amd.backward), so the reference Trainer's
+        `losses.mean(0)[0].backward(); optimizer.step()` (scripts/main.py:138-197) works unchanged."""
         image_pairs = self.get_image_pairs(image_tensor)
         B, T = image_pairs.shape[:2]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if T != 1:
+                raise NotImplementedError("the HIP backward covers N_FRAMES=2 (one interpolation window); N_FRAMES=%d "
+                                          "belongs to the recurrent configuration" % (T + 1))
+            params = list(self.stage1_model.parameters()) + list(self.stage2_model.parameters())
+            return _TrainStep.apply(self, image_pairs[:, 0].contiguous(), t_interp[:, 0].reshape(B).to(torch.float32),
+                                    target_images[:, 0].contiguous(), *params)
         losses = torch.zeros(B, 4, device=image_tensor.device)
         est_img_t = None
         with torch.no_grad():

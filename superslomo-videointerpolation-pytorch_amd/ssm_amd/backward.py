@@ -33,10 +33,12 @@ def bias_grad(dz, out):
     return out
 
 
-def wgrad(x, dz, out, k):
-    """out (OIHW fp32, contiguous) = sum_{b,y,x} dz * x(shifted).  x, dz: hb.Planes of the layer's input / dZ."""
-    assert out.is_contiguous() and tuple(out.shape) == (dz.C, x.C, k, k)
-    hb.check(hb.load().ssm_conv2d_wgrad(x.view(), dz.view(), out.data_ptr(), x.B, x.C, dz.C, x.H, x.W, k, hb.stream_ptr()))
+def wgrad(x, dz, out, k, ci_offset=0, zero_first=True):
+    """out[:, ci_offset:ci_offset+x.C] (OIHW fp32, contiguous) = sum_{b,y,x} dz * x(shifted).
+    x, dz: hb.Planes (or slices) of the layer's input / dZ; two-source convs call this once per source."""
+    assert out.is_contiguous() and out.shape[0] == dz.C and out.shape[2] == k and ci_offset + x.C <= out.shape[1]
+    hb.check(hb.load().ssm_conv2d_wgrad(x.view(), dz.view(), out.data_ptr(), x.B, x.C, dz.C, x.H, x.W, k, out.shape[1],
+                                        ci_offset, 1 if zero_first else 0, hb.stream_ptr()))
     return out
 
 
@@ -44,3 +46,175 @@ def upsample_cat_bwd(du, da, db=None, acc_a=False, acc_b=False):
     hb.check(hb.load().ssm_upsample2x_cat_bwd(du.view(), da.view(), da.C, db.view() if db is not None else hb.NULL_VIEW,
                                               db.C if db is not None else 0, da.B, da.H, da.W, 1 if acc_a else 0,
                                               1 if acc_b else 0, hb.stream_ptr()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# U-Net backward over a UNetPlan (mode "f32", concat+upsample materialised): every activation the adjoints need is
+# still in the plan's buffers (nothing is aliased), so the backward is a second fixed launch sequence.
+# ------------------------------------------------------------------------------------------------------------------
+from .engine import POOLED, layer_scale  # noqa: E402
+from .weights import param_key  # noqa: E402
+
+# (layer, input tensor(s), output tensor) in forward order - scripts/models/flow_computation.py:155-289
+_CONV_IO = [
+    ("conv1a", ("in",), "t1a"), ("conv1b", ("t1a",), "c1"), ("conv2a", ("p2",), "t2a"), ("conv2b", ("t2a",), "c2"),
+    ("conv3a", ("p3",), "t3a"), ("conv3b", ("t3a",), "c3"), ("conv4a", ("p4",), "t4a"), ("conv4b", ("t4a",), "c4"),
+    ("conv5a", ("p5",), "t5a"), ("conv5b", ("t5a",), "c5"), ("conv6.0", ("p6",), "t6a"), ("conv6.1", ("t6a",), "c6"),
+    ("conv7a", ("u7",), "t7a"), ("conv7b", ("t7a",), "c7"), ("conv8a", ("u8",), "t8a"), ("conv8b", ("t8a",), "c8"),
+    ("conv9a", ("u9",), "t9a"), ("conv9b", ("t9a",), "c9"), ("conv10a", ("u10",), "t10a"), ("conv10b", ("t10a",), "c10"),
+    ("conv11a", ("u11",), "t11a"), ("conv11b", ("t11a",), "c11"), ("fuse_conv", ("c11", "c1"), "tf"),
+    ("final_conv", ("tf",), "out"),
+]
+_POOL_OF = {"conv1b": "p2", "conv2b": "p3", "conv3b": "p4", "conv4b": "p5", "conv5b": "p6"}
+_UP_SOURCES = {"u7": ("c6", None), "u8": ("c7", "c5"), "u9": ("c8", "c4"), "u10": ("c9", "c3"), "u11": ("c10", "c2")}
+
+
+class UNetGrad:
+    def __init__(self, plan):
+        assert not plan.hl8 and not plan.fuse_up, "the backward runs on the fp32 plan with materialised upsample tensors"
+        self.plan = plan
+        self.B, self.dev = plan.B, plan.device
+        self.g, self.dz, self.pk_t, self.grads = {}, {}, {}, {}
+        self.io = {n: (srcs, dst) for n, srcs, dst in _CONV_IO}
+
+    def _G(self, name, like=None, C=None):
+        """Gradient buffer with the geometry of activation `like` (default: same name)."""
+        if name not in self.g:
+            ref = self.plan.t[like or name]
+            self.g[name] = hb.Planes(self.B, C or ref.C, ref.H, ref.W, self.dev)
+        return self.g[name]
+
+    def refresh(self, state_dict, need_input_grad):
+        """Repack the data-gradient filters (the weights change every optimizer step)."""
+        for name, (ci, co, k) in self.plan.layers.items():
+            if name == "conv1a" and not need_input_grad:
+                continue
+            s = layer_scale(name)
+            w = state_dict[param_key(name, "weight")].to(device=self.dev, dtype=torch.float32)
+            self.pk_t[name] = hb.PackedConv(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B,
+                                            self.plan.H // s, self.plan.W // s)
+
+    def _layer(self, name, dy, dpool, dx, need_wgrad, act=True):
+        """One convolution: dZ, parameter gradients, data gradient into `dx` (None: not needed)."""
+        plan = self.plan
+        srcs, dst = self.io[name]
+        ci, co, k = plan.layers[name]
+        Y = plan.t[dst]
+        pk = self.pk_t.get(name)
+        cpad = pk.cin_p if pk is not None else co
+        if name not in self.dz:
+            self.dz[name] = hb.Planes(self.B, cpad, Y.H, Y.W, self.dev)
+        dzp = self.dz[name]
+        dz = dzp.slice(0, co)
+        lrelu_bwd(dy, dpool, Y, dz, has_act=act)
+        if need_wgrad:
+            wk, bk = param_key(name, "weight"), param_key(name, "bias")
+            if wk not in self.grads:
+                self.grads[wk] = torch.empty(co, ci, k, k, dtype=torch.float32, device=self.dev)
+                self.grads[bk] = torch.empty(co, dtype=torch.float32, device=self.dev)
+            off = 0
+            for sname in srcs:
+                X = plan.t[sname]
+                wgrad(X, dz, self.grads[wk], k, ci_offset=off, zero_first=(off == 0))
+                off += X.C
+            assert off == ci, "%s: inputs cover %d of %d channels" % (name, off, ci)
+            bias_grad(dz, self.grads[bk])
+        if dx is not None:
+            hb.conv2d(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
+
+    def backward(self, d_out, need_wgrad=True, need_input_grad=False, cross_grad_out=None, c6_grad_init=None):
+        """d_out: Planes with the gradient of final_conv's output (channels padded to the data-gradient chunk).
+        cross_grad_out (stage 2): Planes that receives the gradient wrt the stage-1 bottleneck fed through the
+        cross-skip.  c6_grad_init (stage 1): Planes already holding that gradient; the decoder's own gradient wrt
+        conv6.1's output is added to it.  Returns the gradient of the input (Planes) or None."""
+        L, G = self._layer, self._G
+        plan = self.plan
+        L("final_conv", d_out, None, G("tf"), need_wgrad, act=False)
+        cat = G("cat_fuse", like="tf", C=plan.t["c11"].C + plan.t["c1"].C)
+        L("fuse_conv", G("tf"), None, cat, need_wgrad)
+        d_c11, d_c1 = cat.slice(0, plan.t["c11"].C), cat.slice(plan.t["c11"].C, plan.t["c1"].C)
+        L("conv11b", d_c11, None, G("t11a"), need_wgrad)
+        L("conv11a", G("t11a"), None, G("u11"), need_wgrad)
+        upsample_cat_bwd(G("u11"), G("c10"), G("c2"))
+        L("conv10b", G("c10"), None, G("t10a"), need_wgrad)
+        L("conv10a", G("t10a"), None, G("u10"), need_wgrad)
+        upsample_cat_bwd(G("u10"), G("c9"), G("c3"))
+        L("conv9b", G("c9"), None, G("t9a"), need_wgrad)
+        L("conv9a", G("t9a"), None, G("u9"), need_wgrad)
+        upsample_cat_bwd(G("u9"), G("c8"), G("c4"))
+        L("conv8b", G("c8"), None, G("t8a"), need_wgrad)
+        L("conv8a", G("t8a"), None, G("u8"), need_wgrad)
+        upsample_cat_bwd(G("u8"), G("c7"), G("c5"))
+        L("conv7b", G("c7"), None, G("t7a"), need_wgrad)
+        L("conv7a", G("t7a"), None, G("u7"), need_wgrad)
+        if c6_grad_init is not None:            # stage 1 with a cross-skip: add to the gradient stage 2 left there
+            self.g["c6"] = c6_grad_init
+            upsample_cat_bwd(G("u7"), self.g["c6"], None, acc_a=True)
+        elif plan.cross:                        # stage 2: second source of u7 = stage 1's bottleneck
+            upsample_cat_bwd(G("u7"), G("c6"), cross_grad_out)
+        else:
+            upsample_cat_bwd(G("u7"), G("c6"), None)
+        L("conv6.1", G("c6"), None, G("t6a"), need_wgrad)
+        L("conv6.0", G("t6a"), None, G("p6"), need_wgrad)
+        L("conv5b", G("c5"), G("p6"), G("t5a"), need_wgrad)
+        L("conv5a", G("t5a"), None, G("p5"), need_wgrad)
+        L("conv4b", G("c4"), G("p5"), G("t4a"), need_wgrad)
+        L("conv4a", G("t4a"), None, G("p4"), need_wgrad)
+        L("conv3b", G("c3"), G("p4"), G("t3a"), need_wgrad)
+        L("conv3a", G("t3a"), None, G("p3"), need_wgrad)
+        L("conv2b", G("c2"), G("p3"), G("t2a"), need_wgrad)
+        L("conv2a", G("t2a"), None, G("p2"), need_wgrad)
+        L("conv1b", d_c1, G("p2"), G("t1a"), need_wgrad)
+        d_in = G("in") if need_input_grad else None
+        L("conv1a", G("t1a"), None, d_in, need_wgrad)
+        return d_in
+
+
+class PairGrad:
+    """Backward of one interpolation window on a PairEngine built with mode="f32", fuse_upsample=False, B1 == B2:
+    loss gradient -> synthesis adjoint -> stage-2 U-Net -> compute_inputs adjoint -> stage-1 U-Net."""
+
+    def __init__(self, engine):
+        assert not engine.hl8 and engine.B1 == engine.B2, "training uses the fp32 plan with one t per sample"
+        self.e = engine
+        self.u1, self.u2 = UNetGrad(engine.s1), UNetGrad(engine.s2)
+        B, H, W, dev = engine.B2, engine.H, engine.W, engine.device
+        self.dest = torch.empty(B, 4, H, W, dtype=torch.float32, device=dev)
+        self.cr = torch.empty(B, dtype=torch.float32, device=dev)
+        self.cw = torch.empty(B, dtype=torch.float32, device=dev)
+
+    def backward(self, sd1, sd2, target, g_losses, lambda_r, lambda_w, train_s1, train_s2, n_windows=1):
+        """target [B,3,H,W]; g_losses [B,4] = upstream gradient of the [B,4] loss tensor (columns total, recon, warp,
+        perceptual); returns {state-dict key: gradient} for the stages that train.  The warp-loss terms follow the
+        FREEZE gating of scripts/models/losses.py:159-167."""
+        e = self.e
+        lib = hb.load()
+        st = hb.stream_ptr()
+        B, H, W = e.B2, e.H, e.W
+        n = 3.0 * H * W * n_windows
+        self.cr.copy_((g_losses[:, 0] + g_losses[:, 1]) * (lambda_r / n))
+        self.cw.copy_((g_losses[:, 0] + g_losses[:, 2]) * (lambda_w / n))
+        target = target.contiguous()
+        img6 = hb.view_of(e.img6)
+        in16, out5, flow4 = e.s2.t["in"], e.s2.t["out"], e.s1.t["out"]
+        need_s1 = train_s1
+        self.u2.refresh(sd2, need_input_grad=need_s1)
+        d_out5 = self.u2._G("out", C=self.u2.pk_t["final_conv"].cin_p)
+        hb.check(lib.ssm_synthesize_bwd(img6, in16.view(6), out5.view(), hb.view_of(target), e.t_dev.data_ptr(),
+                                        self.cr.data_ptr(), self.cw.data_ptr(), d_out5.view(), hb.view_of(self.dest), B, H, W,
+                                        1 if train_s2 else 0, st))
+        dcross = None
+        if e.cross and need_s1:
+            dcross = self.u1._G("c6")
+        d_in16 = self.u2.backward(d_out5, need_wgrad=train_s2, need_input_grad=need_s1, cross_grad_out=dcross)
+        grads = {}
+        if train_s2:
+            grads.update({"stage2." + k: v for k, v in self.u2.grads.items()})
+        if need_s1:
+            self.u1.refresh(sd1, need_input_grad=False)
+            d_flow4 = self.u1._G("out", C=self.u1.pk_t["final_conv"].cin_p)
+            hb.check(lib.ssm_flowinterp_inputs_bwd(img6, flow4.view(), d_in16.view(), hb.view_of(self.dest), e.t_dev.data_ptr(),
+                                                   self.cw.data_ptr(), d_flow4.view(), B, H, W, 1, st))
+            self.u1.backward(d_flow4, need_wgrad=True, c6_grad_init=dcross)
+            grads.update({"stage1." + k: v for k, v in self.u1.grads.items()})
+        return grads

@@ -115,6 +115,17 @@ class UNetPlan:
         t["tf"] = P(32, 1)
         t["out"] = hb.Planes(B, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
 
+    def refresh_weights(self, state_dict):
+        """Repack every filter from `state_dict` (training: the parameters change each optimizer step)."""
+        for name, (ci, co, k) in self.layers.items():
+            w = state_dict[param_key(name, "weight")].to(device=self.device, dtype=torch.float32)
+            b = state_dict[param_key(name, "bias")].to(device=self.device, dtype=torch.float32)
+            s = layer_scale(name)
+            if self.hl8:
+                self.pk[name] = hb.PackedConv16(w, b, self.W // s)
+            else:
+                self.pk[name] = hb.PackedConv(w, b, self.B, self.H // s, self.W // s, pool=name in POOLED)
+
     def _conv(self, name, src, dst, pool=None, src2=None, lrelu=True):
         pk = self.pk[name]
         s = self.t[src]
@@ -214,14 +225,14 @@ class PairEngine:
     Either B2 == B1 (one t per sample: FullModel.forward) or B1 == 1 and B2 = number
     of intermediates of that pair (stage-1 tensors broadcast over the t batch)."""
 
-    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32"):
+    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True):
         assert B2 == B1 or B1 == 1, "stage-2 batch must equal stage-1 batch, or stage-1 batch must be 1"
         self.B1, self.B2, self.H, self.W, self.device = B1, B2, H, W, device
         self.cross = bool(cross_skip)
         self.mode, self.hl8 = mode, mode != "f32"
         self.bcast = (B1 == 1 and B2 > 1)
-        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode)
-        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode)
+        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode, fuse_upsample)
+        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode, fuse_upsample)
         self.t_dev = torch.empty(B2, dtype=torch.float32, device=device)
         self.img = torch.empty(B2, 3, H, W, dtype=torch.float32, device=device)
         self.aux = torch.empty(B2, 5, H, W, dtype=torch.float32, device=device)

@@ -67,7 +67,7 @@ SIGNATURES = {
                                       ctypes.POINTER(_c_float), _c_int, _vp]),
     "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
-    "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_bwd": (_c_int, [SsmView, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_synthesize_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int,
                                     _c_int, _vp]),
@@ -150,6 +150,22 @@ class Planes:
         base = self.buf.data_ptr() + 4 * ((c0 * self.Hp + SSM_PADY) * self.Wp + SSM_PADX)
         sc = self.Hp * self.Wp
         return SsmView(base, 0 if broadcast else self.C * sc, sc, self.Wp)
+
+    def slice(self, c0, c):
+        """Channels [c0, c0+c) as a Planes-like object over the same storage (same batch stride)."""
+        parent = self
+
+        class _Slice:
+            B, C, H, W, Hp, Wp = parent.B, c, parent.H, parent.W, parent.Hp, parent.Wp
+
+            @staticmethod
+            def view(cc=0, broadcast=False):
+                return parent.view(c0 + cc, broadcast)
+
+            @property
+            def interior(self):
+                return parent.interior[:, c0:c0 + c]
+        return _Slice()
 
     def load(self, x):
         """Copy a [B,C,H,W] device tensor into the interior (HIP strided copy)."""

@@ -39,27 +39,21 @@ def test_conv_backward(dev, k, cin, cout, B, H, W, act):
     wt = Bk.transposed_filter(w).to(dev)
     pk = hb.PackedConv(wt, torch.zeros(cin, device=dev), B, H, W)
     dzp = hb.Planes(B, pk.cin_p, H, W, dev)
-    Bk.lrelu_bwd(dyp, None, yp, _sub(dzp, cout), has_act=act)
+    Bk.lrelu_bwd(dyp, None, yp, dzp.slice(0, cout), has_act=act)
     dx = torch.empty(B, cin, H, W, device=dev)
     hb.conv2d(dzp.view(), pk.cin_p, None, 0, pk, hb.view_of(dx), None, B, H, W, lrelu=False)
     xp = hb.Planes(B, cin, H, W, dev).load(x.detach().to(dev))
-    dw = Bk.wgrad(xp, _sub(dzp, cout), torch.empty(cout, cin, k, k, device=dev), k)
-    db = Bk.bias_grad(_sub(dzp, cout), torch.empty(cout, device=dev))
+    if cin >= 32:           # two-source form: the filter's input range filled by two calls
+        h = cin // 2
+        dw = torch.empty(cout, cin, k, k, device=dev)
+        Bk.wgrad(xp.slice(0, h), dzp.slice(0, cout), dw, k, ci_offset=0, zero_first=True)
+        Bk.wgrad(xp.slice(h, cin - h), dzp.slice(0, cout), dw, k, ci_offset=h, zero_first=False)
+    else:
+        dw = Bk.wgrad(xp, dzp.slice(0, cout), torch.empty(cout, cin, k, k, device=dev), k)
+    db = Bk.bias_grad(dzp.slice(0, cout), torch.empty(cout, device=dev))
     assert rel_err(dx.cpu(), x.grad) < 2e-4, "dX"
     assert rel_err(dw.cpu(), w.grad) < 2e-4, "dW"
     assert rel_err(db.cpu(), bias.grad) < 2e-4, "db"
-
-
-def _sub(planes, c):
-    """The first c channels of a Planes buffer as a Planes-like object (same storage, same batch stride)."""
-    from ssm_amd import hipbind as hb
-
-    class Sub:
-        pass
-    s = Sub()
-    s.B, s.C, s.H, s.W = planes.B, c, planes.H, planes.W
-    s.view = lambda c0=0, broadcast=False: planes.view(c0, broadcast)
-    return s
 
 
 def test_pool_adjoint_fused_in_lrelu_bwd(dev):
@@ -141,3 +135,89 @@ def test_synthesis_and_inputs_adjoints_with_losses(dev, s1_terms, s2_terms):
                                            hb.stream_ptr()))
     assert rel_err(dout5.cpu(), out5.grad) < 2e-4, "d out5"
     assert rel_err(dflow4.cpu(), flow4.grad) < 2e-4, "d flow4"
+
+
+def _oracle_training_loss(p1, p2, img6, t, target, lr, lw):
+    """The reference's total loss (losses.py:196-249 with FREEZE=FALSE, perceptual term off), batch mean of column 0."""
+    from oracle import ssm_oracle as O
+    c6, flow4 = O.stage1(p1, img6)
+    in16 = O.flow_interp_inputs(img6, flow4, t)
+    out5 = O.stage2(p2, in16, c6)
+    pred = O.synthesize(img6, in16, out5, t)
+    i0, i1 = img6[:, 0:3], img6[:, 3:6]
+    m = lambda z: z.flatten(1).mean(1)        # noqa: E731
+    ft1, ft0 = in16[:, 6:8] + out5[:, 1:3], in16[:, 8:10] + out5[:, 3:5]
+    warp = ((O.warp(i1, flow4[:, 0:2]) - i0).abs() + (O.warp(i0, flow4[:, 2:4]) - i1).abs()
+            + (O.warp(i0, ft0) - target).abs() + (O.warp(i1, ft1) - target).abs())
+    total = lr * m((pred - target).abs()) + lw * m(warp)
+    return total.mean(), pred
+
+
+def test_training_step_gradients_vs_oracle_autograd(dev):
+    """FullModel (FREEZE=FALSE) forward + `losses.mean(0)[0].backward()` on the HIP path: every one of the 96 parameter
+    gradients against CPU autograd of the oracle on the same 64x64 batch of 2."""
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    ov = synthetic_weight_overrides()
+    ov[("STAGE1", "FREEZE")] = "FALSE"
+    ov[("STAGE2", "FREEZE")] = "FALSE"
+    m = FullModel(load_config("superslomo_original.ini", ov))
+    sd1, sd2 = synthetic_state_dict(1), synthetic_state_dict(2)
+    m.stage1_model.load_state_dict(sd1)
+    m.stage2_model.load_state_dict(sd2)
+    m = m.to(dev).train()
+    clips = torch.cat([synthetic_frames(3, 64, 64, seed=70), synthetic_frames(3, 64, 64, seed=71)], 0)      # [2,3,3,64,64]
+    xin, tgt = clips[:, [0, 2]], clips[:, 1:2]
+    t = torch.tensor([0.5, 0.375]).view(2, 1, 1, 1, 1)
+    img, losses = m(xin.to(dev), t.to(dev), tgt.to(dev), None, False)
+    assert losses.requires_grad and not img.requires_grad
+    losses.mean(dim=0)[0].backward()
+    # oracle
+    p1 = {k: v.clone().requires_grad_() for k, v in sd1.items()}
+    p2 = {k: v.clone().requires_grad_() for k, v in sd2.items()}
+    img6 = torch.cat([xin[:, 0], xin[:, 1]], 1)
+    L, pred = _oracle_training_loss(p1, p2, img6, t.view(2, 1, 1, 1), tgt[:, 0], 60.0, 10.0)
+    L.backward()
+    assert float((img.cpu() - pred.detach()).abs().max()) < 1e-3
+    assert abs(float(losses.mean(0)[0]) - float(L)) < 1e-4 * abs(float(L))
+    worst = []
+    for stage, mod, ref in (("s1", m.stage1_model, p1), ("s2", m.stage2_model, p2)):
+        for name, p in mod.named_parameters():
+            assert p.grad is not None, name
+            g, w = p.grad.cpu().flatten(), ref[name].grad.flatten()
+            cos = float(torch.dot(g, w) / (g.norm() * w.norm() + 1e-30))
+            rel = float((g - w).abs().max() / (w.abs().max() + 1e-30))
+            worst.append((rel, cos, stage + "." + name))
+    worst.sort(reverse=True)
+    print("worst gradients (rel max err, cosine):", worst[:4])
+    assert all(c > 0.999 for _, c, _ in worst), worst[:4]
+    assert worst[0][0] < 2e-2, worst[:4]
+
+
+def test_training_step_with_adam_reduces_loss(dev):
+    """Three optimizer steps of the reference's recipe (Adam, scripts/main.py:255-257) on one batch lower the loss."""
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    ov = synthetic_weight_overrides()
+    ov[("STAGE1", "FREEZE")] = "FALSE"
+    ov[("STAGE2", "FREEZE")] = "FALSE"
+    m = FullModel(load_config("superslomo_original.ini", ov))
+    m.stage1_model.load_state_dict(synthetic_state_dict(1))
+    m.stage2_model.load_state_dict(synthetic_state_dict(2))
+    m = m.to(dev).train()
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=1e-4)
+    clips = torch.cat([synthetic_frames(3, 64, 96, seed=80), synthetic_frames(3, 64, 96, seed=81)], 0).to(dev)
+    xin, tgt = clips[:, [0, 2]], clips[:, 1:2]
+    t = torch.full((2, 1, 1, 1, 1), 0.5, device=dev)
+    hist = []
+    for _ in range(4):
+        _, losses = m(xin, t, tgt, None, False)
+        loss = losses.mean(dim=0)[0]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        hist.append(float(loss))
+    print("loss history:", hist)
+    assert hist[-1] < hist[0]
