@@ -59,6 +59,73 @@ def conv_flops_per_pair(h, w, n_t):
     return stage(1) + n_t * stage(2)
 
 
+def train_bench(args):
+    """BASELINE configs[2]: superslomo_original.ini training (FREEZE=FALSE), batch 16 = 2 samples per GPU x 8 of 352x352
+    crops, t = i/8 per sample; forward + hand-written backward + gradient all-reduce (RCCL) + Adam.  A step = one
+    batch of 2 samples per rank; value = samples/s over all ranks (weak scaling)."""
+    from ssm_amd import dist as sdist
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.engine import KernelTimer, UNetPlan
+    from ssm_amd.training import Trainer
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    from models.superslomo_r import FullModel
+
+    rank, local_rank, world = sdist.env_world()
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    sdist.init("nccl")
+    ov = synthetic_weight_overrides()
+    ov[("STAGE1", "FREEZE")] = "FALSE"          # documented override: the shipped ini freezes both stages
+    ov[("STAGE2", "FREEZE")] = "FALSE"
+    cfg = load_config("superslomo_original.ini", ov)
+    model = FullModel(cfg)
+    model.stage1_model.load_state_dict(synthetic_state_dict(1))
+    model.stage2_model.load_state_dict(synthetic_state_dict(2))
+    model = model.to(dev).train()
+    trainer = Trainer(model, cfg)
+    B, S = 2, 352
+    clips = torch.cat([synthetic_frames(3, S, S, seed=100 + 2 * rank + i) for i in range(B)], 0).to(dev)   # [B,3,3,S,S]
+    xin, tgt = clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous()
+    t = torch.tensor([(3 + i + rank) % 7 + 1 for i in range(B)], dtype=torch.float32, device=dev).view(B, 1, 1, 1, 1) / 8.0
+    ar = [0.0]
+
+    def step():
+        trainer.train_step(xin, tgt, t)
+        ar[0] += trainer.last_allreduce_s
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ar[0] = 0.0
+    elapsed = sdist.timed_steps(step, args.steps, 0, sync)
+    ar_ms = 1e3 * ar[0] / args.steps
+    timer = KernelTimer()
+    UNetPlan.timer = timer
+    for _ in range(3):
+        step()
+    sync()
+    UNetPlan.timer = None
+    out = {"metric": "training samples/sec (352x352 crops, forward+backward+Adam)", "value": round(B * world * args.steps / elapsed, 3),
+           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "superslomo_original.ini training, FREEZE=FALSE, %d samples/GPU of 352x352, %d GPU(s); "
+                                  "losses: L1 reconstruction + 4 L1 warp terms (VGG perceptual term unpinned, off)" % (B, world),
+                      "global_batch": B * world},
+           "allreduce": {"bytes": trainer.allreduce.bytes, "ms_per_step": round(ar_ms, 3)}}
+    if rank == 0:
+        summ = timer.summary()
+        out["time_split_ms_per_step"] = {fam: round(d["ms"] / 3, 3) for fam, d in summ.items()}
+        out["tflops"] = {fam: round(d["flops"] / d["ms"] / 1e9, 1) for fam, d in summ.items() if d["flops"] > 0}
+        print(json.dumps(out))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +135,9 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
                     help="conv arithmetic (default: models.superslomo_r.DEFAULT_PRECISION / $SSM_PRECISION)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer = the headline (BASELINE configs[1]); train = configs[2]: training step on 352x352 crops, "
+                         "2 samples per GPU, gradient all-reduce over RCCL")
     ap.add_argument("--size", default="720p", choices=["720p", "4k"],
                     help="720p = BASELINE configs[1] (the headline); 4k = configs[4] shape (3840x2160, use --precision f16)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (= frame pairs in flight) per GPU")
@@ -80,6 +150,8 @@ def main():
     from ssm_amd.weights import synthetic_frames, synthetic_state_dict
     from models.superslomo_r import FullModel
 
+    if args.mode == "train":
+        return train_bench(args)
     rank, local_rank, world = sdist.env_world()
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"

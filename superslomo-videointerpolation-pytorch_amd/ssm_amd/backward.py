@@ -107,7 +107,13 @@ class UNetGrad:
         dzp = self.dz[name]
         dz = dzp.slice(0, co)
         lrelu_bwd(dy, dpool, Y, dz, has_act=act)
+        from .engine import UNetPlan
+        tm = UNetPlan.timer
+        flops = 2.0 * self.B * Y.H * Y.W * co * ci * k * k
         if need_wgrad:
+            if tm is not None:
+                e0, e1 = tm.span("wgrad", "s%d.%s" % (plan.stage, name), flops)
+                e0.record()
             wk, bk = param_key(name, "weight"), param_key(name, "bias")
             if wk not in self.grads:
                 self.grads[wk] = torch.empty(co, ci, k, k, dtype=torch.float32, device=self.dev)
@@ -119,8 +125,15 @@ class UNetGrad:
                 off += X.C
             assert off == ci, "%s: inputs cover %d of %d channels" % (name, off, ci)
             bias_grad(dz, self.grads[bk])
+            if tm is not None:
+                e1.record()
         if dx is not None:
+            if tm is not None:
+                e0, e1 = tm.span("dgrad", "s%d.%s" % (plan.stage, name), flops)
+                e0.record()
             hb.conv2d(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
+            if tm is not None:
+                e1.record()
 
     def backward(self, d_out, need_wgrad=True, need_input_grad=False, cross_grad_out=None, c6_grad_init=None):
         """d_out: Planes with the gradient of final_conv's output (channels padded to the data-gradient chunk).

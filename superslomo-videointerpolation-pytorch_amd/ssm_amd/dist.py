@@ -91,3 +91,47 @@ def gather_frames(frames_by_index, n_pairs):
 
 def _dist_device():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+# ---- training: the one exchange step of the path -------------------------------------------------------
+class GradientAllReduce:
+    """Sum-then-average all-reduce of every trainable parameter's gradient in ONE flat fp32 buffer (38,848,553
+    floats = 155.4 MB for the two U-Nets) over RCCL/xGMI.  Replaces DataParallel's per-iteration parameter
+    broadcast + reduce_add + output gather (scripts/main.py:74-76).  One large collective per step suits xGMI's
+    point-to-point links better than many small buckets; the hand-written backward produces all gradients at the
+    end of the step anyway, so there is nothing to overlap with yet."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.bytes = 4 * n
+
+    def __call__(self):
+        """Average the gradients over the ranks (no-op when not distributed).  Returns seconds spent (host clock
+        around an explicitly synchronised region when on a GPU)."""
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return 0.0
+        cuda = self.flat.is_cuda
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=self.flat.device))
+            off += n
+        if cuda:
+            torch.cuda.synchronize(self.flat.device)
+        t0 = time.perf_counter()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if cuda:
+            torch.cuda.synchronize(self.flat.device)
+        el = time.perf_counter() - t0
+        self.flat.div_(dist.get_world_size())
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+        return el

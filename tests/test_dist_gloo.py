@@ -61,3 +61,29 @@ def test_single_process_defaults():
     assert sd.reduce_max(1.5) == 1.5
     out = sd.gather_frames({0: torch.zeros(1), 1: torch.ones(1)}, 2)
     assert len(out) == 2
+
+
+def _ar_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ssm_amd import dist as sd
+    sd.init("gloo")
+    g = torch.Generator().manual_seed(5)
+    params = [torch.nn.Parameter(torch.randn(7, 3, generator=g)), torch.nn.Parameter(torch.randn(11, generator=g)),
+              torch.nn.Parameter(torch.randn(2, generator=g), requires_grad=False)]
+    params[0].grad = torch.full((7, 3), float(rank + 1))
+    params[1].grad = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    ar = sd.GradientAllReduce(params)
+    ar()
+    ret[rank] = (params[0].grad.clone(), params[1].grad.clone(), ar.bytes)
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks():
+    """All-reduced gradients == mean of the per-rank gradients (the build's multi-GPU check)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ar_worker, args=(2, free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert torch.allclose(ret[r][0], torch.full((7, 3), 1.5))
+        assert torch.allclose(ret[r][1], torch.arange(11, dtype=torch.float32) * 1.5)
+        assert ret[r][2] == 4 * (21 + 11)
