@@ -121,6 +121,11 @@ def train_bench(args):
         summ = timer.summary()
         out["time_split_ms_per_step"] = {fam: round(d["ms"] / 3, 3) for fam, d in summ.items()}
         out["tflops"] = {fam: round(d["flops"] / d["ms"] / 1e9, 1) for fam, d in summ.items() if d["flops"] > 0}
+        if args.detail:
+            det = {fam: {n: {"ms_per_step": v[0] / 3, "tflops": (v[1] / v[0] / 1e9 if v[0] > 0 else 0.0)}
+                         for n, v in d["by_name"].items()} for fam, d in summ.items()}
+            with open(args.detail, "w") as f:
+                json.dump(det, f, indent=1)
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

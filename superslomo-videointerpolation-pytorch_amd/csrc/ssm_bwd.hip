@@ -6,7 +6,7 @@
 //
 //   lrelu_bwd       dZ = (dY + 1/4 dP[y/2][x/2]) * (Y > 0 ? 1 : slope)        LeakyReLU' and the fused 2x2-mean adjoint
 //   bias_grad       db[c] = sum_{b,y,x} dZ
-//   wgrad           dW[co][ci][ky][kx] = sum_{b,y,x} dZ[b,co,y,x] * X[b,ci,y+ky-p,x+kx-p]      (VALU, LDS-tiled)
+//   wgrad           dW[co][ci][ky][kx] = sum_{b,y,x} dZ[b,co,y,x] * X[b,ci,y+ky-p,x+kx-p]      (fp32 MFMA GEMM over pixels)
 //   upsample_cat_bwd  adjoint of cat + bilinear x2 (F.upsample align_corners=False, edge clamp folded in)
 //   synth_bwd       adjoint of extract_outputs + compute_output_image, fused with the gradients of the L1
 //                   reconstruction loss and of the two stage-2 warp-loss terms (losses.py:113-170,217)
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(ssm_view dy, ssm_view dp
 __global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__restrict__ db, int B, int H, int W) {
     const int c = blockIdx.x;
     float s = 0.f;
-    const int n = B * H * W;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int xx = i % W, r = i / W;
-        const int yy = r % H, bb = r / H;
-        s += vp(dz, bb, c, yy)[xx];
+    const int rows = B * H;
+    for (int r = blockIdx.y * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.y * 4) {       // one wave per image row
+        const int bb = r / H, yy = r - bb * H;
+        const float *row = vp(dz, bb, c, yy);
+        for (int xx = threadIdx.x & 63; xx < W; xx += 64) s += row[xx];
     }
     __shared__ float red[256];
     red[threadIdx.x] = s;
@@ -55,61 +55,103 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__re
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) db[c] = red[0];
+    if (threadIdx.x == 0) atomicAdd(db + c, red[0]);
 }
 
-// dW tile of 16 couts x 16 cins per workgroup (thread = one (co, ci) pair, all k*k taps in registers); the
-// workgroup walks image rows (b, y) strided by gridDim.z and adds its partial sums with fp32 atomics.
-template <int KS>
-__global__ __launch_bounds__(256) void wgrad_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout, int H,
-                                                    int W, int cin_total, int ci_offset) {
-    constexpr int PAD = (KS - 1) / 2, MAXW = 64;
-    __shared__ float sdz[16][MAXW + 1];
-    __shared__ float sx[16][KS][MAXW + 2 * PAD + 1];
-    const int tid = threadIdx.x;
-    const int tci = tid & 15, tco = tid >> 4;
-    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
-    float acc[KS][KS];
+// Weight gradient on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+//     dW[co][col] = sum_pixels dZ[co][p] * X[ci(col)][p + tap(col)],      col = ci*k*k + tap  (OIHW order)
+// GEMM with M = couts, N = (ci, tap) columns, K = pixels.  A operand = dZ (32 couts x 2 pixels) from an LDS tile
+// [co][pixel] with an odd row stride; B operand = 32 columns x 2 pixels: every lane owns one column and reads the
+// staged activation rows at a constant per-lane offset (its channel, filter row and filter column) plus the running
+// pixel index.  The accumulator has the column on the lane, so a register is 32 consecutive floats of one
+// filter row of dW.  A workgroup (4 waves) owns NTC*32 couts x 128 columns, walks image rows (b, y) strided by
+// gridDim.z in 64-pixel segments and adds its partial sums with fp32 atomics.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KS, int XC, int NTC>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
+                                                         int H, int W, int cin_total, int ci_offset) {
+    // CT column tiles per wave (256 columns per workgroup), RR image rows per staging: 4x the MFMA work per barrier
+    constexpr int KS2 = KS * KS, PAD = (KS - 1) / 2, SEG = 64, RR = 2, CT = 2;
+    constexpr int DS = RR * SEG + 1;                 // dZ tile row stride (odd: conflict-free across couts)
+    constexpr int XR = KS + RR - 1;                  // staged activation rows
+    constexpr int RS = SEG + 2 * PAD + 1;
+    __shared__ float sdz[NTC * 32 * DS];
+    __shared__ float sx[XC * XR * RS + 8];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = tid >> 6;
+    const int co0 = blockIdx.y * (NTC * 32);
+    const int colbase = blockIdx.x * (128 * CT);
+    const int ncols = Cin * KS2;
+    const int c_lo = colbase / KS2;                  // first input channel this workgroup touches
+    int colOff[CT], cci[CT], tap[CT];
+    bool cvalid[CT];
 #pragma unroll
-    for (int a = 0; a < KS; ++a)
+    for (int t = 0; t < CT; ++t) {
+        const int col = colbase + (wid * CT + t) * 32 + l31;      // this lane's (ci, tap) columns
+        cvalid[t] = col < ncols;
+        cci[t] = cvalid[t] ? col / KS2 : c_lo;
+        tap[t] = cvalid[t] ? col - cci[t] * KS2 : 0;
+        const int ky = tap[t] / KS, kx = tap[t] - ky * KS;
+        colOff[t] = ((cci[t] - c_lo) * XR + ky) * RS + kx + half;   // + row*RS + pixel = LDS address of this lane's B value
+    }
+    f32x16 acc[NTC][CT];
 #pragma unroll
-        for (int c = 0; c < KS; ++c) acc[a][c] = 0.f;
-    const int rows = B * H;
-    for (int r = blockIdx.z; r < rows; r += gridDim.z) {
-        const int b = r / H, y = r - b * H;
-        for (int xs = 0; xs < W; xs += MAXW) {
-            const int wseg = min(MAXW, W - xs);
+    for (int n = 0; n < NTC; ++n)
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][t][r] = 0.f;
+    const int rowpairs = B * ((H + RR - 1) / RR);
+    for (int rp = blockIdx.z; rp < rowpairs; rp += gridDim.z) {
+        const int b = rp / ((H + RR - 1) / RR), y = (rp - b * ((H + RR - 1) / RR)) * RR;
+        for (int xs = 0; xs < W; xs += SEG) {
+            const int wseg = min(SEG, W - xs);
             __syncthreads();
-            for (int i = tid; i < 16 * MAXW; i += 256) {
-                const int c = i / MAXW, xx = i - c * MAXW;
-                sdz[c][xx] = (co0 + c < Cout && xx < wseg) ? vp(dz, b, co0 + c, y)[xs + xx] : 0.f;
+            for (int i = tid; i < NTC * 32 * RR * SEG; i += 256) {
+                const int c = i / (RR * SEG), rem = i - c * (RR * SEG);
+                const int rr = rem / SEG, xx = rem - rr * SEG;
+                const bool ok = co0 + c < Cout && xx < wseg && y + rr < H;
+                sdz[c * DS + rr * SEG + xx] = ok ? vp(dz, b, co0 + c, y + rr)[xs + xx] : 0.f;     // zero tail: those products vanish
             }
-            // X rows y-PAD..y+PAD, columns xs-PAD .. xs+wseg+PAD-1: the padded-plane frame supplies the zeros
-            for (int i = tid; i < 16 * KS * (MAXW + 2 * PAD); i += 256) {
-                const int c = i / (KS * (MAXW + 2 * PAD));
-                const int rem = i - c * (KS * (MAXW + 2 * PAD));
-                const int ky = rem / (MAXW + 2 * PAD), xx = rem - ky * (MAXW + 2 * PAD);
-                float v = 0.f;
-                if (ci0 + c < Cin && xx < wseg + 2 * PAD) v = vp(x, b, ci0 + c, y + ky - PAD)[xs + xx - PAD];
-                sx[c][ky][xx] = v;
+            for (int i = tid; i < XC * XR * (SEG + 2 * PAD); i += 256) {
+                const int c = i / (XR * (SEG + 2 * PAD));
+                const int rem = i - c * (XR * (SEG + 2 * PAD));
+                const int ry = rem / (SEG + 2 * PAD), xx = rem - ry * (SEG + 2 * PAD);
+                float v = 0.f;      // rows / columns outside the image come from the padded-plane zero frame
+                if (c_lo + c < Cin && xx < wseg + 2 * PAD && y + ry - PAD < H + PAD) v = vp(x, b, c_lo + c, y + ry - PAD)[xs + xx - PAD];
+                sx[(c * XR + ry) * RS + xx] = v;
             }
             __syncthreads();
-            for (int xx = 0; xx < wseg; ++xx) {
-                const float g = sdz[tco][xx];
+            const int nsteps = (wseg + 1) >> 1;
 #pragma unroll
-                for (int ky = 0; ky < KS; ++ky)
+            for (int rr = 0; rr < RR; ++rr) {
+                for (int st = 0; st < nsteps; ++st) {
+                    const int pp = 2 * st;
+                    float bv[CT];
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) acc[ky][kx] += g * sx[tci][ky][xx + kx];
+                    for (int t = 0; t < CT; ++t) bv[t] = cvalid[t] ? sx[colOff[t] + rr * RS + pp] : 0.f;
+#pragma unroll
+                    for (int n = 0; n < NTC; ++n) {
+                        const float av = sdz[(n * 32 + l31) * DS + rr * SEG + pp + half];
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[n][t], 0, 0, 0);
+                    }
+                }
             }
         }
     }
-    if (co0 + tco < Cout && ci0 + tci < Cin) {
-        float *d = dw + ((long long)(co0 + tco) * cin_total + (ci_offset + ci0 + tci)) * (KS * KS);
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
+    for (int t = 0; t < CT; ++t)
+        if (cvalid[t]) {
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) atomicAdd(d + ky * KS + kx, acc[ky][kx]);
-    }
+            for (int n = 0; n < NTC; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + n * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < Cout) atomicAdd(dw + ((long long)co * cin_total + ci_offset + cci[t]) * KS2 + tap[t], acc[n][t][r]);
+                }
+        }
 }
 
 // adjoint of  U = upsample2x(cat[a, b])  (see upsample2x_cat_kernel): one thread per LOW-res pixel and channel
@@ -306,7 +348,15 @@ extern "C" int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view d
 
 extern "C" int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream) {
     SSM_REQUIRE(dz.ptr && db && B > 0 && C > 0 && H > 0 && W > 0, "bias_grad: bad arguments");
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dz, db, B, H, W);
+    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        ssm::set_error("bias_grad: memset failed: %s", hipGetErrorString(e));
+        return SSM_E_LAUNCH;
+    }
+    int chunks = (B * H + 63) / 64;          // ~16 rows per wave
+    if (chunks < 1) chunks = 1;
+    if (chunks > 1024) chunks = 1024;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, db, B, H, W);
     return ssm::check_launch("ssm_bias_grad");
 }
 
@@ -324,19 +374,29 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
             return SSM_E_LAUNCH;
         }
     }
-    const int tiles = ((Cin + 15) / 16) * ((Cout + 15) / 16);
-    int split = (2048 + tiles - 1) / tiles;          // aim for >= 2048 workgroups
-    const int rows = B * H;
+    const int ntc = Cout > 32 ? 2 : 1;
+    const int gx = (Cin * k * k + 255) / 256, gy = (Cout + ntc * 32 - 1) / (ntc * 32);
+    const int tiles = gx * gy;
+    int split = (1024 + tiles - 1) / tiles;          // aim for >= 1024 workgroups
+    const int rows = B * ((H + 1) / 2);
     if (split > rows) split = rows;
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
-    const dim3 grid((Cin + 15) / 16, (Cout + 15) / 16, split);
-    switch (k) {
-        case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total, ci_offset); break;
-        case 5: hipLaunchKernelGGL(wgrad_kernel<5>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total, ci_offset); break;
-        case 7: hipLaunchKernelGGL(wgrad_kernel<7>, grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total, ci_offset); break;
+    const dim3 grid(gx, gy, split);
+#define SSM_WGRAD(KS_, XC_)                                                                                                       \
+    if (ntc == 2)                                                                                                                 \
+        hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, 2>), grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total,  \
+                           ci_offset);                                                                                            \
+    else                                                                                                                          \
+        hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, 1>), grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total,  \
+                           ci_offset);
+    switch (k) {          // XC = input channels a 256-column workgroup can touch: ceil((256 + k*k - 1) / (k*k))
+        case 3: SSM_WGRAD(3, 30) break;
+        case 5: SSM_WGRAD(5, 12) break;
+        case 7: SSM_WGRAD(7, 7) break;
         default: ssm::set_error("wgrad: kernel size %d unsupported", k); return SSM_E_UNSUPPORTED;
     }
+#undef SSM_WGRAD
     return ssm::check_launch("ssm_conv2d_wgrad");
 }
 
