@@ -28,10 +28,17 @@ __device__ __forceinline__ float *vp(const ssm_view &v, int b, int c, int y) {
 
 inline dim3 pix_grid(int B, int H, int W) { return dim3((W + 63) / 64, (H + 3) / 4, B); }
 
+// channels are spread over blockIdx.z in groups of BWD_CPT so small maps with many channels still fill the chip
+#define BWD_CPT 4
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(ssm_view dy, ssm_view dpool, ssm_view yv, ssm_view dz, int C, int H, int W,
-                                                        float slope, int has_act) {
-    SSM_PIXEL_INDEX();
-    for (int c = 0; c < C; ++c) {
+                                                        float slope, int has_act, int cgroups) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / cgroups, cg = blockIdx.z - b * cgroups;
+    if (x >= W || y >= H) return;
+#pragma unroll
+    for (int i = 0; i < BWD_CPT; ++i) {
+        const int c = cg * BWD_CPT + i;
+        if (c >= C) break;
         float g = dy.ptr ? vp(dy, b, c, y)[x] : 0.f;
         if (dpool.ptr) g += 0.25f * vp(dpool, b, c, y >> 1)[x >> 1];
         if (has_act) g *= (vp(yv, b, c, y)[x] > 0.f) ? 1.0f : slope;
@@ -158,8 +165,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ssm_view x, ssm_view dz
 // gathers its 4x4 hi-res neighbourhood.  1-D weights of x[i] in U(Y): Y=2i: .75 (1 at i=0); Y=2i+1: .75 (1 at
 // i=h-1); Y=2i+2: .25 if i+1<h; Y=2i-1: .25 if i>0.
 __global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(ssm_view du, ssm_view da, int Ca, ssm_view dbv, int Cb, int H, int W,
-                                                               int acc_a, int acc_b) {
-    SSM_PIXEL_INDEX();          // H, W = LOW-res dims
+                                                               int acc_a, int acc_b, int cgroups) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;      // H, W = LOW-res dims
+    const int b = blockIdx.z / cgroups, cg = blockIdx.z - b * cgroups;
+    if (x >= W || y >= H) return;
     float wy[4], wx[4];
     wy[0] = y > 0 ? 0.25f : 0.f;
     wy[1] = y > 0 ? 0.75f : 1.0f;
@@ -170,7 +179,10 @@ __global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(ssm_view du, ssm_
     wx[2] = x < W - 1 ? 0.75f : 1.0f;
     wx[3] = x < W - 1 ? 0.25f : 0.f;
     const int C = Ca + Cb;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int ci = 0; ci < BWD_CPT; ++ci) {
+        const int c = cg * BWD_CPT + ci;
+        if (c >= C) break;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -342,7 +354,10 @@ extern "C" int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view d
                              int has_act, void *stream) {
     SSM_CHECK_DIMS("lrelu_bwd");
     SSM_REQUIRE(dz.ptr && (dy.ptr || dpool.ptr) && (!has_act || y.ptr) && C > 0, "lrelu_bwd: null pointer / C");
-    hipLaunchKernelGGL(lrelu_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act);
+    const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "lrelu_bwd: B*C too large for one launch");
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y,
+                       dz, C, H, W, slope, has_act, cgroups);
     return ssm::check_launch("ssm_lrelu_bwd");
 }
 
@@ -404,8 +419,10 @@ extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view
                                       void *stream) {
     SSM_CHECK_DIMS("upsample2x_cat_bwd");
     SSM_REQUIRE(du.ptr && da.ptr && Ca > 0 && Cb >= 0 && (Cb == 0 || db.ptr), "upsample2x_cat_bwd: null pointer / channels");
-    hipLaunchKernelGGL(upsample_cat_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, du, da, Ca, Cb ? db : da, Cb, H,
-                       W, acc_a, acc_b);
+    const int cgroups = (Ca + Cb + BWD_CPT - 1) / BWD_CPT;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "upsample2x_cat_bwd: B*C too large for one launch");
+    hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, du, da,
+                       Ca, Cb ? db : da, Cb, H, W, acc_a, acc_b, cgroups);
     return ssm::check_launch("ssm_upsample2x_cat_bwd");
 }
 
