@@ -213,6 +213,26 @@ int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view tar
 int ssm_flowinterp_inputs_bwd(ssm_view img6, ssm_view flow4, ssm_view din16, ssm_view dest4, const float *t, const float *c_warp,
                               ssm_view dflow4, int B, int H, int W, int stage1_terms, void *stream);
 
+/* ---- recurrent bottleneck (BOTTLENECK=CLSTM|CGRU; BASELINE config 4) -----------------------------------------
+ * Replaces ConvBLSTM / ConvBGRU(in_channels=512, hidden_channels=512, kernel_size=(3,3), num_layers=2,
+ * batch_first=True) as constructed at scripts/models/flow_computation.py:73-88 / flow_interpolation.py:73-88 and
+ * called at flow_computation.py:208-211 / flow_interpolation.py:284-287 (`conv6(x_fwd, x_rev)`).  Their source is
+ * an un-vendored submodule (.gitmodules:1-3, SreenivasVRao/ConvGRU-ConvLSTM-PyTorch, commit not recorded); the
+ * cells below restate that package's published equations - parity UNPINNED.
+ * The gate convolutions are ssm_conv2d_fwd / ssm_conv2d_hl8_fwd launches without activation: `gates_x` = the
+ * filter's input-channel part applied to x_t (+ bias; batched over the sequence), `gates_h` = its hidden-channel
+ * part applied to h_{t-1} (NULL view at the first step: h_0 = c_0 = 0).  All tensors [B,*,H,W]; Hc % 8 == 0.
+ * Outputs go to fp32 planes (h_f32) and/or an HL8 view (h_hl8), either may be a NULL view.
+ *  ssm_convlstm_cell_fwd   gates [i|f|o|g] (4*Hc ch): c' = s(f)*c + s(i)*tanh(g);  h' = s(o)*tanh(c')
+ *  ssm_convgru_reset_fwd   gates [gamma|beta] (2*Hc ch): rh = s(gamma) * h          (input of the candidate conv)
+ *  ssm_convgru_update_fwd  u = s(beta); h' = (1-u)*h + u*tanh(cand_x + cand_h)      (cand_* = Hc ch)            */
+int ssm_convlstm_cell_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view c_prev, ssm_view c_next, ssm_view h_f32,
+                          ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream);
+int ssm_convgru_reset_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view h_prev, ssm_view rh_f32, ssm_hview rh_hl8, int B,
+                          int Hc, int H, int W, void *stream);
+int ssm_convgru_update_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view cand_x, ssm_view cand_h, ssm_view h_prev,
+                           ssm_view h_f32, ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,8 +12,13 @@ repository root).  Parity is PINNED: `tests/golden/make_golden.py` imports the
 reference itself (in the build container) and commits its outputs as fixtures;
 `tests/test_oracle_golden.py` holds this file to those fixtures.
 
-Unpinned pieces (stated in DESIGN.md): ConvBLSTM/ConvBGRU bottleneck (source
-absent from the reference tree) and the pretrained-VGG perceptual loss.
+PARITY UNPINNED for one part (stated in DESIGN.md): the ConvBLSTM/ConvBGRU
+bottleneck (section "recurrent bottleneck" below).  Its source is an un-vendored
+submodule of the reference (.gitmodules:1-3 -> SreenivasVRao/ConvGRU-ConvLSTM-PyTorch,
+pinned commit not recorded, directory empty), so no golden vector of the
+reference can be produced for it; the section restates that package's published
+cell equations and is anchored on the reference's call sites only.  The
+pretrained-VGG perceptual loss is unpinned too (weights need the network).
 """
 
 import torch
@@ -221,6 +226,107 @@ def interpolate_pair(p1, p2, img6, ts, cross_skip=True, hoist=True):
         out5 = stage2(p2, in16, c6 if cross_skip else None)
         outs.append(synthesize(img6, in16, out5, t))
     return outs
+
+
+# --------------------------------------------------------------------------
+# recurrent bottleneck (BOTTLENECK = CLSTM | CGRU) - PARITY UNPINNED
+# --------------------------------------------------------------------------
+# Third-party arithmetic: `ConvBLSTM` / `ConvBGRU` of SreenivasVRao/ConvGRU-ConvLSTM-PyTorch, imported by the
+# reference as models.CLSTM.{convlstm,convgru} (flow_computation.py:7-8) from an empty submodule directory.
+# Anchors in the reference: constructor arguments (in_channels=512, hidden_channels=512, kernel_size=(3,3),
+# num_layers=2, batch_first=True; flow_computation.py:73-88), the call `conv6(x_fwd, x_rev)` with
+# x_rev = the time-reversed stack (:208-211) and the asserted result shape [B,T,512,h,w] (:313-314).
+# Published algorithm restated here:
+#   * ConvLSTM cell: one conv over cat[x, h] -> 4*hidden channels split in the order i, f, o, g;
+#     c' = sigmoid(f)*c + sigmoid(i)*tanh(g); h' = sigmoid(o)*tanh(c'); zero initial state.
+#   * ConvGRU cell: conv_gates over cat[x, h] -> 2*hidden split (gamma, beta): reset = sigmoid(gamma),
+#     update = sigmoid(beta); conv_can over cat[x, reset*h] -> tanh = candidate;
+#     h' = (1-update)*h + update*candidate.
+#   * Multi-layer: layer l consumes the full output sequence of layer l-1.
+#   * Bidirectional: two independent nets of hidden_channels//2 each; the reverse net runs on x_rev, its
+#     output sequence is flipped back in time and concatenated after the forward net's on the channel axis.
+#   * State-dict keys: conv6.{forward_net,reverse_net}.cell_list.<l>.conv.{weight,bias} (LSTM),
+#     ...cell_list.<l>.{conv_gates,conv_can}.{weight,bias} (GRU).
+def convlstm_cell(x, h, c, w, b):
+    hc = w.shape[0] // 4
+    z = conv2d(torch.cat([x, h], dim=1), w, b)
+    i, f, o, g = torch.split(z, hc, dim=1)
+    c_next = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    return torch.sigmoid(o) * torch.tanh(c_next), c_next
+
+
+def convgru_cell(x, h, wg, bg, wc, bc):
+    hc = wc.shape[0]
+    gamma, beta = torch.split(conv2d(torch.cat([x, h], dim=1), wg, bg), hc, dim=1)
+    reset, update = torch.sigmoid(gamma), torch.sigmoid(beta)
+    cand = torch.tanh(conv2d(torch.cat([x, reset * h], dim=1), wc, bc))
+    return (1 - update) * h + update * cand
+
+
+def _recurrent_net(p, prefix, kind, xs, num_layers=2):
+    """One direction: list of T [B,C,h,w] -> list of T outputs of the last layer."""
+    seq = xs
+    for l in range(num_layers):
+        cell = "%scell_list.%d." % (prefix, l)
+        if kind == "CLSTM":
+            w, b = p[cell + "conv.weight"], p[cell + "conv.bias"]
+            hc = w.shape[0] // 4
+        else:
+            wg, bg = p[cell + "conv_gates.weight"], p[cell + "conv_gates.bias"]
+            wc, bc = p[cell + "conv_can.weight"], p[cell + "conv_can.bias"]
+            hc = wc.shape[0]
+        B, _, hh, ww = seq[0].shape
+        h = torch.zeros(B, hc, hh, ww, dtype=seq[0].dtype)
+        c = torch.zeros_like(h)
+        outs = []
+        for x in seq:
+            if kind == "CLSTM":
+                h, c = convlstm_cell(x, h, c, w, b)
+            else:
+                h = convgru_cell(x, h, wg, bg, wc, bc)
+            outs.append(h)
+        seq = outs
+    return seq
+
+
+def unet_bottleneck_recurrent(p, kind, xs_fwd, xs_rev=None, prefix="conv6."):
+    """conv6(x_fwd, x_rev) of flow_computation.py:208-211: list of T pool6 tensors -> list of T [B,512,h,w]."""
+    assert kind in ("CLSTM", "CGRU")
+    xs_rev = list(xs_fwd[::-1]) if xs_rev is None else xs_rev
+    yf = _recurrent_net(p, prefix + "forward_net.", kind, list(xs_fwd))
+    yr = _recurrent_net(p, prefix + "reverse_net.", kind, list(xs_rev))[::-1]
+    return [torch.cat([a, b], dim=1) for a, b in zip(yf, yr)]
+
+
+def stage_forward(p, xs, bottleneck="CONV", cross=None):
+    """A stage model's forward on T windows (flow_computation.py:291-325 / flow_interpolation.py:296-336):
+    encoders, the bottleneck over the window sequence, decoders.  xs: list of T inputs; cross: list of T
+    stage-1 encodings or None.  Returns (list of conv6 outputs, list of final outputs)."""
+    encs = [unet_encoder(p, x) for x in xs]
+    if bottleneck == "CONV":
+        hs = [unet_bottleneck_conv(p, e[-1]) for e in encs]
+    else:
+        hs = unet_bottleneck_recurrent(p, bottleneck, [e[-1] for e in encs])
+    outs = [unet_decoder(p, h, e, cross=None if cross is None else cross[k]) for k, (h, e) in enumerate(zip(hs, encs))]
+    return hs, outs
+
+
+def full_model_infer_windows(p1, p2, image_tensor, t_interp, cross_skip=True, bottleneck="CONV"):
+    """FullModel.forward(inference_mode=True) for any N_FRAMES and bottleneck (superslomo_r.py:152-293):
+    stage 1 on all T windows, compute_inputs per window with t_interp[:, k], stage 2 on all windows, the middle
+    window's frame and intermediates returned.  Equals full_model_infer for BOTTLENECK=CONV."""
+    N = image_tensor.shape[1]
+    T = N - 1
+    mid = T // 2
+    pairs = [torch.cat([image_tensor[:, k], image_tensor[:, k + 1]], dim=1) for k in range(T)]
+    enc1, flows = stage_forward(p1, pairs, bottleneck)
+    in16 = [flow_interp_inputs(pairs[k], flows[k], t_interp[:, k]) for k in range(T)]
+    _, out5 = stage_forward(p2, in16, bottleneck, cross=enc1 if cross_skip else None)
+    k = mid
+    img_t = synthesize(pairs[k], in16[k], out5[k], t_interp[:, k])
+    v0 = 1 - torch.sigmoid(out5[k][:, 0:1])
+    return img_t, (flows[k][:, 0:2], flows[k][:, 2:4], in16[k][:, 6:8], in16[k][:, 8:10],
+                   in16[k][:, 6:8] + out5[k][:, 1:3], in16[k][:, 8:10] + out5[k][:, 3:5], v0)
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,137 @@
+// Pointwise halves of the recurrent bottleneck (BOTTLENECK=CLSTM|CGRU, reference call sites
+// scripts/models/flow_computation.py:73-88,208-211 / flow_interpolation.py:73-88,284-287).
+// The gate convolutions run on the MFMA conv kernels, split into an input part (batched over the whole
+// sequence) and a hidden-state part (one launch per step); these kernels add the two pre-activations,
+// apply the gates and write the new state - as fp32 planes and/or straight into the HL8 tensor the next
+// convolution reads.  One thread = one pixel x one 8-channel group.  The cell equations restate the
+// published ConvLSTM / ConvGRU cells of SreenivasVRao/ConvGRU-ConvLSTM-PyTorch (an un-vendored submodule of
+// the reference: parity UNPINNED).
+#include "ssm_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float *vp(const ssm_view &v, int b, int c, int y) {
+    return v.ptr + (long long)b * v.sb + (long long)c * v.sc + (long long)y * v.sh;
+}
+
+__device__ __forceinline__ void hl8_store(const ssm_hview &v, int b, int g, int y, int x, const float (&o)[8]) {
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (_Float16)o[e];
+        lo[e] = (_Float16)(o[e] - (float)hi[e]);
+    }
+    char *d = (char *)v.ptr + ((long long)b * v.sb + (long long)g * v.sg + (long long)y * v.sh + x) * 16;
+    *reinterpret_cast<h8 *>(d) = hi;
+    *reinterpret_cast<h8 *>(d + v.sp * 16) = lo;
+}
+
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+#define SSM_CELL_INDEX()                                      \
+    const int x = blockIdx.x * 64 + threadIdx.x;              \
+    const int y = blockIdx.y * 4 + threadIdx.y;               \
+    const int G = Hc >> 3;                                    \
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;     \
+    if (x >= W || y >= H) return;
+
+// ConvLSTM cell: pre-activations [i | f | o | g] (Hc channels each);
+//   c' = sigmoid(f) * c + sigmoid(i) * tanh(g);   h' = sigmoid(o) * tanh(c')
+__global__ __launch_bounds__(256) void convlstm_cell_kernel(ssm_view gx, ssm_view gh, ssm_view cprev, ssm_view cnext, ssm_view h32,
+                                                            ssm_hview h16, int Hc, int H, int W) {
+    SSM_CELL_INDEX();
+    float hv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        float pi = vp(gx, b, c, y)[x], pf = vp(gx, b, Hc + c, y)[x], po = vp(gx, b, 2 * Hc + c, y)[x], pg = vp(gx, b, 3 * Hc + c, y)[x];
+        if (gh.ptr) {
+            pi = pi + vp(gh, b, c, y)[x];
+            pf = pf + vp(gh, b, Hc + c, y)[x];
+            po = po + vp(gh, b, 2 * Hc + c, y)[x];
+            pg = pg + vp(gh, b, 3 * Hc + c, y)[x];
+        }
+        const float cp = cprev.ptr ? vp(cprev, b, c, y)[x] : 0.0f;
+        const float cn = sigm(pf) * cp + sigm(pi) * tanhf(pg);
+        vp(cnext, b, c, y)[x] = cn;
+        hv[e] = sigm(po) * tanhf(cn);
+        if (h32.ptr) vp(h32, b, c, y)[x] = hv[e];
+    }
+    if (h16.ptr) hl8_store(h16, b, g, y, x, hv);
+}
+
+// ConvGRU, first half: gates [gamma | beta]; reset = sigmoid(gamma); writes reset * h (input of the candidate conv).
+__global__ __launch_bounds__(256) void convgru_reset_kernel(ssm_view gx, ssm_view gh, ssm_view hprev, ssm_view rh32, ssm_hview rh16,
+                                                            int Hc, int H, int W) {
+    SSM_CELL_INDEX();
+    float rv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float pr = vp(gx, b, c, y)[x] + vp(gh, b, c, y)[x];
+        rv[e] = sigm(pr) * vp(hprev, b, c, y)[x];
+        if (rh32.ptr) vp(rh32, b, c, y)[x] = rv[e];
+    }
+    if (rh16.ptr) hl8_store(rh16, b, g, y, x, rv);
+}
+
+// ConvGRU, second half: update = sigmoid(beta); h' = (1 - update) * h + update * tanh(candidate pre-activation).
+__global__ __launch_bounds__(256) void convgru_update_kernel(ssm_view gx, ssm_view gh, ssm_view cx, ssm_view ch, ssm_view hprev,
+                                                             ssm_view h32, ssm_hview h16, int Hc, int H, int W) {
+    SSM_CELL_INDEX();
+    float hv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        float pu = vp(gx, b, Hc + c, y)[x], pc = vp(cx, b, c, y)[x];
+        if (gh.ptr) pu = pu + vp(gh, b, Hc + c, y)[x];
+        if (ch.ptr) pc = pc + vp(ch, b, c, y)[x];
+        const float u = sigm(pu);
+        const float hp = hprev.ptr ? vp(hprev, b, c, y)[x] : 0.0f;
+        hv[e] = (1.0f - u) * hp + u * tanhf(pc);
+        if (h32.ptr) vp(h32, b, c, y)[x] = hv[e];
+    }
+    if (h16.ptr) hl8_store(h16, b, g, y, x, hv);
+}
+
+inline dim3 cell_grid(int B, int Hc, int H, int W) { return dim3((W + 63) / 64, (H + 3) / 4, B * (Hc / 8)); }
+
+}  // namespace
+
+#define SSM_CELL_DIMS(what)                                                                                          \
+    SSM_REQUIRE(B > 0 && Hc > 0 && Hc % 8 == 0 && H > 0 && W > 0, what ": bad sizes (hidden channels must be a multiple of 8)"); \
+    SSM_REQUIRE((long long)B * (Hc / 8) <= 65535, what ": B*Hc too large for one launch")
+
+extern "C" int ssm_convlstm_cell_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view c_prev, ssm_view c_next, ssm_view h_f32,
+                                     ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream) {
+    SSM_CELL_DIMS("convlstm_cell");
+    SSM_REQUIRE(gates_x.ptr && c_next.ptr && (h_f32.ptr || h_hl8.ptr), "convlstm_cell: null pointer");
+    SSM_REQUIRE(!h_hl8.ptr || ssm::aligned16(h_hl8.ptr), "convlstm_cell: HL8 output must be 16-byte aligned");
+    hipLaunchKernelGGL(convlstm_cell_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, c_prev,
+                       c_next, h_f32, h_hl8, Hc, H, W);
+    return ssm::check_launch("ssm_convlstm_cell_fwd");
+}
+
+extern "C" int ssm_convgru_reset_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view h_prev, ssm_view rh_f32, ssm_hview rh_hl8, int B,
+                                     int Hc, int H, int W, void *stream) {
+    SSM_CELL_DIMS("convgru_reset");
+    SSM_REQUIRE(gates_x.ptr && gates_h.ptr && h_prev.ptr && (rh_f32.ptr || rh_hl8.ptr), "convgru_reset: null pointer");
+    SSM_REQUIRE(!rh_hl8.ptr || ssm::aligned16(rh_hl8.ptr), "convgru_reset: HL8 output must be 16-byte aligned");
+    hipLaunchKernelGGL(convgru_reset_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, h_prev,
+                       rh_f32, rh_hl8, Hc, H, W);
+    return ssm::check_launch("ssm_convgru_reset_fwd");
+}
+
+extern "C" int ssm_convgru_update_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view cand_x, ssm_view cand_h, ssm_view h_prev,
+                                      ssm_view h_f32, ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream) {
+    SSM_CELL_DIMS("convgru_update");
+    SSM_REQUIRE(gates_x.ptr && cand_x.ptr && (h_f32.ptr || h_hl8.ptr), "convgru_update: null pointer");
+    SSM_REQUIRE((gates_h.ptr != nullptr) == (h_prev.ptr != nullptr) && (cand_h.ptr != nullptr) == (h_prev.ptr != nullptr),
+                "convgru_update: hidden-state inputs must be all present or all absent (first step)");
+    SSM_REQUIRE(!h_hl8.ptr || ssm::aligned16(h_hl8.ptr), "convgru_update: HL8 output must be 16-byte aligned");
+    hipLaunchKernelGGL(convgru_update_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, cand_x,
+                       cand_h, h_prev, h_f32, h_hl8, Hc, H, W);
+    return ssm::check_launch("ssm_convgru_update_fwd");
+}

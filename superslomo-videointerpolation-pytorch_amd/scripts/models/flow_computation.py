@@ -18,6 +18,9 @@ class FlowComputationModel(StageUNet):
         """unet_in [B,T,6,H,W] -> list of T tuples (conv6_out or None, flow [B,4,H,W])."""
         assert len(unet_in.shape) == 5, "Tensor not of shape: B T C H W"
         decodings = []
+        if self.bottleneck_type != "CONV":
+            encs, flows = self._run_planned_windows(unet_in)
+            return [(e if self.cross_skip_connect else None, f) for e, f in zip(encs, flows)]
         for t in range(unet_in.shape[1]):
             enc, flow = self._run_planned(unet_in[:, t, ...])
             decodings.append((enc if self.cross_skip_connect else None, flow))

@@ -35,6 +35,8 @@ class FlowInterpolationModel(StageUNet):
         """unet_in [B,T,16,H,W], stage1_encoder_output list of T [B,512,H/32,W/32] -> list of T [B,5,H,W]."""
         assert len(unet_in.shape) == 5, "Tensor not of shape: B T C H W"
         decodings = []
+        if self.bottleneck_type != "CONV":
+            return self._run_planned_windows(unet_in, stage1_encoder_output if self.cross_skip_connect else None)[1]
         for t in range(unet_in.shape[1]):
             cross = stage1_encoder_output[t] if self.cross_skip_connect else None
             decodings.append(self._run_planned(unet_in[:, t, ...], cross)[1])

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from ssm_amd import hipbind as hb
-from ssm_amd.engine import PairEngine
+from ssm_amd.engine import PairEngine, WindowEngine
 
 # Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f16x3" evaluates every fp32
 # product as three fp16 MFMAs on hi/lo-split operands with fp32 accumulation (fp32-grade results, held to the
@@ -97,6 +97,8 @@ class FullModel(nn.Module):
         log.info("STAGE 2 %s", self.cfg.get("STAGE2", "ENCODER"))
         self.stage2_model = unet.get_model(stage2_weights, 16, 5, self.cross_skip, stage=2, cfg=self.cfg)
         log.info("Cross stage Skip Connections Present? %s ", self.cross_skip)
+        self.bottlenecks = (self.cfg.get("STAGE1", "BOTTLENECK"), self.cfg.get("STAGE2", "BOTTLENECK"))
+        self.recurrent = any(b != "CONV" for b in self.bottlenecks)      # windows coupled through conv6 (config 4)
 
     def freeze_weights(self):
         for name, model in (("STAGE1", self.stage1_model), ("STAGE2", self.stage2_model)):
@@ -127,6 +129,30 @@ class FullModel(nn.Module):
             self._engine = None      # free the old plan's activations before allocating the new one
             self._engine = (key, PairEngine(sd1, sd2, B1, B2, H, W, device, self.cross_skip, mode))
         return self._engine[1]
+
+    def window_engine_for(self, T, S1, S2, H, W, device, decode_all=False):
+        mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)
+        key = ("win", T, S1, S2, H, W, str(device), mode, decode_all, self._stamp())
+        if self._engine is None or self._engine[0] != key:
+            sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
+            sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
+            self._engine = None
+            self._engine = (key, WindowEngine(sd1, sd2, T, S1, S2, H, W, device, self.cross_skip, mode, self.bottlenecks,
+                                              decode_all))
+        return self._engine[1]
+
+    @torch.no_grad()
+    def interpolate_windows(self, frames, t_values):
+        """One clip [1,N,3,H,W] of N = N_FRAMES frames -> [len(t_values),3,H,W]: the frames between the two middle
+        inputs at every t (the per-t loop of evaluate_interpolation_results.py:234-242 for the recurrent
+        configuration), stage 1 once per clip, the t values batched through stage 2."""
+        hb.require_device(frames, "frame window")
+        assert frames.dim() == 5 and frames.shape[0] == 1, "interpolate_windows() takes one clip [1,N,3,H,W]"
+        T = frames.shape[1] - 1
+        t = torch.as_tensor(t_values, dtype=torch.float32, device=frames.device).reshape(-1)
+        assert bool((t > 0).all() and (t < 1).all()), "Interpolation values out of bounds."
+        eng = self.window_engine_for(T, 1, t.numel(), frames.shape[3], frames.shape[4], frames.device)
+        return eng.run(frames.contiguous(), t[:, None].expand(-1, T), want_aux=False).clone()
 
     @torch.no_grad()
     def interpolate(self, image_pair, t_values):
@@ -184,14 +210,26 @@ class FullModel(nn.Module):
         image_pairs = self.get_image_pairs(image_tensor)
         B, T = image_pairs.shape[:2]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if T != 1:
-                raise NotImplementedError("the HIP backward covers N_FRAMES=2 (one interpolation window); N_FRAMES=%d "
-                                          "belongs to the recurrent configuration" % (T + 1))
+            if T != 1 or self.recurrent:
+                raise NotImplementedError("the HIP backward covers N_FRAMES=2 with the CONV bottleneck (one interpolation "
+                                          "window); N_FRAMES=%d / BOTTLENECK=%s is forward-only" % (T + 1, self.bottlenecks))
             params = list(self.stage1_model.parameters()) + list(self.stage2_model.parameters())
             return _TrainStep.apply(self, image_pairs[:, 0].contiguous(), t_interp[:, 0].reshape(B).to(torch.float32),
                                     target_images[:, 0].contiguous(), *params)
         losses = torch.zeros(B, 4, device=image_tensor.device)
         est_img_t = None
+        if self.recurrent:
+            with torch.no_grad():
+                H, W = image_tensor.shape[-2:]
+                eng = self.window_engine_for(T, B, B, H, W, image_tensor.device, decode_all=True)
+                preds = eng.run(image_tensor.contiguous(), t_interp.reshape(B, T), want_aux=True)
+                for k in range(T):
+                    f01, f10, e1, e0, _, _, _ = eng.intermediates(k)
+                    sl = slice(k * B, (k + 1) * B)
+                    losses = losses + self.loss.losses_from_parts(eng.img6[sl], torch.cat([f01, f10], 1), e1, e0,
+                                                                  eng.s2.t["out"].interior[sl], preds[sl], target_images[:, k])
+                est_img_t = preds[(T // 2) * B:(T // 2 + 1) * B].clone()
+            return est_img_t, losses / T
         with torch.no_grad():
             for k in range(T):
                 img6 = image_pairs[:, k].contiguous()
@@ -217,6 +255,13 @@ class FullModel(nn.Module):
         mid_idx = T // 2
         if iteration == 1:
             log.info("%s interpolation windows. Mid_idx: %s", T, mid_idx)
+        if self.recurrent:      # windows coupled through conv6: all T encoded, the middle one decoded
+            with torch.no_grad():
+                H, W = image_tensor.shape[-2:]
+                eng = self.window_engine_for(T, B, B, H, W, image_tensor.device)
+                est_img_t = eng.run(image_tensor.contiguous(), t_interp.reshape(B, T), want_aux=True).clone()
+                outputs = tuple(x.clone() for x in eng.intermediates())
+            return est_img_t, outputs
         # CONV bottleneck: windows are independent and only the middle one is returned
         # (superslomo_r.py:237-238), so only that window is computed.
         with torch.no_grad():

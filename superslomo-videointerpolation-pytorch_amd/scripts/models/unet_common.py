@@ -17,6 +17,8 @@ import torch.nn as nn
 from ssm_amd import hipbind as hb
 from ssm_amd.engine import UNetPlan
 
+from .CLSTM.convgru import ConvBGRU
+from .CLSTM.convlstm import ConvBLSTM
 from .layers import HipConv2d, avg_pool, conv, upsample2x_cat
 
 log = logging.getLogger(__name__)
@@ -60,10 +62,8 @@ class StageUNet(nn.Module):
         if self.bottleneck_type == "CONV":
             self.conv6 = nn.Sequential(conv(512, 512, kernel_size=3), conv(512, 512, kernel_size=3))
         elif self.bottleneck_type in ("CLSTM", "CGRU"):
-            raise NotImplementedError(
-                "BOTTLENECK=%s needs ConvBLSTM/ConvBGRU from the un-vendored submodule scripts/models/CLSTM "
-                "(.gitmodules:1-3); its source is absent from the reference tree, so its arithmetic cannot be "
-                "pinned - not built (DESIGN.md, 'out of scope')." % self.bottleneck_type)
+            cls = ConvBLSTM if self.bottleneck_type == "CLSTM" else ConvBGRU
+            self.conv6 = cls(in_channels=512, hidden_channels=512, kernel_size=(3, 3), num_layers=2, batch_first=True)
         else:
             raise Exception("Unknown bottleneck type: %s" % self.bottleneck_type)
         self.upsample7 = self.upsample8 = self.upsample9 = self.upsample10 = self.upsample11 = upsample2x_cat
@@ -92,6 +92,10 @@ class StageUNet(nn.Module):
         return c1, c2, c3, c4, c5, self.pool6(c5)
 
     def bottleneck(self, tensor_list):
+        if self.bottleneck_type in ("CLSTM", "CGRU"):
+            x_fwd = torch.stack(tensor_list, dim=1)
+            x_rev = torch.stack(tensor_list[::-1], dim=1)
+            return self.conv6(x_fwd, x_rev)
         return torch.stack([self.conv6(x) for x in tensor_list], dim=1)
 
     def _decode(self, conv6_out, encoder_outputs, cross=None):
@@ -108,15 +112,32 @@ class StageUNet(nn.Module):
     def _stamp(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def plan_for(self, B, H, W, device):
-        key = (B, H, W, str(device))
+    def plan_for(self, B, H, W, device, seq_len=1):
+        key = (B, H, W, str(device), seq_len)
         stamp = self._stamp()
         hit = self._plans.get(key)
         if hit is None or hit[0] != stamp:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            hit = (stamp, UNetPlan(self.STAGE, sd, B, H, W, device, self.cross_skip_connect))
+            hit = (stamp, UNetPlan(self.STAGE, sd, B, H, W, device, self.cross_skip_connect,
+                                   bottleneck=self.bottleneck_type, seq_len=seq_len))
             self._plans = {key: hit}          # one live plan per module: activations are large
         return hit[1]
+
+    def _run_planned_windows(self, unet_in, cross_list=None):
+        """unet_in [B,T,C,H,W] -> (list of T conv6 outputs, list of T final outputs), windows coupled by the
+        recurrent bottleneck: all T windows go through one plan as a time-major batch."""
+        hb.require_device(unet_in, "U-Net input")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the recurrent bottleneck has no HIP backward; use torch.no_grad() or FREEZE=TRUE")
+        B, T, C, H, W = unet_in.shape
+        plan = self.plan_for(T * B, H, W, unet_in.device, seq_len=T)
+        plan.t["in"].load(unet_in.transpose(0, 1).reshape(T * B, C, H, W))
+        cross_planes = None
+        if plan.cross:
+            cross_planes = hb.Planes(T * B, 512, H // 32, W // 32, unet_in.device).load(torch.cat(list(cross_list), dim=0))
+        out = plan.run(cross_planes=cross_planes).to_nchw()
+        c6 = plan.t["c6"].to_nchw()
+        return list(c6.reshape(T, B, *c6.shape[1:]).unbind(0)), list(out.reshape(T, B, *out.shape[1:]).unbind(0))
 
     def _run_planned(self, x, cross=None):
         """x [B,C,H,W] -> (conv6_out [B,512,H/32,W/32], final [B,Cout,H,W]) as fresh NCHW tensors."""

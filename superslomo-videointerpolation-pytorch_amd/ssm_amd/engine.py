@@ -17,7 +17,7 @@ scripts/evaluate_interpolation_results.py:234-242 - same numbers, fewer FLOPs).
 import torch
 
 from . import hipbind as hb
-from .weights import param_key, unet_layers
+from .weights import RECURRENT_HIDDEN, RECURRENT_LAYERS, param_key, recurrent_convs, unet_layers
 
 
 class KernelTimer:
@@ -70,8 +70,23 @@ def layer_scale(name):
 class UNetPlan:
     timer = None     # a KernelTimer, or None
 
-    def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True):
+    DECODER = ("conv7a", "conv7b", "conv8a", "conv8b", "conv9a", "conv9b", "conv10a", "conv10b", "conv11a", "conv11b",
+               "fuse_conv", "final_conv")
+    ENCODER_T = ("c1", "c2", "c3", "c4", "c5", "c6")      # encoder-batch tensors the decoder reads
+
+    def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True,
+                 bottleneck="CONV", seq_len=1, dec=None):
+        """B = encoder batch.  With a recurrent bottleneck the batch holds `seq_len` windows of B/seq_len
+        sequences in time-major order (index = window * S + sequence).  dec = (b0, Bd): the decoder runs on
+        encoder batch entries [b0, b0+Bd) only (inference returns the middle window); None = all."""
         assert mode in MODES, "precision mode must be one of %s" % (MODES,)
+        assert bottleneck in ("CONV", "CLSTM", "CGRU"), "Unknown bottleneck type: %s" % bottleneck
+        assert B % seq_len == 0
+        self.bottleneck = bottleneck
+        self.dec_b0, self.Bd = dec if dec is not None else (0, B)
+        assert 0 <= self.dec_b0 and self.dec_b0 + self.Bd <= B
+        self._b0 = 0            # batch offset applied to ENCODER_T views (set while the decoder runs)
+        self._Bcur = B
         self.mode, self.hl8 = mode, mode != "f32"
         self.fuse_up = bool(fuse_upsample) and self.hl8      # concat+upsample fused into the consumer conv's loader
         if H % 32 or W % 32:
@@ -79,21 +94,19 @@ class UNetPlan:
                                  "and concatenates skips (unchecked in the reference, fails in torch.cat)" % (H, W))
         self.stage, self.B, self.H, self.W, self.device = stage, B, H, W, device
         self.cross = bool(cross_skip) and stage == 2
-        self.layers = {n: (ci, co, k) for n, ci, co, k in unet_layers(stage, cross_skip)}
+        self.layers = {n: (ci, co, k) for n, ci, co, k in unet_layers(stage, cross_skip, bottleneck)}
         self.pk = {}
-        for name, (ci, co, k) in self.layers.items():
-            w = state_dict[param_key(name, "weight")].to(device=device, dtype=torch.float32)
-            b = state_dict[param_key(name, "bias")].to(device=device, dtype=torch.float32)
-            assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
-            s = layer_scale(name)
-            if self.hl8:
-                self.pk[name] = hb.PackedConv16(w, b, W // s)
-            else:
-                self.pk[name] = hb.PackedConv(w, b, B, H // s, W // s, pool=name in POOLED)
+        self.refresh_weights(state_dict, check_shapes=True)
+        self.rnn = None
+        if bottleneck != "CONV":
+            self.rnn = RecurrentBottleneck(bottleneck, state_dict, B // seq_len, seq_len, H // 32, W // 32, device, mode)
+        Bd = self.Bd
         if self.hl8:
             P = lambda c, s: hb.HPlanes(B, c, H // s, W // s, device)  # noqa: E731
+            D = lambda c, s: hb.HPlanes(Bd, c, H // s, W // s, device)  # noqa: E731
         else:
             P = lambda c, s: hb.Planes(B, c, H // s, W // s, device)  # noqa: E731
+            D = lambda c, s: hb.Planes(Bd, c, H // s, W // s, device)  # noqa: E731
         cin0 = self.layers["conv1a"][0]
         cfin = self.layers["final_conv"][1]
         t = self.t = {}
@@ -103,28 +116,41 @@ class UNetPlan:
         t["t3a"], t["c3"], t["p4"] = P(128, 4), P(128, 4), P(128, 8)
         t["t4a"], t["c4"], t["p5"] = P(256, 8), P(256, 8), P(256, 16)
         t["t5a"], t["c5"], t["p6"] = P(512, 16), P(512, 16), P(512, 32)
-        t["t6a"], t["c6"] = P(512, 32), P(512, 32)
+        t["c6"] = P(512, 32)
+        if bottleneck == "CONV":
+            t["t6a"] = P(512, 32)
         if not self.fuse_up:        # materialised concat+upsample tensors (the largest activations of the net)
-            t["u7"] = P(1024 if self.cross else 512, 16)
-            t["u8"], t["u9"], t["u10"], t["u11"] = P(1024, 8), P(512, 4), P(256, 2), P(128, 1)
-        t["t7a"], t["c7"] = P(512, 16), P(512, 16)
-        t["t8a"], t["c8"] = P(256, 8), P(256, 8)
-        t["t9a"], t["c9"] = P(128, 4), P(128, 4)
-        t["t10a"], t["c10"] = P(64, 2), P(64, 2)
-        t["t11a"], t["c11"] = P(32, 1), P(32, 1)
-        t["tf"] = P(32, 1)
-        t["out"] = hb.Planes(B, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
+            t["u7"] = D(1024 if self.cross else 512, 16)
+            t["u8"], t["u9"], t["u10"], t["u11"] = D(1024, 8), D(512, 4), D(256, 2), D(128, 1)
+        t["t7a"], t["c7"] = D(512, 16), D(512, 16)
+        t["t8a"], t["c8"] = D(256, 8), D(256, 8)
+        t["t9a"], t["c9"] = D(128, 4), D(128, 4)
+        t["t10a"], t["c10"] = D(64, 2), D(64, 2)
+        t["t11a"], t["c11"] = D(32, 1), D(32, 1)
+        t["tf"] = D(32, 1)
+        t["out"] = hb.Planes(Bd, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
 
-    def refresh_weights(self, state_dict):
-        """Repack every filter from `state_dict` (training: the parameters change each optimizer step)."""
+    def refresh_weights(self, state_dict, check_shapes=False):
+        """(Re)pack every filter from `state_dict` (training: the parameters change each optimizer step)."""
         for name, (ci, co, k) in self.layers.items():
             w = state_dict[param_key(name, "weight")].to(device=self.device, dtype=torch.float32)
             b = state_dict[param_key(name, "bias")].to(device=self.device, dtype=torch.float32)
+            if check_shapes:
+                assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
             s = layer_scale(name)
             if self.hl8:
                 self.pk[name] = hb.PackedConv16(w, b, self.W // s)
             else:
-                self.pk[name] = hb.PackedConv(w, b, self.B, self.H // s, self.W // s, pool=name in POOLED)
+                nb = self.Bd if name in self.DECODER else self.B
+                self.pk[name] = hb.PackedConv(w, b, nb, self.H // s, self.W // s, pool=name in POOLED)
+        if getattr(self, "rnn", None) is not None:
+            self.rnn.refresh_weights(state_dict)
+
+    def _v(self, name, **kw):
+        """View of a plan tensor; encoder-batch tensors are offset to the decoder's slice while it runs."""
+        if self._b0 and name in self.ENCODER_T:
+            kw["b0"] = self._b0
+        return self.t[name].view(**kw)
 
     def _conv(self, name, src, dst, pool=None, src2=None, lrelu=True):
         pk = self.pk[name]
@@ -133,60 +159,77 @@ class UNetPlan:
         c2 = self.t[src2].C if src2 else 0
         tm = self.timer
         if tm is not None:
-            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self.B * s.H * s.W * pk.cout * pk.cin * pk.k * pk.k)
+            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * s.H * s.W * pk.cout * pk.cin * pk.k * pk.k)
             e0.record()
+        v = self._v
         if self.hl8:
             final = name == "final_conv"
-            hb.conv2d_hl8(s.view(), s.G * 8, self.t[src2].view() if src2 else None, c2, pk, None if final else d.view(),
-                          d.view() if final else None, self.t[pool].view() if pool else None, self.B, s.H, s.W,
+            hb.conv2d_hl8(v(src), s.G * 8, v(src2) if src2 else None, c2, pk, None if final else v(dst),
+                          v(dst) if final else None, v(pool) if pool else None, self._Bcur, s.H, s.W,
                           lrelu=lrelu, fast=self.mode == "f16")
         else:
-            hb.conv2d(s.view(), s.C, self.t[src2].view() if src2 else None, c2, pk, d.view(),
-                      self.t[pool].view() if pool else None, self.B, s.H, s.W, lrelu=lrelu)
+            hb.conv2d(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst),
+                      v(pool) if pool else None, self._Bcur, s.H, s.W, lrelu=lrelu)
         if tm is not None:
             e1.record()
 
-    def _up_conv(self, name, a, b, u, dst, b_planes=None, b_broadcast=False):
+    def _bview(self, b, b_planes, b_broadcast, b_b0):
+        """View of the second concat source: a plan tensor, or foreign planes (stage-1 encoding) at batch b_b0."""
+        if b_planes is not None:
+            return b_planes, b_planes.view(broadcast=b_broadcast, b0=b_b0)
+        if b:
+            return self.t[b], self._v(b)
+        return None, None
+
+    def _up_conv(self, name, a, b, u, dst, b_planes=None, b_broadcast=False, b_b0=0):
         """dst = conv(name)( upsample2x(cat[a, b]) ): fused in one kernel, or via the materialised tensor `u`."""
         if not self.fuse_up:
-            self._up(a, b, u, b_planes=b_planes, b_broadcast=b_broadcast)
+            self._up(a, b, u, b_planes=b_planes, b_broadcast=b_broadcast, b_b0=b_b0)
             return self._conv(name, u, dst)
         pk = self.pk[name]
         A = self.t[a]
-        Bp = b_planes if b_planes is not None else (self.t[b] if b else None)
+        Bp, bview = self._bview(b, b_planes, b_broadcast, b_b0)
         d = self.t[dst]
         tm = self.timer
         if tm is not None:
-            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self.B * d.H * d.W * pk.cout * pk.cin * 9)
+            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * d.H * d.W * pk.cout * pk.cin * 9)
             e0.record()
-        hb.conv2d_ups_hl8(A.view(), A.G * 8, Bp.view(broadcast=b_broadcast) if Bp else None, Bp.G * 8 if Bp else 0, pk,
-                          d.view(), None, self.B, d.H, d.W, lrelu=True, fast=self.mode == "f16")
+        hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
+                          d.view(), None, self._Bcur, d.H, d.W, lrelu=True, fast=self.mode == "f16")
         if tm is not None:
             e1.record()
 
-    def _up(self, a, b, dst, b_planes=None, b_broadcast=False):
+    def _up(self, a, b, dst, b_planes=None, b_broadcast=False, b_b0=0):
         lib = hb.load()
         A = self.t[a]
-        Bp = b_planes if b_planes is not None else (self.t[b] if b else None)
+        Bp, bview = self._bview(b, b_planes, b_broadcast, b_b0)
         tm = self.timer
         if tm is not None:   # algorithmic bytes: read the sources once, write 4x as many pixels
             e0, e1 = tm.span("upsample_cat", "s%d.%s" % (self.stage, dst),
-                             nbytes=4.0 * self.B * A.H * A.W * (A.C + (Bp.C if Bp else 0)) * 5)
+                             nbytes=4.0 * self._Bcur * A.H * A.W * (A.C + (Bp.C if Bp else 0)) * 5)
             e0.record()
         if self.hl8:
-            hb.check(lib.ssm_upsample2x_cat_hl8_fwd(A.view(), A.G, Bp.view(broadcast=b_broadcast) if Bp else hb.NULL_HVIEW,
-                                                    Bp.G if Bp else 0, self.t[dst].view(), self.B, A.H, A.W,
+            hb.check(lib.ssm_upsample2x_cat_hl8_fwd(self._v(a), A.G, bview if Bp else hb.NULL_HVIEW,
+                                                    Bp.G if Bp else 0, self.t[dst].view(), self._Bcur, A.H, A.W,
                                                     hb.stream_ptr()))
         else:
-            hb.check(lib.ssm_upsample2x_cat_fwd(A.view(), A.C, Bp.view(broadcast=b_broadcast) if Bp else hb.NULL_VIEW,
-                                                Bp.C if Bp else 0, self.t[dst].view(), self.B, A.H, A.W,
+            hb.check(lib.ssm_upsample2x_cat_fwd(self._v(a), A.C, bview if Bp else hb.NULL_VIEW,
+                                                Bp.C if Bp else 0, self.t[dst].view(), self._Bcur, A.H, A.W,
                                                 hb.stream_ptr()))
         if tm is not None:
             e1.record()
 
-    def run(self, cross_planes=None, cross_broadcast=False):
-        """Input must already be in self.t['in'].  Returns the Planes of final_conv's output."""
+    def run(self, cross_planes=None, cross_broadcast=False, cross_b0=0):
+        """Input must already be in self.t['in'].  Returns the Planes of final_conv's output (decoder batch).
+        cross_planes: stage-1 conv6 output; its entries [cross_b0, cross_b0+Bd) pair with the decoder's batch
+        (cross_broadcast: entry cross_b0 serves the whole batch)."""
+        self.run_encoder()
+        self.run_bottleneck()
+        return self.run_decoder(cross_planes, cross_broadcast, cross_b0)
+
+    def run_encoder(self):
         c = self._conv
+        self._b0, self._Bcur = 0, self.B
         c("conv1a", "in", "t1a")
         c("conv1b", "t1a", "c1", pool="p2")
         c("conv2a", "p2", "t2a")
@@ -197,13 +240,34 @@ class UNetPlan:
         c("conv4b", "t4a", "c4", pool="p5")
         c("conv5a", "p5", "t5a")
         c("conv5b", "t5a", "c5", pool="p6")
-        c("conv6.0", "p6", "t6a")
-        c("conv6.1", "t6a", "c6")
-        uc = self._up_conv
+
+    def run_bottleneck(self):
+        self._b0, self._Bcur = 0, self.B
+        if self.rnn is not None:
+            tm = self.timer
+            if tm is not None:
+                e0, e1 = tm.span("conv", "s%d.conv6(%s)" % (self.stage, self.bottleneck), self.rnn.flops())
+                e0.record()
+            self.rnn.run(self.t["p6"], self.t["c6"])
+            if tm is not None:
+                e1.record()
+            return
+        self._conv("conv6.0", "p6", "t6a")
+        self._conv("conv6.1", "t6a", "c6")
+
+    def run_decoder(self, cross_planes=None, cross_broadcast=False, cross_b0=0):
+        c, uc = self._conv, self._up_conv
+        self._b0, self._Bcur = self.dec_b0, self.Bd
+        try:
+            return self._decode(c, uc, cross_planes, cross_broadcast, cross_b0)
+        finally:
+            self._b0, self._Bcur = 0, self.B
+
+    def _decode(self, c, uc, cross_planes, cross_broadcast, cross_b0):
         if self.cross:
             if cross_planes is None:
                 raise RuntimeError("stage 2 was built with CROSS_SKIP but no stage-1 encoding was given")
-            uc("conv7a", "c6", None, "u7", "t7a", b_planes=cross_planes, b_broadcast=cross_broadcast)
+            uc("conv7a", "c6", None, "u7", "t7a", b_planes=cross_planes, b_broadcast=cross_broadcast, b_b0=cross_b0)
         else:
             uc("conv7a", "c6", None, "u7", "t7a")
         c("conv7b", "t7a", "c7")
@@ -218,6 +282,117 @@ class UNetPlan:
         c("fuse_conv", "c11", "tf", src2="c1")
         c("final_conv", "tf", "out", lrelu=False)
         return self.t["out"]
+
+
+class RecurrentBottleneck:
+    """conv6 = ConvBLSTM / ConvBGRU(in_channels=512, hidden_channels=512, kernel_size=(3,3), num_layers=2,
+    batch_first=True) on the 1/32 maps of a window sequence (reference call sites
+    scripts/models/flow_computation.py:73-88,208-211; definition restated from the un-vendored
+    SreenivasVRao/ConvGRU-ConvLSTM-PyTorch package - parity unpinned, see oracle/ssm_oracle.py).
+
+    Tensors hold T windows x S sequences in time-major batch order (slot k = batch entries [k*S, (k+1)*S)).
+    Each gate convolution over cat[x_t, h_{t-1}] is split by input channel: the x part runs ONCE for the whole
+    sequence (batch T*S), the h part once per step (batch S; skipped at the first step where h = 0); the pointwise
+    kernel adds the two and writes the new state straight into the next convolution's input layout.  The reverse
+    net is the same recurrence walked from the last slot to the first with its outputs stored per slot, which is
+    the reference's "reverse the input, run, reverse the output" without moving data."""
+
+    def __init__(self, kind, state_dict, S, T, h, w, device, mode="f32", prefix="conv6."):
+        assert kind in ("CLSTM", "CGRU")
+        self.kind, self.S, self.T, self.h, self.w, self.device = kind, S, T, h, w, device
+        self.mode, self.hl8, self.prefix = mode, mode != "f32", prefix
+        self.hid = RECURRENT_HIDDEN
+        self.ng = 4 * self.hid if kind == "CLSTM" else 2 * self.hid
+        self.pk = {}
+        self.refresh_weights(state_dict)
+        P32 = lambda B, C: hb.Planes(B, C, h, w, device)  # noqa: E731
+        X = (lambda B, C: hb.HPlanes(B, C, h, w, device)) if self.hl8 else P32  # noqa: E731
+        self.gx, self.gh = P32(T * S, self.ng), P32(S, self.ng)
+        self.seq0 = X(T * S, self.hid)                     # layer-0 output sequence (input of layer 1)
+        if kind == "CLSTM":
+            self.c = [P32(S, self.hid), P32(S, self.hid)]
+        else:
+            self.cx, self.ch, self.rh = P32(T * S, self.hid), P32(S, self.hid), X(S, self.hid)
+            self.h32 = P32(T * S, self.hid) if self.hl8 else None     # fp32 copy of the state for the update rule
+
+    def _pack(self, w, b, batch):
+        if self.hl8:
+            return hb.PackedConv16(w.contiguous(), b, self.w)
+        return hb.PackedConv(w.contiguous(), b, batch, self.h, self.w)
+
+    def refresh_weights(self, state_dict):
+        dev = self.device
+        for key, cin, hid, cout in recurrent_convs(self.kind):
+            full = self.prefix + key[len("conv6."):]
+            w = state_dict[full + ".weight"].to(device=dev, dtype=torch.float32)
+            b = state_dict[full + ".bias"].to(device=dev, dtype=torch.float32)
+            assert tuple(w.shape) == (cout, cin + hid, 3, 3), "%s: weight shape %s" % (full, tuple(w.shape))
+            self.pk[key, "x"] = self._pack(w[:, :cin], b, self.T * self.S)
+            self.pk[key, "h"] = self._pack(w[:, cin:], torch.zeros_like(b), self.S)
+
+    def flops(self):
+        per_px = 0.0
+        for key, cin, hid, cout in recurrent_convs(self.kind):
+            per_px += 2.0 * 9 * cout * (cin * self.T + hid * (self.T - 1))
+        return per_px * self.S * self.h * self.w
+
+    def _conv(self, pk, src_view, cin, dst_view, batch):
+        if self.hl8:
+            hb.conv2d_hl8(src_view, cin, None, 0, pk, None, dst_view, None, batch, self.h, self.w, lrelu=False,
+                          fast=self.mode == "f16")
+        else:
+            hb.conv2d(src_view, cin, None, 0, pk, dst_view, None, batch, self.h, self.w, lrelu=False)
+
+    def _hview(self, planes, ch, slot):
+        """View of `hid` channels starting at channel ch of slot `slot` in the layout the convolutions read."""
+        return planes.view(ch // 8 if self.hl8 else ch, b0=slot * self.S)
+
+    def _direction(self, net, x, out, ch_out, order):
+        lib, st, S, hid = hb.load(), hb.stream_ptr(), self.S, self.hid
+        nv, nh = hb.NULL_VIEW, hb.NULL_HVIEW
+        for l in range(RECURRENT_LAYERS):
+            cell = "conv6.%s.cell_list.%d." % (net, l)
+            src, cin = (x, 512) if l == 0 else (self.seq0, hid)
+            dst, ch = (self.seq0, 0) if l < RECURRENT_LAYERS - 1 else (out, ch_out)
+            gkey = cell + ("conv" if self.kind == "CLSTM" else "conv_gates")
+            self._conv(self.pk[gkey, "x"], src.view(), cin, self.gx.view(), self.T * S)
+            if self.kind == "CGRU":
+                self._conv(self.pk[cell + "conv_can", "x"], src.view(), cin, self.cx.view(), self.T * S)
+            prev = None
+            for i, k in enumerate(order):
+                hv = self._hview(dst, ch, k)
+                h16, h32 = (hv, nv) if self.hl8 else (nh, hv)
+                if prev is not None:
+                    self._conv(self.pk[gkey, "h"], self._hview(dst, ch, prev), hid, self.gh.view(), S)
+                if self.kind == "CLSTM":
+                    hb.check(lib.ssm_convlstm_cell_fwd(self.gx.view(b0=k * S), self.gh.view() if prev is not None else nv,
+                                                       self.c[(i + 1) % 2].view() if prev is not None else nv,
+                                                       self.c[i % 2].view(), h32, h16, S, hid, self.h, self.w, st))
+                else:
+                    state = self.h32 if self.hl8 else dst        # fp32 state tensor and the channel it starts at
+                    sch = 0 if self.hl8 else ch
+                    if self.hl8:
+                        h32 = state.view(0, b0=k * S)
+                    if prev is not None:
+                        hp = state.view(sch, b0=prev * S)
+                        r16, r32 = (self.rh.view(), nv) if self.hl8 else (nh, self.rh.view())
+                        hb.check(lib.ssm_convgru_reset_fwd(self.gx.view(b0=k * S), self.gh.view(), hp, r32, r16, S, hid,
+                                                           self.h, self.w, st))
+                        self._conv(self.pk[cell + "conv_can", "h"], self.rh.view(), hid, self.ch.view(), S)
+                        hb.check(lib.ssm_convgru_update_fwd(self.gx.view(b0=k * S), self.gh.view(), self.cx.view(b0=k * S),
+                                                            self.ch.view(), hp, h32, h16, S, hid, self.h, self.w, st))
+                    else:
+                        hb.check(lib.ssm_convgru_update_fwd(self.gx.view(b0=k * S), nv, self.cx.view(b0=k * S), nv, nv,
+                                                            h32, h16, S, hid, self.h, self.w, st))
+                prev = k
+
+    def run(self, x_fwd, out, x_rev=None):
+        """x_fwd, out: [T*S, 512, h, w] plan tensors (HL8 in the fp16 modes, fp32 planes in mode f32).
+        x_rev: the reverse net's input ALREADY in slot order (slot k = what it consumes for window k); default
+        x_fwd, i.e. the reference's x_rev = time-reversed x_fwd."""
+        self._direction("forward_net", x_fwd, out, 0, list(range(self.T)))
+        self._direction("reverse_net", x_fwd if x_rev is None else x_rev, out, self.hid, list(range(self.T - 1, -1, -1)))
+        return out
 
 
 class PairEngine:
@@ -308,6 +483,104 @@ class PairEngine:
             in16 = self.s2.t["in"].interior
             e1, e0 = in16[:, 6:8], in16[:, 8:10]
         return (flow[:, 0:2], flow[:, 2:4], e1, e0, self.aux[:, 0:2], self.aux[:, 2:4], self.aux[:, 4:5])
+
+
+class WindowEngine:
+    """N_FRAMES-1 = T interpolation windows whose U-Nets are coupled by a recurrent bottleneck
+    (BASELINE config 4; scripts/models/superslomo_r.py:152-293 with BOTTLENECK=CLSTM|CGRU).
+
+    Stage 1 runs on all T windows of S1 clips (its flows feed every window's stage-2 input); stage 2 encodes all
+    T windows of S2 sequences, runs its own recurrent bottleneck over them and decodes ONLY the middle window
+    unless decode_all (the reference decodes all T and returns the middle one - same frame, 1/T of the decoder
+    work).  Either S2 == S1 (FullModel.forward: one t per clip and window) or S1 == 1 and S2 = number of
+    intermediate times of that clip (stage 1 hoisted out of the t loop; its tensors are batch-broadcast)."""
+
+    def __init__(self, sd1, sd2, T, S1, S2, H, W, device, cross_skip=True, mode="f16x3", bottleneck="CLSTM",
+                 decode_all=False):
+        assert S2 == S1 or S1 == 1, "stage-2 sequences must equal stage-1 clips, or there must be one clip"
+        self.T, self.S1, self.S2, self.H, self.W, self.device = T, S1, S2, H, W, device
+        self.mid = T // 2
+        self.cross, self.mode, self.hl8 = bool(cross_skip), mode, mode != "f32"
+        self.bcast = S1 == 1 and S2 > 1
+        self.decode_all = decode_all
+        b1, b2 = bottleneck if isinstance(bottleneck, (tuple, list)) else (bottleneck, bottleneck)
+        self.s1 = UNetPlan(1, sd1, T * S1, H, W, device, cross_skip, mode, True, b1, seq_len=T)
+        self.s2 = UNetPlan(2, sd2, T * S2, H, W, device, cross_skip, mode, True, b2, seq_len=T,
+                           dec=None if decode_all else (self.mid * S2, S2))
+        nd = T * S2 if decode_all else S2
+        self.t_dev = torch.empty(T * S2, dtype=torch.float32, device=device)
+        self.img = torch.empty(nd, 3, H, W, dtype=torch.float32, device=device)
+        self.aux = torch.empty(nd, 5, H, W, dtype=torch.float32, device=device)
+        self.est = torch.empty(T * S2, 4, H, W, dtype=torch.float32, device=device) if self.hl8 else None
+        self.img6 = None
+
+    def load_frames(self, frames):
+        """frames [S1, T+1, 3, H, W] -> the T*S1 window pairs, time-major."""
+        assert tuple(frames.shape) == (self.S1, self.T + 1, 3, self.H, self.W), "frame tensor has shape %s" % (tuple(frames.shape),)
+        pairs = torch.cat([frames[:, :-1], frames[:, 1:]], dim=2)                 # [S1, T, 6, H, W]
+        self.img6 = pairs.transpose(0, 1).reshape(self.T * self.S1, 6, self.H, self.W).contiguous()
+        self.s1.t["in"].load(self.img6)
+
+    def _img6_view(self, k):
+        v = hb.view_of(self.img6[k * self.S1:(k + 1) * self.S1])
+        if self.bcast:
+            v.sb = 0
+        return v
+
+    def _est_view(self, b0):
+        ev = hb.view_of(self.est[b0:])
+        return hb.SsmView(ev.ptr - 4 * 6 * ev.sc, ev.sb, ev.sc, ev.sh)      # channels 6..9 alias the 4 est-flow planes
+
+    def run(self, frames, t, want_aux=True):
+        """t: [S2, T] interpolation times (per sequence and window).  Returns [S2,3,H,W] (middle window) or, with
+        decode_all, [T*S2,3,H,W] in time-major order."""
+        lib, st = hb.load(), hb.stream_ptr()
+        T, S1, S2 = self.T, self.S1, self.S2
+        self.load_frames(frames)
+        self.s1.run()
+        self.t_dev.copy_(t.to(torch.float32).reshape(S2, T).t().reshape(-1), non_blocking=True)
+        flow4, in16 = self.s1.t["out"], self.s2.t["in"]
+        tptr = self.t_dev.data_ptr()
+        for k in range(T):
+            fv = flow4.view(broadcast=self.bcast, b0=k * S1)
+            if self.hl8:
+                hb.check(lib.ssm_flowinterp_inputs_hl8_fwd(self._img6_view(k), fv, tptr + 4 * k * S2, in16.view(b0=k * S2),
+                                                           hb.view_of(self.est[k * S2:]), S2, self.H, self.W, st))
+            else:
+                hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(k), fv, tptr + 4 * k * S2, in16.view(b0=k * S2),
+                                                       S2, self.H, self.W, st))
+        if self.decode_all:
+            assert not self.bcast
+            out5 = self.s2.run(cross_planes=self.s1.t["c6"] if self.cross else None)
+            windows = range(T)
+        else:
+            out5 = self.s2.run(cross_planes=self.s1.t["c6"] if self.cross else None, cross_broadcast=self.bcast,
+                               cross_b0=self.mid * S1)
+            windows = [self.mid]
+        for j, k in enumerate(windows):
+            o0 = k * S2 if self.decode_all else 0
+            in16_view = self._est_view(k * S2) if self.hl8 else in16.view(b0=k * S2)
+            hb.check(lib.ssm_synthesize_fwd(self._img6_view(k), in16_view, out5.view(b0=o0), tptr + 4 * k * S2,
+                                            hb.view_of(self.img[o0:]), hb.view_of(self.aux[o0:]) if want_aux else hb.NULL_VIEW,
+                                            S2, self.H, self.W, st))
+        return self.img
+
+    def intermediates(self, k=None):
+        """(F01, F10, Ft1^, Ft0^, Ft1, Ft0, V0) of window k (default: the middle one)."""
+        k = self.mid if k is None else k
+        S1, S2 = self.S1, self.S2
+        flow = self.s1.t["out"].interior[k * S1:(k + 1) * S1]
+        if self.bcast:
+            flow = flow.expand(S2, -1, -1, -1)
+        if self.hl8:
+            e = self.est[k * S2:(k + 1) * S2]
+            e1, e0 = e[:, 0:2], e[:, 2:4]
+        else:
+            in16 = self.s2.t["in"].interior[k * S2:(k + 1) * S2]
+            e1, e0 = in16[:, 6:8], in16[:, 8:10]
+        o0 = k * S2 if self.decode_all else 0
+        aux = self.aux[o0:o0 + S2]
+        return (flow[:, 0:2], flow[:, 2:4], e1, e0, aux[:, 0:2], aux[:, 2:4], aux[:, 4:5])
 
 
 class PairPipeline:

@@ -73,6 +73,10 @@ SIGNATURES = {
                                     _c_int, _vp]),
     "ssm_flowinterp_inputs_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int,
                                            _vp]),
+    "ssm_convlstm_cell_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_convgru_reset_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_convgru_update_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int,
+                                        _c_int, _vp]),
     "ssm_avgpool2_fwd": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -146,9 +150,10 @@ class Planes:
         """torch view of the logical tensor (non-contiguous)."""
         return self.full[:, :, SSM_PADY:SSM_PADY + self.H, SSM_PADX:SSM_PADX + self.W]
 
-    def view(self, c0=0, broadcast=False):
-        base = self.buf.data_ptr() + 4 * ((c0 * self.Hp + SSM_PADY) * self.Wp + SSM_PADX)
+    def view(self, c0=0, broadcast=False, b0=0):
+        """ssm_view of channels c0.. of batch entries b0.. (broadcast: every batch index reads entry b0)."""
         sc = self.Hp * self.Wp
+        base = self.buf.data_ptr() + 4 * (((b0 * self.C + c0) * self.Hp + SSM_PADY) * self.Wp + SSM_PADX)
         return SsmView(base, 0 if broadcast else self.C * sc, sc, self.Wp)
 
     def slice(self, c0, c):
@@ -232,9 +237,10 @@ class HPlanes:
         n = B * self.G * 2 * self.Hp * self.Wp * 8
         self.buf = torch.zeros(n + 2 * SSM_TAIL_SLACK_FLOATS, dtype=torch.float16, device=device)
 
-    def view(self, g0=0, broadcast=False):
+    def view(self, g0=0, broadcast=False, b0=0):
+        """ssm_hview of channel groups g0.. of batch entries b0.. (broadcast: every batch index reads entry b0)."""
         pix = self.Hp * self.Wp
-        base = self.buf.data_ptr() + 16 * (g0 * 2 * pix + SSM_PADY * self.Wp + SSM_PADX)
+        base = self.buf.data_ptr() + 16 * ((b0 * self.G + g0) * 2 * pix + SSM_PADY * self.Wp + SSM_PADX)
         return SsmHView(base, 0 if broadcast else self.G * 2 * pix, 2 * pix, pix, self.Wp)
 
     def load(self, x):

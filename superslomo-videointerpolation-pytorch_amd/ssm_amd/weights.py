@@ -40,13 +40,39 @@ _DEC = [
 ]
 
 
-def unet_layers(stage, cross_skip=True):
-    """List of (name, cin, cout, k) for stage 1 (6->4) or stage 2 (16->5)."""
+RECURRENT_HIDDEN = 256      # per direction: ConvBLSTM/ConvBGRU(hidden_channels=512) splits it over the two nets
+RECURRENT_LAYERS = 2
+
+
+def recurrent_convs(kind):
+    """Convolutions of the recurrent bottleneck (BOTTLENECK=CLSTM|CGRU): list of (state-dict prefix, cin_x,
+    hidden, cout).  Filters are [cout, cin_x + hidden, 3, 3] over cat[x, h] (ConvLSTM: cout = 4*hidden, gate order
+    i,f,o,g; ConvGRU: conv_gates 2*hidden (reset, update) and conv_can hidden).  Key names follow the published
+    SreenivasVRao/ConvGRU-ConvLSTM-PyTorch modules the reference constructs at flow_computation.py:73-88."""
+    assert kind in ("CLSTM", "CGRU"), kind
+    out = []
+    for net in ("forward_net", "reverse_net"):
+        for l in range(RECURRENT_LAYERS):
+            cin = 512 if l == 0 else RECURRENT_HIDDEN
+            cell = "conv6.%s.cell_list.%d." % (net, l)
+            if kind == "CLSTM":
+                out.append((cell + "conv", cin, RECURRENT_HIDDEN, 4 * RECURRENT_HIDDEN))
+            else:
+                out.append((cell + "conv_gates", cin, RECURRENT_HIDDEN, 2 * RECURRENT_HIDDEN))
+                out.append((cell + "conv_can", cin, RECURRENT_HIDDEN, RECURRENT_HIDDEN))
+    return out
+
+
+def unet_layers(stage, cross_skip=True, bottleneck="CONV"):
+    """List of (name, cin, cout, k) for stage 1 (6->4) or stage 2 (16->5).  With a recurrent bottleneck the two
+    conv6 layers are absent (see recurrent_convs)."""
     assert stage in (1, 2), "Unsupported stage id."
     cin0, cout_final = (6, 4) if stage == 1 else (16, 5)
     c7 = 1024 if (stage == 2 and cross_skip) else 512
     out = []
     for name, cin, cout, k in _ENC + _DEC:
+        if name.startswith("conv6.") and bottleneck != "CONV":
+            continue
         if name == "conv1a":
             cin = cin0
         if name == "conv7a":
@@ -73,10 +99,19 @@ def _hash_uniform(tag, n):
     return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
 
 
-def synthetic_state_dict(stage, cross_skip=True, gain=1.0):
+def synthetic_state_dict(stage, cross_skip=True, gain=1.0, bottleneck="CONV"):
     """Deterministic OIHW fp32 state dict with the reference's keys."""
     sd = {}
-    for name, cin, cout, k in unet_layers(stage, cross_skip):
+    if bottleneck != "CONV":
+        for prefix, cin, hid, cout in recurrent_convs(bottleneck):
+            fan_in = (cin + hid) * 9
+            bound = 4.0 * gain * float(np.sqrt(6.0 / fan_in))   # x4: gate pre-activations O(1), |h| ~ 0.2
+            tag = "stage%d/%s" % (stage, prefix)
+            w = (_hash_uniform(tag + "/w", cout * (cin + hid) * 9) * 2.0 - 1.0) * bound
+            b = (_hash_uniform(tag + "/b", cout) * 2.0 - 1.0) * 0.05
+            sd[prefix + ".weight"] = torch.from_numpy(w.astype(np.float32).reshape(cout, cin + hid, 3, 3).copy())
+            sd[prefix + ".bias"] = torch.from_numpy(b.astype(np.float32).copy())
+    for name, cin, cout, k in unet_layers(stage, cross_skip, bottleneck):
         fan_in = cin * k * k
         bound = gain * float(np.sqrt(6.0 / (1.01 * fan_in)))
         if name == "final_conv":

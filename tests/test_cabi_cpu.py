@@ -90,7 +90,7 @@ def test_configs_parse_and_gate():
     cfg = load_config("superslomo_eval.ini", synthetic_weight_overrides())
     fm = FullModel(cfg)
     assert fm.cross_skip and not any(p.requires_grad for p in fm.parameters())     # FREEZE=TRUE in the ini
-    with pytest.raises(NotImplementedError):
-        FullModel(load_config("superslomo_recurrent.ini", synthetic_weight_overrides()))   # CLSTM: unpinned
+    rec = FullModel(load_config("superslomo_recurrent.ini", synthetic_weight_overrides()))   # CLSTM (tests/test_oracle_recurrent.py)
+    assert rec.recurrent and rec.bottlenecks == ("CLSTM", "CLSTM")
     x = torch.zeros(2, 4, 3, 8, 8)
     assert tuple(fm.get_image_pairs(x).shape) == (2, 3, 6, 8, 8)
