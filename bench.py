@@ -131,6 +131,82 @@ def train_bench(args):
         torch.distributed.destroy_process_group()
 
 
+def recurrent_bench(args):
+    """BASELINE configs[3]: superslomo_recurrent.ini (N_FRAMES=4, BOTTLENECK=CLSTM) at 720p.  A step = one clip of 4
+    synthetic frames -> the 7 intermediates between its two middle frames; stage 1 (3 windows + its ConvBLSTM) runs
+    once per clip, stage 2 encodes 3 windows x 7 t, runs its ConvBLSTM over them and decodes the middle window.
+    Clips shard across ranks like frame pairs (no collective)."""
+    from ssm_amd import dist as sdist
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.engine import KernelTimer, UNetPlan
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    from models.superslomo_r import FullModel
+
+    rank, local_rank, world = sdist.env_world()
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    sdist.init("nccl")
+    cfg = load_config("superslomo_recurrent.ini", synthetic_weight_overrides())
+    kind = cfg.get("STAGE1", "BOTTLENECK")
+    model = FullModel(cfg)
+    p1, p2 = synthetic_state_dict(1, bottleneck=kind), synthetic_state_dict(2, bottleneck=kind)
+    model.stage1_model.load_state_dict(p1)
+    model.stage2_model.load_state_dict(p2)
+    model.precision = args.precision or "f16x3"
+    model = model.to(dev).eval()
+    n_frames = cfg.getint("TRAIN", "N_FRAMES")
+    clips = [synthetic_frames(n_frames, H_IN, W_IN, seed=42 + 2 * rank + i).to(dev) for i in range(2)]
+    ts = [i / 8.0 for i in range(1, N_T + 1)]
+    k = [0]
+
+    def step():
+        k[0] += 1
+        return model.interpolate_windows(clips[k[0] % 2], ts)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    elapsed = sdist.timed_steps(step, args.steps, args.warmup, sync)
+    timer = KernelTimer()
+    UNetPlan.timer = timer
+    for _ in range(3):
+        step()
+    sync()
+    UNetPlan.timer = None
+    out = {"metric": "interpolated 1280x720 frames/sec (recurrent, N_FRAMES=%d)" % n_frames,
+           "value": round(N_T * world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NOTE[model.precision], "data": "synthetic",
+           "config": {"workload": "superslomo_recurrent.ini inference (BOTTLENECK=%s, parity unpinned: restated cells): synthetic "
+                                  "%d-frame 1280x720 clip -> 7 intermediates of the middle window, stage 1 once per clip" % (kind, n_frames),
+                      "precision": model.precision, "clips_per_step": 1, "frames_per_step": N_T}}
+    if rank == 0:
+        summ = timer.summary()
+        conv = summ["conv"]
+        out["time_split_ms_per_step"] = {"conv": round(conv["ms"] / 3, 3),
+                                         "conv6_recurrent": round(sum(v[0] for n, v in conv["by_name"].items() if "conv6(" in n) / 3, 3)}
+        out["tflops"] = round(conv["flops"] / conv["ms"] / 1e9, 1)
+        if not args.no_cpu_baseline:
+            from oracle import ssm_oracle as O
+            xs = clips[k[0] % 2].cpu()
+            t0 = time.time()
+            want, _ = O.full_model_infer_windows(p1, p2, xs, torch.full((1, n_frames - 1, 1, 1, 1), 0.5), True, kind)
+            cpu_s = time.time() - t0
+            got = model.interpolate_windows(clips[k[0] % 2], [0.5])
+            out["parity"] = {"max_abs_vs_oracle": float((got.cpu() - want).abs().max()), "tolerance": 1e-3, "frames": 1,
+                             "size": "%dx%d" % tuple(xs.shape[-2:])}
+            out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": "1 clip x 1 intermediate (t=0.5), torch CPU fp32 oracle; %.1f s" % cpu_s}
+        if args.detail:
+            with open(args.detail, "w") as f:
+                json.dump({n: {"ms_per_step": v[0] / 3, "tflops": (v[1] / v[0] / 1e9 if v[0] > 0 else 0.0)}
+                           for n, v in conv["by_name"].items()}, f, indent=1)
+        print(json.dumps(out))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,9 +216,10 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (roofline = null)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
                     help="conv arithmetic (default: models.superslomo_r.DEFAULT_PRECISION / $SSM_PRECISION)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "recurrent"],
                     help="infer = the headline (BASELINE configs[1]); train = configs[2]: training step on 352x352 crops, "
-                         "2 samples per GPU, gradient all-reduce over RCCL")
+                         "2 samples per GPU, gradient all-reduce over RCCL; recurrent = configs[3]: superslomo_recurrent.ini "
+                         "(N_FRAMES=4, ConvBLSTM bottleneck) at 720p")
     ap.add_argument("--size", default="720p", choices=["720p", "4k"],
                     help="720p = BASELINE configs[1] (the headline); 4k = configs[4] shape (3840x2160, use --precision f16)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (= frame pairs in flight) per GPU")
@@ -155,6 +232,8 @@ def main():
     from ssm_amd.weights import synthetic_frames, synthetic_state_dict
     from models.superslomo_r import FullModel
 
+    if args.mode == "recurrent":
+        return recurrent_bench(args)
     if args.mode == "train":
         return train_bench(args)
     rank, local_rank, world = sdist.env_world()
