@@ -82,6 +82,9 @@ def train_bench(args):
     model = FullModel(cfg)
     model.stage1_model.load_state_dict(synthetic_state_dict(1))
     model.stage2_model.load_state_dict(synthetic_state_dict(2))
+    if not args.no_perceptual:      # VGG16 conv4_3 feature loss (lambda_p = 20) with synthetic VGG weights: same FLOPs as the
+        from ssm_amd.perceptual import VGGFeatures, synthetic_vgg_state_dict      # pretrained net the reference downloads
+        model.loss.load_vgg16(synthetic_vgg_state_dict())
     model = model.to(dev).train()
     trainer = Trainer(model, cfg)
     B, S = 2, 352
@@ -105,16 +108,21 @@ def train_bench(args):
     ar_ms = 1e3 * ar[0] / args.steps
     timer = KernelTimer()
     UNetPlan.timer = timer
+    if not args.no_perceptual:
+        VGGFeatures.timer = timer
     for _ in range(3):
         step()
     sync()
     UNetPlan.timer = None
+    if not args.no_perceptual:
+        VGGFeatures.timer = None
     out = {"metric": "training samples/sec (352x352 crops, forward+backward+Adam)", "value": round(B * world * args.steps / elapsed, 3),
            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "superslomo_original.ini training, FREEZE=FALSE, %d samples/GPU of 352x352, %d GPU(s); "
-                                  "losses: L1 reconstruction + 4 L1 warp terms (VGG perceptual term unpinned, off)" % (B, world),
+                                  "losses: L1 reconstruction + 4 L1 warp terms + %s" % (B, world, "VGG16 conv4_3 perceptual term OFF" if args.no_perceptual else
+                                                                                  "VGG16 conv4_3 perceptual term (synthetic VGG weights)"),
                       "global_batch": B * world},
            "allreduce": {"bytes": trainer.allreduce.bytes, "ms_per_step": round(ar_ms, 3)}}
     if rank == 0:
@@ -223,6 +231,7 @@ def main():
     ap.add_argument("--size", default="720p", choices=["720p", "4k"],
                     help="720p = BASELINE configs[1] (the headline); 4k = configs[4] shape (3840x2160, use --precision f16)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (= frame pairs in flight) per GPU")
+    ap.add_argument("--no-perceptual", action="store_true", help="--mode train: leave the VGG16 perceptual loss term out")
     ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")
     args = ap.parse_args()
 

@@ -198,7 +198,8 @@ int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int N, int H, i
  * ssm_upsample2x_cat_bwd  adjoint of ssm_upsample2x_cat_fwd; acc_a/acc_b: add into da/db instead of overwriting
  * ssm_synthesize_bwd      adjoint of ssm_synthesize_fwd fused with d(L1 reconstruction) and, if stage2_terms, the two
  *                         refined-flow warp-loss terms (scripts/models/losses.py:160-161,217); c_rec[b], c_warp[b] =
- *                         lambda * upstream gradient / (3*H*W) per sample (device arrays); est4 = Ft1^ | Ft0^
+ *                         lambda * upstream gradient / (3*H*W) per sample (device arrays); est4 = Ft1^ | Ft0^;
+ *                         dy_extra (NULL view = none): gradient of further loss terms wrt the frame (the perceptual term)
  * ssm_flowinterp_inputs_bwd  adjoint of ssm_flowinterp_inputs_fwd wrt the stage-1 flows, fused with the two stage-1
  *                         warp-loss terms (losses.py:152-154) if stage1_terms                                   */
 int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, int B, int C, int H, int W, float slope, int has_act,
@@ -209,9 +210,20 @@ int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, in
 int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int h, int w, int acc_a, int acc_b,
                            void *stream);
 int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,
-                       const float *c_warp, ssm_view dout5, ssm_view dest4, int B, int H, int W, int stage2_terms, void *stream);
+                       const float *c_warp, ssm_view dy_extra, ssm_view dout5, ssm_view dest4, int B, int H, int W, int stage2_terms,
+                       void *stream);
 int ssm_flowinterp_inputs_bwd(ssm_view img6, ssm_view flow4, ssm_view din16, ssm_view dest4, const float *t, const float *c_warp,
                               ssm_view dflow4, int B, int H, int W, int stage1_terms, void *stream);
+
+/* ---- perceptual loss (PerceptualLoss: vgg16.features[:23] + MSELoss, scripts/models/losses.py:12-41,172-181,218-233) --
+ * The VGG convolutions are ssm_conv2d_fwd launches with SSM_FLAG_LRELU and slope 0 (= ReLU); their data gradients are the
+ * same kernel on the transposed filters, ReLU' is ssm_lrelu_bwd with slope 0.  fp32 planes.
+ *  ssm_maxpool2_fwd   y[B,C,H/2,W/2] = nn.MaxPool2d(2, 2)(x)                       (H, W = input size, even)
+ *  ssm_maxpool2_bwd   dx = dy routed to the first maximum of each 2x2 window (row-major scan, as torch's backward)
+ *  ssm_sqdiff_grad    out = coef[b] * (a - b): gradient of the per-sample mean squared feature difference         */
+int ssm_maxpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int W, void *stream);
+int ssm_maxpool2_bwd(ssm_view x, ssm_view dy, ssm_view dx, int B, int C, int H, int W, void *stream);
+int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_view out, int B, int C, int H, int W, void *stream);
 
 /* ---- recurrent bottleneck (BOTTLENECK=CLSTM|CGRU; BASELINE config 4) -----------------------------------------
  * Replaces ConvBLSTM / ConvBGRU(in_channels=512, hidden_channels=512, kernel_size=(3,3), num_layers=2,

@@ -330,6 +330,32 @@ def full_model_infer_windows(p1, p2, image_tensor, t_interp, cross_skip=True, bo
 
 
 # --------------------------------------------------------------------------
+# perceptual loss (training only) - architecture pinned, pretrained weights UNPINNED
+# --------------------------------------------------------------------------
+# torchvision.models.vgg16().features[:23] = [conv3x3+ReLU]x2, MaxPool, [conv+ReLU]x2, MaxPool, [conv+ReLU]x3,
+# MaxPool, [conv+ReLU]x3 (conv indices 0,2,5,7,10,12,14,17,19,21; channels 64,64,128,128,256,256,256,512,512,512).
+# torchvision is not installed here and the pretrained numbers need the network, so `p` is any state dict with
+# torchvision's keys (`features.<idx>.weight|bias`).
+_VGG16_CONV4_3 = (0, 2, "M", 5, 7, "M", 10, 12, 14, "M", 17, 19, 21)
+
+
+def vgg16_conv4_3(p, x):
+    """PerceptualLoss.vgg_conv4_3 (scripts/models/losses.py:23-39): features[:23] ends with the ReLU after conv4_3."""
+    for item in _VGG16_CONV4_3:
+        if item == "M":
+            x = F.max_pool2d(x, kernel_size=2, stride=2)
+        else:
+            x = F.relu(F.conv2d(x, p["features.%d.weight" % item], p["features.%d.bias" % item], padding=1))
+    return x
+
+
+def perceptual_loss(p, pred, target):
+    """Per-sample mean of MSELoss(reduce=False)(phi(pred), phi(target)) (losses.py:38-41,218,227)."""
+    d = vgg16_conv4_3(p, pred) - vgg16_conv4_3(p, target)
+    return (d * d).flatten(1).mean(dim=1)
+
+
+# --------------------------------------------------------------------------
 # frame formats either side of the path (uint8 <-> normalised padded tensors)
 # --------------------------------------------------------------------------
 def frames_from_u8(frames_u8, mean, std, pad_before_norm=False, multiple=32):

@@ -248,8 +248,8 @@ __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f 
 // Outputs: dout5 [B,5,H,W] and dest [B,4,H,W] (gradient wrt the approximated flows Ft1^(u,v) | Ft0^(u,v)).
 __global__ __launch_bounds__(256) void synth_bwd_kernel(ssm_view img6, ssm_view est, ssm_view out5, ssm_view target,
                                                         const float *__restrict__ tarr, const float *__restrict__ cr,
-                                                        const float *__restrict__ cw, ssm_view dout5, ssm_view dest, int H, int W,
-                                                        int stage2_terms) {
+                                                        const float *__restrict__ cw, ssm_view dyx, ssm_view dout5, ssm_view dest,
+                                                        int H, int W, int stage2_terms) {
     SSM_PIXEL_INDEX();
     const float t = tarr[b], omt = 1.0f - t;
     const float v1 = 1.0f / (1.0f + expf(-vp(out5, b, 0, y)[x])), v0 = 1.0f - v1;
@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void synth_bwd_kernel(ssm_view img6, ssm_view 
         const float tg = vp(target, b, c, y)[x];
         const float num = omt * v0 * w0 + t * v1 * w1;
         const float pred = num / den;
-        const float dpred = cr[b] * sgn(pred - tg);
+        float dpred = cr[b] * sgn(pred - tg);
+        if (dyx.ptr) dpred += vp(dyx, b, c, y)[x];     // gradient of the other loss terms (perceptual) wrt the frame
         const float dnum = dpred / den;
         dden -= dpred * pred / den;
         float dw0 = dnum * omt * v0, dw1 = dnum * t * v1;
@@ -343,6 +344,52 @@ __global__ __launch_bounds__(256) void inputs_bwd_kernel(ssm_view img6, ssm_view
     vp(dflow4, b, 1, y)[x] = dF01v;
     vp(dflow4, b, 2, y)[x] = dF10u;
     vp(dflow4, b, 3, y)[x] = dF10v;
+}
+
+
+// ---- perceptual-loss pieces (VGG16 features[:23], scripts/models/losses.py:12-41) ---------------------------------
+// MaxPool2d(2,2): y = max of the 2x2 window.  Backward routes the gradient to the FIRST maximum of the window in
+// row-major scan order (what torch's max_pool2d backward does with its saved argmax).
+#define SSM_PIXEL_CGROUP()                                            \
+    const int x = blockIdx.x * 64 + threadIdx.x;                      \
+    const int y = blockIdx.y * 4 + threadIdx.y;                       \
+    const int b = blockIdx.z / cgroups;                               \
+    const int c0 = (blockIdx.z - b * cgroups) * BWD_CPT;              \
+    const int c1 = c0 + BWD_CPT < C ? c0 + BWD_CPT : C;               \
+    if (x >= W || y >= H) return;
+
+__global__ __launch_bounds__(256) void maxpool2_kernel(ssm_view xin, ssm_view yout, int C, int H, int W, int cgroups) {   // H, W = OUTPUT dims
+    SSM_PIXEL_CGROUP();
+    for (int c = c0; c < c1; ++c) {
+        const float *r0 = vp(xin, b, c, 2 * y) + 2 * x, *r1 = vp(xin, b, c, 2 * y + 1) + 2 * x;
+        vp(yout, b, c, y)[x] = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r1[0], r1[1]));
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(ssm_view xin, ssm_view dy, ssm_view dx, int C, int H, int W, int cgroups) {   // pooled dims
+    SSM_PIXEL_CGROUP();
+    for (int c = c0; c < c1; ++c) {
+        const float *r0 = vp(xin, b, c, 2 * y) + 2 * x, *r1 = vp(xin, b, c, 2 * y + 1) + 2 * x;
+        const float v[4] = {r0[0], r0[1], r1[0], r1[1]};
+        int am = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (v[i] > v[am]) am = i;
+        const float g = vp(dy, b, c, y)[x];
+        float *d0 = vp(dx, b, c, 2 * y) + 2 * x, *d1 = vp(dx, b, c, 2 * y + 1) + 2 * x;
+        d0[0] = am == 0 ? g : 0.f;
+        d0[1] = am == 1 ? g : 0.f;
+        d1[0] = am == 2 ? g : 0.f;
+        d1[1] = am == 3 ? g : 0.f;
+    }
+}
+
+// out = coef[b] * (a - b): gradient of coef/2 * sum (a-b)^2 wrt a (the MSE feature loss, losses.py:40,218-233)
+__global__ __launch_bounds__(256) void sqdiff_grad_kernel(ssm_view a, ssm_view bb, const float *__restrict__ coef, ssm_view out, int C,
+                                                          int H, int W, int cgroups) {
+    SSM_PIXEL_CGROUP();
+    const float k = coef[b];
+    for (int c = c0; c < c1; ++c) vp(out, b, c, y)[x] = k * (vp(a, b, c, y)[x] - vp(bb, b, c, y)[x]);
 }
 
 }  // namespace
@@ -427,12 +474,12 @@ extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view
 }
 
 extern "C" int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,
-                                  const float *c_warp, ssm_view dout5, ssm_view dest4, int B, int H, int W, int stage2_terms,
-                                  void *stream) {
+                                  const float *c_warp, ssm_view dy_extra, ssm_view dout5, ssm_view dest4, int B, int H, int W,
+                                  int stage2_terms, void *stream) {
     SSM_CHECK_DIMS("synthesize_bwd");
     SSM_REQUIRE(img6.ptr && est4.ptr && out5.ptr && target.ptr && t && c_rec && c_warp && dout5.ptr && dest4.ptr, "synthesize_bwd: null pointer");
     hipLaunchKernelGGL(synth_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, est4, out5, target, t, c_rec,
-                       c_warp, dout5, dest4, H, W, stage2_terms);
+                       c_warp, dy_extra, dout5, dest4, H, W, stage2_terms);
     return ssm::check_launch("ssm_synthesize_bwd");
 }
 
@@ -443,4 +490,32 @@ extern "C" int ssm_flowinterp_inputs_bwd(ssm_view img6, ssm_view flow4, ssm_view
     hipLaunchKernelGGL(inputs_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, din16, dest4, t, c_warp,
                        dflow4, H, W, stage1_terms);
     return ssm::check_launch("ssm_flowinterp_inputs_bwd");
+}
+
+extern "C" int ssm_maxpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("maxpool2");
+    SSM_REQUIRE(x.ptr && y.ptr && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2: null pointer / odd size");
+    const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "maxpool2: B*C too large for one launch");
+    hipLaunchKernelGGL(maxpool2_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, y, C, H / 2, W / 2, cgroups);
+    return ssm::check_launch("ssm_maxpool2_fwd");
+}
+
+extern "C" int ssm_maxpool2_bwd(ssm_view x, ssm_view dy, ssm_view dx, int B, int C, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("maxpool2_bwd");
+    SSM_REQUIRE(x.ptr && dy.ptr && dx.ptr && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: null pointer / odd size");
+    const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "maxpool2_bwd: B*C too large for one launch");
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, dy, dx, C, H / 2, W / 2,
+                       cgroups);
+    return ssm::check_launch("ssm_maxpool2_bwd");
+}
+
+extern "C" int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_view out, int B, int C, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("sqdiff_grad");
+    SSM_REQUIRE(a.ptr && b.ptr && coef && out.ptr && C > 0, "sqdiff_grad: null pointer");
+    const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "sqdiff_grad: B*C too large for one launch");
+    hipLaunchKernelGGL(sqdiff_grad_kernel, pix_grid(B * cgroups, H, W), dim3(64, 4), 0, (hipStream_t)stream, a, b, coef, out, C, H, W, cgroups);
+    return ssm::check_launch("ssm_sqdiff_grad");
 }

@@ -2,11 +2,13 @@
 
 Forward values of all four entries of the reference's [B,4] loss tensor:
   [total, lambda_r * L1(I_t^, I_t), lambda_w * (sum of the L1 warp terms), lambda_p * MSE(phi(I_t^), phi(I_t))]
-with the warps on the HIP sampler.  Scope: there is NO backward yet - the training step is the next
-row - and the reference's phi = torchvision.models.vgg16(pretrained=True).features[:23] (losses.py:23,34)
-needs weights from the network, so the perceptual term is computed only when a `feature_extractor` is supplied
-(`perceptual_available`), otherwise reported as 0.
+with the warps on the HIP sampler; the gradients are ssm_amd.backward (fused into the synthesis / input adjoints).
+phi = torchvision.models.vgg16(pretrained=True).features[:23] in the reference (losses.py:23,34); its pretrained
+weights need the network, so here phi runs on the HIP kernels (ssm_amd.perceptual.VGGFeatures) from a
+torchvision-format state dict given with `load_vgg16()` or the file named by $SSM_VGG16_WEIGHTS.  Without weights
+(`perceptual_available` False) the term is reported as 0 and contributes no gradient.
 """
+import os
 import logging
 
 import torch
@@ -22,11 +24,32 @@ class SSMLosses(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.loss_weights = self.read_loss_weights(cfg)
-        self.feature_extractor = feature_extractor        # callable [B,3,H,W] -> features; None: term reported as 0
+        self.feature_extractor = feature_extractor        # optional callable [B,3,H,W] -> features (forward value only)
+        self.__dict__["_vgg_sd"] = None
+        self.__dict__["_pterm"] = None
+        path = os.environ.get("SSM_VGG16_WEIGHTS")
+        if path:
+            self.load_vgg16(torch.load(path, map_location="cpu"))
+
+    def load_vgg16(self, state_dict):
+        """torchvision vgg16 state dict (keys `features.<idx>.weight|bias`; the classifier entries are ignored)."""
+        self.__dict__["_vgg_sd"] = {k: v for k, v in state_dict.items() if k.startswith("features.")}
+        self.__dict__["_pterm"] = None
 
     @property
     def perceptual_available(self):
-        return self.feature_extractor is not None
+        return self.feature_extractor is not None or self._vgg_sd is not None
+
+    def perceptual_term(self, B, H, W, device):
+        """The HIP VGG16 plan for this batch geometry (None without weights)."""
+        if self._vgg_sd is None:
+            return None
+        key = (B, H, W, str(device))
+        if self._pterm is None or self._pterm[0] != key:
+            from ssm_amd.perceptual import PerceptualTerm
+            self.__dict__["_pterm"] = None
+            self.__dict__["_pterm"] = (key, PerceptualTerm(self._vgg_sd, B, H, W, device))
+        return self._pterm[1]
 
     def read_loss_weights(self, cfg):
         lambda_r = cfg.getfloat("TRAIN", "LAMBDA_R")
@@ -59,7 +82,11 @@ class SSMLosses(nn.Module):
         with torch.no_grad():
             rec = lambda_r * self._mean((interpolated_image - target_image).abs())
             wrp = lambda_w * self.warp_terms(img_tensor, flowC_output, est_flow_t1, est_flow_t0, flowI_output, target_image)
-            if self.feature_extractor is not None:
+            Bn, _, Hn, Wn = interpolated_image.shape
+            pt = self.perceptual_term(Bn, Hn, Wn, interpolated_image.device)
+            if pt is not None:
+                per = lambda_p * pt.forward(interpolated_image, target_image)
+            elif self.feature_extractor is not None:
                 per = lambda_p * self._mean((self.feature_extractor(interpolated_image) - self.feature_extractor(target_image)) ** 2)
             else:
                 per = torch.zeros_like(rec)

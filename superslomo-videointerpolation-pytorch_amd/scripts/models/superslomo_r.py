@@ -62,10 +62,17 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_pred, d_losses):
         model = ctx.model
-        lambda_r, _, lambda_w = model.loss.loss_weights
+        lambda_r, lambda_p, lambda_w = model.loss.loss_weights
         train_s1 = not model.cfg.getboolean("STAGE1", "FREEZE")
         train_s2 = not model.cfg.getboolean("STAGE2", "FREEZE")
-        grads = ctx.pg.backward(ctx.sd[0], ctx.sd[1], ctx.target, d_losses.contiguous(), lambda_r, lambda_w, train_s1, train_s2)
+        d_losses = d_losses.contiguous()
+        dy_extra = None
+        B, _, H, W = ctx.target.shape
+        pt = model.loss.perceptual_term(B, H, W, ctx.target.device)
+        if pt is not None:        # VGG activations of this step's forward are still in the plan's buffers
+            dy_extra = pt.grad_pred((d_losses[:, 0] + d_losses[:, 3]) * lambda_p).view()
+        grads = ctx.pg.backward(ctx.sd[0], ctx.sd[1], ctx.target, d_losses, lambda_r, lambda_w, train_s1, train_s2,
+                                dy_extra=dy_extra)
         out = []
         for stage, mod in (("stage1.", model.stage1_model), ("stage2.", model.stage2_model)):
             for name, p in mod.named_parameters():

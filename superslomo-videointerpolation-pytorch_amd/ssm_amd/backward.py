@@ -196,10 +196,10 @@ class PairGrad:
         self.cr = torch.empty(B, dtype=torch.float32, device=dev)
         self.cw = torch.empty(B, dtype=torch.float32, device=dev)
 
-    def backward(self, sd1, sd2, target, g_losses, lambda_r, lambda_w, train_s1, train_s2, n_windows=1):
+    def backward(self, sd1, sd2, target, g_losses, lambda_r, lambda_w, train_s1, train_s2, n_windows=1, dy_extra=None):
         """target [B,3,H,W]; g_losses [B,4] = upstream gradient of the [B,4] loss tensor (columns total, recon, warp,
         perceptual); returns {state-dict key: gradient} for the stages that train.  The warp-loss terms follow the
-        FREEZE gating of scripts/models/losses.py:159-167."""
+        FREEZE gating of scripts/models/losses.py:159-167.  dy_extra: ssm_view of d(perceptual term)/d(frame), or None."""
         e = self.e
         lib = hb.load()
         st = hb.stream_ptr()
@@ -214,7 +214,8 @@ class PairGrad:
         self.u2.refresh(sd2, need_input_grad=need_s1)
         d_out5 = self.u2._G("out", C=self.u2.pk_t["final_conv"].cin_p)
         hb.check(lib.ssm_synthesize_bwd(img6, in16.view(6), out5.view(), hb.view_of(target), e.t_dev.data_ptr(),
-                                        self.cr.data_ptr(), self.cw.data_ptr(), d_out5.view(), hb.view_of(self.dest), B, H, W,
+                                        self.cr.data_ptr(), self.cw.data_ptr(), dy_extra if dy_extra is not None else hb.NULL_VIEW,
+                                        d_out5.view(), hb.view_of(self.dest), B, H, W,
                                         1 if train_s2 else 0, st))
         dcross = None
         if e.cross and need_s1:

@@ -1,0 +1,165 @@
+"""Perceptual-loss feature network on the HIP kernels: torchvision's vgg16.features[:23] (conv1_1 ... relu4_3), the
+phi of the reference's PerceptualLoss (scripts/models/losses.py:12-41).  Forward on fp32 padded planes (3x3 convs with
+fused ReLU = the MFMA conv kernel with slope 0, MaxPool2d(2,2) = ssm_maxpool2_fwd) and the gradient wrt the input
+image (the network is frozen, losses.py:30-33: no weight gradients) by the same kernels on transposed filters.
+
+Weights: the reference downloads `vgg16(pretrained=True)`; there is no network here, so the extractor takes a
+torchvision-format state dict (`features.<idx>.weight|bias`, e.g. a local vgg16-397923af.pth) or, for tests and the
+benchmark, `synthetic_vgg_state_dict()`.  Architecture pinned, pretrained numbers unpinned.
+"""
+import numpy as np
+import torch
+
+from . import hipbind as hb
+from .backward import transposed_filter
+from .weights import _hash_uniform
+
+# torchvision vgg16 "D" configuration up to relu4_3: (index in .features, cin, cout) and 'M' = MaxPool2d(2,2)
+VGG16_CONV4_3 = [(0, 3, 64), (2, 64, 64), "M", (5, 64, 128), (7, 128, 128), "M", (10, 128, 256), (12, 256, 256), (14, 256, 256), "M",
+                 (17, 256, 512), (19, 512, 512), (21, 512, 512)]
+
+
+def synthetic_vgg_state_dict(gain=1.0):
+    """Deterministic stand-in for the pretrained VGG16 (He-uniform for ReLU: activations stay O(1) through the 10 layers)."""
+    sd = {}
+    for item in VGG16_CONV4_3:
+        if item == "M":
+            continue
+        idx, cin, cout = item
+        bound = gain * float(np.sqrt(6.0 / (cin * 9)))
+        w = (_hash_uniform("vgg16/features.%d/w" % idx, cout * cin * 9) * 2.0 - 1.0) * bound
+        b = (_hash_uniform("vgg16/features.%d/b" % idx, cout) * 2.0 - 1.0) * 0.05
+        sd["features.%d.weight" % idx] = torch.from_numpy(w.astype(np.float32).reshape(cout, cin, 3, 3).copy())
+        sd["features.%d.bias" % idx] = torch.from_numpy(b.astype(np.float32).copy())
+    return sd
+
+
+class VGGFeatures:
+    """phi(x) for a batch [B,3,H,W] (H, W multiples of 8) and d(phi)/dx applied to a feature gradient."""
+
+    timer = None        # a ssm_amd.engine.KernelTimer, or None
+
+    def __init__(self, state_dict, B, H, W, device):
+        assert H % 8 == 0 and W % 8 == 0, "VGG16 conv4_3 pools three times: H, W must be multiples of 8"
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.steps = []          # ("conv", idx, cin, cout, src, dst) | ("pool", src, dst)
+        self.t, self.pk, self.w = {}, {}, {}
+        h, w, c, name = H, W, 3, "x"
+        for item in VGG16_CONV4_3:
+            if item == "M":
+                dst = "p%d" % len(self.steps)
+                self.t[dst] = hb.Planes(B, c, h // 2, w // 2, device)
+                self.steps.append(("pool", name, dst))
+                h, w, name = h // 2, w // 2, dst
+                continue
+            idx, cin, cout = item
+            wt = state_dict["features.%d.weight" % idx].to(device=device, dtype=torch.float32)
+            bs = state_dict["features.%d.bias" % idx].to(device=device, dtype=torch.float32)
+            assert tuple(wt.shape) == (cout, cin, 3, 3), "features.%d.weight has shape %s" % (idx, tuple(wt.shape))
+            self.w[idx] = wt
+            self.pk[idx] = hb.PackedConv(wt, bs, B, h, w)
+            if name == "x":
+                self.t["x"] = hb.Planes(B, self.pk[idx].cin_p, h, w, device)     # 3 channels padded to the conv's chunk
+            dst = "a%d" % idx
+            self.t[dst] = hb.Planes(B, cout, h, w, device)
+            self.steps.append(("conv", idx, cin, cout, name, dst))
+            c, name = cout, dst
+        self.out = name
+        self.g, self.pk_t = {}, {}
+
+    def _span(self, fam, name, flops):
+        tm = VGGFeatures.timer
+        if tm is None:
+            return None
+        e0, e1 = tm.span(fam, name, flops)
+        e0.record()
+        return e1
+
+    def forward(self, x):
+        """x: [B,3,H,W] device tensor -> Planes [B,512,H/8,W/8] (valid until the next forward)."""
+        hb.require_device(x, "perceptual-loss input")
+        assert tuple(x.shape) == (self.B, 3, self.H, self.W), "VGG input has shape %s" % (tuple(x.shape),)
+        lib, st = hb.load(), hb.stream_ptr()
+        xs = x if x.stride(3) == 1 else x.contiguous()
+        hb.check(lib.ssm_copy_view(hb.view_of(xs), self.t["x"].view(), self.B, 3, self.H, self.W, st))
+        for s in self.steps:
+            if s[0] == "pool":
+                src, dst = self.t[s[1]], self.t[s[2]]
+                hb.check(lib.ssm_maxpool2_fwd(src.view(), dst.view(), self.B, src.C, src.H, src.W, st))
+                continue
+            _, idx, cin, cout, sname, dname = s
+            src, dst, pk = self.t[sname], self.t[dname], self.pk[idx]
+            e1 = self._span("vgg_fwd", "features.%d" % idx, 2.0 * self.B * src.H * src.W * cin * cout * 9)
+            hb.conv2d(src.view(), pk.cin_p, None, 0, pk, dst.view(), None, self.B, src.H, src.W, lrelu=True, slope=0.0)
+            if e1 is not None:
+                e1.record()
+        return self.t[self.out]
+
+    def _G(self, name, C=None):
+        if name not in self.g:
+            ref = self.t[name]
+            self.g[name] = hb.Planes(self.B, C or ref.C, ref.H, ref.W, self.device)
+        return self.g[name]
+
+    def input_grad(self, dphi, nb=None):
+        """dphi: Planes gradient wrt phi (first nb batch entries; default all) -> Planes [B,3,H,W] holding the gradient
+        wrt the input image in its first nb entries."""
+        lib, st = hb.load(), hb.stream_ptr()
+        nb = self.B if nb is None else nb
+        dy = dphi
+        for s in reversed(self.steps):
+            if s[0] == "pool":
+                src = self.t[s[1]]
+                dx = self._G(s[1])
+                hb.check(lib.ssm_maxpool2_bwd(src.view(), dy.view(), dx.view(), nb, src.C, src.H, src.W, st))
+                dy = dx
+                continue
+            _, idx, cin, cout, sname, dname = s
+            Y = self.t[dname]
+            if idx not in self.pk_t:
+                self.pk_t[idx] = (nb, hb.PackedConv(transposed_filter(self.w[idx]), torch.zeros(cin, device=self.device), nb, Y.H, Y.W))
+            assert self.pk_t[idx][0] == nb, "input_grad was planned for %d batch entries" % self.pk_t[idx][0]
+            pk = self.pk_t[idx][1]
+            key = "dz%d" % idx
+            if key not in self.g:
+                self.g[key] = hb.Planes(self.B, pk.cin_p, Y.H, Y.W, self.device)
+            dzp = self.g[key]
+            hb.check(lib.ssm_lrelu_bwd(dy.view(), hb.NULL_VIEW, Y.view(), dzp.view(), nb, cout, Y.H, Y.W, 0.0, 1, st))
+            dx = self._G(sname, C=cin)
+            e1 = self._span("vgg_bwd", "features.%d" % idx, 2.0 * nb * Y.H * Y.W * cin * cout * 9)
+            hb.conv2d(dzp.view(), pk.cin_p, None, 0, pk, dx.view(), None, nb, Y.H, Y.W, lrelu=False)
+            if e1 is not None:
+                e1.record()
+            dy = dx
+        return dy
+
+
+class PerceptualTerm:
+    """mean_{C,h,w} (phi(pred) - phi(target))^2 per sample and its gradient wrt pred (losses.py:218,227:
+    MSELoss(reduce=False), then the per-sample mean).  pred and target go through ONE VGG pass as a batch of 2B;
+    the backward walks the first B entries only."""
+
+    def __init__(self, vgg_state_dict, B, H, W, device):
+        self.B = B
+        self.vgg = VGGFeatures(vgg_state_dict, 2 * B, H, W, device)
+        self.coef = torch.empty(B, dtype=torch.float32, device=device)
+        self.both = torch.empty(2 * B, 3, H, W, dtype=torch.float32, device=device)
+
+    def forward(self, pred, target):
+        """-> [B] unweighted per-sample feature MSE."""
+        B = self.B
+        self.both[:B].copy_(pred)
+        self.both[B:].copy_(target)
+        f = self.vgg.forward(self.both).interior
+        return ((f[:B] - f[B:]) ** 2).reshape(B, -1).mean(dim=1)
+
+    def grad_pred(self, weight):
+        """weight [B] = (upstream gradient x lambda_p) per sample -> Planes [2B,3,H,W] whose first B entries hold
+        d(loss)/d(pred)."""
+        B, phi = self.B, self.vgg.t[self.vgg.out]
+        n = float(phi.C * phi.H * phi.W)
+        self.coef.copy_(weight * (2.0 / n))
+        dphi = self.vgg._G(self.vgg.out)
+        hb.check(hb.load().ssm_sqdiff_grad(phi.view(), phi.view(b0=B), self.coef.data_ptr(), dphi.view(), B, phi.C, phi.H, phi.W,
+                                           hb.stream_ptr()))
+        return self.vgg.input_grad(dphi, nb=B)

@@ -128,7 +128,7 @@ def test_synthesis_and_inputs_adjoints_with_losses(dev, s1_terms, s2_terms):
     dout5, dest, dflow4 = (torch.empty(B, 5, H, W, device=dev), torch.empty(B, 4, H, W, device=dev),
                            torch.empty(B, 4, H, W, device=dev))
     hb.check(lib.ssm_synthesize_bwd(hb.view_of(img6d), hb.view_of(est), hb.view_of(out5d), hb.view_of(tgtd), td.data_ptr(),
-                                    crd.data_ptr(), cwd.data_ptr(), hb.view_of(dout5), hb.view_of(dest), B, H, W,
+                                    crd.data_ptr(), cwd.data_ptr(), hb.NULL_VIEW, hb.view_of(dout5), hb.view_of(dest), B, H, W,
                                     1 if s2_terms else 0, hb.stream_ptr()))
     hb.check(lib.ssm_flowinterp_inputs_bwd(hb.view_of(img6d), hb.view_of(flow4d), hb.view_of(r16d), hb.view_of(dest),
                                            td.data_ptr(), cwd.data_ptr(), hb.view_of(dflow4), B, H, W, 1 if s1_terms else 0,
@@ -137,8 +137,9 @@ def test_synthesis_and_inputs_adjoints_with_losses(dev, s1_terms, s2_terms):
     assert rel_err(dflow4.cpu(), flow4.grad) < 2e-4, "d flow4"
 
 
-def _oracle_training_loss(p1, p2, img6, t, target, lr, lw):
-    """The reference's total loss (losses.py:196-249 with FREEZE=FALSE, perceptual term off), batch mean of column 0."""
+def _oracle_training_loss(p1, p2, img6, t, target, lr, lw, vgg=None, lp=0.0):
+    """The reference's total loss (losses.py:196-249 with FREEZE=FALSE; perceptual term on when `vgg` weights are
+    given), batch mean of column 0."""
     from oracle import ssm_oracle as O
     c6, flow4 = O.stage1(p1, img6)
     in16 = O.flow_interp_inputs(img6, flow4, t)
@@ -150,6 +151,8 @@ def _oracle_training_loss(p1, p2, img6, t, target, lr, lw):
     warp = ((O.warp(i1, flow4[:, 0:2]) - i0).abs() + (O.warp(i0, flow4[:, 2:4]) - i1).abs()
             + (O.warp(i0, ft0) - target).abs() + (O.warp(i1, ft1) - target).abs())
     total = lr * m((pred - target).abs()) + lw * m(warp)
+    if vgg is not None:
+        total = total + lp * O.perceptual_loss(vgg, pred, target)
     return total.mean(), pred
 
 
@@ -253,3 +256,110 @@ def test_main_entry_point_trains_and_checkpoints(dev, tmp_path):
     init = synthetic_state_dict(1)
     # the model started from torch's default init (LOADPREV=FALSE), trained 4 steps: weights are finite and loadable
     assert all(torch.isfinite(v).all() for v in s1.state_dict().values()) and set(s1.state_dict()) == set(init)
+
+
+def test_maxpool_and_feature_mse_kernels(dev):
+    from ssm_amd import hipbind as hb
+    lib = hb.load()
+    torch.manual_seed(5)
+    B, C, H, W = 2, 10, 12, 20
+    x = torch.randn(B, C, H, W)
+    x[0, 0, 0:2, 0:2] = 0.0                              # a tie: the first element of the window takes the gradient
+    xr = x.clone().requires_grad_()
+    y = torch.nn.functional.max_pool2d(xr, 2, 2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd, yd, dxd = x.to(dev), torch.empty(B, C, H // 2, W // 2, device=dev), torch.empty(B, C, H, W, device=dev)
+    hb.check(lib.ssm_maxpool2_fwd(hb.view_of(xd), hb.view_of(yd), B, C, H, W, hb.stream_ptr()))
+    gyd = gy.to(dev)
+    hb.check(lib.ssm_maxpool2_bwd(hb.view_of(xd), hb.view_of(gyd), hb.view_of(dxd), B, C, H, W, hb.stream_ptr()))
+    assert torch.equal(yd.cpu(), y.detach()) and torch.equal(dxd.cpu(), xr.grad)
+    a, b = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    coef = torch.tensor([0.5, -2.0])
+    out = torch.empty(B, C, H, W, device=dev)
+    ad, bd, cd = a.to(dev), b.to(dev), coef.to(dev)          # keep the device copies alive across the call
+    hb.check(lib.ssm_sqdiff_grad(hb.view_of(ad), hb.view_of(bd), cd.data_ptr(), hb.view_of(out), B, C, H, W, hb.stream_ptr()))
+    assert float((out.cpu() - coef.view(B, 1, 1, 1) * (a - b)).abs().max()) < 1e-6
+    with pytest.raises(RuntimeError):
+        hb.check(lib.ssm_maxpool2_fwd(hb.view_of(xd), hb.view_of(yd), B, C, H - 1, W, hb.stream_ptr()))
+
+
+def test_vgg_features_and_input_gradient_vs_oracle(dev):
+    """phi = vgg16.features[:23] on the HIP kernels and d<phi, R>/dx against the CPU oracle + autograd."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    from ssm_amd.perceptual import PerceptualTerm, VGGFeatures, synthetic_vgg_state_dict
+    vsd = synthetic_vgg_state_dict()
+    assert sum(v.numel() for v in vsd.values()) == 7635264          # conv1_1 .. conv4_3 of VGG16
+    torch.manual_seed(6)
+    B, H, W = 2, 48, 64
+    x = torch.randn(B, 3, H, W)
+    xr = x.clone().requires_grad_()
+    phi = O.vgg16_conv4_3(vsd, xr)
+    R = torch.randn_like(phi)
+    (phi * R).sum().backward()
+    net = VGGFeatures(vsd, B, H, W, dev)
+    got = net.forward(x.to(dev))
+    assert tuple(got.interior.shape) == (B, 512, H // 8, W // 8)
+    assert rel_err(got.to_nchw().cpu(), phi.detach()) < 1e-4
+    dphi = hb.Planes(B, 512, H // 8, W // 8, dev).load(R.to(dev))
+    dx = net.input_grad(dphi)
+    assert rel_err(dx.to_nchw().cpu()[:, :3], xr.grad) < 1e-3
+    # the loss term: value and gradient wrt pred
+    pred, tgt = torch.randn(B, 3, H, W), torch.randn(B, 3, H, W)
+    pr = pred.clone().requires_grad_()
+    want = O.perceptual_loss(vsd, pr, tgt)
+    wts = torch.tensor([1.5, 0.25])
+    (want * wts).sum().backward()
+    term = PerceptualTerm(vsd, B, H, W, dev)
+    val = term.forward(pred.to(dev), tgt.to(dev))
+    assert float(((val.cpu() - want.detach()).abs() / want.detach().abs()).max()) < 1e-4
+    g = term.grad_pred(wts.to(dev))
+    assert rel_err(g.to_nchw().cpu()[:B, :3], pr.grad) < 1e-3
+
+
+def test_training_step_with_perceptual_term_vs_oracle_autograd(dev):
+    """All four entries of the [B,4] loss tensor and every parameter gradient with the VGG term ON (synthetic VGG16
+    weights; lambda_p = 20 from the ini) against CPU autograd of the oracle."""
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.perceptual import synthetic_vgg_state_dict
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    ov = synthetic_weight_overrides()
+    ov[("STAGE1", "FREEZE")] = "FALSE"
+    ov[("STAGE2", "FREEZE")] = "FALSE"
+    cfg = load_config("superslomo_original.ini", ov)
+    m = FullModel(cfg)
+    sd1, sd2, vsd = synthetic_state_dict(1), synthetic_state_dict(2), synthetic_vgg_state_dict()
+    m.stage1_model.load_state_dict(sd1)
+    m.stage2_model.load_state_dict(sd2)
+    assert not m.loss.perceptual_available
+    m.loss.load_vgg16(vsd)
+    assert m.loss.perceptual_available
+    m = m.to(dev).train()
+    clips = torch.cat([synthetic_frames(3, 64, 64, seed=72), synthetic_frames(3, 64, 64, seed=73)], 0)
+    xin, tgt = clips[:, [0, 2]], clips[:, 1:2]
+    t = torch.tensor([0.625, 0.25]).view(2, 1, 1, 1, 1)
+    img, losses = m(xin.to(dev), t.to(dev), tgt.to(dev), None, False)
+    losses.mean(dim=0)[0].backward()
+    p1 = {k: v.clone().requires_grad_() for k, v in sd1.items()}
+    p2 = {k: v.clone().requires_grad_() for k, v in sd2.items()}
+    img6 = torch.cat([xin[:, 0], xin[:, 1]], 1)
+    lp = cfg.getfloat("TRAIN", "LAMBDA_P")
+    L, pred = _oracle_training_loss(p1, p2, img6, t.view(2, 1, 1, 1), tgt[:, 0], 60.0, 10.0, vgg=vsd, lp=lp)
+    L.backward()
+    from oracle import ssm_oracle as O
+    per = lp * O.perceptual_loss(vsd, pred.detach(), tgt[:, 0])
+    assert float(per.min()) > 0 and float(((losses[:, 3].detach().cpu() - per).abs() / per).max()) < 2e-3
+    assert abs(float(losses.mean(0)[0]) - float(L)) < 2e-4 * abs(float(L))
+    worst = []
+    for stage, mod, ref in (("s1", m.stage1_model, p1), ("s2", m.stage2_model, p2)):
+        for name, p in mod.named_parameters():
+            g, w = p.grad.cpu().flatten(), ref[name].grad.flatten()
+            cos = float(torch.dot(g, w) / (g.norm() * w.norm() + 1e-30))
+            rel = float((g - w).abs().max() / (w.abs().max() + 1e-30))
+            worst.append((rel, cos, stage + "." + name))
+    worst.sort(reverse=True)
+    print("worst gradients with the perceptual term (rel max err, cosine):", worst[:4])
+    assert all(c > 0.999 for _, c, _ in worst), worst[:4]
+    assert worst[0][0] < 2e-2, worst[:4]

@@ -108,3 +108,31 @@ def test_recurrent_mirror_weight_abi(kind, n1, n2):
     assert "conv6.forward_net.cell_list.0." + leaf in keys and "conv6.reverse_net.cell_list.1." + leaf in keys
     with pytest.raises(RuntimeError):                 # no CPU fallback for the recurrent path either
         m(torch.zeros(1, 4, 3, 32, 32), torch.full((1, 3, 1, 1, 1), 0.5))
+
+
+def test_oracle_vgg16_matches_torchvision_layout():
+    """The oracle's phi against an nn.Sequential built the way torchvision builds vgg16.features (cfg 'D':
+    64,64,M,128,128,M,256,256,256,M,512,512,512,M,...; conv3x3 pad 1 + ReLU(inplace)) and cut at [:23] like
+    losses.py:34 - pins the layer indices / key names of the state dict the HIP extractor consumes."""
+    import torch.nn as nn
+    from ssm_amd.perceptual import VGG16_CONV4_3, synthetic_vgg_state_dict
+    layers, cin = [], 3
+    for v in [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    feats = nn.Sequential(*layers)[:23]
+    assert isinstance(feats[22], nn.ReLU) and isinstance(feats[21], nn.Conv2d)
+    sd = synthetic_vgg_state_dict()
+    feats.load_state_dict({k[len("features."):]: v for k, v in sd.items()})          # strict: same indices and shapes
+    assert [i[0] for i in VGG16_CONV4_3 if i != "M"] == [i for i, m in enumerate(feats) if isinstance(m, nn.Conv2d)]
+    x = torch.randn(2, 3, 32, 40)
+    with torch.no_grad():
+        want = feats(x)
+    got = O.vgg16_conv4_3(sd, x)
+    assert got.shape == (2, 512, 4, 5) and float((got - want).abs().max()) < 1e-5
+    assert float(got.abs().mean()) > 1e-2               # the synthetic weights keep the features alive
+    val = O.perceptual_loss(sd, x, x + 0.1)
+    assert val.shape == (2,) and bool((val > 0).all())
