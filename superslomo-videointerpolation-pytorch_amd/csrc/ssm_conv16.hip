@@ -25,10 +25,16 @@
 #include <utility>
 
 #ifndef SSM_C16_SCHED
-#define SSM_C16_SCHED 1
+#define SSM_C16_SCHED 2
 #endif
 #ifndef SSM_C16_PRIO
 #define SSM_C16_PRIO 0
+#endif
+#ifndef SSM_C16_PRODUCERS   // 1: DMA-only producer waves stage the operands (0: every wave issues its share of the DMA)
+#define SSM_C16_PRODUCERS 1
+#endif
+#ifndef SSM_C16_ABL      // diagnostics (wrong results): 1 = no DMA in the loop, 2 = also no barriers, 3 = also no LDS reads
+#define SSM_C16_ABL 0
 #endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -80,8 +86,14 @@ struct Cfg16 {
     static constexpr int WST_BYTES = WST_PIECES * 16;
     static constexpr int LDS_BYTES = PBUFS * PATCH_BYTES + 2 * WST_BYTES;
     static constexpr int BLOCKS_PER_CU = (2 * LDS_BYTES <= 160 * 1024 && NW <= 4) ? 2 : 1;
-    static constexpr int PM = (PNI + NW - 1) / NW;                // patch DMA instructions per wave
-    static constexpr int WM = (WNI + NW - 1) / NW;                // filter DMA instructions per wave per stage
+    // Producer waves: NP extra waves that only issue the LDS-DMA of the next filter stage / patch slice, so the matrix
+    // waves' in-order instruction streams hold nothing but ds_read_b128 and MFMA (each global_load_lds costs its
+    // issuing wave 60-180 cycles; ablation in profiles/README.md r1h).
+    static constexpr int NP = (SSM_C16_PRODUCERS && NW >= 8) ? 4 : 0;   // 4-wave tiles: iterations too short, measured slower
+    static constexpr int NLOAD = NP ? NP : NW;                    // waves that share the DMA instructions
+    static constexpr int NTHREADS_ALL = 64 * (NW + NP);
+    static constexpr int PM = (PNI + NLOAD - 1) / NLOAD;          // patch DMA instructions per loading wave
+    static constexpr int WM = (WNI + NLOAD - 1) / NLOAD;          // filter DMA instructions per loading wave per stage
     static_assert(KS % KYS == 0, "filter rows per stage must divide k");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(WST_PIECES % 64 == 0, "filter stage is whole DMA instructions");
@@ -127,10 +139,57 @@ __device__ __forceinline__ void conv16_compute(f32x16 (&acc)[C::NT][C::MT], cons
     };
     h8 ah[2][NT], al[2][NT], bh[2][MT], bl[2][MT];
     fetch(0, ah[0], al[0], bh[0], bl[0]);
+#if SSM_C16_SCHED == 2
+    // Source order = issue order (a sched_barrier after every step): MFMAs round-robin over the accumulators (no
+    // back-to-back dependence), and the next tap's ds_read_b128 go ONE per MFMA gap.  A burst of reads ahead of the
+    // MFMAs blocks the wave's in-order issue behind the LDS queue while the matrix pipe idles (ablation: r1h).
+    constexpr int NA = (C::SPLIT3 ? 2 : 1) * NT;                 // A-fragment reads per tap
+    constexpr int NRD = NA + (C::SPLIT3 ? 2 : 1) * MT;           // ds_read_b128 per tap
+    constexpr int NPR = C::SPLIT3 ? 3 : 1;                       // products per (n, m)
+    constexpr int NMF = NPR * NT * MT;
+    auto fetch_one = [&](int tl, int r, h8 (&fah)[NT], h8 (&fal)[NT], h8 (&fbh)[MT], h8 (&fbl)[MT]) {
+        const int kyy = tl / KS, kx = tl - kyy * KS;
+        if (r < NA) {
+            const int n = r % NT, lo = r / NT;
+            const h8 v = *reinterpret_cast<const h8 *>(sa + (tl * 4 * BN + n * 32) * 16 + lo * A_LO);
+            if (lo) fal[n] = v; else fah[n] = v;
+        } else {
+            const int q = r - NA, m = q % MT, lo = q / MT;
+            const int my = m / C::MTX, mx = m - my * C::MTX;
+            const h8 v = *reinterpret_cast<const h8 *>(sb + ((my + kyy) * PW + mx * 32 + kx) * 16 + lo * B_LO);
+            if (lo) fbl[m] = v; else fbh[m] = v;
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tl = 0; tl < KYS * KS; ++tl) {
         const int cur = tl & 1;
+        const bool more = tl + 1 < KYS * KS;
+#pragma unroll
+        for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int idx = (pr * NT + n) * MT + m;
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 2 ? al[cur][n] : ah[cur][n], pr == 1 ? bl[cur][m] : bh[cur][m],
+                                                                       acc[n][m], 0, 0, 0);
+                    if (more && idx < NRD) fetch_one(tl + 1, idx, ah[cur ^ 1], al[cur ^ 1], bh[cur ^ 1], bl[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        if (more) {
+#pragma unroll
+            for (int r = NMF; r < NRD; ++r) fetch_one(tl + 1, r, ah[cur ^ 1], al[cur ^ 1], bh[cur ^ 1], bl[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#else
+#pragma unroll
+    for (int tl = 0; tl < KYS * KS; ++tl) {
+        const int cur = tl & 1;
+#if SSM_C16_ABL < 3
         if (tl + 1 < KYS * KS) fetch(tl + 1, ah[cur ^ 1], al[cur ^ 1], bh[cur ^ 1], bl[cur ^ 1]);
+#endif
 #if SSM_C16_SCHED
         __builtin_amdgcn_sched_barrier(0);      // keep the next tap's LDS reads ahead of this tap's MFMAs
 #endif
@@ -154,6 +213,7 @@ __device__ __forceinline__ void conv16_compute(f32x16 (&acc)[C::NT][C::MT], cons
         __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+#endif
 }
 
 // bias, LeakyReLU, hi/lo split, stores (HL8 and/or fp32 planes), fused 2x2 mean.
@@ -227,15 +287,18 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void conv16_kernel(const Conv16Params p) {
+__global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP) + 3) / 4) void conv16_kernel(const Conv16Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NW = C::NW;
+    constexpr int KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NW = C::NW, NL = C::NLOAD;
     char *const pbuf0 = lds;
     char *const wbuf0 = lds + C::PBUFS * C::PATCH_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = C::NP ? wid >= NW : true;          // issues DMA
+    const bool matrix = wid < NW;                          // runs MFMAs
+    const int lw = C::NP ? wid - NW : wid;                 // index among the loading waves
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
 
     int id = blockIdx.x;
@@ -248,36 +311,39 @@ __global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void con
     const int x0 = tx * C::TW, y0 = ty * C::TH;
 
     const int nchunks = p.Cin / 16;
+    const int total_it = nchunks * C::NIT;
     const long long porg = (long long)(y0 - C::PAD) * p.sh + (x0 - C::PAD);     // pixels
     const char *pbase1 = p.src1 + ((long long)b * p.sb1 + porg) * 16;
     const char *pbase2 = p.src2 + ((long long)b * p.sb2 + porg) * 16;
     const char *wbase = p.wpk + (long long)nb * nchunks * C::NIT * C::WST_BYTES;
 
-    // per-lane source byte offsets of this wave's patch DMA instructions (same for every chunk)
+    // ---- loading side: per-lane source byte offsets of this wave's patch DMA instructions (same for every chunk)
     int poff[C::PM];
+    if (loader) {
 #pragma unroll
-    for (int m = 0; m < C::PM; ++m) {
-        int q = (wid + NW * m) * 64 + lane;
-        if (q >= C::PATCH_PIECES) q = C::PATCH_PIECES - 1;   // tail lanes re-read the last piece into the padding
-        const int pl = q / (PH * PW);
-        const int rem = q - pl * (PH * PW);
-        const int r = rem / PW;
-        const int c = rem - r * PW;
-        poff[m] = (int)(((long long)(pl >> 1) * p.sg + (long long)(pl & 1) * p.sp + (long long)r * p.sh + c) * 16);
+        for (int m = 0; m < C::PM; ++m) {
+            int q = (lw + NL * m) * 64 + lane;
+            if (q >= C::PATCH_PIECES) q = C::PATCH_PIECES - 1;   // tail lanes re-read the last piece into the padding
+            const int pl = q / (PH * PW);
+            const int rem = q - pl * (PH * PW);
+            const int r = rem / PW;
+            const int c = rem - r * PW;
+            poff[m] = (int)(((long long)(pl >> 1) * p.sg + (long long)(pl & 1) * p.sp + (long long)r * p.sh + c) * 16);
+        }
     }
-    const int woff = (wid * 64 + lane) * 16;
+    const int woff = (lw * 64 + lane) * 16;
 
     auto patch_src = [&](int ch) -> const char * {
         const int c0 = ch * 16;
         return (c0 < p.C1) ? pbase1 + (long long)(c0 >> 3) * p.sg * 16 : pbase2 + (long long)((c0 - p.C1) >> 3) * p.sg * 16;
     };
-    // slice j (of NIT) of the patch of chunk ch -> pbuf[ch&1]
+    // slices [jlo, jhi) (of NIT) of the patch of chunk ch -> pbuf[ch&1]
     auto issue_patch = [&](int ch, int jlo, int jhi) {
         const char *ps = patch_src(ch);
         char *pb = pbuf0 + (C::PBUFS == 2 ? (ch & 1) : 0) * C::PATCH_BYTES;
 #pragma unroll
         for (int m = 0; m < C::PM; ++m) {
-            const int ii = wid + NW * m;
+            const int ii = lw + NL * m;
             const int j = m % C::NIT;
             if (ii < C::PNI && j >= jlo && j < jhi) SSM_GLDS16B(ps + poff[m], pb + ii * 1024);
         }
@@ -287,11 +353,40 @@ __global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void con
         char *wb = wbuf0 + (it & 1) * C::WST_BYTES;
 #pragma unroll
         for (int m = 0; m < C::WM; ++m) {
-            const int ii = wid + NW * m;
-            if (ii < C::WNI) SSM_GLDS16B(ws + m * (NW * 1024), wb + ii * 1024);
+            const int ii = lw + NL * m;
+            if (ii < C::WNI) SSM_GLDS16B(ws + m * (NL * 1024), wb + ii * 1024);
         }
     };
+    // Per iteration `it` (chunk ch, filter-row stage j), after the barrier that makes stage `it` visible: the loaders
+    // start stage it+1 (its buffer's readers were iteration it-1) and slice j of the next chunk's patch (PBUFS == 2: the
+    // other buffer, whose readers were chunk ch-1).  PBUFS == 1: the single patch buffer is refilled at the chunk
+    // boundary behind an extra barrier; the CU's second workgroup covers that latency.
+    auto load_step = [&](int it, int ch, int j) {
+#if SSM_C16_ABL < 1
+        if (it + 1 < total_it) issue_w(it + 1);
+        if (C::PBUFS == 2 && ch + 1 < nchunks) issue_patch(ch + 1, j, j + 1);
+#endif
+    };
 
+    if constexpr (C::NP > 0) {
+        if (!matrix) {                                 // ---- producer waves: DMA only ----
+            issue_patch(0, 0, C::NIT);
+            issue_w(0);
+            for (int it = 0, ch = 0, j = 0; it < total_it; ++it) {
+                if (C::PBUFS == 1 && j == 0 && ch > 0) {
+                    __syncthreads();                   // every matrix wave is done reading the previous chunk's patch
+                    issue_patch(ch, 0, C::NIT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                load_step(it, ch, j);
+                if (++j == C::NIT) j = 0, ++ch;
+            }
+            return;
+        }
+    }
+
+    // ---- matrix waves ----
     f32x16 acc[NT][MT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -304,23 +399,22 @@ __global__ __launch_bounds__(C::NTHREADS, C::BLOCKS_PER_CU * C::NW / 4) void con
     const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
     const int aOff = (half * 2 * BN + wn * (NT * 32) + l31) * 16;
 
-    const int total_it = nchunks * C::NIT;
-    issue_patch(0, 0, C::NIT);
-    issue_w(0);
-    for (int it = 0; it < total_it; ++it) {
-        const int ch = it / C::NIT, j = it - ch * C::NIT;
+    if (C::NP == 0) {
+        issue_patch(0, 0, C::NIT);
+        issue_w(0);
+    }
+    for (int it = 0, ch = 0, j = 0; it < total_it; ++it) {
         if (C::PBUFS == 1 && j == 0 && ch > 0) {
-            __syncthreads();                      // every wave is done reading the previous chunk's patch
-            issue_patch(ch, 0, C::NIT);
+            __syncthreads();
+            if (C::NP == 0) issue_patch(ch, 0, C::NIT);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (C::NP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (it + 1 < total_it) issue_w(it + 1);
-        if (C::PBUFS == 2 && ch + 1 < nchunks) issue_patch(ch + 1, j, j + 1);
-
+        if (C::NP == 0) load_step(it, ch, j);
         const char *sb = pbuf0 + (C::PBUFS == 2 ? (ch & 1) : 0) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
         const char *sa = wbuf0 + (it & 1) * C::WST_BYTES + aOff;
         conv16_compute<C>(acc, sb, sa);
+        if (++j == C::NIT) j = 0, ++ch;
     }
 
     conv16_epilogue<C>(p, acc, nb, b, x0, y0, wn, wy, wx, l31, half);
@@ -629,7 +723,7 @@ int launch16(Conv16Params &p, int B, hipStream_t st) {
         return SSM_E_ARG;
     }
     if (!reserve_lds((const void *)conv16_kernel<C>, C::LDS_BYTES)) return SSM_E_LAUNCH;
-    hipLaunchKernelGGL(conv16_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(conv16_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS_ALL), C::LDS_BYTES, st, p);
     return ssm::check_launch("ssm_conv2d_hl8_fwd");
 }
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Diagnostic: shader clock while one conv layer runs back to back (is the matrix pipe clock- or issue-limited?).
+usage: python tools/clock_under_load.py [layer ...]   (default: a few stage-2 layers at B=7, 736x1280)"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd")
+sys.path[:0] = [ROOT, PKG, os.path.join(PKG, "scripts")]
+import torch  # noqa: E402
+
+from ssm_amd import hipbind as hb  # noqa: E402
+from ssm_amd.engine import layer_scale  # noqa: E402
+from ssm_amd.weights import unet_layers  # noqa: E402
+
+probe = ctypes.CDLL(os.path.join(ROOT, "tools", "libclockprobe.so"))
+probe.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p]
+
+
+def measure(fn, ms=30.0):
+    dev = torch.device("cuda:0")
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    probe.clock_probe_launch(out.data_ptr(), int(ms * 1e5), ctypes.c_void_p(side.cuda_stream))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 0
+    while True:
+        for _ in range(20):
+            fn()
+        n += 20
+        e1.record()
+        e1.synchronize()
+        if e0.elapsed_time(e1) > ms * 1.3:
+            break
+    torch.cuda.synchronize()
+    c, r = [int(v) for v in out.cpu()]
+    return c / (r / 100e6) / 1e9, e0.elapsed_time(e1) / n
+
+
+def main():
+    names = sys.argv[1:] or ["conv1b", "conv2b", "conv4b", "conv8b", "conv9b", "conv10b", "conv11b"]
+    B, H, W = 7, 736, 1280
+    dev = torch.device("cuda:0")
+    ghz, _ = measure(lambda: None, 10.0)
+    print("idle: %.3f GHz" % ghz)
+    for name, cin, cout, k in unet_layers(2, True):
+        if name not in names:
+            continue
+        s = layer_scale(name)
+        h, w = H // s, W // s
+        pk = hb.PackedConv16(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5, torch.zeros(cout, device=dev), w)
+        x = hb.HPlanes(B, cin, h, w, dev, groups=pk.cin_p // 8)
+        x.buf.normal_()
+        y = hb.HPlanes(B, cout, h, w, dev)
+        for fast in (False, True):
+            fn = lambda: hb.conv2d_hl8(x.view(), pk.cin_p, None, 0, pk, y.view(), None, None, B, h, w, fast=fast)  # noqa: E731
+            ghz, ms = measure(fn)
+            gf = 2.0 * B * h * w * cout * cin * k * k / 1e9
+            issued = gf / ms * (1 if fast else 3)
+            print("%-8s %-6s %.3f ms  %6.1f TF algorithmic  %7.1f TF issued  clock %.3f GHz  -> MFMA busy %.0f %% of the pipe at that clock"
+                  % (name, "f16" if fast else "f16x3", ms, gf / ms, issued, ghz, 100 * issued / (2500.0 * ghz / 2.4)))
+
+
+if __name__ == "__main__":
+    main()
