@@ -89,7 +89,7 @@ struct Cfg16 {
     // Producer waves: NP extra waves that only issue the LDS-DMA of the next filter stage / patch slice, so the matrix
     // waves' in-order instruction streams hold nothing but ds_read_b128 and MFMA (each global_load_lds costs its
     // issuing wave 60-180 cycles; ablation in profiles/README.md r1h).
-    static constexpr int NP = (SSM_C16_PRODUCERS && NW >= 8) ? 4 : 0;   // 4-wave tiles: iterations too short, measured slower
+    static constexpr int NP = (SSM_C16_PRODUCERS == 2 || (SSM_C16_PRODUCERS == 1 && NW >= 8)) ? 4 : 0;   // 4-wave tiles: iterations too short, measured slower
     static constexpr int NLOAD = NP ? NP : NW;                    // waves that share the DMA instructions
     static constexpr int NTHREADS_ALL = 64 * (NW + NP);
     static constexpr int PM = (PNI + NLOAD - 1) / NLOAD;          // patch DMA instructions per loading wave
