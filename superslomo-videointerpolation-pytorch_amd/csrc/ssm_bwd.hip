@@ -76,13 +76,19 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__re
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KS, int XC, int NTC>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
-                                                         int H, int W, int cin_total, int ci_offset) {
-    // CT column tiles per wave (256 columns per workgroup), RR image rows per staging: 4x the MFMA work per barrier
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
+                                                            int H, int W, int cin_total, int ci_offset) {
+    // CT column tiles per wave (256 columns per workgroup), RR image rows per staging step.
+    // Staging is register-prefetched: the float4 loads of step s+1 are issued before the MFMAs of step s and written
+    // to LDS after them, so global latency hides under 1024 MFMAs instead of standing between two barriers.
     constexpr int KS2 = KS * KS, PAD = (KS - 1) / 2, SEG = 64, RR = 2, CT = 2;
     constexpr int DS = RR * SEG + 1;                 // dZ tile row stride (odd: conflict-free across couts)
     constexpr int XR = KS + RR - 1;                  // staged activation rows
-    constexpr int RS = SEG + 2 * PAD + 1;
+    constexpr int XV = SEG / 4 + 2;                  // float4 per staged row: columns [xs-4, xs+SEG+4)
+    constexpr int RS = 4 * XV + 1;                   // odd row stride
+    constexpr int NDZ = NTC * 32 * RR * (SEG / 4);   // float4 in a dZ tile
+    constexpr int NX = XC * XR * XV;                 // float4 in an activation tile
+    constexpr int LDZ = (NDZ + 255) / 256, LX = (NX + 255) / 256;
     __shared__ float sdz[NTC * 32 * DS];
     __shared__ float sx[XC * XR * RS + 8];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ssm_view x, ssm_view dz
         cci[t] = cvalid[t] ? col / KS2 : c_lo;
         tap[t] = cvalid[t] ? col - cci[t] * KS2 : 0;
         const int ky = tap[t] / KS, kx = tap[t] - ky * KS;
-        colOff[t] = ((cci[t] - c_lo) * XR + ky) * RS + kx + half;   // + row*RS + pixel = LDS address of this lane's B value
+        colOff[t] = ((cci[t] - c_lo) * XR + ky) * RS + kx + (4 - PAD) + half;   // + row*RS + pixel = LDS address of this lane's B value
     }
     f32x16 acc[NTC][CT];
 #pragma unroll
@@ -109,41 +115,92 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(ssm_view x, ssm_view dz
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][t][r] = 0.f;
-    const int rowpairs = B * ((H + RR - 1) / RR);
-    for (int rp = blockIdx.z; rp < rowpairs; rp += gridDim.z) {
-        const int b = rp / ((H + RR - 1) / RR), y = (rp - b * ((H + RR - 1) / RR)) * RR;
-        for (int xs = 0; xs < W; xs += SEG) {
-            const int wseg = min(SEG, W - xs);
-            __syncthreads();
-            for (int i = tid; i < NTC * 32 * RR * SEG; i += 256) {
-                const int c = i / (RR * SEG), rem = i - c * (RR * SEG);
-                const int rr = rem / SEG, xx = rem - rr * SEG;
-                const bool ok = co0 + c < Cout && xx < wseg && y + rr < H;
-                sdz[c * DS + rr * SEG + xx] = ok ? vp(dz, b, co0 + c, y + rr)[xs + xx] : 0.f;     // zero tail: those products vanish
+
+    const int rgroups = (H + RR - 1) / RR, nseg = (W + SEG - 1) / SEG;
+    const int nsteps_total = B * rgroups * nseg;     // staging steps of the whole image batch; this workgroup takes every gridDim.z-th
+    float4 pdz[LDZ], px[LX];
+    auto decode = [&](int s, int &b, int &y, int &xs) {
+        const int rp = s / nseg;
+        xs = (s - rp * nseg) * SEG;
+        b = rp / rgroups;
+        y = (rp - b * rgroups) * RR;
+    };
+    auto prefetch = [&](int s) {
+        int b, y, xs;
+        decode(s, b, y, xs);
+#pragma unroll
+        for (int i = 0; i < LDZ; ++i) {
+            const int f = tid + 256 * i;
+            const int c = f / (RR * (SEG / 4)), rem = f - c * (RR * (SEG / 4));
+            const int rr = rem / (SEG / 4), x4 = rem - rr * (SEG / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < NDZ && co0 + c < Cout && y + rr < H && xs + 4 * x4 < W) {
+                v = *reinterpret_cast<const float4 *>(vp(dz, b, co0 + c, y + rr) + xs + 4 * x4);
+                const int left = W - (xs + 4 * x4);        // zero tail: those products vanish
+                if (left < 4) {
+                    if (left < 2) v.y = 0.f;
+                    if (left < 3) v.z = 0.f;
+                    v.w = 0.f;
+                }
             }
-            for (int i = tid; i < XC * XR * (SEG + 2 * PAD); i += 256) {
-                const int c = i / (XR * (SEG + 2 * PAD));
-                const int rem = i - c * (XR * (SEG + 2 * PAD));
-                const int ry = rem / (SEG + 2 * PAD), xx = rem - ry * (SEG + 2 * PAD);
-                float v = 0.f;      // rows / columns outside the image come from the padded-plane zero frame
-                if (c_lo + c < Cin && xx < wseg + 2 * PAD && y + ry - PAD < H + PAD) v = vp(x, b, c_lo + c, y + ry - PAD)[xs + xx - PAD];
-                sx[(c * XR + ry) * RS + xx] = v;
+            pdz[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int f = tid + 256 * i;
+            const int c = f / (XR * XV), rem = f - c * (XR * XV);
+            const int ry = rem / XV, x4 = rem - ry * XV;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // rows / columns outside the image come from the padded-plane zero frame; columns past the frame only meet zeroed dZ
+            if (f < NX && c_lo + c < Cin && y + ry - PAD < H + PAD)
+                v = *reinterpret_cast<const float4 *>(vp(x, b, c_lo + c, y + ry - PAD) + xs - 4 + 4 * x4);
+            px[i] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < LDZ; ++i) {
+            const int f = tid + 256 * i;
+            if (f < NDZ) {
+                const int c = f / (RR * (SEG / 4)), rem = f - c * (RR * (SEG / 4));
+                float *d = sdz + c * DS + 4 * rem;          // rem = rr*(SEG/4) + x4  ->  rr*SEG + 4*x4
+                d[0] = pdz[i].x; d[1] = pdz[i].y; d[2] = pdz[i].z; d[3] = pdz[i].w;
             }
-            __syncthreads();
-            const int nsteps = (wseg + 1) >> 1;
+        }
 #pragma unroll
-            for (int rr = 0; rr < RR; ++rr) {
-                for (int st = 0; st < nsteps; ++st) {
-                    const int pp = 2 * st;
-                    float bv[CT];
+        for (int i = 0; i < LX; ++i) {
+            const int f = tid + 256 * i;
+            if (f < NX) {
+                const int rowi = f / XV, x4 = f - rowi * XV;        // rowi = c*XR + ry
+                float *d = sx + rowi * RS + 4 * x4;
+                d[0] = px[i].x; d[1] = px[i].y; d[2] = px[i].z; d[3] = px[i].w;
+            }
+        }
+    };
+
+    int s = blockIdx.z;
+    if (s < nsteps_total) prefetch(s);
+    for (; s < nsteps_total; s += gridDim.z) {
+        __syncthreads();                             // everyone is done reading the previous tile
+        commit();
+        __syncthreads();
+        if (s + (int)gridDim.z < nsteps_total) prefetch(s + gridDim.z);
+        int b, y, xs;
+        decode(s, b, y, xs);
+        const int wseg = min(SEG, W - xs);
+        const int nsteps = (wseg + 1) >> 1;
 #pragma unroll
-                    for (int t = 0; t < CT; ++t) bv[t] = cvalid[t] ? sx[colOff[t] + rr * RS + pp] : 0.f;
+        for (int rr = 0; rr < RR; ++rr) {
+            for (int st = 0; st < nsteps; ++st) {
+                const int pp = 2 * st;
+                float bv[CT];
 #pragma unroll
-                    for (int n = 0; n < NTC; ++n) {
-                        const float av = sdz[(n * 32 + l31) * DS + rr * SEG + pp + half];
+                for (int t = 0; t < CT; ++t) bv[t] = cvalid[t] ? sx[colOff[t] + rr * RS + pp] : 0.f;
 #pragma unroll
-                        for (int t = 0; t < CT; ++t) acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[n][t], 0, 0, 0);
-                    }
+                for (int n = 0; n < NTC; ++n) {
+                    const float av = sdz[(n * 32 + l31) * DS + rr * SEG + pp + half];
+#pragma unroll
+                    for (int t = 0; t < CT; ++t) acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[n][t], 0, 0, 0);
                 }
             }
         }
@@ -427,7 +484,10 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
     SSM_REQUIRE(x.ptr && dz.ptr && dw_oihw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad: bad arguments");
     SSM_REQUIRE(ci_offset >= 0 && ci_offset + Cin <= cin_total, "wgrad: channel range [%d,%d) outside the filter's %d inputs", ci_offset,
                 ci_offset + Cin, cin_total);
-    SSM_REQUIRE(x.sh >= W + 2 * SSM_PADX, "wgrad: x must be a padded-plane view (zero frame)");
+    SSM_REQUIRE(x.sh >= W + 2 * SSM_PADX && dz.sh >= W + 3, "wgrad: x and dz must be padded-plane views (zero frame)");
+    SSM_REQUIRE(ssm::aligned16(x.ptr) && ssm::aligned16(dz.ptr) && x.sh % 4 == 0 && x.sc % 4 == 0 && x.sb % 4 == 0 && dz.sh % 4 == 0 &&
+                    dz.sc % 4 == 0 && dz.sb % 4 == 0,
+                "wgrad: views must be 16-byte aligned with strides that are multiples of 4 floats");
     hipStream_t st = (hipStream_t)stream;
     if (zero_first) {
         hipError_t e = hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)Cout * cin_total * k * k, st);
@@ -440,7 +500,7 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
     const int gx = (Cin * k * k + 255) / 256, gy = (Cout + ntc * 32 - 1) / (ntc * 32);
     const int tiles = gx * gy;
     int split = (1024 + tiles - 1) / tiles;          // aim for >= 1024 workgroups
-    const int rows = B * ((H + 1) / 2);
+    const int rows = B * ((H + 1) / 2) * ((W + 63) / 64);       // staging steps (2 image rows x 64 pixels)
     if (split > rows) split = rows;
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
