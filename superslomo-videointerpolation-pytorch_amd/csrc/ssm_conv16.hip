@@ -668,7 +668,7 @@ template <bool S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, 2, S>;       //  8
 template <bool S> using C16K3N32 = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, 1, S>;    //  4   32    8  64    80 KB   2   (short K)
 template <bool S> using C16K3N32D = Cfg16<3, 3, 1, 1, 2, 1, 4, 2, 2, S>;   //  8   32    8  64   121 KB   1   (Cin >= 64)
 template <bool S> using C16K3N64 = Cfg16<3, 3, 2, 1, 2, 1, 4, 2, 2, S>;    //  8   64    8  64   158 KB   1
-template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8  128    4  64    99 KB   1
+template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8  128    4  64    99 KB   1   //  8  128    4  64    99 KB   1
 template <bool S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, 2, S>;  //  4  128    4  32    83 KB   1
 
 //                        KYS NT WN MTY MTX WY WX NWE           matrix+expander waves  BN  TH  TW   LDS
