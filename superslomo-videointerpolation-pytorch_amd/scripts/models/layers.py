@@ -33,8 +33,9 @@ def conv_forward(conv_mod, x, lrelu, slope=0.1):
     """y = [LeakyReLU](conv2d(x)) for a stride-1 'same' nn.Conv2d, on the MFMA kernel."""
     hb.require_device(x, "conv input")
     if torch.is_grad_enabled() and (x.requires_grad or conv_mod.weight.requires_grad):
-        raise NotImplementedError("backward of the HIP convolution is not built yet (SURVEY 8f-1); "
-                                  "run under torch.no_grad() / with FREEZE=TRUE")
+        raise NotImplementedError("the op-by-op HIP convolution carries no autograd graph: the training step runs as one "
+                                  "planned forward/backward (FullModel.forward(inference_mode=False), ssm_amd.backward); "
+                                  "call single operators under torch.no_grad()")
     B, C, H, W = x.shape
     pk = _packed_for(conv_mod, B, H, W)
     assert C == pk.cin, "conv expects %d input channels, got %d" % (pk.cin, C)

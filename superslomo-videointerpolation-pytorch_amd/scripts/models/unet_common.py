@@ -143,8 +143,9 @@ class StageUNet(nn.Module):
         """x [B,C,H,W] -> (conv6_out [B,512,H/32,W/32], final [B,Cout,H,W]) as fresh NCHW tensors."""
         hb.require_device(x, "U-Net input")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("training through the HIP U-Net needs the backward kernels (SURVEY 8f-1, not "
-                                      "built yet); use torch.no_grad() or FREEZE=TRUE")
+            raise NotImplementedError("a stage U-Net called on its own carries no autograd graph: the hand-written backward runs "
+                                      "over the whole window (FullModel.forward(inference_mode=False), ssm_amd.backward.PairGrad); "
+                                      "use torch.no_grad() or FREEZE=TRUE here")
         B, C, H, W = x.shape
         plan = self.plan_for(B, H, W, x.device)
         plan.t["in"].load(x)
