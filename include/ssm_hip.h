@@ -202,6 +202,11 @@ int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int N, int H, i
  *                         dy_extra (NULL view = none): gradient of further loss terms wrt the frame (the perceptual term)
  * ssm_flowinterp_inputs_bwd  adjoint of ssm_flowinterp_inputs_fwd wrt the stage-1 flows, fused with the two stage-1
  *                         warp-loss terms (losses.py:152-154) if stage1_terms                                   */
+/* Adjoint of ssm_warp_bilinear_fwd (autograd of layers.warp, scripts/models/layers.py:73-120, as used by the loss terms
+ * scripts/models/losses.py:152-161): dflow [B,2,H,W] (NULL view = not wanted) and dimg [B,C,H,W] (NULL view = not wanted;
+ * ACCUMULATED into with atomics - zero it first - and it must share img's row stride).                                 */
+int ssm_warp_bilinear_bwd(ssm_view img, ssm_view flow, ssm_view dy, ssm_view dflow, ssm_view dimg, int B, int C, int H, int W,
+                          void *stream);
 int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, int B, int C, int H, int W, float slope, int has_act,
                   void *stream);
 int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream);

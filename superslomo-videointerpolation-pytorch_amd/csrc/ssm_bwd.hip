@@ -300,6 +300,34 @@ __device__ __forceinline__ void sample_d(const float *__restrict__ plane, const 
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
+// Adjoint of the stand-alone backward warp (layers.warp): dflow = sum_c dy[c] * d sample / d(u,v); dimg (ptr NULL = not
+// wanted) += dy[c] scattered with the four bilinear weights (atomics: neighbouring outputs share taps).
+__global__ __launch_bounds__(256) void warp_bwd_kernel(ssm_view img, ssm_view flow, ssm_view dy, ssm_view dflow, ssm_view dimg, int C,
+                                                       int H, int W) {
+    SSM_PIXEL_INDEX();
+    const TapsD t = make_taps_d(x, y, vp(flow, b, 0, y)[x], vp(flow, b, 1, y)[x], H, W, img.sh);
+    const float gx = 1.0f - t.fx, gy = 1.0f - t.fy;
+    float du = 0.f, dv = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float val, sx, sy;
+        sample_d(vp(img, b, c, 0), t, val, sx, sy);
+        const float g = vp(dy, b, c, y)[x];
+        du += g * sx;
+        dv += g * sy;
+        if (dimg.ptr) {        // same tap offsets: dimg must share img's row stride
+            float *pl = vp(dimg, b, c, 0);
+            if (t.o00 >= 0) atomicAdd(pl + t.o00, g * gx * gy);
+            if (t.o01 >= 0) atomicAdd(pl + t.o01, g * t.fx * gy);
+            if (t.o10 >= 0) atomicAdd(pl + t.o10, g * gx * t.fy);
+            if (t.o11 >= 0) atomicAdd(pl + t.o11, g * t.fx * t.fy);
+        }
+    }
+    if (dflow.ptr) {
+        vp(dflow, b, 0, y)[x] = du;
+        vp(dflow, b, 1, y)[x] = dv;
+    }
+}
+
 // Loss + synthesis adjoint.  cr[b], cw[b] = per-sample coefficients of d(L1 recon mean) and d(L1 warp mean)
 // (lambda * upstream / (3*H*W)); stage2_terms = 0 when STAGE2.FREEZE drops the two refined-flow warp terms.
 // Outputs: dout5 [B,5,H,W] and dest [B,4,H,W] (gradient wrt the approximated flows Ft1^(u,v) | Ft0^(u,v)).
@@ -578,4 +606,14 @@ extern "C" int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_vi
     SSM_REQUIRE((long long)B * cgroups <= 65535, "sqdiff_grad: B*C too large for one launch");
     hipLaunchKernelGGL(sqdiff_grad_kernel, pix_grid(B * cgroups, H, W), dim3(64, 4), 0, (hipStream_t)stream, a, b, coef, out, C, H, W, cgroups);
     return ssm::check_launch("ssm_sqdiff_grad");
+}
+
+extern "C" int ssm_warp_bilinear_bwd(ssm_view img, ssm_view flow, ssm_view dy, ssm_view dflow, ssm_view dimg, int B, int C, int H, int W,
+                                     void *stream) {
+    SSM_CHECK_DIMS("warp_bwd");
+    SSM_REQUIRE(img.ptr && flow.ptr && dy.ptr && C > 0 && (dflow.ptr || dimg.ptr), "warp_bwd: null pointer / C");
+    SSM_REQUIRE(!dimg.ptr || dimg.sh == img.sh, "warp_bwd: dimg must have the image's row stride");
+    SSM_REQUIRE((long long)H * img.sh < 0x7fffffffLL, "warp_bwd: plane too large");
+    hipLaunchKernelGGL(warp_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img, flow, dy, dflow, dimg, C, H, W);
+    return ssm::check_launch("ssm_warp_bilinear_bwd");
 }

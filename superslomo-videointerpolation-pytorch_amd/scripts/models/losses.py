@@ -19,6 +19,20 @@ from .layers import warp
 log = logging.getLogger(__name__)
 
 
+class _PerceptualFn(torch.autograd.Function):
+    """Per-sample VGG16 conv4_3 feature MSE on the HIP extractor with its gradient wrt the predicted frame."""
+
+    @staticmethod
+    def forward(ctx, pred, target, term):
+        ctx.term = term
+        return term.forward(pred.detach(), target.detach())
+
+    @staticmethod
+    def backward(ctx, g):           # the VGG activations of the forward are still in the plan's buffers
+        B = g.shape[0]
+        return ctx.term.grad_pred(g.contiguous()).to_nchw()[:B, :3], None, None
+
+
 class SSMLosses(nn.Module):
     def __init__(self, cfg, feature_extractor=None):
         super().__init__()
@@ -78,18 +92,22 @@ class SSMLosses(nn.Module):
 
     def losses_from_parts(self, img_tensor, flowC_output, est_flow_t1, est_flow_t0, flowI_output, interpolated_image,
                           target_image):
+        """Differentiable when its inputs carry an autograd graph (op-by-op path: every operator has its own backward);
+        the planned training step calls it on detached tensors and supplies the gradients itself (ssm_amd.backward)."""
         lambda_r, lambda_p, lambda_w = self.loss_weights
-        with torch.no_grad():
-            rec = lambda_r * self._mean((interpolated_image - target_image).abs())
-            wrp = lambda_w * self.warp_terms(img_tensor, flowC_output, est_flow_t1, est_flow_t0, flowI_output, target_image)
-            Bn, _, Hn, Wn = interpolated_image.shape
-            pt = self.perceptual_term(Bn, Hn, Wn, interpolated_image.device)
-            if pt is not None:
-                per = lambda_p * pt.forward(interpolated_image, target_image)
-            elif self.feature_extractor is not None:
-                per = lambda_p * self._mean((self.feature_extractor(interpolated_image) - self.feature_extractor(target_image)) ** 2)
+        rec = lambda_r * self._mean((interpolated_image - target_image).abs())
+        wrp = lambda_w * self.warp_terms(img_tensor, flowC_output, est_flow_t1, est_flow_t0, flowI_output, target_image)
+        Bn, _, Hn, Wn = interpolated_image.shape
+        pt = self.perceptual_term(Bn, Hn, Wn, interpolated_image.device)
+        if pt is not None:
+            if torch.is_grad_enabled() and interpolated_image.requires_grad:
+                per = lambda_p * _PerceptualFn.apply(interpolated_image, target_image, pt)
             else:
-                per = torch.zeros_like(rec)
+                per = lambda_p * pt.forward(interpolated_image, target_image)
+        elif self.feature_extractor is not None:
+            per = lambda_p * self._mean((self.feature_extractor(interpolated_image) - self.feature_extractor(target_image)) ** 2)
+        else:
+            per = torch.zeros_like(rec)
         return torch.stack([rec + wrp + per, rec, wrp, per], dim=1)          # [B,4] (losses.py:236-249)
 
     def forward(self, flowC_input, flowC_output, flowI_input, flowI_output, interpolated_image, target_image):

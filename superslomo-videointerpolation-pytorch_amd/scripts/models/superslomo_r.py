@@ -217,9 +217,11 @@ class FullModel(nn.Module):
         image_pairs = self.get_image_pairs(image_tensor)
         B, T = image_pairs.shape[:2]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if T != 1 or self.recurrent:
-                raise NotImplementedError("the HIP backward covers N_FRAMES=2 with the CONV bottleneck (one interpolation "
-                                          "window); N_FRAMES=%d / BOTTLENECK=%s is forward-only" % (T + 1, self.bottlenecks))
+            if self.recurrent:
+                raise NotImplementedError("the recurrent bottleneck is forward-only (no backward through the ConvLSTM/ConvGRU "
+                                          "cells); BOTTLENECK=%s cannot be trained here" % (self.bottlenecks,))
+            if T != 1:          # N_FRAMES > 2 with independent windows: op-by-op autograd over every window
+                return self._forward_op_by_op(image_pairs, t_interp, target_images)
             params = list(self.stage1_model.parameters()) + list(self.stage2_model.parameters())
             return _TrainStep.apply(self, image_pairs[:, 0].contiguous(), t_interp[:, 0].reshape(B).to(torch.float32),
                                     target_images[:, 0].contiguous(), *params)
@@ -248,6 +250,26 @@ class FullModel(nn.Module):
                                                               target_images[:, k])
                 if k == T // 2:
                     est_img_t = pred.clone()
+        return est_img_t, losses / T
+
+    def _forward_op_by_op(self, image_pairs, t_interp, target_images):
+        """The reference's own loop (superslomo_r.py:152-243) on the public operators, each carrying its autograd:
+        slower than the planned step but valid for any number of windows."""
+        B, T = image_pairs.shape[:2]
+        s1, s2 = self.stage1_model, self.stage2_model
+        losses, est_img_t = 0.0, None
+        for k in range(T):
+            img6 = image_pairs[:, k].contiguous()
+            t = t_interp[:, k].reshape(B, 1, 1, 1).to(torch.float32)
+            e1 = s1.encoder(img6)
+            enc, flow = s1.decoder(s1.bottleneck([e1[-1]])[:, 0], e1)
+            in16 = s2.compute_inputs(img6, flow, t)
+            e2 = s2.encoder(in16)
+            out5 = s2.decoder(s2.bottleneck([e2[-1]])[:, 0], e2, enc)
+            pred = s2.compute_output_image(img6, in16, out5, t)
+            losses = losses + self.loss(img6, flow, in16, out5, pred, target_images[:, k].contiguous())
+            if k == T // 2:
+                est_img_t = pred.detach()
         return est_img_t, losses / T
 
     @validate_target_tensor

@@ -65,6 +65,7 @@ SIGNATURES = {
                                         ctypes.POINTER(_c_float), ctypes.POINTER(_c_float), _c_int, _vp]),
     "ssm_frames_to_u8_fwd": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_float),
                                       ctypes.POINTER(_c_float), _c_int, _vp]),
+    "ssm_warp_bilinear_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
