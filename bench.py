@@ -232,6 +232,7 @@ def main():
                     help="720p = BASELINE configs[1] (the headline); 4k = configs[4] shape (3840x2160, use --precision f16)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (= frame pairs in flight) per GPU")
     ap.add_argument("--no-perceptual", action="store_true", help="--mode train: leave the VGG16 perceptual loss term out")
+    ap.add_argument("--graphs", type=int, default=0, help="1: replay each pair's launch sequence from a captured HIP graph")
     ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")
     args = ap.parse_args()
 
@@ -270,7 +271,7 @@ def main():
     from ssm_amd.engine import PairPipeline
     sd1d = {k: v.detach() for k, v in model.stage1_model.state_dict().items()}
     sd2d = {k: v.detach() for k, v in model.stage2_model.state_dict().items()}
-    pipe = PairPipeline(sd1d, sd2d, N_T, Hp, Wp, dev, True, precision, args.streams)
+    pipe = PairPipeline(sd1d, sd2d, N_T, Hp, Wp, dev, True, precision, args.streams, graphs=bool(args.graphs))
 
     def step():                 # one pair -> 7 frames; consecutive steps alternate between the streams
         pipe.submit(img6, t_dev, want_aux=False)

@@ -591,11 +591,30 @@ class PairPipeline:
     MFMA-bound convolutions use the idle matrix cores / CUs.  Each engine owns its activations; the input
     pair is read in place.  Results of `submit` stay valid until that slot is reused (N pairs later)."""
 
-    def __init__(self, sd1, sd2, n_t, H, W, device, cross_skip=True, mode="f16x3", n_streams=2):
+    def __init__(self, sd1, sd2, n_t, H, W, device, cross_skip=True, mode="f16x3", n_streams=2, graphs=False):
         self.engines = [PairEngine(sd1, sd2, 1, n_t, H, W, device, cross_skip, mode) for _ in range(n_streams)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
         self.n = n_streams
         self._i = 0
+        # graphs: each slot's ~60 launches of a pair are captured once into a HIP graph (hipGraph via torch.cuda.CUDAGraph,
+        # the C-ABI launches land on the capturing stream) and replayed from static input buffers
+        self.graphs = bool(graphs)
+        self._g = [dict() for _ in range(n_streams)]
+        if self.graphs:
+            self._in = [torch.empty(1, 6, H, W, dtype=torch.float32, device=device) for _ in range(n_streams)]
+            self._t = [torch.empty(n_t, dtype=torch.float32, device=device) for _ in range(n_streams)]
+
+    def _graph(self, k, want_aux):
+        g = self._g[k].get(want_aux)
+        if g is None:
+            eng = self.engines[k]
+            eng.run(self._in[k], self._t[k], want_aux)          # warm-up on this stream: attribute calls, lazy state
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+                eng.run(self._in[k], self._t[k], want_aux)
+            self._g[k][want_aux] = g
+        return g
 
     def submit(self, img6, t, want_aux=False, clone=False):
         """Queue one pair [1,6,H,W] with its t vector on the next stream.  Returns the [n_t,3,H,W] frames:
@@ -606,7 +625,13 @@ class PairPipeline:
         st = self.streams[k]
         st.wait_stream(torch.cuda.current_stream())        # inputs produced on the caller's stream
         with torch.cuda.stream(st):
-            out = self.engines[k].run(img6, t, want_aux)
+            if self.graphs:
+                self._in[k].copy_(img6.reshape(self._in[k].shape), non_blocking=True)
+                self._t[k].copy_(t.reshape(-1), non_blocking=True)
+                self._graph(k, bool(want_aux)).replay()
+                out = self.engines[k].img
+            else:
+                out = self.engines[k].run(img6, t, want_aux)
             if clone:
                 out = out.clone()
                 out.record_stream(torch.cuda.current_stream())
