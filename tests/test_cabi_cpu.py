@@ -94,3 +94,20 @@ def test_configs_parse_and_gate():
     assert rec.recurrent and rec.bottlenecks == ("CLSTM", "CLSTM")
     x = torch.zeros(2, 4, 3, 8, 8)
     assert tuple(fm.get_image_pairs(x).shape) == (2, 3, 6, 8, 8)
+
+
+def test_product_path_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under the package (nor the tools) may import, load or execute it;
+    only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / parity leg do."""
+    import re
+    pkg = os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd")
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|ssm_oracle)\b|import_module\(.*oracle|libssm_oracle", re.M)
+    offenders = []
+    for base in (pkg, os.path.join(ROOT, "tools")):
+        for dirpath, _, files in os.walk(base):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cpp", ".h", ".sh")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if pat.search(text):
+                        offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
