@@ -17,7 +17,7 @@ from ssm_amd.weights import unet_layers  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     fast = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
-    H, W = 736, 1280
+    H, W = int(os.environ.get("SSM_BENCH_H", 736)), int(os.environ.get("SSM_BENCH_W", 1280))
     dev = torch.device("cuda:0")
     tot_t = tot_f = 0.0
     print("mode: %s   B=%d" % ("fp16 fast (1 MFMA)" if fast else "fp16 split (3 MFMA, fp32-grade)", B))
