@@ -33,7 +33,11 @@ class Trainer:
         (total, reconstruction, warp, perceptual), batch-averaged."""
         n = self.cfg.getint("TRAIN", "N_FRAMES")
         assert input_images.shape[1] == n and target_images.shape[1] == t_interp.shape[1] == n - 1
-        assert bool((t_interp > 0).all() and (t_interp < 1).all()), "Interpolation values out of bounds."
+        in_range = ((t_interp > 0) & (t_interp < 1)).all()
+        if t_interp.is_cuda:
+            torch._assert_async(in_range)          # device-side check: no host sync in the step loop
+        else:
+            assert bool(in_range), "Interpolation values out of bounds."
         _, losses = self.model(input_images, t_interp, target_images=target_images, iteration=iteration, inference_mode=False)
         losses = losses.mean(dim=0)
         self.optimizer.zero_grad()
