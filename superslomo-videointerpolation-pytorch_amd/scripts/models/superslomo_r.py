@@ -40,6 +40,18 @@ def validate_target_tensor(model_forward_func):
     return func_wrapper
 
 
+def _t_vector(t_values, device):
+    """Interpolation times as a device vector; the (0,1) range check (validators.py:9-11) runs on the host copy when
+    the values arrive as Python numbers / a CPU tensor, so the common case costs no device sync."""
+    if isinstance(t_values, torch.Tensor) and t_values.is_cuda:
+        t = t_values.to(torch.float32).reshape(-1)
+        assert bool((t > 0).all() and (t < 1).all()), "Interpolation values out of bounds."
+        return t
+    host = torch.as_tensor(t_values, dtype=torch.float32).reshape(-1)
+    assert bool((host > 0).all() and (host < 1).all()), "Interpolation values out of bounds."
+    return host.to(device)
+
+
 class _TrainStep(torch.autograd.Function):
     """forward = the HIP forward of one window + the [B,4] losses; backward = ssm_amd.backward.PairGrad.
     The parameters are inputs of the Function so autograd delivers their gradients to `.grad`."""
@@ -156,8 +168,7 @@ class FullModel(nn.Module):
         hb.require_device(frames, "frame window")
         assert frames.dim() == 5 and frames.shape[0] == 1, "interpolate_windows() takes one clip [1,N,3,H,W]"
         T = frames.shape[1] - 1
-        t = torch.as_tensor(t_values, dtype=torch.float32, device=frames.device).reshape(-1)
-        assert bool((t > 0).all() and (t < 1).all()), "Interpolation values out of bounds."
+        t = _t_vector(t_values, frames.device)
         eng = self.window_engine_for(T, 1, t.numel(), frames.shape[3], frames.shape[4], frames.device)
         return eng.run(frames.contiguous(), t[:, None].expand(-1, T), want_aux=False).clone()
 
@@ -168,8 +179,7 @@ class FullModel(nn.Module):
         hb.require_device(image_pair, "image pair")
         img6 = image_pair.reshape(image_pair.shape[0], 6, *image_pair.shape[-2:])
         assert img6.shape[0] == 1, "interpolate() takes one frame pair"
-        t = torch.as_tensor(t_values, dtype=torch.float32, device=img6.device).reshape(-1)
-        assert bool((t > 0).all() and (t < 1).all()), "Interpolation values out of bounds."
+        t = _t_vector(t_values, img6.device)
         eng = self.engine_for(1, t.numel(), img6.shape[2], img6.shape[3], img6.device)
         return eng.run(img6, t, want_aux=False).clone()
 
@@ -182,8 +192,7 @@ class FullModel(nn.Module):
         first = pairs[0]
         hb.require_device(first, "image pair")
         H, W = first.shape[-2:]
-        t = torch.as_tensor(t_values, dtype=torch.float32, device=first.device).reshape(-1)
-        assert bool((t > 0).all() and (t < 1).all()), "Interpolation values out of bounds."
+        t = _t_vector(t_values, first.device)
         mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)
         key = ("pipe", n_streams, t.numel(), H, W, str(first.device), mode, self._stamp())
         if getattr(self, "_pipe", None) is None or self._pipe[0] != key:
