@@ -31,3 +31,20 @@ inline int check_launch(const char *what) {
     } while (0)
 
 }  // namespace ssm
+
+// XCD-aware tile order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+// L2), so in launch order neighbouring tiles - which share input halos, and for Cout > BN the whole input patch - sit
+// on different L2s.  This maps workgroup i to the logical tile index such that every XCD walks one contiguous
+// 1/8 of the (cout block, x tile, y tile, batch) sequence.
+#ifndef SSM_XCD_REMAP
+#define SSM_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int ssm_xcd_tile(int i, int n) {
+#if SSM_XCD_REMAP
+    const int xcd = i & 7, local = i >> 3;
+    const int per = n >> 3, rem = n & 7;
+    return xcd < rem ? xcd * (per + 1) + local : rem * (per + 1) + (xcd - rem) * per + local;
+#else
+    return i;
+#endif
+}

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
 
-    int id = blockIdx.x;
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
     const int nb = id % p.NB;
     id /= p.NB;
     const int tx = id % p.tilesX;

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP
     const int lw = C::NP ? wid - NW : wid;                 // index among the loading waves
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
 
-    int id = blockIdx.x;
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
     const int nb = id % p.NB;
     id /= p.NB;
     const int tx = id % p.tilesX;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = (wid / (C::WN * C::WY)) % C::WX;   // matrix waves
     const int ew = wid - C::NWM, etid = tid - C::NWM * 64;                                            // expander waves
 
-    int id = blockIdx.x;
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
     const int nb = id % p.NB;
     id /= p.NB;
     const int tx = id % p.tilesX;
