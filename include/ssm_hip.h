@@ -250,6 +250,19 @@ int ssm_convgru_reset_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view h_prev, s
 int ssm_convgru_update_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view cand_x, ssm_view cand_h, ssm_view h_prev,
                            ssm_view h_f32, ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream);
 
+/* Adjoints of the cells above (training through the recurrent bottleneck; the gate convolutions' own gradients are the conv
+ * backward entry points).  fp32 views.
+ *  ssm_convlstm_cell_bwd   d h', d c' (NULL = 0) -> dgates [4*Hc] and d c          (gates_h / c_prev NULL at the first step)
+ *  ssm_convgru_reset_bwd   d(rh) -> dgates[0:Hc] (gamma) and d h;  the caller zeroes / owns dgates[Hc:2Hc]
+ *  ssm_convgru_update_bwd  d h' -> dgates[Hc:2Hc] (beta), d cand and d h (h_prev / dh_prev NULL at the first step);
+ *                          `gates` = the summed pre-activations [gamma|beta], `cand` = the candidate pre-activation          */
+int ssm_convlstm_cell_bwd(ssm_view gates_x, ssm_view gates_h, ssm_view c_prev, ssm_view dh, ssm_view dc_next, ssm_view dgates,
+                          ssm_view dc_prev, int B, int Hc, int H, int W, void *stream);
+int ssm_convgru_reset_bwd(ssm_view gates, ssm_view h_prev, ssm_view drh, ssm_view dgates, ssm_view dh_prev, int B, int Hc, int H, int W,
+                          void *stream);
+int ssm_convgru_update_bwd(ssm_view gates, ssm_view cand, ssm_view h_prev, ssm_view dh_next, ssm_view dgates, ssm_view dcand,
+                           ssm_view dh_prev, int B, int Hc, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

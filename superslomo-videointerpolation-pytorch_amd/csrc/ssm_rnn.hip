@@ -96,6 +96,62 @@ __global__ __launch_bounds__(256) void convgru_update_kernel(ssm_view gx, ssm_vi
     if (h16.ptr) hl8_store(h16, b, g, y, x, hv);
 }
 
+// ---- adjoints of the cells (training through the recurrent bottleneck; fp32 views, one thread = pixel x 8 channels) ----
+// ConvLSTM: given d h' and d c' (NULL = 0) -> d gates [i|f|o|g] and d c.
+__global__ __launch_bounds__(256) void convlstm_cell_bwd_kernel(ssm_view gx, ssm_view gh, ssm_view cprev, ssm_view dh, ssm_view dcn,
+                                                                ssm_view dg, ssm_view dcp, int Hc, int H, int W) {
+    SSM_CELL_INDEX();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        float pi = vp(gx, b, c, y)[x], pf = vp(gx, b, Hc + c, y)[x], po = vp(gx, b, 2 * Hc + c, y)[x], pg = vp(gx, b, 3 * Hc + c, y)[x];
+        if (gh.ptr) {
+            pi = pi + vp(gh, b, c, y)[x];
+            pf = pf + vp(gh, b, Hc + c, y)[x];
+            po = po + vp(gh, b, 2 * Hc + c, y)[x];
+            pg = pg + vp(gh, b, 3 * Hc + c, y)[x];
+        }
+        const float cp = cprev.ptr ? vp(cprev, b, c, y)[x] : 0.0f;
+        const float si = sigm(pi), sf = sigm(pf), so = sigm(po), tg = tanhf(pg);
+        const float cn = sf * cp + si * tg, tc = tanhf(cn);
+        const float dhv = vp(dh, b, c, y)[x];
+        const float dct = (dcn.ptr ? vp(dcn, b, c, y)[x] : 0.0f) + dhv * so * (1.0f - tc * tc);
+        vp(dg, b, c, y)[x] = dct * tg * si * (1.0f - si);
+        vp(dg, b, Hc + c, y)[x] = dct * cp * sf * (1.0f - sf);
+        vp(dg, b, 2 * Hc + c, y)[x] = dhv * tc * so * (1.0f - so);
+        vp(dg, b, 3 * Hc + c, y)[x] = dct * si * (1.0f - tg * tg);
+        vp(dcp, b, c, y)[x] = dct * sf;
+    }
+}
+
+// ConvGRU reset half: rh = s(gamma) * h.  Given d rh -> d gamma (written to dgates[0:Hc]) and d h.
+__global__ __launch_bounds__(256) void convgru_reset_bwd_kernel(ssm_view gates, ssm_view hprev, ssm_view drh, ssm_view dgates, ssm_view dhp,
+                                                                int Hc, int H, int W) {
+    SSM_CELL_INDEX();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float r = sigm(vp(gates, b, c, y)[x]), h = vp(hprev, b, c, y)[x], d = vp(drh, b, c, y)[x];
+        vp(dgates, b, c, y)[x] = d * h * r * (1.0f - r);
+        vp(dhp, b, c, y)[x] = d * r;
+    }
+}
+
+// ConvGRU update half: h' = (1-u) h + u tanh(q), u = s(beta).  Given d h' -> d beta (dgates[Hc:2Hc]), d q and d h.
+__global__ __launch_bounds__(256) void convgru_update_bwd_kernel(ssm_view gates, ssm_view cand, ssm_view hprev, ssm_view dhn, ssm_view dgates,
+                                                                 ssm_view dcand, ssm_view dhp, int Hc, int H, int W) {
+    SSM_CELL_INDEX();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float u = sigm(vp(gates, b, Hc + c, y)[x]), n = tanhf(vp(cand, b, c, y)[x]);
+        const float h = hprev.ptr ? vp(hprev, b, c, y)[x] : 0.0f, d = vp(dhn, b, c, y)[x];
+        vp(dgates, b, Hc + c, y)[x] = d * (n - h) * u * (1.0f - u);
+        vp(dcand, b, c, y)[x] = d * u * (1.0f - n * n);
+        if (dhp.ptr) vp(dhp, b, c, y)[x] = d * (1.0f - u);
+    }
+}
+
 inline dim3 cell_grid(int B, int Hc, int H, int W) { return dim3((W + 63) / 64, (H + 3) / 4, B * (Hc / 8)); }
 
 }  // namespace
@@ -134,4 +190,32 @@ extern "C" int ssm_convgru_update_fwd(ssm_view gates_x, ssm_view gates_h, ssm_vi
     hipLaunchKernelGGL(convgru_update_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, cand_x,
                        cand_h, h_prev, h_f32, h_hl8, Hc, H, W);
     return ssm::check_launch("ssm_convgru_update_fwd");
+}
+
+extern "C" int ssm_convlstm_cell_bwd(ssm_view gates_x, ssm_view gates_h, ssm_view c_prev, ssm_view dh, ssm_view dc_next, ssm_view dgates,
+                                     ssm_view dc_prev, int B, int Hc, int H, int W, void *stream) {
+    SSM_CELL_DIMS("convlstm_cell_bwd");
+    SSM_REQUIRE(gates_x.ptr && dh.ptr && dgates.ptr && dc_prev.ptr, "convlstm_cell_bwd: null pointer");
+    hipLaunchKernelGGL(convlstm_cell_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, c_prev, dh,
+                       dc_next, dgates, dc_prev, Hc, H, W);
+    return ssm::check_launch("ssm_convlstm_cell_bwd");
+}
+
+extern "C" int ssm_convgru_reset_bwd(ssm_view gates, ssm_view h_prev, ssm_view drh, ssm_view dgates, ssm_view dh_prev, int B, int Hc, int H,
+                                     int W, void *stream) {
+    SSM_CELL_DIMS("convgru_reset_bwd");
+    SSM_REQUIRE(gates.ptr && h_prev.ptr && drh.ptr && dgates.ptr && dh_prev.ptr, "convgru_reset_bwd: null pointer");
+    hipLaunchKernelGGL(convgru_reset_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates, h_prev, drh, dgates,
+                       dh_prev, Hc, H, W);
+    return ssm::check_launch("ssm_convgru_reset_bwd");
+}
+
+extern "C" int ssm_convgru_update_bwd(ssm_view gates, ssm_view cand, ssm_view h_prev, ssm_view dh_next, ssm_view dgates, ssm_view dcand,
+                                      ssm_view dh_prev, int B, int Hc, int H, int W, void *stream) {
+    SSM_CELL_DIMS("convgru_update_bwd");
+    SSM_REQUIRE(gates.ptr && cand.ptr && dh_next.ptr && dgates.ptr && dcand.ptr, "convgru_update_bwd: null pointer");
+    SSM_REQUIRE((h_prev.ptr != nullptr) == (dh_prev.ptr != nullptr), "convgru_update_bwd: h_prev and dh_prev go together");
+    hipLaunchKernelGGL(convgru_update_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates, cand, h_prev, dh_next,
+                       dgates, dcand, dh_prev, Hc, H, W);
+    return ssm::check_launch("ssm_convgru_update_bwd");
 }

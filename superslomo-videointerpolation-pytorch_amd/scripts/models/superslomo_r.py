@@ -226,10 +226,7 @@ class FullModel(nn.Module):
         image_pairs = self.get_image_pairs(image_tensor)
         B, T = image_pairs.shape[:2]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.recurrent:
-                raise NotImplementedError("the recurrent bottleneck is forward-only (no backward through the ConvLSTM/ConvGRU "
-                                          "cells); BOTTLENECK=%s cannot be trained here" % (self.bottlenecks,))
-            if T != 1:          # N_FRAMES > 2 with independent windows: op-by-op autograd over every window
+            if T != 1 or self.recurrent:      # several windows and/or recurrent cells: op-by-op autograd
                 return self._forward_op_by_op(image_pairs, t_interp, target_images)
             params = list(self.stage1_model.parameters()) + list(self.stage2_model.parameters())
             return _TrainStep.apply(self, image_pairs[:, 0].contiguous(), t_interp[:, 0].reshape(B).to(torch.float32),
@@ -262,21 +259,25 @@ class FullModel(nn.Module):
         return est_img_t, losses / T
 
     def _forward_op_by_op(self, image_pairs, t_interp, target_images):
-        """The reference's own loop (superslomo_r.py:152-243) on the public operators, each carrying its autograd:
-        slower than the planned step but valid for any number of windows."""
+        """The reference's own loop (superslomo_r.py:152-243; stage forward flow_computation.py:291-325) on the public
+        operators, each carrying its autograd: encoders of all windows, the bottleneck over the window sequence (CONV
+        per window, or the recurrent cells), decoders, losses averaged over the windows.  Slower than the planned step but
+        valid for any number of windows and for the recurrent bottleneck."""
         B, T = image_pairs.shape[:2]
         s1, s2 = self.stage1_model, self.stage2_model
+        pairs = [image_pairs[:, k].contiguous() for k in range(T)]
+        ts = [t_interp[:, k].reshape(B, 1, 1, 1).to(torch.float32) for k in range(T)]
+        e1 = [s1.encoder(p) for p in pairs]
+        h1 = s1.bottleneck([e[-1] for e in e1])
+        dec1 = [s1.decoder(h1[:, k], e1[k]) for k in range(T)]
+        in16 = [s2.compute_inputs(pairs[k], dec1[k][1], ts[k]) for k in range(T)]
+        e2 = [s2.encoder(x) for x in in16]
+        h2 = s2.bottleneck([e[-1] for e in e2])
         losses, est_img_t = 0.0, None
         for k in range(T):
-            img6 = image_pairs[:, k].contiguous()
-            t = t_interp[:, k].reshape(B, 1, 1, 1).to(torch.float32)
-            e1 = s1.encoder(img6)
-            enc, flow = s1.decoder(s1.bottleneck([e1[-1]])[:, 0], e1)
-            in16 = s2.compute_inputs(img6, flow, t)
-            e2 = s2.encoder(in16)
-            out5 = s2.decoder(s2.bottleneck([e2[-1]])[:, 0], e2, enc)
-            pred = s2.compute_output_image(img6, in16, out5, t)
-            losses = losses + self.loss(img6, flow, in16, out5, pred, target_images[:, k].contiguous())
+            out5 = s2.decoder(h2[:, k], e2[k], dec1[k][0])
+            pred = s2.compute_output_image(pairs[k], in16[k], out5, ts[k])
+            losses = losses + self.loss(pairs[k], dec1[k][1], in16[k], out5, pred, target_images[:, k].contiguous())
             if k == T // 2:
                 est_img_t = pred.detach()
         return est_img_t, losses / T

@@ -81,6 +81,9 @@ SIGNATURES = {
     "ssm_convgru_reset_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_convgru_update_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int,
                                         _c_int, _vp]),
+    "ssm_convlstm_cell_bwd": (_c_int, [SsmView] * 7 + [_c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_convgru_reset_bwd": (_c_int, [SsmView] * 5 + [_c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_convgru_update_bwd": (_c_int, [SsmView] * 7 + [_c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_avgpool2_fwd": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
