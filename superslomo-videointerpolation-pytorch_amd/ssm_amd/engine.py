@@ -69,6 +69,7 @@ def layer_scale(name):
 
 class UNetPlan:
     timer = None     # a KernelTimer, or None
+    fast_layers = frozenset()    # diagnostics: "s<stage>.<layer>" names that run hi*hi only inside an f16x3 plan (tools/precision_scan.py)
 
     DECODER = ("conv7a", "conv7b", "conv8a", "conv8b", "conv9a", "conv9b", "conv10a", "conv10b", "conv11a", "conv11b",
                "fuse_conv", "final_conv")
@@ -166,7 +167,7 @@ class UNetPlan:
             final = name == "final_conv"
             hb.conv2d_hl8(v(src), s.G * 8, v(src2) if src2 else None, c2, pk, None if final else v(dst),
                           v(dst) if final else None, v(pool) if pool else None, self._Bcur, s.H, s.W,
-                          lrelu=lrelu, fast=self.mode == "f16")
+                          lrelu=lrelu, fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         else:
             hb.conv2d(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst),
                       v(pool) if pool else None, self._Bcur, s.H, s.W, lrelu=lrelu)
@@ -195,7 +196,8 @@ class UNetPlan:
             e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * d.H * d.W * pk.cout * pk.cin * 9)
             e0.record()
         hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
-                          d.view(), None, self._Bcur, d.H, d.W, lrelu=True, fast=self.mode == "f16")
+                          d.view(), None, self._Bcur, d.H, d.W, lrelu=True,
+                          fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         if tm is not None:
             e1.record()
 
