@@ -41,7 +41,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 DTYPE_NOTE = {"f32": "f32", "f16": "f16 (f32 accumulate)",
-              "f16x3": "f32 via 3x f16 MFMA on hi/lo-split operands (f32 accumulate)"}
+              "f16x3": "f32 via 3x f16 MFMA on hi/lo-split operands (f32 accumulate)",
+              "f16f8": "f32 via 1x f16 MFMA + 2x block-scaled fp8 MFMA (compensation products) on hi/lo-split operands (f32 accumulate)"}
 
 
 def conv_flops_per_pair(h, w, n_t):
@@ -222,7 +223,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (roofline = null)")
-    ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16", "f16f8"],
                     help="conv arithmetic (default: models.superslomo_r.DEFAULT_PRECISION / $SSM_PRECISION)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "recurrent"],
                     help="infer = the headline (BASELINE configs[1]); train = configs[2]: training step on 352x352 crops, "
@@ -334,14 +335,18 @@ def main():
             kname, peak, mfma_per_prod = "conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1
         else:
             kname, peak = "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
-            mfma_per_prod = 3 if precision == "f16x3" else 1
+            # fp16-MFMA units per algorithmic product: f16x3 = 3; f16f8 = 1 fp16 + 2 block-scaled fp8 steps that cover 4x the K in the
+            # cycles of one fp16 step (= 1/4 unit each, up to 4/3 padding on 3-tap rows)
+            mfma_per_prod = {"f16x3": 3, "f16f8": 1.5}.get(precision, 1)
+            if precision == "f16f8":
+                kname = "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4)"
         out["roofline"] = {"bound": "mfma", "kernel": kname + ", all %d launches of a step" % (conv["launches"] // args.steps),
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "mfma_issue_frac": round(mfma_per_prod * ach / peak, 4),
                            "region": "%d single-stream steps run right after the timed region (%.3f ms/step alone); the timed "
                                      "region keeps %d pair(s) in flight, where per-kernel spans overlap" % (args.steps, solo_ms, args.streams),
                            "note": "achieved = ALGORITHMIC conv FLOP / event-timed kernel time; mfma_issue_frac = issued "
-                                   "MFMA FLOP / peak (%d MFMA per algorithmic product)" % mfma_per_prod,
+                                   "MFMA FLOP / peak (%s fp16-MFMA units per algorithmic product)" % mfma_per_prod,
                            "traffic": traffic, "traffic_note": "HBM bytes per step of the conv launches, FETCH_SIZE x2 "
                            "(gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/%s" % pmc_file,
                            "flop_per_step": flops_step, "ms_per_step_in_kernel": round(conv_ms_step, 3)}

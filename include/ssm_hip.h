@@ -51,6 +51,7 @@ extern "C" {
 
 #define SSM_FLAG_LRELU 1    /* apply LeakyReLU(slope) after bias             */
 #define SSM_FLAG_FP16_FAST 2 /* HL8 conv: hi*hi product only (plain fp16 inputs) */
+#define SSM_FLAG_Q8 4        /* HL8 conv on Q8 operands: 1 fp16 MFMA + 2 block-scaled fp8 MFMAs per product */
 
 typedef struct ssm_view {
     float *ptr;
@@ -133,6 +134,20 @@ int ssm_conv16_ups_config(int Cout, int W, int *BN, int *KYS);
 int ssm_conv2d_ups_hl8_fwd(ssm_hview a, int C1, ssm_hview b, int C2, const void *w_packed,
                            const float *bias_packed, float wscale, ssm_hview y_hl8, ssm_view y_f32, int B, int H,
                            int W, int Cout, float slope, int flags, void *stream);
+/* Q8 operand form (SSM_FLAG_Q8 on the two convolution entry points): plane 1 of every pixel group holds
+ * [8 x fp8 e4m3 (x) | 8 x fp8 ((x - fp16(x)) * 2^11)] instead of 8 x fp16(lo); a product is a_hi*b_hi on the fp16 matrix path
+ * plus fp8(a)*fp8(b_lo) + fp8(a_lo)*fp8(b) on the block-scaled fp8 path (v_mfma_scale_f32_32x32x64_f8f6f4, K = 4 taps x 16
+ * channels, E8M0 scale 2^-11 on the lo operand) - 1 + 2*(1/4) fp16-MFMA units per product instead of 3.  Same geometry,
+ * strides and entry points as HL8; filters are packed by ssm_pack16q_weights for the tile ssm_conv16q_config reports.      */
+int ssm_conv16q_config(int k, int Cout, int W, int *BN, int *KYS);
+int ssm_conv16q_ups_config(int Cout, int W, int *BN, int *KYS);      /* tile of ssm_conv2d_ups_hl8_fwd with SSM_FLAG_Q8 */
+size_t ssm_packed16q_weight_bytes(int Cout, int Cin_padded, int k, int BN, int KYS);
+int ssm_pack16q_weights(const float *w_oihw, const float *bias, void *w_packed, float *bias_packed, int Cout, int Cin,
+                        int Cin_padded, int k, int BN, int KYS, float scale, void *stream);
+int ssm_flowinterp_inputs_hq8_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_hview out16, ssm_view flows4, int B, int H,
+                                  int W, void *stream);      /* ssm_flowinterp_inputs_hl8_fwd with a Q8 output */
+int ssm_hq8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream);
+int ssm_hq8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream);
 /* fp32 view [B,C,H,W] <-> HL8 with G >= ceil(C/8) channel groups (extra channels are zeros). */
 int ssm_hl8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream);
 int ssm_hl8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream);

@@ -67,12 +67,14 @@ struct Conv16Params {
     int lrelu;
 };
 
-template <int KS_, int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int PBUFS_, bool SPLIT3_>
+// MODE_: 0 = plain fp16 (hi*hi), 1 = split (3 fp16 MFMAs per product), 2 = Q8 (1 fp16 MFMA + 2 block-scaled fp8 MFMAs per product)
+template <int KS_, int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int PBUFS_, int MODE_>
 struct Cfg16 {
     static constexpr int KS = KS_, KYS = KYS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_;
     static constexpr int PBUFS = PBUFS_;      // 2: patch double-buffered in the workgroup (1 workgroup / CU);
                                               // 1: single patch buffer, latency hidden by a 2nd workgroup on the CU
-    static constexpr bool SPLIT3 = SPLIT3_;
+    static constexpr bool SPLIT3 = MODE_ == 1, Q8 = MODE_ == 2;
+    static constexpr int NQ = (KS + 3) / 4;      // K=64 correction steps per filter row (4 taps x 16 channels each)
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int NW = WN * WY * WX, NTHREADS = 64 * NW;
     static constexpr int BN = 32 * NT * WN, TH = MTY * WY, TW = 32 * MTX * WX, MT = MTY * MTX;
@@ -81,7 +83,8 @@ struct Cfg16 {
     static constexpr int PATCH_PIECES = 4 * PH * PW;              // 16-byte pieces
     static constexpr int PNI = (PATCH_PIECES + 63) / 64;          // 1-KiB DMA instructions per patch
     static constexpr int PATCH_BYTES = PNI * 1024;
-    static constexpr int WST_PIECES = KYS * KS * 4 * BN;          // [tap][h][part][BN]
+    // filter stage: [tap][h][part][BN] x 16 B;  Q8: [tap][h][BN] (fp16 hi) then [row][quad][operand][piece][half][BN] (fp8)
+    static constexpr int WST_PIECES = Q8 ? KYS * KS * 2 * BN + KYS * NQ * 8 * BN : KYS * KS * 4 * BN;
     static constexpr int WNI = WST_PIECES / 64;
     static constexpr int WST_BYTES = WST_PIECES * 16;
     static constexpr int LDS_BYTES = PBUFS * PATCH_BYTES + 2 * WST_BYTES;
@@ -110,6 +113,126 @@ __device__ __forceinline__ void split_store(char *plane_hi, long long sp_bytes, 
     lo[2] = (_Float16)(v2 - (float)hi[2]); lo[3] = (_Float16)(v3 - (float)hi[3]);
     *reinterpret_cast<h4 *>(plane_hi) = hi;
     *reinterpret_cast<h4 *>(plane_hi + sp_bytes) = lo;
+}
+
+// ---- Q8 layout: plane 1 of a pixel group holds [8 x fp8(x) | 8 x fp8((x - fp16(x)) * 2^11)] instead of 8 x fp16(lo) ----
+__device__ __forceinline__ float clamp448(float v) { return fminf(fmaxf(v, -448.0f), 448.0f); }      // e4m3fn: beyond 448 -> NaN
+
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(a), clamp448(b), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(c), clamp448(d), w, true);
+}
+
+// 4 consecutive channels (offset half*4 inside 8-channel group g) of one pixel.  `pix_hi` = the pixel's 16-byte record in the
+// hi plane of group g.  Second planes are shared by a PAIR of groups (16 channels = one K chunk): the even group's holds
+// [fp8(x) of the even group | fp8(x) of the odd group], the odd group's [fp8(lo*2^11) even | fp8(lo*2^11) odd], so that one
+// 16-byte read per tap is half of a 32-byte fp8 MFMA operand with no register shuffling.
+__device__ __forceinline__ void split_store_q8(char *pix_hi, long long sp_bytes, long long sg_bytes, int g, int half, float v0, float v1,
+                                               float v2, float v3) {
+    h4 hi;
+    hi[0] = (_Float16)v0; hi[1] = (_Float16)v1; hi[2] = (_Float16)v2; hi[3] = (_Float16)v3;
+    *reinterpret_cast<h4 *>(pix_hi + half * 8) = hi;
+    const int odd = g & 1;
+    char *even_rec = pix_hi - odd * sg_bytes + sp_bytes;          // second plane of the even group of the pair
+    *reinterpret_cast<int *>(even_rec + odd * 8 + half * 4) = pack4_fp8(v0, v1, v2, v3);
+    *reinterpret_cast<int *>(even_rec + sg_bytes + odd * 8 + half * 4) =
+        pack4_fp8((v0 - (float)hi[0]) * 2048.0f, (v1 - (float)hi[1]) * 2048.0f, (v2 - (float)hi[2]) * 2048.0f, (v3 - (float)hi[3]) * 2048.0f);
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float fp8_byte(int word, int i) {          // byte i of a word of four e4m3 values -> fp32
+    switch (i) {
+        case 0: return __builtin_amdgcn_cvt_f32_fp8(word, 0);
+        case 1: return __builtin_amdgcn_cvt_f32_fp8(word, 1);
+        case 2: return __builtin_amdgcn_cvt_f32_fp8(word, 2);
+        default: return __builtin_amdgcn_cvt_f32_fp8(word, 3);
+    }
+}
+
+// One pipeline iteration in Q8 mode.  Per filter tap ONE fp16 MFMA (a_hi*b_hi); per filter row and group of 4 taps two
+// block-scaled fp8 MFMAs with K = 64 = 4 taps x 16 channels: fp8(a)*fp8(b_lo*2^11) and fp8(a_lo*2^11)*fp8(b), each with the
+// E8M0 scale 2^-11 on the "lo" operand.  Lane half h covers taps (4j+2h, 4j+2h+1) of quad j; taps beyond the filter row have
+// zero filter bytes and re-read the row's last tap on the activation side.
+//   sb / sa   : lane bases of the fp16 operands (group = lane half)        sbq / saq : lane bases of the q operands
+template <class C>
+__device__ __forceinline__ void conv16_compute_q8(f32x16 (&acc)[C::NT][C::MT], const char *sb, const char *sa, const char *sbq,
+                                                  const char *saq, int hoff16) {
+    constexpr int KS = C::KS, KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NQ = C::NQ;
+    constexpr int ATAP = 2 * BN * 16;                 // fp16 filter bytes per tap
+    constexpr int GQ = 2 * PH * PW * 16;              // fp8(x) plane of the chunk -> fp8(lo) plane
+    constexpr int SC_HI = 0x7f7f7f7f, SC_LO = 0x74747474;      // E8M0 127 = 2^0, 116 = 2^-11
+    constexpr int NQR = 4 * (NT + MT);                // fp8 operand reads (16 bytes each) per quad
+    h8 ah[2][NT], bh[2][MT];
+    auto fetch_one = [&](int tl, int r, h8 (&fa)[NT], h8 (&fb)[MT]) {
+        const int kyy = tl / KS, kx = tl - kyy * KS;
+        if (r < NT) {
+            fa[r] = *reinterpret_cast<const h8 *>(sa + tl * ATAP + r * 32 * 16);
+        } else {
+            const int m = r - NT, my = m / C::MTX, mx = m - my * C::MTX;
+            fb[m] = *reinterpret_cast<const h8 *>(sb + ((my + kyy) * PW + mx * 32 + kx) * 16);
+        }
+    };
+    i32x8 a8[NT][2], b8[MT][2];                       // [tile][0 = fp8(x), 1 = fp8(lo * 2^11)]: two 16-byte reads each
+    // fp8 operand read r of quad (ry, j): r < 4*NT: filter (tile, operand, piece); else activation (tile, plane, piece)
+    auto q_read = [&](int ry, int j, int r) {
+        if (r < 4 * NT) {
+            const int n = r >> 2, op = (r >> 1) & 1, pc = r & 1;
+            const i32x4 v = *reinterpret_cast<const i32x4 *>(saq + ((((ry * NQ + j) * 2 + op) * 2 + pc) * 2) * BN * 16 + n * 32 * 16);
+            a8[n][op][4 * pc + 0] = v[0]; a8[n][op][4 * pc + 1] = v[1]; a8[n][op][4 * pc + 2] = v[2]; a8[n][op][4 * pc + 3] = v[3];
+        } else {
+            const int q = r - 4 * NT, m = q >> 2, pl = (q >> 1) & 1, pc = q & 1;
+            const int k0 = 4 * j + pc < KS - 1 ? 4 * j + pc : KS - 1;              // tap of lane half 0
+            const int k1 = 4 * j + 2 + pc < KS - 1 ? 4 * j + 2 + pc : KS - 1;      // tap of lane half 1
+            const int my = m / C::MTX, mx = m - my * C::MTX;
+            const int o = ((my + ry) * PW + mx * 32 + k0) * 16 + pl * GQ;
+            const int hd = (k1 - k0) == 0 ? 0 : ((k1 - k0) == 1 ? hoff16 : 2 * hoff16);
+            const i32x4 v = *reinterpret_cast<const i32x4 *>(sbq + o + hd);
+            b8[m][pl][4 * pc + 0] = v[0]; b8[m][pl][4 * pc + 1] = v[1]; b8[m][pl][4 * pc + 2] = v[2]; b8[m][pl][4 * pc + 3] = v[3];
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < NT + MT; ++r) fetch_one(0, r, ah[0], bh[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tl = 0; tl < KYS * KS; ++tl) {
+        const int cur = tl & 1;
+        const int ry = tl / KS, kx = tl - ry * KS, j = kx / 4;
+        const bool more = tl + 1 < KYS * KS;
+        const int qtaps = KS - 4 * j < 4 ? KS - 4 * j : 4;          // real taps in this quad
+        const int gaps = qtaps * NT * MT;                             // MFMA gaps the quad's fp8 reads are spread over
+        const int per = (NQR + gaps - 1) / gaps;                      // fp8 reads per gap
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int idx = n * MT + m;
+                acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][n], bh[cur][m], acc[n][m], 0, 0, 0);
+                if (more && idx < NT + MT) fetch_one(tl + 1, idx, ah[cur ^ 1], bh[cur ^ 1]);
+                const int gq = (kx & 3) * NT * MT + idx;              // gap index inside the quad
+#pragma unroll
+                for (int u = 0; u < per; ++u)
+                    if (gq * per + u < NQR) q_read(ry, j, gq * per + u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (more) {
+#pragma unroll
+            for (int r = NT * MT; r < NT + MT; ++r) fetch_one(tl + 1, r, ah[cur ^ 1], bh[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((kx & 3) == 3 || kx == KS - 1) {          // last tap of the quad: the two correction products
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[n][m] = op == 0 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[n][0], b8[m][1], acc[n][m], 0, 0, 0, SC_HI, 0, SC_LO)
+                                            : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[n][1], b8[m][0], acc[n][m], 0, 0, 0, SC_LO, 0, SC_HI);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 // One pipeline iteration of a wave: KYS*KS filter taps x (NT x MT) 32x32 tiles.  sb / sa = this lane's base
@@ -251,8 +374,11 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
                     const int y = ybase + my, x = xbase + mx * 32;
                     if (y < p.H && x < p.W) {
                         if (p.dh && co0 < p.Cout) {
-                            char *d = p.dh + (((long long)b * p.dhsb + (long long)(co0 >> 3) * p.dhsg + (long long)y * p.dhsh + x) * 16) + half * 8;
-                            split_store(d, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
+                            char *d = p.dh + (((long long)b * p.dhsb + (long long)(co0 >> 3) * p.dhsg + (long long)y * p.dhsh + x) * 16);
+                            if constexpr (C::Q8)
+                                split_store_q8(d, p.dhsp * 16, p.dhsg * 16, co0 >> 3, half, v[m][0], v[m][1], v[m][2], v[m][3]);
+                            else
+                                split_store(d + half * 8, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
                         }
                         if (p.df) {
 #pragma unroll
@@ -276,8 +402,11 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
                             }
                             const int y = ybase + my, x = xbase + mx * 32;
                             if (!(l31 & 1) && y < p.H && x < p.W && co0 < p.Cout) {
-                                char *d = p.ph + (((long long)b * p.phsb + (long long)(co0 >> 3) * p.phsg + (long long)(y >> 1) * p.phsh + (x >> 1)) * 16) + half * 8;
-                                split_store(d, p.phsp * 16, s[0], s[1], s[2], s[3]);
+                                char *d = p.ph + (((long long)b * p.phsb + (long long)(co0 >> 3) * p.phsg + (long long)(y >> 1) * p.phsh + (x >> 1)) * 16);
+                                if constexpr (C::Q8)
+                                    split_store_q8(d, p.phsp * 16, p.phsg * 16, co0 >> 3, half, s[0], s[1], s[2], s[3]);
+                                else
+                                    split_store(d + half * 8, p.phsp * 16, s[0], s[1], s[2], s[3]);
                             }
                         }
                 }
@@ -397,7 +526,8 @@ __global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP
 
     // per-lane operand byte offsets inside a patch buffer / filter stage
     const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
-    const int aOff = (half * 2 * BN + wn * (NT * 32) + l31) * 16;
+    const int aOff = C::Q8 ? (half * BN + wn * (NT * 32) + l31) * 16 : (half * 2 * BN + wn * (NT * 32) + l31) * 16;
+    const int bqOff = ((PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;      // q plane of group 0 (Q8 mode)
 
     if (C::NP == 0) {
         issue_patch(0, 0, C::NIT);
@@ -411,9 +541,13 @@ __global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP
         if (C::NP == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (C::NP == 0) load_step(it, ch, j);
-        const char *sb = pbuf0 + (C::PBUFS == 2 ? (ch & 1) : 0) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
+        const char *pb = pbuf0 + (C::PBUFS == 2 ? (ch & 1) : 0) * C::PATCH_BYTES + j * (KYS * PW * 16);
+        const char *sb = pb + bOff;
         const char *sa = wbuf0 + (it & 1) * C::WST_BYTES + aOff;
-        conv16_compute<C>(acc, sb, sa);
+        if constexpr (C::Q8)
+            conv16_compute_q8<C>(acc, sb, sa, pb + bqOff, sa + KYS * C::KS * 2 * BN * 16, half * 16);
+        else
+            conv16_compute<C>(acc, sb, sa);
         if (++j == C::NIT) j = 0, ++ch;
     }
 
@@ -431,10 +565,11 @@ __global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP
 // edge clamping, zero outside the image = the convolution's zero padding, re-split to hi/lo).  VALU expansion
 // and MFMA run on different pipes of the same CU, so the expansion hides under the matrix work; the conv
 // reads 4x fewer activation bytes than from a materialised upsampled tensor.  One barrier per iteration.
-template <int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int NWE_, bool SPLIT3_>
+template <int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int NWE_, int MODE_>
 struct CfgUps {
     static constexpr int KS = 3, KYS = KYS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_;
-    static constexpr bool SPLIT3 = SPLIT3_;
+    static constexpr bool SPLIT3 = MODE_ == 1, Q8 = MODE_ == 2;
+    static constexpr int NQ = 1;
     static constexpr int PAD = 1;
     static constexpr int NWM = WN * WY * WX, NWE = NWE_, NTHREADS = 64 * (NWM + NWE);
     static constexpr int BN = 32 * NT * WN, TH = MTY * WY, TW = 32 * MTX * WX, MT = MTY * MTX;
@@ -445,7 +580,7 @@ struct CfgUps {
     static constexpr int RAW_PIECES = 4 * RH * RW;
     static constexpr int RNI = (RAW_PIECES + 63) / 64;
     static constexpr int RAW_BYTES = RNI * 1024;
-    static constexpr int WST_PIECES = KYS * KS * 4 * BN;
+    static constexpr int WST_PIECES = Q8 ? KYS * KS * 2 * BN + KYS * NQ * 8 * BN : KYS * KS * 4 * BN;
     static constexpr int WNI = WST_PIECES / 64;
     static constexpr int WST_BYTES = WST_PIECES * 16;
     static constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * RAW_BYTES + 2 * WST_BYTES;
@@ -564,9 +699,15 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
             const char *rg = rb + (g * 2 * RH * RW) * 16 + hs * 8;
             auto ld = [&](int rr, int cc, float (&o)[4]) {
                 const h4 hi = *reinterpret_cast<const h4 *>(rg + (rr * RW + cc) * 16);
-                const h4 lo = *reinterpret_cast<const h4 *>(rg + (rr * RW + cc) * 16 + R_LO);
+                if constexpr (C::Q8) {      // lo bytes of both groups sit in the odd group's second plane (raw plane 3)
+                    const int w = *reinterpret_cast<const int *>(rb + (3 * RH * RW + rr * RW + cc) * 16 + g * 8 + hs * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (float)hi[e] + (float)lo[e];
+                    for (int e = 0; e < 4; ++e) o[e] = (float)hi[e] + fp8_byte(w, e) * (1.0f / 2048.0f);
+                } else {
+                    const h4 lo = *reinterpret_cast<const h4 *>(rg + (rr * RW + cc) * 16 + R_LO);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (float)hi[e] + (float)lo[e];
+                }
             };
             // horizontal pass first (rows i and i+1); X = 2j+1: cols (j,j+1) x (.75,.25), X = 2j+2: (.25,.75)
             float t0[4], t1[4], u0[4], u1[4];
@@ -594,14 +735,22 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
             char *pg = pb + (g * 2 * PH * PW) * 16 + ((2 * by) * PW + 2 * bx) * 16 + hs * 8;
             auto st = [&](char *d, float wa, float wb, const float (&ta)[4], const float (&ua)[4], bool zero) {
                 h4 hi, lo;
+                float x[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x = zero ? 0.f : wa * ta[e] + wb * ua[e];
-                    hi[e] = (_Float16)x;
-                    lo[e] = (_Float16)(x - (float)hi[e]);
+                    x[e] = zero ? 0.f : wa * ta[e] + wb * ua[e];
+                    hi[e] = (_Float16)x[e];
+                    lo[e] = (_Float16)(x[e] - (float)hi[e]);
                 }
                 *reinterpret_cast<h4 *>(d) = hi;
-                *reinterpret_cast<h4 *>(d + P_LO) = lo;
+                if constexpr (C::Q8) {      // d = group g's hi plane + pixel + hs*8: the fp8 planes are patch planes 1 and 3
+                    char *q = d - (g * 2 * PH * PW) * 16 - hs * 8 + P_LO + g * 8 + hs * 4;
+                    *reinterpret_cast<int *>(q) = pack4_fp8(x[0], x[1], x[2], x[3]);
+                    *reinterpret_cast<int *>(q + 2 * P_LO) = pack4_fp8((x[0] - (float)hi[0]) * 2048.0f, (x[1] - (float)hi[1]) * 2048.0f,
+                                                                      (x[2] - (float)hi[2]) * 2048.0f, (x[3] - (float)hi[3]) * 2048.0f);
+                } else {
+                    *reinterpret_cast<h4 *>(d + P_LO) = lo;
+                }
             };
             // vertical pass: Y = 2i+1: rows (i, i+1) x (.75, .25); Y = 2i+2: (.25, .75)
             st(pg, 0.75f, 0.25f, t0, u0, zy0 || zx0);
@@ -613,7 +762,8 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
 
     // ---- matrix-side operand bases ---------------------------------------------------------------------
     const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
-    const int aOff = (half * 2 * BN + wn * (NT * 32) + l31) * 16;
+    const int aOff = C::Q8 ? (half * BN + wn * (NT * 32) + l31) * 16 : (half * 2 * BN + wn * (NT * 32) + l31) * 16;
+    const int bqOff = ((PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
 
     // ---- prologue: raw(0), raw(1), filter stage 0; expand chunk 0 -----------------------------------------
     if (!is_mfma) {
@@ -637,9 +787,12 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
                 for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
         for (int it = 0; it < total_it; ++it) {
             const int ch = it / C::NIT, j = it - ch * C::NIT;
-            const char *sb = pbuf0 + (ch & 1) * C::PATCH_BYTES + bOff + j * (KYS * PW * 16);
+            const char *pb = pbuf0 + (ch & 1) * C::PATCH_BYTES + j * (KYS * PW * 16);
             const char *sa = wbuf0 + (it & 1) * C::WST_BYTES + aOff;
-            conv16_compute<C>(acc, sb, sa);
+            if constexpr (C::Q8)
+                conv16_compute_q8<C>(acc, pb + bOff, sa, pb + bqOff, sa + KYS * C::KS * 2 * BN * 16, half * 16);
+            else
+                conv16_compute<C>(acc, pb + bOff, sa);
             __syncthreads();
         }
         conv16_epilogue<C>(p, acc, nb, b, x0, y0, wn, wy, wx, l31, half);
@@ -663,19 +816,19 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
 
 // ---- tile configurations --------------------------------------------------------------------------
 //                     KS KYS NT WN MTY MTX WY WX PBUFS        waves  BN   TH  TW    LDS     workgroups/CU
-template <bool S> using C16K7 = Cfg16<7, 1, 1, 1, 2, 1, 4, 1, 1, S>;       //  4   32    8  32    63 KB   2
-template <bool S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, 2, S>;       //  8   64    8  64   145 KB   1
-template <bool S> using C16K3N32 = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, 1, S>;    //  4   32    8  64    80 KB   2   (short K)
-template <bool S> using C16K3N32D = Cfg16<3, 3, 1, 1, 2, 1, 4, 2, 2, S>;   //  8   32    8  64   121 KB   1   (Cin >= 64)
-template <bool S> using C16K3N64 = Cfg16<3, 3, 2, 1, 2, 1, 4, 2, 2, S>;    //  8   64    8  64   158 KB   1
-template <bool S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8  128    4  64    99 KB   1   //  8  128    4  64    99 KB   1
-template <bool S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, 2, S>;  //  4  128    4  32    83 KB   1
+template <int S> using C16K7 = Cfg16<7, 1, 1, 1, 2, 1, 4, 1, 1, S>;       //  4   32    8  32    63 KB   2
+template <int S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, 2, S>;       //  8   64    8  64   145 KB   1
+template <int S> using C16K3N32 = Cfg16<3, (S == 2 ? 1 : 3), 1, 1, 2, 2, 4, 1, 1, S>;    //  4   32    8  64    80 KB   2   (short K)
+template <int S> using C16K3N32D = Cfg16<3, (S == 2 ? 1 : 3), 1, 1, 2, 1, 4, 2, 2, S>;   //  8   32    8  64   121 KB   1   (Cin >= 64)
+template <int S> using C16K3N64 = Cfg16<3, (S == 2 ? 1 : 3), 2, 1, 2, 1, 4, 2, 2, S>;    //  8   64    8  64   158 KB   1
+template <int S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8  128    4  64    99 KB   1   //  8  128    4  64    99 KB   1
+template <int S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, (S == 2 ? 1 : 2), S>;   // Q8: single patch buffer, 2 workgroups per CU  //  4  128    4  32    83 KB   1
 
 //                        KYS NT WN MTY MTX WY WX NWE           matrix+expander waves  BN  TH  TW   LDS
-template <bool S> using U3N32 = CfgUps<3, 1, 1, 2, 1, 4, 2, 8, S>;    //  8 + 8   32   8  64  146 KB   conv11a (expansion-heaviest: 8 expander waves, measured 1.90 -> 1.72 ms)
-template <bool S> using U3N64 = CfgUps<1, 2, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4   64   8  64  134 KB   conv10a
-template <bool S> using U3N128 = CfgUps<1, 2, 2, 2, 1, 2, 2, 4, S>;   //  8 + 4  128   4  64  116 KB   conv9a
-template <bool S> using U3N128S = CfgUps<1, 2, 2, 2, 1, 2, 1, 4, S>;  //  4 + 4  128   4  32   84 KB   conv7a, conv8a
+template <int S> using U3N32 = CfgUps<(S == 2 ? 1 : 3), 1, 1, 2, 1, 4, 2, 8, S>;    //  8 + 8   32   8  64  146 KB   conv11a (expansion-heaviest: 8 expander waves, measured 1.90 -> 1.72 ms)
+template <int S> using U3N64 = CfgUps<1, 2, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4   64   8  64  134 KB   conv10a
+template <int S> using U3N128 = CfgUps<1, 2, 2, 2, 1, 2, 2, 4, S>;   //  8 + 4  128   4  64  116 KB   conv9a
+template <int S> using U3N128S = CfgUps<1, 2, 2, 2, 1, 2, 1, 4, S>;  //  4 + 4  128   4  32   84 KB   conv7a, conv8a
 
 enum Kind16 { H7 = 0, H5, H3N32, H3N32D, H3N64, H3N128, H3N128S };
 
@@ -742,7 +895,7 @@ int launch16_ups(Conv16Params &p, int B, hipStream_t st) {
     return ssm::check_launch("ssm_conv2d_ups_hl8_fwd");
 }
 
-template <bool S>
+template <int S>
 int dispatch16_ups(Conv16Params &p, int B, hipStream_t st) {
     switch (pick16(3, p.Cout, p.W, p.Cin)) {
         case H3N32:
@@ -754,7 +907,7 @@ int dispatch16_ups(Conv16Params &p, int B, hipStream_t st) {
     return SSM_E_UNSUPPORTED;
 }
 
-template <bool S>
+template <int S>
 int dispatch16(Conv16Params &p, int B, int k, hipStream_t st) {
     switch (pick16(k, p.Cout, p.W, p.Cin)) {
         case H7: return launch16<C16K7<S>>(p, B, st);
@@ -793,6 +946,88 @@ __global__ void pack16_kernel(const float *__restrict__ w, const float *__restri
     if (i < nbias) bp[i] = (i < Cout) ? bias[i] : 0.f;
 }
 
+// Q8 filter packing: per (cout block, 16-channel chunk, stage of KYS filter rows) one LDS image of the stage:
+//   [tap][h][BN][8] fp16(w*scale)   then   [row][quad][operand][piece][half][BN][16] fp8, where lane half `half` of quad j covers
+//   taps kx = 4j + 2*half + piece (zero bytes beyond the row), byte = group*8 + e, operand 0 = fp8(w*scale), 1 = fp8(lo*2^11).
+__global__ void pack16q_main_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int Cout, int Cin, int CinP, int KS, int KYS,
+                                    int BN, float scale, long long stage_halves, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int n = (int)(r % BN); r /= BN;
+    const int h = (int)(r % 2); r /= 2;
+    const int tl = (int)(r % (KYS * KS)); r /= (KYS * KS);
+    const int j = (int)(r % (KS / KYS)); r /= (KS / KYS);
+    const int ch = (int)(r % (CinP / 16));
+    const int nb = (int)(r / (CinP / 16));
+    const long long stage = ((long long)nb * (CinP / 16) + ch) * (KS / KYS) + j;
+    const int co = nb * BN + n, ci = ch * 16 + h * 8 + e;
+    const int ky = j * KYS + tl / KS, kx = tl % KS;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[(((long long)co * Cin + ci) * KS + ky) * KS + kx] * scale;
+    wp[stage * stage_halves + ((long long)(tl * 2 + h) * BN + n) * 8 + e] = (_Float16)v;
+}
+
+__global__ void pack16q_q_kernel(const float *__restrict__ w, unsigned char *__restrict__ wp, int Cout, int Cin, int CinP, int KS, int KYS,
+                                 int BN, float scale, long long stage_bytes, long long qbase, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int NQ = (KS + 3) / 4;
+    long long r = i;
+    const int byte = (int)(r % 16); r /= 16;
+    const int n = (int)(r % BN); r /= BN;
+    const int half = (int)(r % 2); r /= 2;
+    const int pc = (int)(r % 2); r /= 2;
+    const int op = (int)(r % 2); r /= 2;
+    const int q = (int)(r % NQ); r /= NQ;
+    const int ry = (int)(r % KYS); r /= KYS;
+    const int j = (int)(r % (KS / KYS)); r /= (KS / KYS);
+    const int ch = (int)(r % (CinP / 16));
+    const int nb = (int)(r / (CinP / 16));
+    const long long stage = ((long long)nb * (CinP / 16) + ch) * (KS / KYS) + j;
+    const int co = nb * BN + n, ci = ch * 16 + byte;          // byte = group*8 + e = channel inside the chunk
+    const int ky = j * KYS + ry, kx = 4 * q + 2 * half + pc;
+    float v = 0.f;
+    if (co < Cout && ci < Cin && kx < KS) v = w[(((long long)co * Cin + ci) * KS + ky) * KS + kx] * scale;
+    const float lo = (v - (float)(_Float16)v) * 2048.0f;
+    const int word = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(op ? lo : v), 0.f, 0, false);
+    wp[stage * stage_bytes + qbase + ((((((long long)(ry * NQ + q) * 2 + op) * 2 + pc) * 2 + half) * BN + n) * 16) + byte] = (unsigned char)(word & 0xff);
+}
+
+// fp32 view [B,C,H,W] -> Q8 form of the HL8 geometry, and back (x ~= hi + fp8_lo * 2^-11)
+__global__ __launch_bounds__(256) void to_hq8_kernel(ssm_view src, ssm_hview dst, int C, int G, int H, int W) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;
+    if (x >= W || y >= H) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        v[e] = c < C ? src.ptr[(long long)b * src.sb + (long long)c * src.sc + (long long)y * src.sh + x] : 0.f;
+    }
+    char *d = (char *)dst.ptr + ((long long)b * dst.sb + (long long)g * dst.sg + (long long)y * dst.sh + x) * 16;
+    split_store_q8(d, dst.sp * 16, dst.sg * 16, g, 0, v[0], v[1], v[2], v[3]);
+    split_store_q8(d, dst.sp * 16, dst.sg * 16, g, 1, v[4], v[5], v[6], v[7]);
+}
+
+__global__ __launch_bounds__(256) void from_hq8_kernel(ssm_hview src, ssm_view dst, int C, int G, int H, int W) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;
+    if (x >= W || y >= H) return;
+    const char *s = (const char *)src.ptr + ((long long)b * src.sb + (long long)g * src.sg + (long long)y * src.sh + x) * 16;
+    const h8 hi = *reinterpret_cast<const h8 *>(s);
+    const int odd = g & 1;         // the lo bytes of both groups of a pair live in the ODD group's second plane
+    const int *ql = reinterpret_cast<const int *>(s + (1 - odd) * src.sg * 16 + src.sp * 16 + odd * 8);
+    const int q[2] = {ql[0], ql[1]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float lo = fp8_byte(q[e >> 2], e & 3);
+        if (c < C) dst.ptr[(long long)b * dst.sb + (long long)c * dst.sc + (long long)y * dst.sh + x] = (float)hi[e] + lo * (1.0f / 2048.0f);
+    }
+}
+
 // fp32 view [B,C,H,W] -> HL8 (C padded with zero channels up to 8*G), and back
 __global__ __launch_bounds__(256) void to_hl8_kernel(ssm_view src, ssm_hview dst, int C, int G, int H, int W) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
@@ -828,13 +1063,13 @@ __global__ __launch_bounds__(256) void from_hl8_kernel(ssm_hview src, ssm_view d
 
 extern "C" int ssm_conv16_config(int k, int Cout, int W, int *BN, int *KYS) {
     switch (pick16(k, Cout, W)) {
-        case H7: dims16<C16K7<true>>(BN, KYS); break;
-        case H5: dims16<C16K5<true>>(BN, KYS); break;
+        case H7: dims16<C16K7<1>>(BN, KYS); break;
+        case H5: dims16<C16K5<1>>(BN, KYS); break;
         case H3N32:
-        case H3N32D: dims16<C16K3N32<true>>(BN, KYS); break;
-        case H3N64: dims16<C16K3N64<true>>(BN, KYS); break;
-        case H3N128: dims16<C16K3N128<true>>(BN, KYS); break;
-        case H3N128S: dims16<C16K3N128S<true>>(BN, KYS); break;
+        case H3N32D: dims16<C16K3N32<1>>(BN, KYS); break;
+        case H3N64: dims16<C16K3N64<1>>(BN, KYS); break;
+        case H3N128: dims16<C16K3N128<1>>(BN, KYS); break;
+        case H3N128S: dims16<C16K3N128S<1>>(BN, KYS); break;
         default:
             ssm::set_error("conv16: kernel size %d unsupported (3, 5, 7 are)", k);
             return SSM_E_UNSUPPORTED;
@@ -870,6 +1105,61 @@ extern "C" int ssm_hl8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, 
     SSM_REQUIRE((long long)B * G <= 65535, "hl8_to_f32: B*G too large");
     hipLaunchKernelGGL(from_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
     return ssm::check_launch("ssm_hl8_to_f32");
+}
+
+// ---- Q8 operand form (flag SSM_FLAG_Q8): filter packing and layout conversion ----
+extern "C" int ssm_conv16q_config(int k, int Cout, int W, int *BN, int *KYS) {
+    switch (pick16(k, Cout, W)) {
+        case H7: dims16<C16K7<2>>(BN, KYS); break;
+        case H5: dims16<C16K5<2>>(BN, KYS); break;
+        case H3N32:
+        case H3N32D: dims16<C16K3N32<2>>(BN, KYS); break;
+        case H3N64: dims16<C16K3N64<2>>(BN, KYS); break;
+        case H3N128: dims16<C16K3N128<2>>(BN, KYS); break;
+        case H3N128S: dims16<C16K3N128S<2>>(BN, KYS); break;
+        default:
+            ssm::set_error("conv16q: kernel size %d unsupported (3, 5, 7 are)", k);
+            return SSM_E_UNSUPPORTED;
+    }
+    return SSM_OK;
+}
+
+static inline long long q8_stage_bytes(int k, int KYS, int BN) { return (long long)(KYS * k * 2 + KYS * ((k + 3) / 4) * 8) * BN * 16; }
+
+extern "C" size_t ssm_packed16q_weight_bytes(int Cout, int CinP, int k, int BN, int KYS) {
+    return (size_t)((Cout + BN - 1) / BN) * (size_t)(CinP / 16) * (size_t)(k / KYS) * (size_t)q8_stage_bytes(k, KYS, BN);
+}
+
+extern "C" int ssm_pack16q_weights(const float *w, const float *bias, void *wp, float *bp, int Cout, int Cin, int CinP, int k, int BN,
+                                   int KYS, float scale, void *stream) {
+    SSM_REQUIRE(w && bias && wp && bp, "pack16q: null pointer");
+    SSM_REQUIRE(Cout > 0 && Cin > 0 && CinP >= Cin && CinP % 16 == 0 && BN % 32 == 0 && k % KYS == 0, "pack16q: bad sizes");
+    const long long stages = (long long)((Cout + BN - 1) / BN) * (CinP / 16) * (k / KYS);
+    const long long sb = q8_stage_bytes(k, KYS, BN);
+    const long long qbase = (long long)KYS * k * 2 * BN * 16;
+    const long long nmain = stages * (qbase / 2), nq = stages * (sb - qbase);
+    hipLaunchKernelGGL(pack16q_main_kernel, dim3((unsigned)((nmain + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (_Float16 *)wp,
+                       Cout, Cin, CinP, k, KYS, BN, scale, sb / 2, nmain);
+    hipLaunchKernelGGL(pack16q_q_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned char *)wp, Cout,
+                       Cin, CinP, k, KYS, BN, scale, sb, qbase, nq);
+    const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
+    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((nbias + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, (_Float16 *)nullptr, bp,
+                       Cout, Cin, CinP, k, KYS, BN, scale, 0LL, nbias);
+    return ssm::check_launch("ssm_pack16q_weights");
+}
+
+extern "C" int ssm_hq8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream) {
+    SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && G % 2 == 0 && H > 0 && W > 0, "hq8_from_f32: bad arguments (Q8 tensors hold an even number of channel groups)");
+    SSM_REQUIRE((long long)B * G <= 65535, "hq8_from_f32: B*G too large");
+    hipLaunchKernelGGL(to_hq8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    return ssm::check_launch("ssm_hq8_from_f32");
+}
+
+extern "C" int ssm_hq8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream) {
+    SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && G % 2 == 0 && H > 0 && W > 0, "hq8_to_f32: bad arguments (Q8 tensors hold an even number of channel groups)");
+    SSM_REQUIRE((long long)B * G <= 65535, "hq8_to_f32: B*G too large");
+    hipLaunchKernelGGL(from_hq8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    return ssm::check_launch("ssm_hq8_to_f32");
 }
 
 extern "C" int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, const void *w_packed, const float *bias_packed,
@@ -911,8 +1201,12 @@ extern "C" int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, co
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (flags & SSM_FLAG_FP16_FAST) return dispatch16<false>(p, B, k, st);
-    return dispatch16<true>(p, B, k, st);
+    if (flags & SSM_FLAG_Q8) {
+        SSM_REQUIRE((!y_hl8.ptr && !pool_hl8.ptr) || Cout % 16 == 0, "conv16: Q8 output needs Cout %% 16 == 0 (got %d)", Cout);
+        return dispatch16<2>(p, B, k, st);
+    }
+    if (flags & SSM_FLAG_FP16_FAST) return dispatch16<0>(p, B, k, st);
+    return dispatch16<1>(p, B, k, st);
 }
 
 // conv3x3(upsample2x(cat[a, b])) with a, b LOW-res HL8 tensors [B,C1|C2,H/2,W/2]; H, W = output (hi-res) size.
@@ -920,10 +1214,22 @@ extern "C" int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, co
 extern "C" int ssm_conv16_ups_config(int Cout, int W, int *BN, int *KYS) {
     switch (pick16(3, Cout, W, 0)) {
         case H3N32:
-        case H3N32D: *BN = U3N32<true>::BN; *KYS = U3N32<true>::KYS; break;
-        case H3N64: *BN = U3N64<true>::BN; *KYS = U3N64<true>::KYS; break;
-        case H3N128: *BN = U3N128<true>::BN; *KYS = U3N128<true>::KYS; break;
-        case H3N128S: *BN = U3N128S<true>::BN; *KYS = U3N128S<true>::KYS; break;
+        case H3N32D: *BN = U3N32<1>::BN; *KYS = U3N32<1>::KYS; break;
+        case H3N64: *BN = U3N64<1>::BN; *KYS = U3N64<1>::KYS; break;
+        case H3N128: *BN = U3N128<1>::BN; *KYS = U3N128<1>::KYS; break;
+        case H3N128S: *BN = U3N128S<1>::BN; *KYS = U3N128S<1>::KYS; break;
+        default: return SSM_E_UNSUPPORTED;
+    }
+    return SSM_OK;
+}
+
+extern "C" int ssm_conv16q_ups_config(int Cout, int W, int *BN, int *KYS) {
+    switch (pick16(3, Cout, W, 0)) {
+        case H3N32:
+        case H3N32D: *BN = U3N32<2>::BN; *KYS = U3N32<2>::KYS; break;
+        case H3N64: *BN = U3N64<2>::BN; *KYS = U3N64<2>::KYS; break;
+        case H3N128: *BN = U3N128<2>::BN; *KYS = U3N128<2>::KYS; break;
+        case H3N128S: *BN = U3N128S<2>::BN; *KYS = U3N128S<2>::KYS; break;
         default: return SSM_E_UNSUPPORTED;
     }
     return SSM_OK;
@@ -961,6 +1267,10 @@ extern "C" int ssm_conv2d_ups_hl8_fwd(ssm_hview a, int C1, ssm_hview b, int C2, 
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (flags & SSM_FLAG_FP16_FAST) return dispatch16_ups<false>(p, B, st);
-    return dispatch16_ups<true>(p, B, st);
+    if (flags & SSM_FLAG_Q8) {
+        SSM_REQUIRE(!y_hl8.ptr || Cout % 16 == 0, "conv16_ups: Q8 output needs Cout %% 16 == 0 (got %d)", Cout);
+        return dispatch16_ups<2>(p, B, st);
+    }
+    if (flags & SSM_FLAG_FP16_FAST) return dispatch16_ups<0>(p, B, st);
+    return dispatch16_ups<1>(p, B, st);
 }

@@ -275,8 +275,38 @@ __global__ __launch_bounds__(256) void upsample2x_cat_hl8_kernel(ssm_hview a, in
     hl8_store(yout, b, g, 2 * y + 1, 2 * x + 1, o11);
 }
 
-// compute_inputs writing the 16-channel tensor straight into HL8 (two groups) plus the four approximated
-// flow channels (Ft1^ u,v | Ft0^ u,v) as fp32 planes for the synthesis kernel.
+// Q8 form of a PAIR of channel groups (include/ssm_hip.h): hi planes as fp16; the even group's second plane holds the fp8 values of
+// both groups, the odd group's the fp8 (lo * 2^11) of both.
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+    const float lim = 448.0f;                     // e4m3fn: beyond 448 -> NaN
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a, -lim), lim), fminf(fmaxf(b, -lim), lim), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c, -lim), lim), fminf(fmaxf(d, -lim), lim), w, true);
+}
+
+__device__ __forceinline__ void hq8_store_pair(const ssm_hview &v, int b, int g_even, int y, int x, const float (&a)[8], const float (&c)[8]) {
+    h8 ha, hc;
+    float la[8], lc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ha[e] = (_Float16)a[e];
+        hc[e] = (_Float16)c[e];
+        la[e] = (a[e] - (float)ha[e]) * 2048.0f;
+        lc[e] = (c[e] - (float)hc[e]) * 2048.0f;
+    }
+    char *d0 = const_cast<char *>(hp(v, b, g_even, y, x));
+    char *d1 = d0 + v.sg * 16;
+    *reinterpret_cast<h8 *>(d0) = ha;
+    *reinterpret_cast<h8 *>(d1) = hc;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<i4 *>(d0 + v.sp * 16) = i4{pack4_fp8(a[0], a[1], a[2], a[3]), pack4_fp8(a[4], a[5], a[6], a[7]),
+                                                  pack4_fp8(c[0], c[1], c[2], c[3]), pack4_fp8(c[4], c[5], c[6], c[7])};
+    *reinterpret_cast<i4 *>(d1 + v.sp * 16) = i4{pack4_fp8(la[0], la[1], la[2], la[3]), pack4_fp8(la[4], la[5], la[6], la[7]),
+                                                  pack4_fp8(lc[0], lc[1], lc[2], lc[3]), pack4_fp8(lc[4], lc[5], lc[6], lc[7])};
+}
+
+// compute_inputs writing the 16-channel tensor straight into HL8 (two groups; Q8: the fp8 second planes) plus the four
+// approximated flow channels (Ft1^ u,v | Ft0^ u,v) as fp32 planes for the synthesis kernel.
+template <bool Q8>
 __global__ __launch_bounds__(256) void flowinterp_inputs_hl8_kernel(ssm_view img6, ssm_view flow4, const float *__restrict__ tarr,
                                                                     ssm_hview out16, ssm_view flows, int H, int W) {
     SSM_PIXEL_INDEX();
@@ -302,8 +332,12 @@ __global__ __launch_bounds__(256) void flowinterp_inputs_hl8_kernel(ssm_view img
     ga[7] = ft1v;
     gb[0] = ft0u;
     gb[1] = ft0v;
-    hl8_store(out16, b, 0, y, x, ga);
-    hl8_store(out16, b, 1, y, x, gb);
+    if (Q8) {
+        hq8_store_pair(out16, b, 0, y, x, ga, gb);
+    } else {
+        hl8_store(out16, b, 0, y, x, ga);
+        hl8_store(out16, b, 1, y, x, gb);
+    }
     vp(flows, b, 0, y)[x] = ft1u;
     vp(flows, b, 1, y)[x] = ft1v;
     vp(flows, b, 2, y)[x] = ft0u;
@@ -435,8 +469,17 @@ extern "C" int ssm_flowinterp_inputs_hl8_fwd(ssm_view img6, ssm_view flow4, cons
     SSM_CHECK_DIMS("flowinterp_inputs_hl8");
     SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && flows.ptr && t, "flowinterp_inputs_hl8: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_hl8: plane too large");
-    hipLaunchKernelGGL(flowinterp_inputs_hl8_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
+    hipLaunchKernelGGL(flowinterp_inputs_hl8_kernel<false>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
     return ssm::check_launch("ssm_flowinterp_inputs_hl8_fwd");
+}
+
+extern "C" int ssm_flowinterp_inputs_hq8_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_hview out16, ssm_view flows, int B, int H,
+                                             int W, void *stream) {
+    SSM_CHECK_DIMS("flowinterp_inputs_hq8");
+    SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && flows.ptr && t, "flowinterp_inputs_hq8: null pointer");
+    SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_hq8: plane too large");
+    hipLaunchKernelGGL(flowinterp_inputs_hl8_kernel<true>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
+    return ssm::check_launch("ssm_flowinterp_inputs_hq8_fwd");
 }
 
 extern "C" int ssm_frames_from_u8_fwd(const unsigned char *frames_hwc, ssm_view out, int N, int H, int W, int Hp, int Wp, int top,

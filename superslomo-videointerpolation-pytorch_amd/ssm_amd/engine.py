@@ -50,10 +50,12 @@ class KernelTimer:
         return out
 
 
-MODES = ("f32", "f16x3", "f16")
+MODES = ("f32", "f16x3", "f16", "f16f8")
 # f32   : fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 padded planes
 # f16x3 : fp16 MFMA on hi/lo-split operands, 3 MFMAs per product, fp32 accumulate (fp32-grade results)
 # f16   : fp16 MFMA, hi*hi only (reduced precision; 4K / config 5)
+# f16f8 : fp16 MFMA for hi*hi + two block-scaled fp8 MFMAs (K = 4 taps x 16 channels) for the compensation products, on the
+#         Q8 form of the HL8 layout (fp32-grade results at half the matrix cost of f16x3)
 POOLED = ("conv1b", "conv2b", "conv3b", "conv4b", "conv5b")      # 2x2 mean fused into these convs
 _SCALE = (("conv10", 2), ("conv11", 1), ("conv1", 1), ("conv2", 2), ("conv3", 4), ("conv4", 8), ("conv5", 16),
           ("conv6", 32), ("conv7", 16), ("conv8", 8), ("conv9", 4), ("fuse_conv", 1), ("final_conv", 1))
@@ -74,6 +76,7 @@ class UNetPlan:
     DECODER = ("conv7a", "conv7b", "conv8a", "conv8b", "conv9a", "conv9b", "conv10a", "conv10b", "conv11a", "conv11b",
                "fuse_conv", "final_conv")
     ENCODER_T = ("c1", "c2", "c3", "c4", "c5", "c6")      # encoder-batch tensors the decoder reads
+    UPS = ("conv7a", "conv8a", "conv9a", "conv10a", "conv11a")      # convolutions with the concat+upsample fused in
 
     def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True,
                  bottleneck="CONV", seq_len=1, dec=None):
@@ -88,8 +91,10 @@ class UNetPlan:
         assert 0 <= self.dec_b0 and self.dec_b0 + self.Bd <= B
         self._b0 = 0            # batch offset applied to ENCODER_T views (set while the decoder runs)
         self._Bcur = B
-        self.mode, self.hl8 = mode, mode != "f32"
+        self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.fuse_up = bool(fuse_upsample) and self.hl8      # concat+upsample fused into the consumer conv's loader
+        if self.q8:
+            assert self.fuse_up and bottleneck == "CONV", "mode f16f8 covers the fused plan with the CONV bottleneck"
         if H % 32 or W % 32:
             raise AssertionError("H and W must be multiples of 32 (got %dx%d): the U-Net pools 5 times "
                                  "and concatenates skips (unchecked in the reference, fails in torch.cat)" % (H, W))
@@ -103,15 +108,15 @@ class UNetPlan:
             self.rnn = RecurrentBottleneck(bottleneck, state_dict, B // seq_len, seq_len, H // 32, W // 32, device, mode)
         Bd = self.Bd
         if self.hl8:
-            P = lambda c, s: hb.HPlanes(B, c, H // s, W // s, device)  # noqa: E731
-            D = lambda c, s: hb.HPlanes(Bd, c, H // s, W // s, device)  # noqa: E731
+            P = lambda c, s: hb.HPlanes(B, c, H // s, W // s, device, q8=self.q8)  # noqa: E731
+            D = lambda c, s: hb.HPlanes(Bd, c, H // s, W // s, device, q8=self.q8)  # noqa: E731
         else:
             P = lambda c, s: hb.Planes(B, c, H // s, W // s, device)  # noqa: E731
             D = lambda c, s: hb.Planes(Bd, c, H // s, W // s, device)  # noqa: E731
         cin0 = self.layers["conv1a"][0]
         cfin = self.layers["final_conv"][1]
         t = self.t = {}
-        t["in"] = hb.HPlanes(B, cin0, H, W, device, groups=self.pk["conv1a"].cin_p // 8) if self.hl8 else P(cin0, 1)
+        t["in"] = hb.HPlanes(B, cin0, H, W, device, groups=self.pk["conv1a"].cin_p // 8, q8=self.q8) if self.hl8 else P(cin0, 1)
         t["t1a"], t["c1"], t["p2"] = P(32, 1), P(32, 1), P(32, 2)
         t["t2a"], t["c2"], t["p3"] = P(64, 2), P(64, 2), P(64, 4)
         t["t3a"], t["c3"], t["p4"] = P(128, 4), P(128, 4), P(128, 8)
@@ -140,7 +145,7 @@ class UNetPlan:
                 assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
             s = layer_scale(name)
             if self.hl8:
-                self.pk[name] = hb.PackedConv16(w, b, self.W // s)
+                self.pk[name] = hb.PackedConv16(w, b, self.W // s, q8=self.q8, ups=self.fuse_up and name in self.UPS)
             else:
                 nb = self.Bd if name in self.DECODER else self.B
                 self.pk[name] = hb.PackedConv(w, b, nb, self.H // s, self.W // s, pool=name in POOLED)
@@ -406,7 +411,7 @@ class PairEngine:
         assert B2 == B1 or B1 == 1, "stage-2 batch must equal stage-1 batch, or stage-1 batch must be 1"
         self.B1, self.B2, self.H, self.W, self.device = B1, B2, H, W, device
         self.cross = bool(cross_skip)
-        self.mode, self.hl8 = mode, mode != "f32"
+        self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.bcast = (B1 == 1 and B2 > 1)
         self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode, fuse_upsample)
         self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode, fuse_upsample)
@@ -445,8 +450,9 @@ class PairEngine:
             e0, e1 = tm.span("warp", "flowinterp_inputs", nbytes=104.0 * px)
             e0.record()
         if self.hl8:
-            hb.check(lib.ssm_flowinterp_inputs_hl8_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
-                                                       in16.view(), hb.view_of(self.est), self.B2, self.H, self.W, st))
+            fn = lib.ssm_flowinterp_inputs_hq8_fwd if self.q8 else lib.ssm_flowinterp_inputs_hl8_fwd
+            hb.check(fn(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
+                        in16.view(), hb.view_of(self.est), self.B2, self.H, self.W, st))
         else:
             hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
                                                    in16.view(), self.B2, self.H, self.W, st))

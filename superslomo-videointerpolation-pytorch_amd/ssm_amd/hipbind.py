@@ -33,6 +33,7 @@ class SsmHView(ctypes.Structure):
 
 NULL_HVIEW = SsmHView(None, 0, 0, 0, 0)
 SSM_FLAG_FP16_FAST = 2
+SSM_FLAG_Q8 = 4
 
 _c_int, _c_float, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -54,6 +55,12 @@ SIGNATURES = {
     "ssm_pack16_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _vp]),
     "ssm_conv2d_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, _c_float, SsmHView, SsmView, SsmHView,
                                     _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_conv16q_config": (_c_int, [_c_int, _c_int, _c_int, _ip, _ip]),
+    "ssm_conv16q_ups_config": (_c_int, [_c_int, _c_int, _ip, _ip]),
+    "ssm_packed16q_weight_bytes": (_sz, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ssm_pack16q_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _vp]),
+    "ssm_hq8_from_f32": (_c_int, [SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_hq8_to_f32": (_c_int, [SsmHView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv16_ups_config": (_c_int, [_c_int, _c_int, _ip, _ip]),
     "ssm_conv2d_ups_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, _c_float, SsmHView, SsmView,
                                         _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
@@ -61,6 +68,7 @@ SIGNATURES = {
     "ssm_hl8_to_f32": (_c_int, [SsmHView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_hl8_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, SsmHView, _c_int, _c_int, _c_int, _vp]),
     "ssm_flowinterp_inputs_hl8_fwd": (_c_int, [SsmView, SsmView, _vp, SsmHView, SsmView, _c_int, _c_int, _c_int, _vp]),
+    "ssm_flowinterp_inputs_hq8_fwd": (_c_int, [SsmView, SsmView, _vp, SsmHView, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_frames_from_u8_fwd": (_c_int, [_vp, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         ctypes.POINTER(_c_float), ctypes.POINTER(_c_float), _c_int, _vp]),
     "ssm_frames_to_u8_fwd": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_float),
@@ -237,9 +245,12 @@ class HPlanes:
     """A [B,C,H,W] activation in the HL8 layout (include/ssm_hip.h): [B][G][hi|lo][Hp][Wp][8 x fp16],
     G = ceil(C/8) channel groups (optionally more: zero channels), zero frame, tail slack."""
 
-    def __init__(self, B, C, H, W, device, groups=None):
+    def __init__(self, B, C, H, W, device, groups=None, q8=False):
         self.B, self.C, self.H, self.W = B, C, H, W
+        self.q8 = bool(q8)       # plane 1 = [fp8(x) | fp8(lo * 2^11)] (SSM_FLAG_Q8 operands) instead of fp16(lo)
         self.G = groups if groups is not None else (C + 7) // 8
+        if q8 and self.G % 2:
+            self.G += 1          # second planes are shared by pairs of groups
         self.Hp, self.Wp = plane_dims(H, W)
         n = B * self.G * 2 * self.Hp * self.Wp * 8
         self.buf = torch.zeros(n + 2 * SSM_TAIL_SLACK_FLOATS, dtype=torch.float16, device=device)
@@ -252,12 +263,14 @@ class HPlanes:
 
     def load(self, x):
         x = x if x.stride(3) == 1 else x.contiguous()
-        check(load().ssm_hl8_from_f32(view_of(x), self.view(), self.B, self.C, self.G, self.H, self.W, stream_ptr()))
+        fn = load().ssm_hq8_from_f32 if self.q8 else load().ssm_hl8_from_f32
+        check(fn(view_of(x), self.view(), self.B, self.C, self.G, self.H, self.W, stream_ptr()))
         return self
 
     def to_nchw(self):
         out = torch.empty(self.B, self.C, self.H, self.W, dtype=torch.float32, device=self.buf.device)
-        check(load().ssm_hl8_to_f32(self.view(), view_of(out), self.B, self.C, self.G, self.H, self.W, stream_ptr()))
+        fn = load().ssm_hq8_to_f32 if self.q8 else load().ssm_hl8_to_f32
+        check(fn(self.view(), view_of(out), self.B, self.C, self.G, self.H, self.W, stream_ptr()))
         return out
 
 
@@ -265,29 +278,40 @@ class PackedConv16:
     """Filter split into fp16 hi/lo parts, scaled by a power of two so both parts sit in fp16's
     normal range, repacked for the fp16-MFMA kernel's tile configuration."""
 
-    def __init__(self, weight, bias, W):
+    def __init__(self, weight, bias, W, q8=False, ups=False):
+        """ups: the filter feeds ssm_conv2d_ups_hl8_fwd (W = its OUTPUT width); in Q8 form the packing follows that kernel's tile."""
         require_device(weight, "conv weight")
         self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        self.q8 = bool(q8)
         lib = load()
         bn, kys = ctypes.c_int(0), ctypes.c_int(0)
-        check(lib.ssm_conv16_config(self.k, self.cout, W, ctypes.byref(bn), ctypes.byref(kys)))
+        if q8 and ups:
+            check(lib.ssm_conv16q_ups_config(self.cout, W, ctypes.byref(bn), ctypes.byref(kys)))
+        else:
+            check((lib.ssm_conv16q_config if q8 else lib.ssm_conv16_config)(self.k, self.cout, W, ctypes.byref(bn), ctypes.byref(kys)))
         self.bn, self.kys = bn.value, kys.value
         self.cin_p = (self.cin + 15) // 16 * 16
         wmax = float(weight.detach().abs().max())
         import math
         self.scale = 2.0 ** (3 - math.ceil(math.log2(wmax))) if wmax > 0 else 1.0     # max|w|*scale in (4, 8]
-        nh = lib.ssm_packed16_weight_halves(self.cout, self.cin_p, self.k, self.bn)
         nb = lib.ssm_packed_bias_floats(self.cout, self.bn)
-        self.w = torch.empty(nh, dtype=torch.float16, device=weight.device)
         self.b = torch.empty(nb, dtype=torch.float32, device=weight.device)
         wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        if q8:
+            nbytes = lib.ssm_packed16q_weight_bytes(self.cout, self.cin_p, self.k, self.bn, self.kys)
+            self.w = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+            check(lib.ssm_pack16q_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout,
+                                          self.cin, self.cin_p, self.k, self.bn, self.kys, self.scale, stream_ptr()))
+            return
+        nh = lib.ssm_packed16_weight_halves(self.cout, self.cin_p, self.k, self.bn)
+        self.w = torch.empty(nh, dtype=torch.float16, device=weight.device)
         check(lib.ssm_pack16_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout,
                                      self.cin, self.cin_p, self.k, self.bn, self.kys, self.scale, stream_ptr()))
 
 
 def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slope=0.1, fast=False):
     assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
-    flags = (SSM_FLAG_LRELU if lrelu else 0) | (SSM_FLAG_FP16_FAST if fast else 0)
+    flags = (SSM_FLAG_LRELU if lrelu else 0) | (SSM_FLAG_FP16_FAST if fast else 0) | (SSM_FLAG_Q8 if pk.q8 else 0)
     check(load().ssm_conv2d_hl8_fwd(x1, c1, x2 if x2 is not None else NULL_HVIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(),
                                     1.0 / pk.scale, y_hl8 if y_hl8 is not None else NULL_HVIEW,
                                     y_f32 if y_f32 is not None else NULL_VIEW, pool if pool is not None else NULL_HVIEW,
@@ -297,7 +321,7 @@ def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slop
 def conv2d_ups_hl8(a, c1, b, c2, pk, y_hl8, y_f32, B, H, W, lrelu=True, slope=0.1, fast=False):
     """conv3x3(upsample2x(cat[a, b])): a, b LOW-res HL8 views, H, W the OUTPUT size."""
     assert pk.k == 3 and pk.cin_p == c1 + c2, "packed 3x3 filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
-    flags = (SSM_FLAG_LRELU if lrelu else 0) | (SSM_FLAG_FP16_FAST if fast else 0)
+    flags = (SSM_FLAG_LRELU if lrelu else 0) | (SSM_FLAG_FP16_FAST if fast else 0) | (SSM_FLAG_Q8 if pk.q8 else 0)
     check(load().ssm_conv2d_ups_hl8_fwd(a, c1, b if b is not None else NULL_HVIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(),
                                         1.0 / pk.scale, y_hl8 if y_hl8 is not None else NULL_HVIEW,
                                         y_f32 if y_f32 is not None else NULL_VIEW, B, H, W, pk.cout, slope, flags,

@@ -17,18 +17,19 @@ from ssm_amd.weights import unet_layers  # noqa: E402
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     fast = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+    q8 = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
     H, W = int(os.environ.get("SSM_BENCH_H", 736)), int(os.environ.get("SSM_BENCH_W", 1280))
     dev = torch.device("cuda:0")
     tot_t = tot_f = 0.0
-    print("mode: %s   B=%d" % ("fp16 fast (1 MFMA)" if fast else "fp16 split (3 MFMA, fp32-grade)", B))
+    print("mode: %s   B=%d" % ("fp16 fast (1 MFMA)" if fast else ("fp16 + 2 x scaled fp8 (Q8)" if q8 else "fp16 split (3 MFMA, fp32-grade)"), B))
     print("%-10s %5s %5s %2s %9s %9s %8s %8s" % ("layer", "cin", "cout", "k", "hxw", "GFLOP", "ms", "TFLOP/s"))
     for name, cin, cout, k in unet_layers(2, True):
         s = layer_scale(name)
         h, w = H // s, W // s
         pk = hb.PackedConv16(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5,
-                             torch.zeros(cout, device=dev), w)
-        x = hb.HPlanes(B, cin, h, w, dev, groups=pk.cin_p // 8)
-        x.buf.normal_()
+                             torch.zeros(cout, device=dev), w, q8=q8)
+        x = hb.HPlanes(B, cin, h, w, dev, groups=pk.cin_p // 8, q8=q8)
+        x.load(torch.randn(B, cin, h, w, device=dev))
         y = hb.HPlanes(B, cout, h, w, dev) if cout % 8 == 0 else None
         y32 = torch.empty(B, cout, h, w, device=dev) if y is None else None
         args = (x.view(), pk.cin_p, None, 0, pk, y.view() if y else None, hb.view_of(y32) if y32 is not None else None,
