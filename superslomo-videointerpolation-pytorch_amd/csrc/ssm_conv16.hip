@@ -116,7 +116,7 @@ __device__ __forceinline__ void split_store(char *plane_hi, long long sp_bytes, 
 }
 
 // ---- Q8 layout: plane 1 of a pixel group holds [8 x fp8(x) | 8 x fp8((x - fp16(x)) * 2^11)] instead of 8 x fp16(lo) ----
-__device__ __forceinline__ float clamp448(float v) { return fminf(fmaxf(v, -448.0f), 448.0f); }      // e4m3fn: beyond 448 -> NaN
+__device__ __forceinline__ float clamp448(float v) { return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f); }      // e4m3fn: beyond 448 -> NaN
 
 __device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
     int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(a), clamp448(b), 0, false);
@@ -825,7 +825,7 @@ template <int S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8 
 template <int S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, (S == 2 ? 1 : 2), S>;   // Q8: single patch buffer, 2 workgroups per CU  //  4  128    4  32    83 KB   1
 
 //                        KYS NT WN MTY MTX WY WX NWE           matrix+expander waves  BN  TH  TW   LDS
-template <int S> using U3N32 = CfgUps<(S == 2 ? 1 : 3), 1, 1, 2, 1, 4, 2, 8, S>;    //  8 + 8   32   8  64  146 KB   conv11a (expansion-heaviest: 8 expander waves, measured 1.90 -> 1.72 ms)
+template <int S> using U3N32 = CfgUps<3, 1, 1, 2, 1, 4, 2, 8, S>;    //  8 + 8   32   8  64  146 KB   conv11a (expansion-heaviest: 8 expander waves, measured 1.90 -> 1.72 ms)
 template <int S> using U3N64 = CfgUps<1, 2, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4   64   8  64  134 KB   conv10a
 template <int S> using U3N128 = CfgUps<1, 2, 2, 2, 1, 2, 2, 4, S>;   //  8 + 4  128   4  64  116 KB   conv9a
 template <int S> using U3N128S = CfgUps<1, 2, 2, 2, 1, 2, 1, 4, S>;  //  4 + 4  128   4  32   84 KB   conv7a, conv8a

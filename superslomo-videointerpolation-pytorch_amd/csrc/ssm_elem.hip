@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256) void upsample2x_cat_hl8_kernel(ssm_hview a, in
 // both groups, the odd group's the fp8 (lo * 2^11) of both.
 __device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
     const float lim = 448.0f;                     // e4m3fn: beyond 448 -> NaN
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a, -lim), lim), fminf(fmaxf(b, -lim), lim), 0, false);
-    return __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c, -lim), lim), fminf(fmaxf(d, -lim), lim), w, true);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -lim, lim), __builtin_amdgcn_fmed3f(b, -lim, lim), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -lim, lim), __builtin_amdgcn_fmed3f(d, -lim, lim), w, true);
 }
 
 __device__ __forceinline__ void hq8_store_pair(const ssm_hview &v, int b, int g_even, int y, int x, const float (&a)[8], const float (&c)[8]) {

@@ -19,10 +19,11 @@ import torch.nn as nn
 from ssm_amd import hipbind as hb
 from ssm_amd.engine import PairEngine, WindowEngine
 
-# Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f16x3" evaluates every fp32
-# product as three fp16 MFMAs on hi/lo-split operands with fp32 accumulation (fp32-grade results, held to the
-# same 1e-3 bar by the tests); "f32" is the plain fp32-MFMA kernel; "f16" is reduced precision.
-DEFAULT_PRECISION = "f16x3"
+# Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f16f8" evaluates every fp32 product
+# as one fp16 MFMA on the hi parts plus two block-scaled fp8 MFMAs for the compensation terms; "f16x3" as three fp16
+# MFMAs on hi/lo-split operands (both fp32-accumulated, fp32-grade, held to the same 1e-3 bar by the tests); "f32" is
+# the plain fp32-MFMA kernel; "f16" is reduced precision.
+DEFAULT_PRECISION = "f16f8"
 
 from . import unetflow as unet
 from .losses import SSMLosses
@@ -151,6 +152,8 @@ class FullModel(nn.Module):
 
     def window_engine_for(self, T, S1, S2, H, W, device, decode_all=False):
         mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)
+        if mode == "f16f8":          # the recurrent cells write the HL8 lo planes: this plan runs the f16x3 kernels
+            mode = "f16x3"
         key = ("win", T, S1, S2, H, W, str(device), mode, decode_all, self._stamp())
         if self._engine is None or self._engine[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}

@@ -599,7 +599,7 @@ class PairPipeline:
     MFMA-bound convolutions use the idle matrix cores / CUs.  Each engine owns its activations; the input
     pair is read in place.  Results of `submit` stay valid until that slot is reused (N pairs later)."""
 
-    def __init__(self, sd1, sd2, n_t, H, W, device, cross_skip=True, mode="f16x3", n_streams=2, graphs=False):
+    def __init__(self, sd1, sd2, n_t, H, W, device, cross_skip=True, mode="f16f8", n_streams=2, graphs=False):
         self.engines = [PairEngine(sd1, sd2, 1, n_t, H, W, device, cross_skip, mode) for _ in range(n_streams)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
         self.n = n_streams

@@ -466,7 +466,7 @@ def test_multi_window_training_n_frames_4(dev):
         img0, l0 = m(x, t, tgt, None, False)
     img, losses = m(x, t, tgt, None, False)
     assert losses.requires_grad and float((losses.detach() - l0).abs().max()) < 1e-3 * float(l0.abs().max())
-    assert float((img - img0).abs().max()) < 1e-4
+    assert float((img - img0).abs().max()) < 1e-3            # planned (default precision) vs op-by-op fp32 kernels
     losses.mean(dim=0)[0].backward()
     for name, p in m.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0, name
