@@ -326,7 +326,8 @@ def main():
         ach = flops_step / (conv_ms_step * 1e-3) / 1e12
         traffic = None
         pmc_file, pmc_key = {"f32": ("r1b_pmc_traffic_summary.json", "conv_mfma_kernel"),
-                             "f16x3": ("r1k_pmc_traffic_summary.json", "conv16_kernel")}.get(precision, (None, None))
+                             "f16x3": ("r1k_pmc_traffic_summary.json", "conv16_kernel"),
+                             "f16f8": ("r1l_pmc_traffic_summary.json", "conv16_kernel")}.get(precision, (None, None))
         pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
         if pmc and os.path.exists(pmc):   # HBM bytes per step from rocprofv3 --pmc passes (tools/pmc_traffic.sh), not live
             pj = json.load(open(pmc))
