@@ -11,16 +11,19 @@ are batched through stage 2.  N > 1: every rank processes its own pairs (weak sc
 data-path collective); value = all ranks' frames / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel family = the fp32-MFMA convolutions.  achieved = algorithmic
-                FLOP per step (5.855 TFLOP / pair at 736x1280, 7 t, stage 1 hoisted)
-                / the summed duration of the conv launches of a step, measured with HIP events
-                on the launch stream inside the timed region; peak = 157.3 TFLOP/s.
+  roofline      dominant kernel family = the 48 convolution launches of a step (conv16_kernel + conv16_ups_kernel in the
+                default precision mode f16f8: one fp16 MFMA + two block-scaled fp8 MFMAs per product).  achieved =
+                algorithmic FLOP per step (5.855 TFLOP / pair at 736x1280, 7 t, stage 1 hoisted) / the summed
+                duration of those launches, measured with HIP events on the launch stream in a single-stream region run right
+                after the timed region; peak = the dense fp16 MFMA peak (2.5 PFLOP/s; 157.3 TFLOP/s in mode f32);
+                mfma_issue_frac = issued fp16-MFMA units / peak; traffic = HBM bytes of those launches from rocprofv3 --pmc
+                passes (profiles/*_pmc_traffic_summary.json).
   roofline_warp the HBM-bound gather kernels (compute_inputs + synthesis): algorithmic bytes
                 (104 + 72 B/px per t) / their event-timed duration; peak 8 TB/s.
   cpu_baseline  the CPU oracle (torch CPU fp32 ops, pinned to the reference by golden fixtures),
                 timed on this host on a bounded sample: 1 pair x 1 intermediate, reference-style
                 loop (stage 1 recomputed per t).  A reported baseline, not the target.
-  parity        max|HIP - oracle| over those same 2 full-size frames (bar: 1e-3).
+  parity        max|HIP - oracle| over that same full-size frame (bar: 1e-3).
 """
 import argparse
 import json
