@@ -165,7 +165,7 @@ def recurrent_bench(args):
     p1, p2 = synthetic_state_dict(1, bottleneck=kind), synthetic_state_dict(2, bottleneck=kind)
     model.stage1_model.load_state_dict(p1)
     model.stage2_model.load_state_dict(p2)
-    model.precision = args.precision or "f16x3"
+    model.precision = args.precision or "f16f8"
     model = model.to(dev).eval()
     n_frames = cfg.getint("TRAIN", "N_FRAMES")
     clips = [synthetic_frames(n_frames, H_IN, W_IN, seed=42 + 2 * rank + i).to(dev) for i in range(2)]

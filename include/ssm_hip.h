@@ -258,12 +258,13 @@ int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_view out, int
  *  ssm_convlstm_cell_fwd   gates [i|f|o|g] (4*Hc ch): c' = s(f)*c + s(i)*tanh(g);  h' = s(o)*tanh(c')
  *  ssm_convgru_reset_fwd   gates [gamma|beta] (2*Hc ch): rh = s(gamma) * h          (input of the candidate conv)
  *  ssm_convgru_update_fwd  u = s(beta); h' = (1-u)*h + u*tanh(cand_x + cand_h)      (cand_* = Hc ch)            */
+/* flags: SSM_FLAG_Q8 = write the HL8 output in the Q8 operand form (view starting at an even channel group, Hc % 16 == 0) */
 int ssm_convlstm_cell_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view c_prev, ssm_view c_next, ssm_view h_f32,
-                          ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream);
+                          ssm_hview h_hl8, int B, int Hc, int H, int W, int flags, void *stream);
 int ssm_convgru_reset_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view h_prev, ssm_view rh_f32, ssm_hview rh_hl8, int B,
-                          int Hc, int H, int W, void *stream);
+                          int Hc, int H, int W, int flags, void *stream);
 int ssm_convgru_update_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view cand_x, ssm_view cand_h, ssm_view h_prev,
-                           ssm_view h_f32, ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream);
+                           ssm_view h_f32, ssm_hview h_hl8, int B, int Hc, int H, int W, int flags, void *stream);
 
 /* Adjoints of the cells above (training through the recurrent bottleneck; the gate convolutions' own gradients are the conv
  * backward entry points).  fp32 views.

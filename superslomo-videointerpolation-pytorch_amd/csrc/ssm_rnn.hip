@@ -16,16 +16,38 @@ __device__ __forceinline__ float *vp(const ssm_view &v, int b, int c, int y) {
     return v.ptr + (long long)b * v.sb + (long long)c * v.sc + (long long)y * v.sh;
 }
 
-__device__ __forceinline__ void hl8_store(const ssm_hview &v, int b, int g, int y, int x, const float (&o)[8]) {
-    h8 hi, lo;
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+    const float lim = 448.0f;                     // e4m3fn: beyond 448 -> NaN
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -lim, lim), __builtin_amdgcn_fmed3f(b, -lim, lim), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -lim, lim), __builtin_amdgcn_fmed3f(d, -lim, lim), w, true);
+}
+
+// q8 = 0: HL8 (second plane = fp16 lo).  q8 = 1: Q8 form (include/ssm_hip.h): second planes shared by the pair of groups
+// (g & ~1, g | 1): even group's = fp8(x) of both, odd group's = fp8(lo * 2^11) of both; the view must start at an even group.
+__device__ __forceinline__ void hl8_store(const ssm_hview &v, int b, int g, int y, int x, const float (&o)[8], int q8) {
+    h8 hi;
+    float lo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         hi[e] = (_Float16)o[e];
-        lo[e] = (_Float16)(o[e] - (float)hi[e]);
+        lo[e] = o[e] - (float)hi[e];
     }
     char *d = (char *)v.ptr + ((long long)b * v.sb + (long long)g * v.sg + (long long)y * v.sh + x) * 16;
     *reinterpret_cast<h8 *>(d) = hi;
-    *reinterpret_cast<h8 *>(d + v.sp * 16) = lo;
+    if (q8) {
+        const int odd = g & 1;
+        typedef int i2 __attribute__((ext_vector_type(2)));
+        char *even_rec = d - odd * v.sg * 16 + v.sp * 16;
+        *reinterpret_cast<i2 *>(even_rec + odd * 8) = i2{pack4_fp8(o[0], o[1], o[2], o[3]), pack4_fp8(o[4], o[5], o[6], o[7])};
+        *reinterpret_cast<i2 *>(even_rec + v.sg * 16 + odd * 8) =
+            i2{pack4_fp8(lo[0] * 2048.f, lo[1] * 2048.f, lo[2] * 2048.f, lo[3] * 2048.f),
+               pack4_fp8(lo[4] * 2048.f, lo[5] * 2048.f, lo[6] * 2048.f, lo[7] * 2048.f)};
+    } else {
+        h8 l16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l16[e] = (_Float16)lo[e];
+        *reinterpret_cast<h8 *>(d + v.sp * 16) = l16;
+    }
 }
 
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -40,7 +62,7 @@ __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v))
 // ConvLSTM cell: pre-activations [i | f | o | g] (Hc channels each);
 //   c' = sigmoid(f) * c + sigmoid(i) * tanh(g);   h' = sigmoid(o) * tanh(c')
 __global__ __launch_bounds__(256) void convlstm_cell_kernel(ssm_view gx, ssm_view gh, ssm_view cprev, ssm_view cnext, ssm_view h32,
-                                                            ssm_hview h16, int Hc, int H, int W) {
+                                                            ssm_hview h16, int Hc, int H, int W, int q8) {
     SSM_CELL_INDEX();
     float hv[8];
 #pragma unroll
@@ -59,12 +81,12 @@ __global__ __launch_bounds__(256) void convlstm_cell_kernel(ssm_view gx, ssm_vie
         hv[e] = sigm(po) * tanhf(cn);
         if (h32.ptr) vp(h32, b, c, y)[x] = hv[e];
     }
-    if (h16.ptr) hl8_store(h16, b, g, y, x, hv);
+    if (h16.ptr) hl8_store(h16, b, g, y, x, hv, q8);
 }
 
 // ConvGRU, first half: gates [gamma | beta]; reset = sigmoid(gamma); writes reset * h (input of the candidate conv).
 __global__ __launch_bounds__(256) void convgru_reset_kernel(ssm_view gx, ssm_view gh, ssm_view hprev, ssm_view rh32, ssm_hview rh16,
-                                                            int Hc, int H, int W) {
+                                                            int Hc, int H, int W, int q8) {
     SSM_CELL_INDEX();
     float rv[8];
 #pragma unroll
@@ -74,12 +96,12 @@ __global__ __launch_bounds__(256) void convgru_reset_kernel(ssm_view gx, ssm_vie
         rv[e] = sigm(pr) * vp(hprev, b, c, y)[x];
         if (rh32.ptr) vp(rh32, b, c, y)[x] = rv[e];
     }
-    if (rh16.ptr) hl8_store(rh16, b, g, y, x, rv);
+    if (rh16.ptr) hl8_store(rh16, b, g, y, x, rv, q8);
 }
 
 // ConvGRU, second half: update = sigmoid(beta); h' = (1 - update) * h + update * tanh(candidate pre-activation).
 __global__ __launch_bounds__(256) void convgru_update_kernel(ssm_view gx, ssm_view gh, ssm_view cx, ssm_view ch, ssm_view hprev,
-                                                             ssm_view h32, ssm_hview h16, int Hc, int H, int W) {
+                                                             ssm_view h32, ssm_hview h16, int Hc, int H, int W, int q8) {
     SSM_CELL_INDEX();
     float hv[8];
 #pragma unroll
@@ -93,7 +115,7 @@ __global__ __launch_bounds__(256) void convgru_update_kernel(ssm_view gx, ssm_vi
         hv[e] = (1.0f - u) * hp + u * tanhf(pc);
         if (h32.ptr) vp(h32, b, c, y)[x] = hv[e];
     }
-    if (h16.ptr) hl8_store(h16, b, g, y, x, hv);
+    if (h16.ptr) hl8_store(h16, b, g, y, x, hv, q8);
 }
 
 // ---- adjoints of the cells (training through the recurrent bottleneck; fp32 views, one thread = pixel x 8 channels) ----
@@ -161,34 +183,40 @@ inline dim3 cell_grid(int B, int Hc, int H, int W) { return dim3((W + 63) / 64, 
     SSM_REQUIRE((long long)B * (Hc / 8) <= 65535, what ": B*Hc too large for one launch")
 
 extern "C" int ssm_convlstm_cell_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view c_prev, ssm_view c_next, ssm_view h_f32,
-                                     ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream) {
+                                     ssm_hview h_hl8, int B, int Hc, int H, int W, int flags, void *stream) {
+    const int q8 = (flags & SSM_FLAG_Q8) ? 1 : 0;
+    SSM_REQUIRE(!q8 || Hc % 16 == 0, "convlstm_cell: a Q8 output needs hidden channels in multiples of 16");
     SSM_CELL_DIMS("convlstm_cell");
     SSM_REQUIRE(gates_x.ptr && c_next.ptr && (h_f32.ptr || h_hl8.ptr), "convlstm_cell: null pointer");
     SSM_REQUIRE(!h_hl8.ptr || ssm::aligned16(h_hl8.ptr), "convlstm_cell: HL8 output must be 16-byte aligned");
     hipLaunchKernelGGL(convlstm_cell_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, c_prev,
-                       c_next, h_f32, h_hl8, Hc, H, W);
+                       c_next, h_f32, h_hl8, Hc, H, W, q8);
     return ssm::check_launch("ssm_convlstm_cell_fwd");
 }
 
 extern "C" int ssm_convgru_reset_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view h_prev, ssm_view rh_f32, ssm_hview rh_hl8, int B,
-                                     int Hc, int H, int W, void *stream) {
+                                     int Hc, int H, int W, int flags, void *stream) {
+    const int q8 = (flags & SSM_FLAG_Q8) ? 1 : 0;
+    SSM_REQUIRE(!q8 || Hc % 16 == 0, "convgru_reset: a Q8 output needs hidden channels in multiples of 16");
     SSM_CELL_DIMS("convgru_reset");
     SSM_REQUIRE(gates_x.ptr && gates_h.ptr && h_prev.ptr && (rh_f32.ptr || rh_hl8.ptr), "convgru_reset: null pointer");
     SSM_REQUIRE(!rh_hl8.ptr || ssm::aligned16(rh_hl8.ptr), "convgru_reset: HL8 output must be 16-byte aligned");
     hipLaunchKernelGGL(convgru_reset_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, h_prev,
-                       rh_f32, rh_hl8, Hc, H, W);
+                       rh_f32, rh_hl8, Hc, H, W, q8);
     return ssm::check_launch("ssm_convgru_reset_fwd");
 }
 
 extern "C" int ssm_convgru_update_fwd(ssm_view gates_x, ssm_view gates_h, ssm_view cand_x, ssm_view cand_h, ssm_view h_prev,
-                                      ssm_view h_f32, ssm_hview h_hl8, int B, int Hc, int H, int W, void *stream) {
+                                      ssm_view h_f32, ssm_hview h_hl8, int B, int Hc, int H, int W, int flags, void *stream) {
+    const int q8 = (flags & SSM_FLAG_Q8) ? 1 : 0;
+    SSM_REQUIRE(!q8 || Hc % 16 == 0, "convgru_update: a Q8 output needs hidden channels in multiples of 16");
     SSM_CELL_DIMS("convgru_update");
     SSM_REQUIRE(gates_x.ptr && cand_x.ptr && (h_f32.ptr || h_hl8.ptr), "convgru_update: null pointer");
     SSM_REQUIRE((gates_h.ptr != nullptr) == (h_prev.ptr != nullptr) && (cand_h.ptr != nullptr) == (h_prev.ptr != nullptr),
                 "convgru_update: hidden-state inputs must be all present or all absent (first step)");
     SSM_REQUIRE(!h_hl8.ptr || ssm::aligned16(h_hl8.ptr), "convgru_update: HL8 output must be 16-byte aligned");
     hipLaunchKernelGGL(convgru_update_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, cand_x,
-                       cand_h, h_prev, h_f32, h_hl8, Hc, H, W);
+                       cand_h, h_prev, h_f32, h_hl8, Hc, H, W, q8);
     return ssm::check_launch("ssm_convgru_update_fwd");
 }
 

@@ -24,7 +24,7 @@ class _LSTMCellFn(torch.autograd.Function):
         Hc = G4 // 4
         hn, cn = _z(B, Hc, h, w, device=gates.device), _z(B, Hc, h, w, device=gates.device)
         hb.check(hb.load().ssm_convlstm_cell_fwd(hb.view_of(gates), hb.NULL_VIEW, hb.view_of(cp) if cp is not None else hb.NULL_VIEW,
-                                                 hb.view_of(cn), hb.view_of(hn), hb.NULL_HVIEW, B, Hc, h, w, hb.stream_ptr()))
+                                                 hb.view_of(cn), hb.view_of(hn), hb.NULL_HVIEW, B, Hc, h, w, 0, hb.stream_ptr()))
         ctx.save_for_backward(gates, cp if cp is not None else gates.new_zeros(0))
         ctx.has_c = cp is not None
         return hn, cn
@@ -52,7 +52,7 @@ class _GRUResetFn(torch.autograd.Function):
         rh = _z(B, Hc, h, w, device=hp.device)
         zero = torch.zeros_like(gates)
         hb.check(hb.load().ssm_convgru_reset_fwd(hb.view_of(gates), hb.view_of(zero), hb.view_of(hp), hb.view_of(rh), hb.NULL_HVIEW,
-                                                 B, Hc, h, w, hb.stream_ptr()))
+                                                 B, Hc, h, w, 0, hb.stream_ptr()))
         ctx.save_for_backward(gates, hp)
         return rh
 
@@ -79,7 +79,7 @@ class _GRUUpdateFn(torch.autograd.Function):
         zg, zc = (torch.zeros_like(gates), torch.zeros_like(cand)) if hp is not None else (None, None)
         hb.check(hb.load().ssm_convgru_update_fwd(hb.view_of(gates), hb.view_of(zg) if hp is not None else nv, hb.view_of(cand),
                                                   hb.view_of(zc) if hp is not None else nv, hb.view_of(hp) if hp is not None else nv,
-                                                  hb.view_of(hn), hb.NULL_HVIEW, B, Hc, h, w, hb.stream_ptr()))
+                                                  hb.view_of(hn), hb.NULL_HVIEW, B, Hc, h, w, 0, hb.stream_ptr()))
         ctx.save_for_backward(gates, cand, hp if hp is not None else gates.new_zeros(0))
         ctx.has_h = hp is not None
         return hn

@@ -152,8 +152,6 @@ class FullModel(nn.Module):
 
     def window_engine_for(self, T, S1, S2, H, W, device, decode_all=False):
         mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)
-        if mode == "f16f8":          # the recurrent cells write the HL8 lo planes: this plan runs the f16x3 kernels
-            mode = "f16x3"
         key = ("win", T, S1, S2, H, W, str(device), mode, decode_all, self._stamp())
         if self._engine is None or self._engine[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}

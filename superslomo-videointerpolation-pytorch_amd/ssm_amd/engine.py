@@ -94,7 +94,7 @@ class UNetPlan:
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.fuse_up = bool(fuse_upsample) and self.hl8      # concat+upsample fused into the consumer conv's loader
         if self.q8:
-            assert self.fuse_up and bottleneck == "CONV", "mode f16f8 covers the fused plan with the CONV bottleneck"
+            assert self.fuse_up, "mode f16f8 covers the plan with the concat+upsample fused into the convolutions"
         if H % 32 or W % 32:
             raise AssertionError("H and W must be multiples of 32 (got %dx%d): the U-Net pools 5 times "
                                  "and concatenates skips (unchecked in the reference, fails in torch.cat)" % (H, W))
@@ -308,12 +308,14 @@ class RecurrentBottleneck:
         assert kind in ("CLSTM", "CGRU")
         self.kind, self.S, self.T, self.h, self.w, self.device = kind, S, T, h, w, device
         self.mode, self.hl8, self.prefix = mode, mode != "f32", prefix
+        self.q8 = mode == "f16f8"
+        self.flags = hb.SSM_FLAG_Q8 if self.q8 else 0
         self.hid = RECURRENT_HIDDEN
         self.ng = 4 * self.hid if kind == "CLSTM" else 2 * self.hid
         self.pk = {}
         self.refresh_weights(state_dict)
         P32 = lambda B, C: hb.Planes(B, C, h, w, device)  # noqa: E731
-        X = (lambda B, C: hb.HPlanes(B, C, h, w, device)) if self.hl8 else P32  # noqa: E731
+        X = (lambda B, C: hb.HPlanes(B, C, h, w, device, q8=self.q8)) if self.hl8 else P32  # noqa: E731
         self.gx, self.gh = P32(T * S, self.ng), P32(S, self.ng)
         self.seq0 = X(T * S, self.hid)                     # layer-0 output sequence (input of layer 1)
         if kind == "CLSTM":
@@ -324,7 +326,7 @@ class RecurrentBottleneck:
 
     def _pack(self, w, b, batch):
         if self.hl8:
-            return hb.PackedConv16(w.contiguous(), b, self.w)
+            return hb.PackedConv16(w.contiguous(), b, self.w, q8=self.q8)
         return hb.PackedConv(w.contiguous(), b, batch, self.h, self.w)
 
     def refresh_weights(self, state_dict):
@@ -374,7 +376,7 @@ class RecurrentBottleneck:
                 if self.kind == "CLSTM":
                     hb.check(lib.ssm_convlstm_cell_fwd(self.gx.view(b0=k * S), self.gh.view() if prev is not None else nv,
                                                        self.c[(i + 1) % 2].view() if prev is not None else nv,
-                                                       self.c[i % 2].view(), h32, h16, S, hid, self.h, self.w, st))
+                                                       self.c[i % 2].view(), h32, h16, S, hid, self.h, self.w, self.flags, st))
                 else:
                     state = self.h32 if self.hl8 else dst        # fp32 state tensor and the channel it starts at
                     sch = 0 if self.hl8 else ch
@@ -384,13 +386,13 @@ class RecurrentBottleneck:
                         hp = state.view(sch, b0=prev * S)
                         r16, r32 = (self.rh.view(), nv) if self.hl8 else (nh, self.rh.view())
                         hb.check(lib.ssm_convgru_reset_fwd(self.gx.view(b0=k * S), self.gh.view(), hp, r32, r16, S, hid,
-                                                           self.h, self.w, st))
+                                                           self.h, self.w, self.flags, st))
                         self._conv(self.pk[cell + "conv_can", "h"], self.rh.view(), hid, self.ch.view(), S)
                         hb.check(lib.ssm_convgru_update_fwd(self.gx.view(b0=k * S), self.gh.view(), self.cx.view(b0=k * S),
-                                                            self.ch.view(), hp, h32, h16, S, hid, self.h, self.w, st))
+                                                            self.ch.view(), hp, h32, h16, S, hid, self.h, self.w, self.flags, st))
                     else:
                         hb.check(lib.ssm_convgru_update_fwd(self.gx.view(b0=k * S), nv, self.cx.view(b0=k * S), nv, nv,
-                                                            h32, h16, S, hid, self.h, self.w, st))
+                                                            h32, h16, S, hid, self.h, self.w, self.flags, st))
                 prev = k
 
     def run(self, x_fwd, out, x_rev=None):
@@ -503,12 +505,12 @@ class WindowEngine:
     work).  Either S2 == S1 (FullModel.forward: one t per clip and window) or S1 == 1 and S2 = number of
     intermediate times of that clip (stage 1 hoisted out of the t loop; its tensors are batch-broadcast)."""
 
-    def __init__(self, sd1, sd2, T, S1, S2, H, W, device, cross_skip=True, mode="f16x3", bottleneck="CLSTM",
+    def __init__(self, sd1, sd2, T, S1, S2, H, W, device, cross_skip=True, mode="f16f8", bottleneck="CLSTM",
                  decode_all=False):
         assert S2 == S1 or S1 == 1, "stage-2 sequences must equal stage-1 clips, or there must be one clip"
         self.T, self.S1, self.S2, self.H, self.W, self.device = T, S1, S2, H, W, device
         self.mid = T // 2
-        self.cross, self.mode, self.hl8 = bool(cross_skip), mode, mode != "f32"
+        self.cross, self.mode, self.hl8, self.q8 = bool(cross_skip), mode, mode != "f32", mode == "f16f8"
         self.bcast = S1 == 1 and S2 > 1
         self.decode_all = decode_all
         b1, b2 = bottleneck if isinstance(bottleneck, (tuple, list)) else (bottleneck, bottleneck)
@@ -552,8 +554,9 @@ class WindowEngine:
         for k in range(T):
             fv = flow4.view(broadcast=self.bcast, b0=k * S1)
             if self.hl8:
-                hb.check(lib.ssm_flowinterp_inputs_hl8_fwd(self._img6_view(k), fv, tptr + 4 * k * S2, in16.view(b0=k * S2),
-                                                           hb.view_of(self.est[k * S2:]), S2, self.H, self.W, st))
+                fn = lib.ssm_flowinterp_inputs_hq8_fwd if self.q8 else lib.ssm_flowinterp_inputs_hl8_fwd
+                hb.check(fn(self._img6_view(k), fv, tptr + 4 * k * S2, in16.view(b0=k * S2),
+                            hb.view_of(self.est[k * S2:]), S2, self.H, self.W, st))
             else:
                 hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(k), fv, tptr + 4 * k * S2, in16.view(b0=k * S2),
                                                        S2, self.H, self.W, st))

@@ -85,10 +85,10 @@ SIGNATURES = {
     "ssm_sqdiff_grad": (_c_int, [SsmView, SsmView, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_flowinterp_inputs_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int,
                                            _vp]),
-    "ssm_convlstm_cell_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _vp]),
-    "ssm_convgru_reset_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_convlstm_cell_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_convgru_reset_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_convgru_update_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int,
-                                        _c_int, _vp]),
+                                        _c_int, _c_int, _vp]),
     "ssm_convlstm_cell_bwd": (_c_int, [SsmView] * 7 + [_c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_convgru_reset_bwd": (_c_int, [SsmView] * 5 + [_c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_convgru_update_bwd": (_c_int, [SsmView] * 7 + [_c_int, _c_int, _c_int, _c_int, _vp]),
