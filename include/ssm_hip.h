@@ -224,6 +224,10 @@ int ssm_warp_bilinear_bwd(ssm_view img, ssm_view flow, ssm_view dy, ssm_view dfl
                           void *stream);
 int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, int B, int C, int H, int W, float slope, int has_act,
                   void *stream);
+/* ssm_lrelu_bwd that also writes dZ in the Q8 operand form (dz_q8: an even number of channel groups >= ceil(C/8), zero-initialised
+ * beyond C) - the input of the data-gradient convolution when the training step runs the fp16 + fp8 kernels.               */
+int ssm_lrelu_bwd_q8(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, ssm_hview dz_q8, int B, int C, int H, int W, float slope,
+                     int has_act, void *stream);
 int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream);
 int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
                      int ci_offset, int zero_first, void *stream);

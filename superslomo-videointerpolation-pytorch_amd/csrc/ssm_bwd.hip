@@ -46,6 +46,45 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(ssm_view dy, ssm_view dp
     }
 }
 
+// lrelu_bwd that ALSO writes dZ in the Q8 operand form (include/ssm_hip.h) for the data-gradient convolution on the fp16 + fp8
+// matrix path; a thread's 4 channels are half of an 8-channel group.
+typedef _Float16 bh4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int bwd_pack4_fp8(float a, float b, float c, float d) {
+    const float lim = 448.0f;
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -lim, lim), __builtin_amdgcn_fmed3f(b, -lim, lim), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -lim, lim), __builtin_amdgcn_fmed3f(d, -lim, lim), w, true);
+}
+
+__global__ __launch_bounds__(256) void lrelu_bwd_q8_kernel(ssm_view dy, ssm_view dpool, ssm_view yv, ssm_view dz, ssm_hview dq, int C,
+                                                           int H, int W, float slope, int has_act, int cgroups) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / cgroups, cg = blockIdx.z - b * cgroups;
+    if (x >= W || y >= H) return;
+    float v[BWD_CPT];
+#pragma unroll
+    for (int i = 0; i < BWD_CPT; ++i) {
+        const int c = cg * BWD_CPT + i;
+        float g = 0.f;
+        if (c < C) {
+            g = dy.ptr ? vp(dy, b, c, y)[x] : 0.f;
+            if (dpool.ptr) g += 0.25f * vp(dpool, b, c, y >> 1)[x >> 1];
+            if (has_act) g *= (vp(yv, b, c, y)[x] > 0.f) ? 1.0f : slope;
+            vp(dz, b, c, y)[x] = g;
+        }
+        v[i] = g;
+    }
+    const int grp = cg >> 1, half = cg & 1, odd = grp & 1;
+    char *rec = (char *)dq.ptr + ((long long)b * dq.sb + (long long)grp * dq.sg + (long long)y * dq.sh + x) * 16;
+    bh4 hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hi[i] = (_Float16)v[i];
+    *reinterpret_cast<bh4 *>(rec + half * 8) = hi;
+    char *even_rec = rec - odd * dq.sg * 16 + dq.sp * 16;
+    *reinterpret_cast<int *>(even_rec + odd * 8 + half * 4) = bwd_pack4_fp8(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<int *>(even_rec + dq.sg * 16 + odd * 8 + half * 4) =
+        bwd_pack4_fp8((v[0] - (float)hi[0]) * 2048.f, (v[1] - (float)hi[1]) * 2048.f, (v[2] - (float)hi[2]) * 2048.f, (v[3] - (float)hi[3]) * 2048.f);
+}
+
 __global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__restrict__ db, int B, int H, int W) {
     const int c = blockIdx.x;
     float s = 0.f;
@@ -491,6 +530,18 @@ extern "C" int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view d
     hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y,
                        dz, C, H, W, slope, has_act, cgroups);
     return ssm::check_launch("ssm_lrelu_bwd");
+}
+
+extern "C" int ssm_lrelu_bwd_q8(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, ssm_hview dz_q8, int B, int C, int H, int W, float slope,
+                                int has_act, void *stream) {
+    SSM_CHECK_DIMS("lrelu_bwd_q8");
+    SSM_REQUIRE(dz.ptr && dz_q8.ptr && (dy.ptr || dpool.ptr) && (!has_act || y.ptr) && C > 0, "lrelu_bwd_q8: null pointer / C");
+    SSM_REQUIRE(ssm::aligned16(dz_q8.ptr), "lrelu_bwd_q8: the Q8 view must be 16-byte aligned");
+    const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "lrelu_bwd_q8: B*C too large for one launch");
+    hipLaunchKernelGGL(lrelu_bwd_q8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y,
+                       dz, dz_q8, C, H, W, slope, has_act, cgroups);
+    return ssm::check_launch("ssm_lrelu_bwd_q8");
 }
 
 extern "C" int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream) {

@@ -949,50 +949,60 @@ __global__ void pack16_kernel(const float *__restrict__ w, const float *__restri
 // Q8 filter packing: per (cout block, 16-channel chunk, stage of KYS filter rows) one LDS image of the stage:
 //   [tap][h][BN][8] fp16(w*scale)   then   [row][quad][operand][piece][half][BN][16] fp8, where lane half `half` of quad j covers
 //   taps kx = 4j + 2*half + piece (zero bytes beyond the row), byte = group*8 + e, operand 0 = fp8(w*scale), 1 = fp8(lo*2^11).
-__global__ void pack16q_main_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int Cout, int Cin, int CinP, int KS, int KYS,
-                                    int BN, float scale, long long stage_halves, long long total) {
+// One thread = one filter row of one (cout, 16-channel chunk): it reads the chunk's 16 x KS weights of the row (the 16 x KS^2 block of
+// a cout is contiguous in OIHW, so the KS threads of a block of rows use every byte of the cache lines they touch) and emits the
+// row's fp16 and fp8 pieces.
+template <int KS>
+__global__ void pack16q_kernel(const float *__restrict__ w, char *__restrict__ wp, int Cout, int Cin, int CinP, int KYS, int BN, float scale,
+                               long long stage_bytes, long long qbase, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    long long r = i;
-    const int e = (int)(r % 8); r /= 8;
-    const int n = (int)(r % BN); r /= BN;
-    const int h = (int)(r % 2); r /= 2;
-    const int tl = (int)(r % (KYS * KS)); r /= (KYS * KS);
-    const int j = (int)(r % (KS / KYS)); r /= (KS / KYS);
-    const int ch = (int)(r % (CinP / 16));
-    const int nb = (int)(r / (CinP / 16));
-    const long long stage = ((long long)nb * (CinP / 16) + ch) * (KS / KYS) + j;
-    const int co = nb * BN + n, ci = ch * 16 + h * 8 + e;
-    const int ky = j * KYS + tl / KS, kx = tl % KS;
-    float v = 0.f;
-    if (co < Cout && ci < Cin) v = w[(((long long)co * Cin + ci) * KS + ky) * KS + kx] * scale;
-    wp[stage * stage_halves + ((long long)(tl * 2 + h) * BN + n) * 8 + e] = (_Float16)v;
-}
-
-__global__ void pack16q_q_kernel(const float *__restrict__ w, unsigned char *__restrict__ wp, int Cout, int Cin, int CinP, int KS, int KYS,
-                                 int BN, float scale, long long stage_bytes, long long qbase, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int NQ = (KS + 3) / 4;
-    long long r = i;
-    const int byte = (int)(r % 16); r /= 16;
-    const int n = (int)(r % BN); r /= BN;
-    const int half = (int)(r % 2); r /= 2;
-    const int pc = (int)(r % 2); r /= 2;
-    const int op = (int)(r % 2); r /= 2;
-    const int q = (int)(r % NQ); r /= NQ;
-    const int ry = (int)(r % KYS); r /= KYS;
-    const int j = (int)(r % (KS / KYS)); r /= (KS / KYS);
-    const int ch = (int)(r % (CinP / 16));
-    const int nb = (int)(r / (CinP / 16));
-    const long long stage = ((long long)nb * (CinP / 16) + ch) * (KS / KYS) + j;
-    const int co = nb * BN + n, ci = ch * 16 + byte;          // byte = group*8 + e = channel inside the chunk
-    const int ky = j * KYS + ry, kx = 4 * q + 2 * half + pc;
-    float v = 0.f;
-    if (co < Cout && ci < Cin && kx < KS) v = w[(((long long)co * Cin + ci) * KS + ky) * KS + kx] * scale;
-    const float lo = (v - (float)(_Float16)v) * 2048.0f;
-    const int word = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(op ? lo : v), 0.f, 0, false);
-    wp[stage * stage_bytes + qbase + ((((((long long)(ry * NQ + q) * 2 + op) * 2 + pc) * 2 + half) * BN + n) * 16) + byte] = (unsigned char)(word & 0xff);
+    constexpr int NQ = (KS + 3) / 4;
+    const int ky = (int)(i % KS);
+    const int n = (int)((i / KS) % BN);
+    const int ch = (int)((i / KS / BN) % (CinP / 16));
+    const int nb = (int)(i / KS / BN / (CinP / 16));
+    const int co = nb * BN + n;
+    {
+        const int j = ky / KYS, ry = ky - j * KYS;
+        char *st = wp + (((long long)nb * (CinP / 16) + ch) * (KS / KYS) + j) * stage_bytes;
+        float v[16][KS];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = ch * 16 + e;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx)
+                v[e][kx] = (co < Cout && ci < Cin) ? w[(((long long)co * Cin + ci) * KS + ky) * KS + kx] * scale : 0.f;
+        }
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                h8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (_Float16)v[h * 8 + e][kx];
+                *reinterpret_cast<h8 *>(st + ((long long)((ry * KS + kx) * 2 + h) * BN + n) * 16) = hv;
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int op = 0; op < 2; ++op)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int kx = 4 * q + 2 * half + pc;
+                        float x[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float t = kx < KS ? v[e][kx < KS ? kx : 0] : 0.f;
+                            x[e] = op ? (t - (float)(_Float16)t) * 2048.0f : t;
+                        }
+                        const i32x4 word = {pack4_fp8(x[0], x[1], x[2], x[3]), pack4_fp8(x[4], x[5], x[6], x[7]),
+                                            pack4_fp8(x[8], x[9], x[10], x[11]), pack4_fp8(x[12], x[13], x[14], x[15])};
+                        *reinterpret_cast<i32x4 *>(st + qbase + ((((((long long)(ry * NQ + q) * 2 + op) * 2 + pc) * 2 + half) * BN + n) * 16)) = word;
+                    }
+    }
 }
 
 // fp32 view [B,C,H,W] -> Q8 form of the HL8 geometry, and back (x ~= hi + fp8_lo * 2^-11)
@@ -1137,11 +1147,15 @@ extern "C" int ssm_pack16q_weights(const float *w, const float *bias, void *wp, 
     const long long stages = (long long)((Cout + BN - 1) / BN) * (CinP / 16) * (k / KYS);
     const long long sb = q8_stage_bytes(k, KYS, BN);
     const long long qbase = (long long)KYS * k * 2 * BN * 16;
-    const long long nmain = stages * (qbase / 2), nq = stages * (sb - qbase);
-    hipLaunchKernelGGL(pack16q_main_kernel, dim3((unsigned)((nmain + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (_Float16 *)wp,
-                       Cout, Cin, CinP, k, KYS, BN, scale, sb / 2, nmain);
-    hipLaunchKernelGGL(pack16q_q_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (unsigned char *)wp, Cout,
-                       Cin, CinP, k, KYS, BN, scale, sb, qbase, nq);
+    const long long total = (long long)((Cout + BN - 1) / BN) * (CinP / 16) * BN * k;
+    const dim3 grid((unsigned)((total + 63) / 64));
+    (void)stages;
+    switch (k) {
+        case 3: hipLaunchKernelGGL(pack16q_kernel<3>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
+        case 5: hipLaunchKernelGGL(pack16q_kernel<5>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
+        case 7: hipLaunchKernelGGL(pack16q_kernel<7>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
+        default: ssm::set_error("pack16q: kernel size %d unsupported", k); return SSM_E_UNSUPPORTED;
+    }
     const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
     hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((nbias + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, (_Float16 *)nullptr, bp,
                        Cout, Cin, CinP, k, KYS, BN, scale, 0LL, nbias);

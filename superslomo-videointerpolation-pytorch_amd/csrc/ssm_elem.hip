@@ -136,9 +136,12 @@ __global__ __launch_bounds__(256) void copy_view_kernel(ssm_view src, ssm_view d
 }
 
 // layers.avg_pool(2): scripts/models/layers.py:60-63.  H, W here are the OUTPUT dims.
-__global__ __launch_bounds__(256) void avgpool2_kernel(ssm_view xin, ssm_view yout, int C, int H, int W) {
-    SSM_PIXEL_INDEX();
-    for (int c = 0; c < C; ++c) {
+// channels are spread over blockIdx.z in groups of 4 so small maps with many channels still fill the chip
+__global__ __launch_bounds__(256) void avgpool2_kernel(ssm_view xin, ssm_view yout, int C, int H, int W, int cgroups) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / cgroups, c0 = (blockIdx.z - b * cgroups) * 4;
+    if (x >= W || y >= H) return;
+    for (int c = c0; c < c0 + 4 && c < C; ++c) {
         const float *r0 = vp(xin, b, c, 2 * y), *r1 = vp(xin, b, c, 2 * y + 1);
         const float2 a = *reinterpret_cast<const float2 *>(r0 + 2 * x);
         const float2 d = *reinterpret_cast<const float2 *>(r1 + 2 * x);
@@ -414,7 +417,9 @@ extern "C" int ssm_avgpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int
     SSM_REQUIRE(x.ptr && y.ptr && C > 0, "avgpool2: null pointer / C");
     SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "avgpool2: H and W must be even (got %dx%d)", H, W);
     SSM_REQUIRE(even_view(x), "avgpool2: input view must be 8-byte aligned with even strides");
-    hipLaunchKernelGGL(avgpool2_kernel, pix_grid(B, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, y, C, H / 2, W / 2);
+    const int cgroups = (C + 3) / 4;
+    SSM_REQUIRE((long long)B * cgroups <= 65535, "avgpool2: B*C too large for one launch");
+    hipLaunchKernelGGL(avgpool2_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, y, C, H / 2, W / 2, cgroups);
     return ssm::check_launch("ssm_avgpool2_fwd");
 }
 

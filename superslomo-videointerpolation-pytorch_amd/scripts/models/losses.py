@@ -58,11 +58,12 @@ class SSMLosses(nn.Module):
         """The HIP VGG16 plan for this batch geometry (None without weights)."""
         if self._vgg_sd is None:
             return None
-        key = (B, H, W, str(device))
+        mode = os.environ.get("SSM_TRAIN_PRECISION", "f16f8")
+        key = (B, H, W, str(device), mode)
         if self._pterm is None or self._pterm[0] != key:
             from ssm_amd.perceptual import PerceptualTerm
             self.__dict__["_pterm"] = None
-            self.__dict__["_pterm"] = (key, PerceptualTerm(self._vgg_sd, B, H, W, device))
+            self.__dict__["_pterm"] = (key, PerceptualTerm(self._vgg_sd, B, H, W, device, mode))
         return self._pterm[1]
 
     def read_loss_weights(self, cfg):

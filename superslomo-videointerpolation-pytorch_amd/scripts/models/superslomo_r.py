@@ -207,15 +207,24 @@ class FullModel(nn.Module):
         return outs
 
     # ---- training step ------------------------------------------------------------------------------------------
+    train_precision = None      # "f16f8" (default; $SSM_TRAIN_PRECISION) | "f32"
+
     def _train_engine(self, B, H, W, device):
-        """fp32 plan with materialised upsample tensors (what the hand-written backward walks) + its PairGrad."""
+        """The training plan + its PairGrad.  f16f8: the inference plan (fused upsample, fp16 + fp8 matrix path) writing fp32
+        twins of every conv output for the backward, data gradients on the same kernels; f32: exact-fp32 MFMA plan with
+        materialised upsample tensors."""
         from ssm_amd.backward import PairGrad
-        key = (B, H, W, str(device))
+        mode = self.train_precision or os.environ.get("SSM_TRAIN_PRECISION", "f16f8")
+        assert mode in ("f16f8", "f32"), "training precision must be f16f8 or f32"
+        key = (B, H, W, str(device), mode)
         if getattr(self, "_train", None) is None or self._train[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
             sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
             self._train = None
-            eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, "f32", fuse_upsample=False)
+            if mode == "f32":
+                eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, "f32", fuse_upsample=False)
+            else:
+                eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, "f16f8", fuse_upsample=True, twins=True)
             self._train = (key, eng, PairGrad(eng))
         return self._train[1], self._train[2]
 

@@ -70,17 +70,51 @@ _UP_SOURCES = {"u7": ("c6", None), "u8": ("c7", "c5"), "u9": ("c8", "c4"), "u10"
 
 
 class UNetGrad:
+    """Two forward plans are supported: the fp32 plan with materialised upsample tensors (every activation is an fp32 plane),
+    and the Q8 plan (mode f16f8, fused upsample) with fp32 twins: there the data gradients run on the fp16 + fp8 convolution
+    kernel (dZ is written in the Q8 form by ssm_lrelu_bwd_q8), the weight gradients read the fp32 twins, and the pooled / upsampled
+    operands the fused forward never materialised are recomputed in fp32 by `prepare`."""
+
     def __init__(self, plan):
-        assert not plan.hl8 and not plan.fuse_up, "the backward runs on the fp32 plan with materialised upsample tensors"
         self.plan = plan
+        self.hl8 = plan.hl8
+        if self.hl8:
+            assert plan.q8 and plan.twins, "the backward over an HL8 plan needs mode f16f8 with fp32 twins"
+        else:
+            assert not plan.fuse_up, "the fp32 plan must materialise the upsample tensors for the backward"
         self.B, self.dev = plan.B, plan.device
-        self.g, self.dz, self.pk_t, self.grads = {}, {}, {}, {}
+        self.g, self.dz, self.dzq, self.pk_t, self.grads, self.tw = {}, {}, {}, {}, {}, {}
         self.io = {n: (srcs, dst) for n, srcs, dst in _CONV_IO}
+
+    def act(self, name):
+        """fp32 planes of a forward activation."""
+        if not self.hl8:
+            return self.plan.t[name]
+        return self.plan.f32[name] if name in self.plan.f32 else self.tw[name]
+
+    def prepare(self, cross=None):
+        """Q8 plan: recompute in fp32 the pooled and the concatenated+upsampled conv inputs (weight-gradient operands)."""
+        if not self.hl8:
+            return
+        lib, st, f32 = hb.load(), hb.stream_ptr(), self.plan.f32
+        for conv, pname in _POOL_OF.items():
+            src = f32[self.io[conv][1]]
+            if pname not in self.tw:
+                self.tw[pname] = hb.Planes(self.B, src.C, src.H // 2, src.W // 2, self.dev)
+            hb.check(lib.ssm_avgpool2_fwd(src.view(), self.tw[pname].view(), self.B, src.C, src.H, src.W, st))
+        for uname, (a, b) in _UP_SOURCES.items():
+            A = f32[a]
+            Bp = cross if (uname == "u7" and self.plan.cross) else (f32[b] if b else None)
+            cb = Bp.C if Bp is not None else 0
+            if uname not in self.tw:
+                self.tw[uname] = hb.Planes(self.B, A.C + cb, 2 * A.H, 2 * A.W, self.dev)
+            hb.check(lib.ssm_upsample2x_cat_fwd(A.view(), A.C, Bp.view() if Bp is not None else hb.NULL_VIEW, cb,
+                                                self.tw[uname].view(), self.B, A.H, A.W, st))
 
     def _G(self, name, like=None, C=None):
         """Gradient buffer with the geometry of activation `like` (default: same name)."""
         if name not in self.g:
-            ref = self.plan.t[like or name]
+            ref = self.act(like or name) if (like or name) != "out" else self.plan.t["out"]
             self.g[name] = hb.Planes(self.B, C or ref.C, ref.H, ref.W, self.dev)
         return self.g[name]
 
@@ -91,22 +125,33 @@ class UNetGrad:
                 continue
             s = layer_scale(name)
             w = state_dict[param_key(name, "weight")].to(device=self.dev, dtype=torch.float32)
-            self.pk_t[name] = hb.PackedConv(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B,
-                                            self.plan.H // s, self.plan.W // s)
+            if self.hl8:
+                self.pk_t[name] = hb.PackedConv16(transposed_filter(w), torch.zeros(ci, device=self.dev), self.plan.W // s, q8=True,
+                                                  scale=self.plan.scales[name])
+            else:
+                self.pk_t[name] = hb.PackedConv(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B,
+                                                self.plan.H // s, self.plan.W // s)
 
     def _layer(self, name, dy, dpool, dx, need_wgrad, act=True):
         """One convolution: dZ, parameter gradients, data gradient into `dx` (None: not needed)."""
         plan = self.plan
         srcs, dst = self.io[name]
         ci, co, k = plan.layers[name]
-        Y = plan.t[dst]
+        Y = self.act(dst) if dst != "out" else plan.t["out"]
         pk = self.pk_t.get(name)
         cpad = pk.cin_p if pk is not None else co
         if name not in self.dz:
             self.dz[name] = hb.Planes(self.B, cpad, Y.H, Y.W, self.dev)
         dzp = self.dz[name]
         dz = dzp.slice(0, co)
-        lrelu_bwd(dy, dpool, Y, dz, has_act=act)
+        if self.hl8 and dx is not None:          # dZ also in the Q8 form: operand of the data-gradient convolution
+            if name not in self.dzq:
+                self.dzq[name] = hb.HPlanes(self.B, cpad, Y.H, Y.W, self.dev, q8=True)
+            hb.check(hb.load().ssm_lrelu_bwd_q8(dy.view() if dy is not None else hb.NULL_VIEW,
+                                                dpool.view() if dpool is not None else hb.NULL_VIEW, Y.view(), dz.view(),
+                                                self.dzq[name].view(), self.B, co, Y.H, Y.W, 0.1, 1 if act else 0, hb.stream_ptr()))
+        else:
+            lrelu_bwd(dy, dpool, Y, dz, has_act=act)
         from .engine import UNetPlan
         tm = UNetPlan.timer
         flops = 2.0 * self.B * Y.H * Y.W * co * ci * k * k
@@ -120,7 +165,7 @@ class UNetGrad:
                 self.grads[bk] = torch.empty(co, dtype=torch.float32, device=self.dev)
             off = 0
             for sname in srcs:
-                X = plan.t[sname]
+                X = self.act(sname)
                 wgrad(X, dz, self.grads[wk], k, ci_offset=off, zero_first=(off == 0))
                 off += X.C
             assert off == ci, "%s: inputs cover %d of %d channels" % (name, off, ci)
@@ -131,7 +176,10 @@ class UNetGrad:
             if tm is not None:
                 e0, e1 = tm.span("dgrad", "s%d.%s" % (plan.stage, name), flops)
                 e0.record()
-            hb.conv2d(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
+            if self.hl8:
+                hb.conv2d_hl8(self.dzq[name].view(), cpad, None, 0, pk, None, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
+            else:
+                hb.conv2d(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             if tm is not None:
                 e1.record()
 
@@ -188,7 +236,8 @@ class PairGrad:
     loss gradient -> synthesis adjoint -> stage-2 U-Net -> compute_inputs adjoint -> stage-1 U-Net."""
 
     def __init__(self, engine):
-        assert not engine.hl8 and engine.B1 == engine.B2, "training uses the fp32 plan with one t per sample"
+        assert engine.B1 == engine.B2, "training runs one t per sample"
+        assert not engine.hl8 or (engine.q8 and engine.twins), "an HL8 training engine must be mode f16f8 with fp32 twins"
         self.e = engine
         self.u1, self.u2 = UNetGrad(engine.s1), UNetGrad(engine.s2)
         B, H, W, dev = engine.B2, engine.H, engine.W, engine.device
@@ -212,8 +261,14 @@ class PairGrad:
         in16, out5, flow4 = e.s2.t["in"], e.s2.t["out"], e.s1.t["out"]
         need_s1 = train_s1
         self.u2.refresh(sd2, need_input_grad=need_s1)
+        self.u2.prepare(cross=e.s1.f32.get("c6") if e.hl8 else None)
         d_out5 = self.u2._G("out", C=self.u2.pk_t["final_conv"].cin_p)
-        hb.check(lib.ssm_synthesize_bwd(img6, in16.view(6), out5.view(), hb.view_of(target), e.t_dev.data_ptr(),
+        if e.hl8:       # the approximated flows live in their own fp32 tensor (the 16-channel input is Q8)
+            ev = hb.view_of(e.est)
+            est_view = ev
+        else:
+            est_view = in16.view(6)
+        hb.check(lib.ssm_synthesize_bwd(img6, est_view, out5.view(), hb.view_of(target), e.t_dev.data_ptr(),
                                         self.cr.data_ptr(), self.cw.data_ptr(), dy_extra if dy_extra is not None else hb.NULL_VIEW,
                                         d_out5.view(), hb.view_of(self.dest), B, H, W,
                                         1 if train_s2 else 0, st))
@@ -226,6 +281,7 @@ class PairGrad:
             grads.update({"stage2." + k: v for k, v in self.u2.grads.items()})
         if need_s1:
             self.u1.refresh(sd1, need_input_grad=False)
+            self.u1.prepare()
             d_flow4 = self.u1._G("out", C=self.u1.pk_t["final_conv"].cin_p)
             hb.check(lib.ssm_flowinterp_inputs_bwd(img6, flow4.view(), d_in16.view(), hb.view_of(self.dest), e.t_dev.data_ptr(),
                                                    self.cw.data_ptr(), d_flow4.view(), B, H, W, 1, st))

@@ -78,8 +78,11 @@ class UNetPlan:
     ENCODER_T = ("c1", "c2", "c3", "c4", "c5", "c6")      # encoder-batch tensors the decoder reads
     UPS = ("conv7a", "conv8a", "conv9a", "conv10a", "conv11a")      # convolutions with the concat+upsample fused in
 
+    CONV_OUT = ("t1a", "c1", "t2a", "c2", "t3a", "c3", "t4a", "c4", "t5a", "c5", "t6a", "c6", "t7a", "c7", "t8a", "c8", "t9a", "c9",
+                "t10a", "c10", "t11a", "c11", "tf")
+
     def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True,
-                 bottleneck="CONV", seq_len=1, dec=None):
+                 bottleneck="CONV", seq_len=1, dec=None, twins=False):
         """B = encoder batch.  With a recurrent bottleneck the batch holds `seq_len` windows of B/seq_len
         sequences in time-major order (index = window * S + sequence).  dec = (b0, Bd): the decoder runs on
         encoder batch entries [b0, b0+Bd) only (inference returns the middle window); None = all."""
@@ -87,6 +90,10 @@ class UNetPlan:
         assert bottleneck in ("CONV", "CLSTM", "CGRU"), "Unknown bottleneck type: %s" % bottleneck
         assert B % seq_len == 0
         self.bottleneck = bottleneck
+        # twins: every convolution also writes its output as fp32 planes (and the input is kept in fp32) - what the
+        # hand-written backward reads (LeakyReLU', weight-gradient operands) when the forward runs on the HL8 / Q8 kernels
+        self.twins = bool(twins) and mode != "f32"
+        self.scales = {}
         self.dec_b0, self.Bd = dec if dec is not None else (0, B)
         assert 0 <= self.dec_b0 and self.dec_b0 + self.Bd <= B
         self._b0 = 0            # batch offset applied to ENCODER_T views (set while the decoder runs)
@@ -135,6 +142,12 @@ class UNetPlan:
         t["t11a"], t["c11"] = D(32, 1), D(32, 1)
         t["tf"] = D(32, 1)
         t["out"] = hb.Planes(Bd, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
+        self.f32 = {}
+        if self.twins:
+            assert bottleneck == "CONV" and dec is None, "fp32 twins are for the training plan"
+            for name in self.CONV_OUT + ("in",):
+                ref = t[name]
+                self.f32[name] = hb.Planes(B, ref.C if name != "in" else cin0, ref.H, ref.W, device)
 
     def refresh_weights(self, state_dict, check_shapes=False):
         """(Re)pack every filter from `state_dict` (training: the parameters change each optimizer step)."""
@@ -145,7 +158,9 @@ class UNetPlan:
                 assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
             s = layer_scale(name)
             if self.hl8:
-                self.pk[name] = hb.PackedConv16(w, b, self.W // s, q8=self.q8, ups=self.fuse_up and name in self.UPS)
+                self.pk[name] = hb.PackedConv16(w, b, self.W // s, q8=self.q8, ups=self.fuse_up and name in self.UPS,
+                                                scale=self.scales.get(name))
+                self.scales.setdefault(name, self.pk[name].scale)      # later repacks (training) skip the host-side max|w|
             else:
                 nb = self.Bd if name in self.DECODER else self.B
                 self.pk[name] = hb.PackedConv(w, b, nb, self.H // s, self.W // s, pool=name in POOLED)
@@ -170,8 +185,9 @@ class UNetPlan:
         v = self._v
         if self.hl8:
             final = name == "final_conv"
+            y32 = v(dst) if final else (self.f32[dst].view() if self.twins else None)
             hb.conv2d_hl8(v(src), s.G * 8, v(src2) if src2 else None, c2, pk, None if final else v(dst),
-                          v(dst) if final else None, v(pool) if pool else None, self._Bcur, s.H, s.W,
+                          y32, v(pool) if pool else None, self._Bcur, s.H, s.W,
                           lrelu=lrelu, fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         else:
             hb.conv2d(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst),
@@ -201,7 +217,7 @@ class UNetPlan:
             e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * d.H * d.W * pk.cout * pk.cin * 9)
             e0.record()
         hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
-                          d.view(), None, self._Bcur, d.H, d.W, lrelu=True,
+                          d.view(), self.f32[dst].view() if self.twins else None, self._Bcur, d.H, d.W, lrelu=True,
                           fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         if tm is not None:
             e1.record()
@@ -409,14 +425,15 @@ class PairEngine:
     Either B2 == B1 (one t per sample: FullModel.forward) or B1 == 1 and B2 = number
     of intermediates of that pair (stage-1 tensors broadcast over the t batch)."""
 
-    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True):
+    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True, twins=False):
         assert B2 == B1 or B1 == 1, "stage-2 batch must equal stage-1 batch, or stage-1 batch must be 1"
+        self.twins = bool(twins) and mode != "f32"
         self.B1, self.B2, self.H, self.W, self.device = B1, B2, H, W, device
         self.cross = bool(cross_skip)
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.bcast = (B1 == 1 and B2 > 1)
-        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode, fuse_upsample)
-        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode, fuse_upsample)
+        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode, fuse_upsample, twins=twins)
+        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode, fuse_upsample, twins=twins)
         self.t_dev = torch.empty(B2, dtype=torch.float32, device=device)
         self.img = torch.empty(B2, 3, H, W, dtype=torch.float32, device=device)
         self.aux = torch.empty(B2, 5, H, W, dtype=torch.float32, device=device)
@@ -428,6 +445,8 @@ class PairEngine:
         assert tuple(img6.shape) == (self.B1, 6, self.H, self.W), "image pair tensor has shape %s" % (tuple(img6.shape),)
         self.img6 = img6.contiguous()
         self.s1.t["in"].load(self.img6)
+        if self.twins:
+            self.s1.f32["in"].load(self.img6)
 
     def run_stage1(self):
         return self.s1.run()
@@ -455,6 +474,9 @@ class PairEngine:
             fn = lib.ssm_flowinterp_inputs_hq8_fwd if self.q8 else lib.ssm_flowinterp_inputs_hl8_fwd
             hb.check(fn(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
                         in16.view(), hb.view_of(self.est), self.B2, self.H, self.W, st))
+            if self.twins:      # fp32 copy of the 16-channel stage-2 input for the weight gradient of conv1a
+                hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
+                                                       self.s2.f32["in"].view(), self.B2, self.H, self.W, st))
         else:
             hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
                                                    in16.view(), self.B2, self.H, self.W, st))

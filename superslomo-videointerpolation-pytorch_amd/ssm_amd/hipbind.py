@@ -75,6 +75,7 @@ SIGNATURES = {
                                       ctypes.POINTER(_c_float), _c_int, _vp]),
     "ssm_warp_bilinear_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_lrelu_bwd_q8": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_upsample2x_cat_bwd": (_c_int, [SsmView, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -278,8 +279,9 @@ class PackedConv16:
     """Filter split into fp16 hi/lo parts, scaled by a power of two so both parts sit in fp16's
     normal range, repacked for the fp16-MFMA kernel's tile configuration."""
 
-    def __init__(self, weight, bias, W, q8=False, ups=False):
-        """ups: the filter feeds ssm_conv2d_ups_hl8_fwd (W = its OUTPUT width); in Q8 form the packing follows that kernel's tile."""
+    def __init__(self, weight, bias, W, q8=False, ups=False, scale=None):
+        """ups: the filter feeds ssm_conv2d_ups_hl8_fwd (W = its OUTPUT width); in Q8 form the packing follows that kernel's tile.
+        scale: reuse a power-of-two pre-scale chosen earlier (training repacks every step; choosing it needs max|w| on the host)."""
         require_device(weight, "conv weight")
         self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
         self.q8 = bool(q8)
@@ -291,9 +293,11 @@ class PackedConv16:
             check((lib.ssm_conv16q_config if q8 else lib.ssm_conv16_config)(self.k, self.cout, W, ctypes.byref(bn), ctypes.byref(kys)))
         self.bn, self.kys = bn.value, kys.value
         self.cin_p = (self.cin + 15) // 16 * 16
-        wmax = float(weight.detach().abs().max())
-        import math
-        self.scale = 2.0 ** (3 - math.ceil(math.log2(wmax))) if wmax > 0 else 1.0     # max|w|*scale in (4, 8]
+        if scale is None:
+            wmax = float(weight.detach().abs().max())
+            import math
+            scale = 2.0 ** (3 - math.ceil(math.log2(wmax))) if wmax > 0 else 1.0     # max|w|*scale in (4, 8]
+        self.scale = float(scale)
         nb = lib.ssm_packed_bias_floats(self.cout, self.bn)
         self.b = torch.empty(nb, dtype=torch.float32, device=weight.device)
         wc, bc = weight.detach().contiguous(), bias.detach().contiguous()

@@ -39,16 +39,22 @@ class VGGFeatures:
 
     timer = None        # a ssm_amd.engine.KernelTimer, or None
 
-    def __init__(self, state_dict, B, H, W, device):
+    def __init__(self, state_dict, B, H, W, device, mode="f16f8"):
+        """mode f16f8: the convolutions run on the fp16 + fp8 matrix path (Q8 operands; the fp32 planes the ReLU mask, the max
+        pooling and the feature loss read are written by the same launches); mode f32: exact-fp32 MFMA kernels."""
         assert H % 8 == 0 and W % 8 == 0, "VGG16 conv4_3 pools three times: H, W must be multiples of 8"
+        assert mode in ("f16f8", "f32")
         self.B, self.H, self.W, self.device = B, H, W, device
+        self.q8 = mode == "f16f8"
         self.steps = []          # ("conv", idx, cin, cout, src, dst) | ("pool", src, dst)
-        self.t, self.pk, self.w = {}, {}, {}
+        self.t, self.pk, self.w, self.q = {}, {}, {}, {}        # q: Q8 twins of the conv inputs (mode f16f8)
         h, w, c, name = H, W, 3, "x"
         for item in VGG16_CONV4_3:
             if item == "M":
                 dst = "p%d" % len(self.steps)
                 self.t[dst] = hb.Planes(B, c, h // 2, w // 2, device)
+                if self.q8:
+                    self.q[dst] = hb.HPlanes(B, c, h // 2, w // 2, device, q8=True)
                 self.steps.append(("pool", name, dst))
                 h, w, name = h // 2, w // 2, dst
                 continue
@@ -57,11 +63,15 @@ class VGGFeatures:
             bs = state_dict["features.%d.bias" % idx].to(device=device, dtype=torch.float32)
             assert tuple(wt.shape) == (cout, cin, 3, 3), "features.%d.weight has shape %s" % (idx, tuple(wt.shape))
             self.w[idx] = wt
-            self.pk[idx] = hb.PackedConv(wt, bs, B, h, w)
+            self.pk[idx] = hb.PackedConv16(wt, bs, w, q8=True) if self.q8 else hb.PackedConv(wt, bs, B, h, w)
             if name == "x":
                 self.t["x"] = hb.Planes(B, self.pk[idx].cin_p, h, w, device)     # 3 channels padded to the conv's chunk
+                if self.q8:
+                    self.q["x"] = hb.HPlanes(B, 3, h, w, device, groups=self.pk[idx].cin_p // 8, q8=True)
             dst = "a%d" % idx
             self.t[dst] = hb.Planes(B, cout, h, w, device)
+            if self.q8:
+                self.q[dst] = hb.HPlanes(B, cout, h, w, device, q8=True)
             self.steps.append(("conv", idx, cin, cout, name, dst))
             c, name = cout, dst
         self.out = name
@@ -82,15 +92,24 @@ class VGGFeatures:
         lib, st = hb.load(), hb.stream_ptr()
         xs = x if x.stride(3) == 1 else x.contiguous()
         hb.check(lib.ssm_copy_view(hb.view_of(xs), self.t["x"].view(), self.B, 3, self.H, self.W, st))
+        if self.q8:
+            self.q["x"].load(xs)
         for s in self.steps:
             if s[0] == "pool":
                 src, dst = self.t[s[1]], self.t[s[2]]
                 hb.check(lib.ssm_maxpool2_fwd(src.view(), dst.view(), self.B, src.C, src.H, src.W, st))
+                if self.q8:          # the next convolution reads the pooled tensor in the Q8 form
+                    q = self.q[s[2]]
+                    hb.check(lib.ssm_hq8_from_f32(dst.view(), q.view(), self.B, dst.C, q.G, dst.H, dst.W, st))
                 continue
             _, idx, cin, cout, sname, dname = s
             src, dst, pk = self.t[sname], self.t[dname], self.pk[idx]
             e1 = self._span("vgg_fwd", "features.%d" % idx, 2.0 * self.B * src.H * src.W * cin * cout * 9)
-            hb.conv2d(src.view(), pk.cin_p, None, 0, pk, dst.view(), None, self.B, src.H, src.W, lrelu=True, slope=0.0)
+            if self.q8:
+                hb.conv2d_hl8(self.q[sname].view(), pk.cin_p, None, 0, pk, self.q[dname].view(), dst.view(), None, self.B, src.H, src.W,
+                              lrelu=True, slope=0.0)
+            else:
+                hb.conv2d(src.view(), pk.cin_p, None, 0, pk, dst.view(), None, self.B, src.H, src.W, lrelu=True, slope=0.0)
             if e1 is not None:
                 e1.record()
         return self.t[self.out]
@@ -117,17 +136,25 @@ class VGGFeatures:
             _, idx, cin, cout, sname, dname = s
             Y = self.t[dname]
             if idx not in self.pk_t:
-                self.pk_t[idx] = (nb, hb.PackedConv(transposed_filter(self.w[idx]), torch.zeros(cin, device=self.device), nb, Y.H, Y.W))
+                wt_t, zb = transposed_filter(self.w[idx]), torch.zeros(cin, device=self.device)
+                self.pk_t[idx] = (nb, hb.PackedConv16(wt_t, zb, Y.W, q8=True) if self.q8 else hb.PackedConv(wt_t, zb, nb, Y.H, Y.W))
             assert self.pk_t[idx][0] == nb, "input_grad was planned for %d batch entries" % self.pk_t[idx][0]
             pk = self.pk_t[idx][1]
             key = "dz%d" % idx
             if key not in self.g:
                 self.g[key] = hb.Planes(self.B, pk.cin_p, Y.H, Y.W, self.device)
+                if self.q8:
+                    self.g[key + "q"] = hb.HPlanes(self.B, pk.cin_p, Y.H, Y.W, self.device, q8=True)
             dzp = self.g[key]
-            hb.check(lib.ssm_lrelu_bwd(dy.view(), hb.NULL_VIEW, Y.view(), dzp.view(), nb, cout, Y.H, Y.W, 0.0, 1, st))
             dx = self._G(sname, C=cin)
             e1 = self._span("vgg_bwd", "features.%d" % idx, 2.0 * nb * Y.H * Y.W * cin * cout * 9)
-            hb.conv2d(dzp.view(), pk.cin_p, None, 0, pk, dx.view(), None, nb, Y.H, Y.W, lrelu=False)
+            if self.q8:
+                dzq = self.g[key + "q"]
+                hb.check(lib.ssm_lrelu_bwd_q8(dy.view(), hb.NULL_VIEW, Y.view(), dzp.view(), dzq.view(), nb, cout, Y.H, Y.W, 0.0, 1, st))
+                hb.conv2d_hl8(dzq.view(), pk.cin_p, None, 0, pk, None, dx.view(), None, nb, Y.H, Y.W, lrelu=False)
+            else:
+                hb.check(lib.ssm_lrelu_bwd(dy.view(), hb.NULL_VIEW, Y.view(), dzp.view(), nb, cout, Y.H, Y.W, 0.0, 1, st))
+                hb.conv2d(dzp.view(), pk.cin_p, None, 0, pk, dx.view(), None, nb, Y.H, Y.W, lrelu=False)
             if e1 is not None:
                 e1.record()
             dy = dx
@@ -139,9 +166,9 @@ class PerceptualTerm:
     MSELoss(reduce=False), then the per-sample mean).  pred and target go through ONE VGG pass as a batch of 2B;
     the backward walks the first B entries only."""
 
-    def __init__(self, vgg_state_dict, B, H, W, device):
+    def __init__(self, vgg_state_dict, B, H, W, device, mode="f16f8"):
         self.B = B
-        self.vgg = VGGFeatures(vgg_state_dict, 2 * B, H, W, device)
+        self.vgg = VGGFeatures(vgg_state_dict, 2 * B, H, W, device, mode)
         self.coef = torch.empty(B, dtype=torch.float32, device=device)
         self.both = torch.empty(2 * B, 3, H, W, dtype=torch.float32, device=device)
 

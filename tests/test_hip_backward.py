@@ -156,7 +156,15 @@ def _oracle_training_loss(p1, p2, img6, t, target, lr, lw, vgg=None, lp=0.0):
     return total.mean(), pred
 
 
-def test_training_step_gradients_vs_oracle_autograd(dev):
+# Gradient bars per training precision.  f32: exact-fp32 products, gradients agree to fp32 reassociation.  f16f8 (default): the
+# forward activations carry ~3e-5 of fp8-compensation noise, which flips the LeakyReLU branch of the few elements that sit within
+# that distance of zero - the gradient is exact for the perturbed network, so single tensors (the 2x2-pixel bottleneck at 64x64)
+# can differ by several per cent in max-abs while the direction stays put.
+GRAD_BARS = {"f32": (0.9999, 2e-2), "f16f8": (0.999, 1e-1)}
+
+
+@pytest.mark.parametrize("train_precision", ["f16f8", "f32"])
+def test_training_step_gradients_vs_oracle_autograd(dev, train_precision):
     """FullModel (FREEZE=FALSE) forward + `losses.mean(0)[0].backward()` on the HIP path: every one of the 96 parameter
     gradients against CPU autograd of the oracle on the same 64x64 batch of 2."""
     from models.superslomo_r import FullModel
@@ -170,6 +178,7 @@ def test_training_step_gradients_vs_oracle_autograd(dev):
     m.stage1_model.load_state_dict(sd1)
     m.stage2_model.load_state_dict(sd2)
     m = m.to(dev).train()
+    m.train_precision = train_precision
     clips = torch.cat([synthetic_frames(3, 64, 64, seed=70), synthetic_frames(3, 64, 64, seed=71)], 0)      # [2,3,3,64,64]
     xin, tgt = clips[:, [0, 2]], clips[:, 1:2]
     t = torch.tensor([0.5, 0.375]).view(2, 1, 1, 1, 1)
@@ -193,9 +202,10 @@ def test_training_step_gradients_vs_oracle_autograd(dev):
             rel = float((g - w).abs().max() / (w.abs().max() + 1e-30))
             worst.append((rel, cos, stage + "." + name))
     worst.sort(reverse=True)
-    print("worst gradients (rel max err, cosine):", worst[:4])
-    assert all(c > 0.999 for _, c, _ in worst), worst[:4]
-    assert worst[0][0] < 2e-2, worst[:4]
+    print("worst gradients [%s] (rel max err, cosine):" % train_precision, worst[:4])
+    cos_bar, rel_bar = GRAD_BARS[train_precision]
+    assert all(c > cos_bar for _, c, _ in worst), worst[:4]
+    assert worst[0][0] < rel_bar, worst[:4]
 
 
 def test_training_step_with_adam_reduces_loss(dev):
@@ -284,8 +294,15 @@ def test_maxpool_and_feature_mse_kernels(dev):
         hb.check(lib.ssm_maxpool2_fwd(hb.view_of(xd), hb.view_of(yd), B, C, H - 1, W, hb.stream_ptr()))
 
 
-def test_vgg_features_and_input_gradient_vs_oracle(dev):
-    """phi = vgg16.features[:23] on the HIP kernels and d<phi, R>/dx against the CPU oracle + autograd."""
+def _cos(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("mode,tv,tg", [("f32", 1e-4, 1e-3), ("f16f8", 5e-4, 1.5e-1)])
+def test_vgg_features_and_input_gradient_vs_oracle(dev, mode, tv, tg):
+    """phi = vgg16.features[:23] on the HIP kernels and d<phi, R>/dx against the CPU oracle + autograd (f16f8: features within
+    fp8-compensation noise; its input gradient sees the ReLU branch flips of elements within that noise of zero)."""
     from oracle import ssm_oracle as O
     from ssm_amd import hipbind as hb
     from ssm_amd.perceptual import PerceptualTerm, VGGFeatures, synthetic_vgg_state_dict
@@ -298,27 +315,28 @@ def test_vgg_features_and_input_gradient_vs_oracle(dev):
     phi = O.vgg16_conv4_3(vsd, xr)
     R = torch.randn_like(phi)
     (phi * R).sum().backward()
-    net = VGGFeatures(vsd, B, H, W, dev)
+    net = VGGFeatures(vsd, B, H, W, dev, mode)
     got = net.forward(x.to(dev))
     assert tuple(got.interior.shape) == (B, 512, H // 8, W // 8)
-    assert rel_err(got.to_nchw().cpu(), phi.detach()) < 1e-4
+    assert rel_err(got.to_nchw().cpu(), phi.detach()) < tv
     dphi = hb.Planes(B, 512, H // 8, W // 8, dev).load(R.to(dev))
     dx = net.input_grad(dphi)
-    assert rel_err(dx.to_nchw().cpu()[:, :3], xr.grad) < 1e-3
+    assert rel_err(dx.to_nchw().cpu()[:, :3], xr.grad) < tg and _cos(dx.to_nchw().cpu()[:, :3], xr.grad) > 0.9995
     # the loss term: value and gradient wrt pred
     pred, tgt = torch.randn(B, 3, H, W), torch.randn(B, 3, H, W)
     pr = pred.clone().requires_grad_()
     want = O.perceptual_loss(vsd, pr, tgt)
     wts = torch.tensor([1.5, 0.25])
     (want * wts).sum().backward()
-    term = PerceptualTerm(vsd, B, H, W, dev)
+    term = PerceptualTerm(vsd, B, H, W, dev, mode)
     val = term.forward(pred.to(dev), tgt.to(dev))
-    assert float(((val.cpu() - want.detach()).abs() / want.detach().abs()).max()) < 1e-4
+    assert float(((val.cpu() - want.detach()).abs() / want.detach().abs()).max()) < tv
     g = term.grad_pred(wts.to(dev))
-    assert rel_err(g.to_nchw().cpu()[:B, :3], pr.grad) < 1e-3
+    assert rel_err(g.to_nchw().cpu()[:B, :3], pr.grad) < tg and _cos(g.to_nchw().cpu()[:B, :3], pr.grad) > 0.9995
 
 
-def test_training_step_with_perceptual_term_vs_oracle_autograd(dev):
+@pytest.mark.parametrize("train_precision", ["f16f8", "f32"])
+def test_training_step_with_perceptual_term_vs_oracle_autograd(dev, train_precision):
     """All four entries of the [B,4] loss tensor and every parameter gradient with the VGG term ON (synthetic VGG16
     weights; lambda_p = 20 from the ini) against CPU autograd of the oracle."""
     from models.superslomo_r import FullModel
@@ -337,6 +355,7 @@ def test_training_step_with_perceptual_term_vs_oracle_autograd(dev):
     m.loss.load_vgg16(vsd)
     assert m.loss.perceptual_available
     m = m.to(dev).train()
+    m.train_precision = train_precision
     clips = torch.cat([synthetic_frames(3, 64, 64, seed=72), synthetic_frames(3, 64, 64, seed=73)], 0)
     xin, tgt = clips[:, [0, 2]], clips[:, 1:2]
     t = torch.tensor([0.625, 0.25]).view(2, 1, 1, 1, 1)
@@ -360,9 +379,10 @@ def test_training_step_with_perceptual_term_vs_oracle_autograd(dev):
             rel = float((g - w).abs().max() / (w.abs().max() + 1e-30))
             worst.append((rel, cos, stage + "." + name))
     worst.sort(reverse=True)
-    print("worst gradients with the perceptual term (rel max err, cosine):", worst[:4])
-    assert all(c > 0.999 for _, c, _ in worst), worst[:4]
-    assert worst[0][0] < 2e-2, worst[:4]
+    print("worst gradients with the perceptual term [%s] (rel max err, cosine):" % train_precision, worst[:4])
+    cos_bar, rel_bar = GRAD_BARS[train_precision]
+    assert all(c > cos_bar for _, c, _ in worst), worst[:4]
+    assert worst[0][0] < rel_bar, worst[:4]
 
 
 def test_warp_backward_vs_oracle_autograd(dev):
