@@ -128,7 +128,8 @@ def train_bench(args):
                                   "losses: L1 reconstruction + 4 L1 warp terms + %s" % (B, world, "VGG16 conv4_3 perceptual term OFF" if args.no_perceptual else
                                                                                   "VGG16 conv4_3 perceptual term (synthetic VGG weights)"),
                       "global_batch": B * world},
-           "allreduce": {"bytes": trainer.allreduce.bytes, "ms_per_step": round(ar_ms, 3)}}
+           "allreduce": {"bytes": trainer.allreduce.bytes, "ms_per_step": round(ar_ms, 3)},
+           "host_enqueue_ms_per_step": round(1e3 * sdist.timed_steps.last_enqueue_s / args.steps, 3)}
     if rank == 0:
         summ = timer.summary()
         out["time_split_ms_per_step"] = {fam: round(d["ms"] / 3, 3) for fam, d in summ.items()}

@@ -229,8 +229,16 @@ int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, int B, i
 int ssm_lrelu_bwd_q8(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view dz, ssm_hview dz_q8, int B, int C, int H, int W, float slope,
                      int has_act, void *stream);
 int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream);
+/* db[c] += sum dz (no zeroing): the training step zeroes one flat buffer holding every parameter gradient of a U-Net once. */
+int ssm_bias_grad_acc(ssm_view dz, float *db, int B, int C, int H, int W, void *stream);
 int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
                      int ci_offset, int zero_first, void *stream);
+/* Same contract as ssm_conv2d_wgrad (what autograd computes for nn.Conv2d.weight, scripts/models/layers.py:21-33 trained by
+ * scripts/main.py:138-197) on the bf16 matrix cores with split operands: v = bf16(v) + bf16(v - bf16(v)) + r, products
+ * hi*hi + hi*lo + lo*hi accumulated in fp32 (dropped terms ~2^-17 relative; no scaling needed, bf16 has fp32's exponent).
+ * The weight gradient of the f16f8 training plan; the exact-fp32 plan keeps ssm_conv2d_wgrad.                                 */
+int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
+                            int ci_offset, int zero_first, void *stream);
 int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int h, int w, int acc_a, int acc_b,
                            void *stream);
 int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,

@@ -257,6 +257,248 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
         }
 }
 
+// Weight gradient on the bf16 matrix cores with split operands (v_mfma_f32_32x32x16_bf16, the training plan of mode f16f8):
+//     v = hi + lo + r,  hi = bf16(v),  lo = bf16(v - hi),  |r| <= 2^-17 |v|;     dz*x ~= hi*hi + hi*lo + lo*hi   (fp32 accumulate)
+// bf16 keeps fp32's exponent, so gradients of any magnitude need no scaling; the dropped terms are ~2^-17 relative per product.
+// GEMM per filter tap: D[co][ci] = sum_p dZ[co][p] * X[ci][p + tap],  M = 32 couts (A operand, rows of dZ, 8 consecutive pixels per
+// lane = one aligned 16-byte LDS read of the bf16 row), N = 32 input channels (B operand), K = 16 pixels of one image row.  The
+// horizontal tap offset kx is applied in REGISTERS: a lane reads the 16-pixel window [q-4, q+12) of its channel's row once (8+16+8
+// bytes, aligned) and every kx takes its 8 pixels from it - whole dwords for even offsets, v_alignbit_b32 for odd ones - so one
+// window feeds KS taps x 3 products.  The vertical offset selects the staged row: a workgroup owns TY filter rows (all 3 of a 3x3
+// filter, with the 3 activation rows kept in an LDS ring while it walks down the image; one row of a 5x5/7x7 filter) of a
+// (32*WAN couts) x (32*WBN input channels) tile; its 4 waves split the tile and, when the tile is smaller than four 32x32 blocks,
+// the 16-pixel steps of a segment (WKN).  fp32 planes are converted to hi/lo bf16 while staging (register-prefetched: the loads of
+// step s+1 are issued before the MFMAs of step s).  Image rows are split over gridDim.z; partial sums are added with fp32 atomics.
+typedef __bf16 wg_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf2 __attribute__((ext_vector_type(2)));
+typedef float wg_f2 __attribute__((ext_vector_type(2)));
+typedef int wg_i4 __attribute__((ext_vector_type(4)));
+typedef int wg_i2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned wg_pk_bf16(float a, float b) {        // low half = bf16(a), high half = bf16(b), round to nearest even
+    const wg_f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_bf2));
+}
+
+// 4 fp32 -> hi (2 dwords) and lo (2 dwords)
+__device__ __forceinline__ void wg_split4(const float4 &v, wg_i2 &hi, wg_i2 &lo) {
+    const unsigned h0 = wg_pk_bf16(v.x, v.y), h1 = wg_pk_bf16(v.z, v.w);
+    hi = wg_i2{(int)h0, (int)h1};
+    lo = wg_i2{(int)wg_pk_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u)),
+               (int)wg_pk_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u))};
+}
+
+constexpr int wg_odd16(int bytes) { return (((bytes + 15) / 16) | 1) * 16; }      // LDS row pitch: an odd number of 16-byte units
+
+template <int KS, int TY, int SEG, int WAN, int WBN>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
+                                                              int H, int W, int cin_total, int ci_offset, int steps_per_slice) {
+    constexpr int P = (KS - 1) / 2, WKN = 4 / (WAN * WBN), NK = SEG / 16, NKY = KS / TY;
+    static_assert(WAN * WBN * WKN == 4 && NK % WKN == 0 && NKY * TY == KS && P <= 3, "tile configuration");
+    constexpr int COT = 32 * WAN, CIT = 32 * WBN;
+    constexpr int DZB = wg_odd16(SEG * 2);           // bytes per staged dZ row (bf16)
+    constexpr int XE = SEG + 16;                     // staged activation columns [xs-8, xs+SEG+8)
+    constexpr int XB = wg_odd16(XE * 2);
+    constexpr int NDZ4 = COT * (SEG / 4), NX4 = CIT * (XE / 4);
+    constexpr int LDZ = (NDZ4 + 255) / 256, LX = (NX4 + 255) / 256;
+    constexpr int TAPS = TY * KS;
+    constexpr int EPI_FLOATS = WAN * 8 * CIT * TAPS;  // epilogue: one 8-row band of every cout tile, in dW order [co][ci][ky][kx]
+    constexpr int STAGE_BYTES = 2 * COT * DZB + 2 * TY * CIT * XB;
+    constexpr int SMEM_BYTES = STAGE_BYTES > 4 * WKN * EPI_FLOATS ? STAGE_BYTES : 4 * WKN * EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    char *const s_dzh = smem, *const s_dzl = smem + COT * DZB, *const s_xh = smem + 2 * COT * DZB,
+                *const s_xl = smem + 2 * COT * DZB + TY * CIT * XB;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5, wid = tid >> 6;
+    const int wa = wid / (WBN * WKN), wb = (wid / WKN) % WBN, wk = wid % WKN;
+    const int ci0 = blockIdx.x * CIT;
+    const int cog = blockIdx.y / NKY, ky0 = (blockIdx.y - cog * NKY) * TY;
+    const int co0 = cog * COT;
+    const int nseg = (W + SEG - 1) / SEG;
+    const int total = B * nseg * H;
+    const int s0 = blockIdx.z * steps_per_slice;
+    const int s1 = min(total, s0 + steps_per_slice);
+    if (s0 >= s1) return;
+
+    f32x16 acc[TY][KS];
+#pragma unroll
+    for (int a = 0; a < TY; ++a)
+#pragma unroll
+        for (int t = 0; t < KS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    auto decode = [&](int s, int &b, int &y, int &xs) {      // y fastest: a slice walks down the image, the ring stays warm
+        const int t = s / H;
+        y = s - t * H;
+        b = t / nseg;
+        xs = (t - b * nseg) * SEG;
+    };
+    // one float4 of an activation row: columns col..col+3 of row yy (may lie in the zero frame), zero outside [-4, W+4)
+    auto load_x4 = [&](int b, int c, int yy, int col) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci0 + c < Cin && col >= -4 && col < W + 4) {
+            v = *reinterpret_cast<const float4 *>(vp(x, b, ci0 + c, yy) + col);
+            const int left = W + 4 - col;
+            if (left < 4) {
+                if (left < 2) v.y = 0.f;
+                if (left < 3) v.z = 0.f;
+                v.w = 0.f;
+            }
+        }
+        return v;
+    };
+    auto store_x4 = [&](int slot, int f, const float4 &v) {
+        const int c = f / (XE / 4), x4 = f - c * (XE / 4);
+        wg_i2 hi, lo;
+        wg_split4(v, hi, lo);
+        const int off = (slot * CIT + c) * XB + 8 * x4;
+        *reinterpret_cast<wg_i2 *>(s_xh + off) = hi;
+        *reinterpret_cast<wg_i2 *>(s_xl + off) = lo;
+    };
+    float4 pdz[LDZ], px[LX];
+    auto prefetch = [&](int s) {
+        int b, y, xs;
+        decode(s, b, y, xs);
+#pragma unroll
+        for (int i = 0; i < LDZ; ++i) {
+            const int f = tid + 256 * i;
+            const int c = f / (SEG / 4), x4 = f - c * (SEG / 4);
+            const int col = xs + 4 * x4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < NDZ4 && co0 + c < Cout && col < W) {
+                v = *reinterpret_cast<const float4 *>(vp(dz, b, co0 + c, y) + col);
+                const int left = W - col;                  // zero tail: those products vanish
+                if (left < 4) {
+                    if (left < 2) v.y = 0.f;
+                    if (left < 3) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            pdz[i] = v;
+        }
+        const int yy = y + ky0 + TY - 1 - P;               // the newest activation row of this step
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int f = tid + 256 * i;
+            const int c = f / (XE / 4), x4 = f - c * (XE / 4);
+            px[i] = f < NX4 ? load_x4(b, c, yy, xs - 8 + 4 * x4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int s) {
+        int b, y, xs;
+        decode(s, b, y, xs);
+#pragma unroll
+        for (int i = 0; i < LDZ; ++i) {
+            const int f = tid + 256 * i;
+            if (f < NDZ4) {
+                const int c = f / (SEG / 4), x4 = f - c * (SEG / 4);
+                wg_i2 hi, lo;
+                wg_split4(pdz[i], hi, lo);
+                *reinterpret_cast<wg_i2 *>(s_dzh + c * DZB + 8 * x4) = hi;
+                *reinterpret_cast<wg_i2 *>(s_dzl + c * DZB + 8 * x4) = lo;
+            }
+        }
+        const int slot = (y + ky0 + TY - 1 - P + 3) % TY;
+#pragma unroll
+        for (int i = 0; i < LX; ++i) {
+            const int f = tid + 256 * i;
+            if (f < NX4) store_x4(slot, f, px[i]);
+        }
+        if (TY > 1 && (s == s0 || y == 0)) {              // ring is cold: stage the older rows of this step directly
+            for (int r = 0; r < TY - 1; ++r) {
+                const int yy = y + ky0 + r - P;
+                const int sl = (yy + 3) % TY;
+                for (int f = tid; f < NX4; f += 256) {
+                    const int c = f / (XE / 4), x4 = f - c * (XE / 4);
+                    store_x4(sl, f, load_x4(b, c, yy, xs - 8 + 4 * x4));
+                }
+            }
+        }
+    };
+
+    prefetch(s0);
+    for (int s = s0; s < s1; ++s) {
+        __syncthreads();                                   // everyone is done reading the previous step's tiles
+        commit(s);
+        __syncthreads();
+        if (s + 1 < s1) prefetch(s + 1);
+        int b, y, xs;
+        decode(s, b, y, xs);
+        const int nk = (min(SEG, W - xs) + 15) >> 4;       // 16-pixel steps that hold image pixels
+        for (int j = wk; j < nk; j += WKN) {
+            const int q = 16 * j + 8 * half;               // this lane's 8 pixels: columns xs+q .. xs+q+7
+            const int arow = (wa * 32 + l31) * DZB + 2 * q;
+            const wg_i4 ah = *reinterpret_cast<const wg_i4 *>(s_dzh + arow);
+            const wg_i4 al = *reinterpret_cast<const wg_i4 *>(s_dzl + arow);
+            const wg_bf8 Ah = __builtin_bit_cast(wg_bf8, ah), Al = __builtin_bit_cast(wg_bf8, al);
+#pragma unroll
+            for (int a = 0; a < TY; ++a) {
+                const int slot = (y + ky0 + a - P + 3) % TY;
+                const int xrow = (slot * CIT + wb * 32 + l31) * XB + 2 * (q + 8);      // staged column 0 = image column xs-8
+                int wh[8], wl[8];                          // window: pixels q-4 .. q+11 of this lane's channel, 2 per dword
+                {
+                    const wg_i2 h0 = *reinterpret_cast<const wg_i2 *>(s_xh + xrow - 8), l0 = *reinterpret_cast<const wg_i2 *>(s_xl + xrow - 8);
+                    const wg_i4 h1 = *reinterpret_cast<const wg_i4 *>(s_xh + xrow), l1 = *reinterpret_cast<const wg_i4 *>(s_xl + xrow);
+                    const wg_i2 h2 = *reinterpret_cast<const wg_i2 *>(s_xh + xrow + 16), l2 = *reinterpret_cast<const wg_i2 *>(s_xl + xrow + 16);
+                    wh[0] = h0[0]; wh[1] = h0[1]; wh[2] = h1[0]; wh[3] = h1[1]; wh[4] = h1[2]; wh[5] = h1[3]; wh[6] = h2[0]; wh[7] = h2[1];
+                    wl[0] = l0[0]; wl[1] = l0[1]; wl[2] = l1[0]; wl[3] = l1[1]; wl[4] = l1[2]; wl[5] = l1[3]; wl[6] = l2[0]; wl[7] = l2[1];
+                }
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    const int idx = t - P + 4;             // window element of the first pixel this tap needs (compile-time after unrolling)
+                    const int d = idx >> 1;
+                    wg_i4 bh, bl;
+                    if ((idx & 1) == 0) {
+                        bh = wg_i4{wh[d], wh[d + 1], wh[d + 2], wh[d + 3]};
+                        bl = wg_i4{wl[d], wl[d + 1], wl[d + 2], wl[d + 3]};
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            bh[i] = (int)__builtin_amdgcn_alignbit((unsigned)wh[d + i + 1], (unsigned)wh[d + i], 16);
+                            bl[i] = (int)__builtin_amdgcn_alignbit((unsigned)wl[d + i + 1], (unsigned)wl[d + i], 16);
+                        }
+                    }
+                    const wg_bf8 Bh = __builtin_bit_cast(wg_bf8, bh), Bl = __builtin_bit_cast(wg_bf8, bl);
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[a][t], 0, 0, 0);
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[a][t], 0, 0, 0);
+                    acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[a][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // Epilogue.  The accumulators have the input channel on the lane, i.e. a stride of KS*KS floats in dW: written straight out, every
+    // lane's atomic would be its own L2 operation on a line that hundreds of other workgroups also hit (measured: 10x the MFMA time).
+    // So the tile goes through LDS in dW order, 8 cout rows at a time: each of the WKN waves that share a tile stores its partial in
+    // its own copy, the copies are summed on the way out, and the global atomics run along contiguous (ci, ky, kx) runs - 16 lanes per
+    // cache line.  The barriers wait for LDS only (not for the atomics in flight), so a band's atomics overlap the next band's stores.
+    float *const tile = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // staging buffers (g = 0) / the previous band are no longer read
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * half + rr;                 // cout row within the band: co = co0 + wa*32 + 8*g + row
+            float *d = tile + wk * EPI_FLOATS + ((wa * 8 + row) * CIT + wb * 32 + l31) * TAPS;
+#pragma unroll
+            for (int a = 0; a < TY; ++a)
+#pragma unroll
+                for (int t = 0; t < KS; ++t) d[a * KS + t] = acc[a][t][4 * g + rr];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int e = tid; e < EPI_FLOATS; e += 256) {
+            const int wr = e / (CIT * TAPS), rem = e - wr * (CIT * TAPS);      // wr = wa*8 + row
+            const int cil = rem / TAPS, tp = rem - cil * TAPS;
+            const int co = co0 + (wr >> 3) * 32 + 8 * g + (wr & 7);
+            const int ci = ci0 + cil;
+            float v = tile[e];
+#pragma unroll
+            for (int w = 1; w < WKN; ++w) v += tile[w * EPI_FLOATS + e];
+            if (co < Cout && ci < Cin)
+                atomicAdd(dw + ((long long)co * cin_total + ci_offset + ci) * (KS * KS) + ky0 * KS + tp, v);
+        }
+    }
+}
+
 // adjoint of  U = upsample2x(cat[a, b])  (see upsample2x_cat_kernel): one thread per LOW-res pixel and channel
 // gathers its 4x4 hi-res neighbourhood.  1-D weights of x[i] in U(Y): Y=2i: .75 (1 at i=0); Y=2i+1: .75 (1 at
 // i=h-1); Y=2i+2: .25 if i+1<h; Y=2i-1: .25 if i>0.
@@ -544,18 +786,28 @@ extern "C" int ssm_lrelu_bwd_q8(ssm_view dy, ssm_view dpool, ssm_view y, ssm_vie
     return ssm::check_launch("ssm_lrelu_bwd_q8");
 }
 
-extern "C" int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream) {
+static int bias_grad_launch(ssm_view dz, float *db, int B, int C, int H, int W, int zero_first, void *stream) {
     SSM_REQUIRE(dz.ptr && db && B > 0 && C > 0 && H > 0 && W > 0, "bias_grad: bad arguments");
-    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        ssm::set_error("bias_grad: memset failed: %s", hipGetErrorString(e));
-        return SSM_E_LAUNCH;
+    if (zero_first) {
+        hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, (hipStream_t)stream);
+        if (e != hipSuccess) {
+            ssm::set_error("bias_grad: memset failed: %s", hipGetErrorString(e));
+            return SSM_E_LAUNCH;
+        }
     }
     int chunks = (B * H + 63) / 64;          // ~16 rows per wave
     if (chunks < 1) chunks = 1;
     if (chunks > 1024) chunks = 1024;
     hipLaunchKernelGGL(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, db, B, H, W);
     return ssm::check_launch("ssm_bias_grad");
+}
+
+extern "C" int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stream) {
+    return bias_grad_launch(dz, db, B, C, H, W, 1, stream);
+}
+
+extern "C" int ssm_bias_grad_acc(ssm_view dz, float *db, int B, int C, int H, int W, void *stream) {
+    return bias_grad_launch(dz, db, B, C, H, W, 0, stream);
 }
 
 extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
@@ -599,6 +851,61 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
     }
 #undef SSM_WGRAD
     return ssm::check_launch("ssm_conv2d_wgrad");
+}
+
+extern "C" int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
+                                       int ci_offset, int zero_first, void *stream) {
+    SSM_REQUIRE(x.ptr && dz.ptr && dw_oihw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad_bf16x3: bad arguments");
+    SSM_REQUIRE(ci_offset >= 0 && ci_offset + Cin <= cin_total, "wgrad_bf16x3: channel range [%d,%d) outside the filter's %d inputs",
+                ci_offset, ci_offset + Cin, cin_total);
+    SSM_REQUIRE(x.sh >= W + 2 * SSM_PADX && dz.sh >= W + 3, "wgrad_bf16x3: x and dz must be padded-plane views (zero frame)");
+    SSM_REQUIRE(ssm::aligned16(x.ptr) && ssm::aligned16(dz.ptr) && x.sh % 4 == 0 && x.sc % 4 == 0 && x.sb % 4 == 0 && dz.sh % 4 == 0 &&
+                    dz.sc % 4 == 0 && dz.sb % 4 == 0,
+                "wgrad_bf16x3: views must be 16-byte aligned with strides that are multiples of 4 floats");
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_first) {
+        hipError_t e = hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)Cout * cin_total * k * k, st);
+        if (e != hipSuccess) {
+            ssm::set_error("wgrad_bf16x3: memset failed: %s", hipGetErrorString(e));
+            return SSM_E_LAUNCH;
+        }
+    }
+    const int ca = (Cout + 31) / 32, cb = (Cin + 31) / 32;
+    // split of the image rows over gridDim.z: about two workgroups per CU, each walking >= 16 rows (shorter slices pay the ring
+    // warm-up and the atomic epilogue more often: 2048 workgroups x 8 rows measured 40 % slower over the step's layers)
+    static const int tgt_wgs = getenv("SSM_WGRAD_WGS") ? atoi(getenv("SSM_WGRAD_WGS")) : 512;
+    static const int min_steps = getenv("SSM_WGRAD_MINSTEPS") ? atoi(getenv("SSM_WGRAD_MINSTEPS")) : 16;
+    // tile configuration: (filter size, filter rows per workgroup, segment, cout tiles, cin tiles of the 4 waves)
+#define SSM_WGRAD16(KS_, TY_, SEG_, WAN_, WBN_)                                                                                   \
+    {                                                                                                                             \
+        const int gx = (cb + WBN_ - 1) / WBN_, gy = ((ca + WAN_ - 1) / WAN_) * (KS_ / TY_);                                       \
+        const int total = B * ((W + SEG_ - 1) / SEG_) * H;                                                                        \
+        int nsl = (tgt_wgs + gx * gy - 1) / (gx * gy);                                                                            \
+        if (nsl > (total + min_steps - 1) / min_steps) nsl = (total + min_steps - 1) / min_steps;                                 \
+        if (nsl < 1) nsl = 1;                                                                                                     \
+        if (nsl > 65535) nsl = 65535;                                                                                             \
+        const int sps = (total + nsl - 1) / nsl;                                                                                  \
+        nsl = (total + sps - 1) / sps;                                                                                            \
+        hipLaunchKernelGGL((wgrad_bf16x3_kernel<KS_, TY_, SEG_, WAN_, WBN_>), dim3(gx, gy, nsl), dim3(256), 0, st, x, dz, dw_oihw, B, \
+                           Cin, Cout, H, W, cin_total, ci_offset, sps);                                                           \
+    }
+    switch (k) {
+        case 3:
+            if (ca >= 2 && cb >= 2) SSM_WGRAD16(3, 3, 32, 2, 2)
+            else if (cb >= 2) SSM_WGRAD16(3, 3, 64, 1, 2)
+            else if (ca >= 2) SSM_WGRAD16(3, 3, 64, 2, 1)
+            else SSM_WGRAD16(3, 3, 64, 1, 1)
+            break;
+        case 5:
+            if (ca >= 2 && cb >= 2) SSM_WGRAD16(5, 1, 64, 2, 2)
+            else if (ca >= 2) SSM_WGRAD16(5, 1, 128, 2, 1)
+            else SSM_WGRAD16(5, 1, 128, 1, 1)
+            break;
+        case 7: SSM_WGRAD16(7, 1, 128, 1, 1) break;      // the reference's 7x7 layers have 32 outputs and <= 32 inputs (one tile per filter row)
+        default: ssm::set_error("wgrad_bf16x3: kernel size %d unsupported", k); return SSM_E_UNSUPPORTED;
+    }
+#undef SSM_WGRAD16
+    return ssm::check_launch("ssm_conv2d_wgrad_bf16x3");
 }
 
 extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int H, int W, int acc_a, int acc_b,

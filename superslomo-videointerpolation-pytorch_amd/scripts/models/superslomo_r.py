@@ -84,14 +84,24 @@ class _TrainStep(torch.autograd.Function):
         pt = model.loss.perceptual_term(B, H, W, ctx.target.device)
         if pt is not None:        # VGG activations of this step's forward are still in the plan's buffers
             dy_extra = pt.grad_pred((d_losses[:, 0] + d_losses[:, 3]) * lambda_p).view()
+        named = [(stage + name, p) for stage, mod in (("stage1.", model.stage1_model), ("stage2.", model.stage2_model))
+                 for name, p in mod.named_parameters()]
+        for _, p in named:          # a gradient kept from an earlier backward lives in the buffers this backward rewrites: detach it
+            if p.grad is not None and ctx.pg.owns(p.grad):
+                p.grad = p.grad.clone()
         grads = ctx.pg.backward(ctx.sd[0], ctx.sd[1], ctx.target, d_losses, lambda_r, lambda_w, train_s1, train_s2,
                                 dy_extra=dy_extra)
-        out = []
-        for stage, mod in (("stage1.", model.stage1_model), ("stage2.", model.stage2_model)):
-            for name, p in mod.named_parameters():
-                g = grads.get(stage + name)
-                out.append(g.clone() if (g is not None and p.requires_grad) else None)
-        return (None, None, None, None) + tuple(out)
+        # The gradients are handed to `.grad` directly (what AccumulateGrad would do, minus 96 clone launches per step): slices of the
+        # per-U-Net flat buffers, valid until this model's next backward; an existing .grad is accumulated into, as autograd does.
+        for key, p in named:
+            g = grads.get(key)
+            if g is None or not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return (None, None, None, None) + (None,) * len(named)
 
 
 class FullModel(nn.Module):

@@ -9,6 +9,9 @@ planes (the training plan runs in precision mode "f32"):
   adjoints of compute_inputs / compute_output_image fused with the L1 loss gradients = ssm_flowinterp_inputs_bwd /
   ssm_synthesize_bwd
 """
+import contextlib
+import os
+
 import torch
 
 from . import hipbind as hb
@@ -28,17 +31,21 @@ def lrelu_bwd(dy, dpool, y, dz, slope=0.1, has_act=True):
     return dz
 
 
-def bias_grad(dz, out):
-    hb.check(hb.load().ssm_bias_grad(dz.view(), out.data_ptr(), dz.B, dz.C, dz.H, dz.W, hb.stream_ptr()))
+def bias_grad(dz, out, zero_first=True):
+    fn = hb.load().ssm_bias_grad if zero_first else hb.load().ssm_bias_grad_acc
+    hb.check(fn(dz.view(), out.data_ptr(), dz.B, dz.C, dz.H, dz.W, hb.stream_ptr()))
     return out
 
 
-def wgrad(x, dz, out, k, ci_offset=0, zero_first=True):
+def wgrad(x, dz, out, k, ci_offset=0, zero_first=True, split=False):
     """out[:, ci_offset:ci_offset+x.C] (OIHW fp32, contiguous) = sum_{b,y,x} dz * x(shifted).
-    x, dz: hb.Planes (or slices) of the layer's input / dZ; two-source convs call this once per source."""
+    x, dz: hb.Planes (or slices) of the layer's input / dZ; two-source convs call this once per source.
+    split: the bf16 matrix path with hi/lo-split operands (ssm_conv2d_wgrad_bf16x3) instead of the fp32 one."""
     assert out.is_contiguous() and out.shape[0] == dz.C and out.shape[2] == k and ci_offset + x.C <= out.shape[1]
-    hb.check(hb.load().ssm_conv2d_wgrad(x.view(), dz.view(), out.data_ptr(), x.B, x.C, dz.C, x.H, x.W, k, out.shape[1],
-                                        ci_offset, 1 if zero_first else 0, hb.stream_ptr()))
+    lib = hb.load()
+    fn = lib.ssm_conv2d_wgrad_bf16x3 if split else lib.ssm_conv2d_wgrad
+    hb.check(fn(x.view(), dz.view(), out.data_ptr(), x.B, x.C, dz.C, x.H, x.W, k, out.shape[1],
+                ci_offset, 1 if zero_first else 0, hb.stream_ptr()))
     return out
 
 
@@ -85,6 +92,28 @@ class UNetGrad:
         self.B, self.dev = plan.B, plan.device
         self.g, self.dz, self.dzq, self.pk_t, self.grads, self.tw = {}, {}, {}, {}, {}, {}
         self.io = {n: (srcs, dst) for n, srcs, dst in _CONV_IO}
+        # Parameter gradients leave the critical path: with `side` set (a HIP stream) every layer's weight/bias-gradient launches go
+        # there, ordered after that layer's dZ by an event, while the data-gradient chain continues on the caller's stream.  Nothing
+        # they read (dZ of the layer, forward activations) is rewritten before join(); their outputs are read after it.
+        self.side, self._ev = None, {}
+        # the f16f8 plan's weight gradients run on the split-bf16 matrix path; the exact plan's on fp32 MFMA
+        self.split_wgrad = self.hl8 and os.environ.get("SSM_WGRAD", "bf16x3") != "f32"
+        # every parameter gradient of the U-Net lives in ONE flat buffer (state-dict order), zeroed by one launch per backward; the
+        # weight / bias gradient kernels accumulate into their slices (they add partial sums with atomics anyway)
+        sizes = []
+        for name, (ci, co, k) in plan.layers.items():
+            sizes += [(param_key(name, "weight"), (co, ci, k, k)), (param_key(name, "bias"), (co,))]
+        self.flat = torch.empty(sum(int(torch.Size(sh).numel()) for _, sh in sizes), dtype=torch.float32, device=self.dev)
+        off = 0
+        for key, sh in sizes:
+            n = int(torch.Size(sh).numel())
+            self.grads[key] = self.flat[off:off + n].view(sh)
+            off += n
+
+    def join(self):
+        """The caller's stream waits for the parameter gradients queued on the side stream."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def act(self, name):
         """fp32 planes of a forward activation."""
@@ -156,22 +185,26 @@ class UNetGrad:
         tm = UNetPlan.timer
         flops = 2.0 * self.B * Y.H * Y.W * co * ci * k * k
         if need_wgrad:
-            if tm is not None:
-                e0, e1 = tm.span("wgrad", "s%d.%s" % (plan.stage, name), flops)
-                e0.record()
             wk, bk = param_key(name, "weight"), param_key(name, "bias")
-            if wk not in self.grads:
-                self.grads[wk] = torch.empty(co, ci, k, k, dtype=torch.float32, device=self.dev)
-                self.grads[bk] = torch.empty(co, dtype=torch.float32, device=self.dev)
-            off = 0
-            for sname in srcs:
-                X = self.act(sname)
-                wgrad(X, dz, self.grads[wk], k, ci_offset=off, zero_first=(off == 0))
-                off += X.C
-            assert off == ci, "%s: inputs cover %d of %d channels" % (name, off, ci)
-            bias_grad(dz, self.grads[bk])
-            if tm is not None:
-                e1.record()
+            if self.side is not None:
+                ev = self._ev.get(name)
+                if ev is None:
+                    ev = self._ev[name] = torch.cuda.Event()
+                ev.record()                      # dZ of this layer is complete on the caller's stream
+                self.side.wait_event(ev)
+            with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
+                if tm is not None:
+                    e0, e1 = tm.span("wgrad", "s%d.%s" % (plan.stage, name), flops)
+                    e0.record()
+                off = 0
+                for sname in srcs:
+                    X = self.act(sname)
+                    wgrad(X, dz, self.grads[wk], k, ci_offset=off, zero_first=False, split=self.split_wgrad)
+                    off += X.C
+                assert off == ci, "%s: inputs cover %d of %d channels" % (name, off, ci)
+                bias_grad(dz, self.grads[bk], zero_first=False)
+                if tm is not None:
+                    e1.record()
         if dx is not None:
             if tm is not None:
                 e0, e1 = tm.span("dgrad", "s%d.%s" % (plan.stage, name), flops)
@@ -190,6 +223,11 @@ class UNetGrad:
         conv6.1's output is added to it.  Returns the gradient of the input (Planes) or None."""
         L, G = self._layer, self._G
         plan = self.plan
+        if need_wgrad:
+            if self.side is not None:
+                self.side.wait_stream(torch.cuda.current_stream())       # last step's consumers of the gradients are done
+            with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
+                self.flat.zero_()
         L("final_conv", d_out, None, G("tf"), need_wgrad, act=False)
         cat = G("cat_fuse", like="tf", C=plan.t["c11"].C + plan.t["c1"].C)
         L("fuse_conv", G("tf"), None, cat, need_wgrad)
@@ -240,10 +278,20 @@ class PairGrad:
         assert not engine.hl8 or (engine.q8 and engine.twins), "an HL8 training engine must be mode f16f8 with fp32 twins"
         self.e = engine
         self.u1, self.u2 = UNetGrad(engine.s1), UNetGrad(engine.s2)
+        if os.environ.get("SSM_WGRAD_STREAM", "1") != "0":
+            self.u1.side = self.u2.side = torch.cuda.Stream(device=engine.device)
         B, H, W, dev = engine.B2, engine.H, engine.W, engine.device
         self.dest = torch.empty(B, 4, H, W, dtype=torch.float32, device=dev)
         self.cr = torch.empty(B, dtype=torch.float32, device=dev)
         self.cw = torch.empty(B, dtype=torch.float32, device=dev)
+
+    def owns(self, t):
+        """True if tensor `t` is a slice of the flat gradient buffers the next backward rewrites."""
+        for u in (self.u1, self.u2):
+            a = u.flat.data_ptr()
+            if a <= t.data_ptr() < a + 4 * u.flat.numel():
+                return True
+        return False
 
     def backward(self, sd1, sd2, target, g_losses, lambda_r, lambda_w, train_s1, train_s2, n_windows=1, dy_extra=None):
         """target [B,3,H,W]; g_losses [B,4] = upstream gradient of the [B,4] loss tensor (columns total, recon, warp,
@@ -287,4 +335,5 @@ class PairGrad:
                                                    self.cw.data_ptr(), d_flow4.view(), B, H, W, 1, st))
             self.u1.backward(d_flow4, need_wgrad=True, c6_grad_init=dcross)
             grads.update({"stage1." + k: v for k, v in self.u1.grads.items()})
+        self.u2.join()
         return grads

@@ -60,10 +60,14 @@ def timed_steps(step_fn, steps, warmup, sync_fn):
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+    timed_steps.last_enqueue_s = time.perf_counter() - t0      # host time spent issuing the steps (launch-bound if ~= elapsed)
     sync_fn()
     barrier()
     el = time.perf_counter() - t0
     return reduce_max(el)
+
+
+timed_steps.last_enqueue_s = 0.0
 
 
 def reduce_max(value, device=None):

@@ -56,6 +56,34 @@ def test_conv_backward(dev, k, cin, cout, B, H, W, act):
     assert rel_err(db.cpu(), bias.grad) < 2e-4, "db"
 
 
+@pytest.mark.parametrize("k,cin,cout,B,H,W,gscale", [
+    (7, 6, 32, 2, 16, 40, 1.0), (7, 32, 32, 1, 20, 150, 1e-6), (5, 32, 64, 1, 12, 32, 1.0), (5, 64, 64, 2, 9, 70, 1.0),
+    (3, 64, 32, 2, 9, 33, 1.0), (3, 32, 5, 1, 16, 64, 1.0), (3, 32, 32, 1, 11, 11, 1.0), (3, 128, 256, 1, 8, 16, 1e-7),
+    (3, 96, 64, 1, 70, 130, 1.0), (3, 160, 40, 2, 5, 19, 1.0), (3, 16, 128, 1, 13, 45, 1.0)])
+def test_wgrad_bf16x3(dev, k, cin, cout, B, H, W, gscale):
+    """Weight gradient on the split-bf16 matrix path (the f16f8 training plan's) vs autograd of the oracle conv: every tile
+    configuration, ragged widths, channel counts off the 32-tile, two-source accumulation, tiny gradient magnitudes (no scaling
+    is needed: bf16 has fp32's exponent).  Bar: 2e-4 of the largest entry, the same as the fp32-MFMA kernel's."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import backward as Bk
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(k * 1000 + cin + cout + H + W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_()
+    r = torch.randn(B, cout, H, W, generator=g) * gscale
+    (O.conv2d(x, w, torch.zeros(cout)) * r).sum().backward()
+    xp = hb.Planes(B, cin, H, W, dev).load(x.to(dev))
+    dzp = hb.Planes(B, cout, H, W, dev).load(r.to(dev))
+    dw = torch.full((cout, cin, k, k), 7.0, device=dev)
+    if cin >= 64:           # two-source form
+        h = cin // 2 + 8
+        Bk.wgrad(xp.slice(0, h), dzp, dw, k, ci_offset=0, zero_first=True, split=True)
+        Bk.wgrad(xp.slice(h, cin - h), dzp, dw, k, ci_offset=h, zero_first=False, split=True)
+    else:
+        Bk.wgrad(xp, dzp, dw, k, split=True)
+    assert rel_err(dw.cpu(), w.grad) < 2e-4
+
+
 def test_pool_adjoint_fused_in_lrelu_bwd(dev):
     from oracle import ssm_oracle as O
     from ssm_amd import backward as Bk
