@@ -146,6 +146,23 @@ int ssm_pack16q_weights(const float *w_oihw, const float *bias, void *w_packed, 
                         int Cin_padded, int k, int BN, int KYS, float scale, void *stream);
 int ssm_flowinterp_inputs_hq8_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_hview out16, ssm_view flows4, int B, int H,
                                   int W, void *stream);      /* ssm_flowinterp_inputs_hl8_fwd with a Q8 output */
+/* All filters of a U-Net packed (Q8 form) by ONE launch: the training step repacks every filter after each optimizer step
+ * (scripts/main.py:188-197 updates the nn.Conv2d weights of scripts/models/layers.py:21-33 in place).  A job describes one
+ * ssm_pack16q_weights call; transposed = 1 packs the data-gradient filter W'[co][ci][ky][kx] = w[ci][co][k-1-ky][k-1-kx] straight
+ * from the forward OIHW tensor `w` (Cout/Cin are those of W'), bias = NULL packs zeros.  block_start = running sum of
+ * row_blocks + bias_blocks (ssm_pack16q_job_blocks) over the preceding jobs; the job array lives in device memory.        */
+typedef struct ssm_pack16q_job {
+    const float *w;
+    const float *bias;
+    void *wp;
+    float *bp;
+    int Cout, Cin, CinP, k, BN, KYS;
+    float scale;
+    int transposed;
+    int block_start, row_blocks;
+} ssm_pack16q_job;
+int ssm_pack16q_job_blocks(int Cout, int CinP, int k, int BN, int *row_blocks, int *bias_blocks);
+int ssm_pack16q_weights_batch(const ssm_pack16q_job *jobs_device, int n_jobs, int total_blocks, void *stream);
 int ssm_hq8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream);
 int ssm_hq8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream);
 /* fp32 view [B,C,H,W] <-> HL8 with G >= ceil(C/8) channel groups (extra channels are zeros). */

@@ -952,11 +952,11 @@ __global__ void pack16_kernel(const float *__restrict__ w, const float *__restri
 // One thread = one filter row of one (cout, 16-channel chunk): it reads the chunk's 16 x KS weights of the row (the 16 x KS^2 block of
 // a cout is contiguous in OIHW, so the KS threads of a block of rows use every byte of the cache lines they touch) and emits the
 // row's fp16 and fp8 pieces.
+// transposed: `w` is the OIHW filter of the FORWARD convolution ([Cin][Cout][KS][KS] seen from here) and the packed filter is its
+// data-gradient counterpart W'[co][ci][ky][kx] = w[ci][co][KS-1-ky][KS-1-kx] (no materialised permute/flip).
 template <int KS>
-__global__ void pack16q_kernel(const float *__restrict__ w, char *__restrict__ wp, int Cout, int Cin, int CinP, int KYS, int BN, float scale,
-                               long long stage_bytes, long long qbase, long long total) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+__device__ __forceinline__ void pack16q_row(const float *__restrict__ w, char *__restrict__ wp, int Cout, int Cin, int CinP, int KYS, int BN,
+                                            float scale, long long stage_bytes, long long qbase, long long i, int transposed) {
     constexpr int NQ = (KS + 3) / 4;
     const int ky = (int)(i % KS);
     const int n = (int)((i / KS) % BN);
@@ -972,7 +972,10 @@ __global__ void pack16q_kernel(const float *__restrict__ w, char *__restrict__ w
             const int ci = ch * 16 + e;
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx)
-                v[e][kx] = (co < Cout && ci < Cin) ? w[(((long long)co * Cin + ci) * KS + ky) * KS + kx] * scale : 0.f;
+                v[e][kx] = (co < Cout && ci < Cin)
+                               ? (transposed ? w[(((long long)ci * Cout + co) * KS + (KS - 1 - ky)) * KS + (KS - 1 - kx)]
+                                             : w[(((long long)co * Cin + ci) * KS + ky) * KS + kx]) * scale
+                               : 0.f;
         }
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx)
@@ -1002,6 +1005,46 @@ __global__ void pack16q_kernel(const float *__restrict__ w, char *__restrict__ w
                                             pack4_fp8(x[8], x[9], x[10], x[11]), pack4_fp8(x[12], x[13], x[14], x[15])};
                         *reinterpret_cast<i32x4 *>(st + qbase + ((((((long long)(ry * NQ + q) * 2 + op) * 2 + pc) * 2 + half) * BN + n) * 16)) = word;
                     }
+    }
+}
+
+template <int KS>
+__global__ void pack16q_kernel(const float *__restrict__ w, char *__restrict__ wp, int Cout, int Cin, int CinP, int KYS, int BN, float scale,
+                               long long stage_bytes, long long qbase, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    pack16q_row<KS>(w, wp, Cout, Cin, CinP, KYS, BN, scale, stage_bytes, qbase, i, 0);
+}
+
+// Every filter of a U-Net in ONE launch (training repacks all of them after each optimizer step: 2 launches per layer and a
+// torch permute/flip/copy per data-gradient filter made the step launch-bound).  jobs: device array; block b belongs to the job with
+// block_start <= b < block_start + row_blocks + bias_blocks.
+__global__ __launch_bounds__(64) void pack16q_batch_kernel(const ssm_pack16q_job *__restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    const int blk = blockIdx.x;
+    while (lo < hi) {                                   // last job whose block_start <= blk
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_start <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const ssm_pack16q_job jb = jobs[lo];
+    const int rel = blk - jb.block_start;
+    if (rel >= jb.row_blocks) {                         // packed bias (zeros for a data-gradient filter)
+        const int i = (rel - jb.row_blocks) * 64 + threadIdx.x;
+        const int nbias = (jb.Cout + jb.BN - 1) / jb.BN * jb.BN;
+        if (i < nbias) jb.bp[i] = (i < jb.Cout && jb.bias) ? jb.bias[i] : 0.f;
+        return;
+    }
+    const long long i = (long long)rel * 64 + threadIdx.x;
+    const long long total = (long long)((jb.Cout + jb.BN - 1) / jb.BN) * (jb.CinP / 16) * jb.BN * jb.k;
+    if (i >= total) return;
+    const long long sb = (long long)(jb.KYS * jb.k * 2 + jb.KYS * ((jb.k + 3) / 4) * 8) * jb.BN * 16;
+    const long long qbase = (long long)jb.KYS * jb.k * 2 * jb.BN * 16;
+    switch (jb.k) {
+        case 3: pack16q_row<3>(jb.w, (char *)jb.wp, jb.Cout, jb.Cin, jb.CinP, jb.KYS, jb.BN, jb.scale, sb, qbase, i, jb.transposed); break;
+        case 5: pack16q_row<5>(jb.w, (char *)jb.wp, jb.Cout, jb.Cin, jb.CinP, jb.KYS, jb.BN, jb.scale, sb, qbase, i, jb.transposed); break;
+        case 7: pack16q_row<7>(jb.w, (char *)jb.wp, jb.Cout, jb.Cin, jb.CinP, jb.KYS, jb.BN, jb.scale, sb, qbase, i, jb.transposed); break;
+        default: break;
     }
 }
 
@@ -1160,6 +1203,20 @@ extern "C" int ssm_pack16q_weights(const float *w, const float *bias, void *wp, 
     hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((nbias + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, (_Float16 *)nullptr, bp,
                        Cout, Cin, CinP, k, KYS, BN, scale, 0LL, nbias);
     return ssm::check_launch("ssm_pack16q_weights");
+}
+
+extern "C" int ssm_pack16q_job_blocks(int Cout, int CinP, int k, int BN, int *row_blocks, int *bias_blocks) {
+    SSM_REQUIRE(row_blocks && bias_blocks && Cout > 0 && CinP % 16 == 0 && BN % 32 == 0, "pack16q_job_blocks: bad arguments");
+    const long long total = (long long)((Cout + BN - 1) / BN) * (CinP / 16) * BN * k;
+    *row_blocks = (int)((total + 63) / 64);
+    *bias_blocks = (int)((ssm_packed_bias_floats(Cout, BN) + 63) / 64);
+    return SSM_OK;
+}
+
+extern "C" int ssm_pack16q_weights_batch(const ssm_pack16q_job *jobs_device, int n_jobs, int total_blocks, void *stream) {
+    SSM_REQUIRE(jobs_device && n_jobs > 0 && total_blocks > 0, "pack16q_batch: bad arguments");
+    hipLaunchKernelGGL(pack16q_batch_kernel, dim3((unsigned)total_blocks), dim3(64), 0, (hipStream_t)stream, jobs_device, n_jobs);
+    return ssm::check_launch("ssm_pack16q_weights_batch");
 }
 
 extern "C" int ssm_hq8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream) {

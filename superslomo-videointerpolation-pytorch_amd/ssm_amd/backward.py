@@ -148,10 +148,27 @@ class UNetGrad:
         return self.g[name]
 
     def refresh(self, state_dict, need_input_grad):
-        """Repack the data-gradient filters (the weights change every optimizer step)."""
-        for name, (ci, co, k) in self.plan.layers.items():
-            if name == "conv1a" and not need_input_grad:
-                continue
+        """Repack the data-gradient filters (the weights change every optimizer step).  Q8 plan: all of them by one launch straight
+        from the forward OIHW parameters (hb.PackBatch, transposed jobs); fp32 plan: layer by layer from the materialised
+        transposed + flipped filters."""
+        names = [n for n in self.plan.layers if not (n == "conv1a" and not need_input_grad)]
+        if self.hl8:
+            ws = [state_dict[param_key(n, "weight")] for n in names]
+            if all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in ws):
+                key = (tuple(names), hb.PackBatch.key(ws))
+                if getattr(self, "_pack", None) is None or self._pack[0] != key:
+                    entries = []
+                    for n, w in zip(names, ws):
+                        ci, co, k = self.plan.layers[n]
+                        if n not in self.pk_t:
+                            self.pk_t[n] = hb.PackedConv16(None, None, self.plan.W // layer_scale(n), q8=True, scale=self.plan.scales[n],
+                                                           shape=(ci, co, k), device=self.dev)
+                        entries.append((self.pk_t[n], w, None, True))
+                    self._pack = (key, hb.PackBatch(entries, self.dev))
+                self._pack[1].run()
+                return
+        for name in names:
+            ci, co, k = self.plan.layers[name]
             s = layer_scale(name)
             w = state_dict[param_key(name, "weight")].to(device=self.dev, dtype=torch.float32)
             if self.hl8:

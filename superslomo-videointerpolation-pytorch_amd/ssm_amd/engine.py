@@ -150,7 +150,18 @@ class UNetPlan:
                 self.f32[name] = hb.Planes(B, ref.C if name != "in" else cin0, ref.H, ref.W, device)
 
     def refresh_weights(self, state_dict, check_shapes=False):
-        """(Re)pack every filter from `state_dict` (training: the parameters change each optimizer step)."""
+        """(Re)pack every filter from `state_dict` (training: the parameters change each optimizer step).  Mode f16f8 repacks all
+        layers with ONE launch once the filters exist (hb.PackBatch over the parameters' storage); the first call, and any call
+        with tensors at other addresses, goes layer by layer (it also chooses the power-of-two pre-scales on the host)."""
+        tensors = []
+        for name in self.layers:
+            tensors += [state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")]]
+        batchable = self.q8 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
+        if batchable and getattr(self, "_pack", None) is not None and self._pack[0] == hb.PackBatch.key(tensors):
+            self._pack[1].run()
+            if getattr(self, "rnn", None) is not None:
+                self.rnn.refresh_weights(state_dict)
+            return
         for name, (ci, co, k) in self.layers.items():
             w = state_dict[param_key(name, "weight")].to(device=self.device, dtype=torch.float32)
             b = state_dict[param_key(name, "bias")].to(device=self.device, dtype=torch.float32)
@@ -164,6 +175,11 @@ class UNetPlan:
             else:
                 nb = self.Bd if name in self.DECODER else self.B
                 self.pk[name] = hb.PackedConv(w, b, nb, self.H // s, self.W // s, pool=name in POOLED)
+        self._pack = None
+        if batchable:
+            entries = [(self.pk[name], state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")], False)
+                       for name in self.layers]
+            self._pack = (hb.PackBatch.key(tensors), hb.PackBatch(entries, self.device))
         if getattr(self, "rnn", None) is not None:
             self.rnn.refresh_weights(state_dict)
 

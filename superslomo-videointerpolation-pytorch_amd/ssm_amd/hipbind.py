@@ -77,6 +77,8 @@ SIGNATURES = {
     "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_lrelu_bwd_q8": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_pack16q_job_blocks": (_c_int, [_c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "ssm_pack16q_weights_batch": (_c_int, [_vp, _c_int, _c_int, _vp]),
     "ssm_bias_grad_acc": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_wgrad_bf16x3": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -281,11 +283,17 @@ class PackedConv16:
     """Filter split into fp16 hi/lo parts, scaled by a power of two so both parts sit in fp16's
     normal range, repacked for the fp16-MFMA kernel's tile configuration."""
 
-    def __init__(self, weight, bias, W, q8=False, ups=False, scale=None):
+    def __init__(self, weight, bias, W, q8=False, ups=False, scale=None, shape=None, device=None):
         """ups: the filter feeds ssm_conv2d_ups_hl8_fwd (W = its OUTPUT width); in Q8 form the packing follows that kernel's tile.
-        scale: reuse a power-of-two pre-scale chosen earlier (training repacks every step; choosing it needs max|w| on the host)."""
-        require_device(weight, "conv weight")
-        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        scale: reuse a power-of-two pre-scale chosen earlier (training repacks every step; choosing it needs max|w| on the host).
+        weight=None with shape=(cout, cin, k), device and scale: buffers only, filled later by a PackBatch."""
+        if weight is None:
+            assert q8 and scale is not None and shape is not None and device is not None
+            self.cout, self.cin, self.k = shape
+        else:
+            require_device(weight, "conv weight")
+            self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+            device = weight.device
         self.q8 = bool(q8)
         lib = load()
         bn, kys = ctypes.c_int(0), ctypes.c_int(0)
@@ -301,7 +309,11 @@ class PackedConv16:
             scale = 2.0 ** (3 - math.ceil(math.log2(wmax))) if wmax > 0 else 1.0     # max|w|*scale in (4, 8]
         self.scale = float(scale)
         nb = lib.ssm_packed_bias_floats(self.cout, self.bn)
-        self.b = torch.empty(nb, dtype=torch.float32, device=weight.device)
+        self.b = torch.empty(nb, dtype=torch.float32, device=device)
+        if weight is None:
+            nbytes = lib.ssm_packed16q_weight_bytes(self.cout, self.cin_p, self.k, self.bn, self.kys)
+            self.w = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            return
         wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
         if q8:
             nbytes = lib.ssm_packed16q_weight_bytes(self.cout, self.cin_p, self.k, self.bn, self.kys)
@@ -313,6 +325,45 @@ class PackedConv16:
         self.w = torch.empty(nh, dtype=torch.float16, device=weight.device)
         check(lib.ssm_pack16_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout,
                                      self.cin, self.cin_p, self.k, self.bn, self.kys, self.scale, stream_ptr()))
+
+
+class SsmPackJob(ctypes.Structure):
+    """ssm_pack16q_job (include/ssm_hip.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("bp", ctypes.c_void_p),
+                ("Cout", ctypes.c_int), ("Cin", ctypes.c_int), ("CinP", ctypes.c_int), ("k", ctypes.c_int), ("BN", ctypes.c_int),
+                ("KYS", ctypes.c_int), ("scale", ctypes.c_float), ("transposed", ctypes.c_int), ("block_start", ctypes.c_int),
+                ("row_blocks", ctypes.c_int)]
+
+
+class PackBatch:
+    """Every Q8 filter of a U-Net repacked by one launch (ssm_pack16q_weights_batch).  entries: (PackedConv16 with q8 buffers,
+    fp32 OIHW weight tensor on the device, bias tensor or None, transposed) - transposed packs the data-gradient filter of the
+    forward weight.  The job table holds raw pointers: rebuild it when `key()` of the parameters changes."""
+
+    def __init__(self, entries, device):
+        lib = load()
+        jobs = (SsmPackJob * len(entries))()
+        off = 0
+        self.keep = []
+        for j, (pk, w, b, transposed) in zip(jobs, entries):
+            assert pk.q8 and w.is_contiguous() and w.dtype == torch.float32 and w.device == pk.w.device
+            assert tuple(w.shape) == ((pk.cin, pk.cout, pk.k, pk.k) if transposed else (pk.cout, pk.cin, pk.k, pk.k))
+            rb, bb = ctypes.c_int(0), ctypes.c_int(0)
+            check(lib.ssm_pack16q_job_blocks(pk.cout, pk.cin_p, pk.k, pk.bn, ctypes.byref(rb), ctypes.byref(bb)))
+            j.w, j.bias, j.wp, j.bp = w.data_ptr(), (b.data_ptr() if b is not None else None), pk.w.data_ptr(), pk.b.data_ptr()
+            j.Cout, j.Cin, j.CinP, j.k, j.BN, j.KYS = pk.cout, pk.cin, pk.cin_p, pk.k, pk.bn, pk.kys
+            j.scale, j.transposed, j.block_start, j.row_blocks = pk.scale, 1 if transposed else 0, off, rb.value
+            off += rb.value + bb.value
+            self.keep.append((pk, w, b))
+        self.n, self.total = len(entries), off
+        self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
+
+    @staticmethod
+    def key(tensors):
+        return tuple((t.data_ptr(), tuple(t.shape)) for t in tensors)
+
+    def run(self):
+        check(load().ssm_pack16q_weights_batch(self.table.data_ptr(), self.n, self.total, stream_ptr()))
 
 
 def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slope=0.1, fast=False):

@@ -120,3 +120,30 @@ def test_f16f8_pipeline_vs_f32_path_720p(dev):
     d = float((a - ref).abs().max())
     print("f16f8 vs f32 path at 736x1280: max-abs %.2e" % d)
     assert d < 7e-4
+
+
+def test_batched_pack_matches_per_layer_pack(dev):
+    """ssm_pack16q_weights_batch (one launch for many filters; transposed jobs read the forward OIHW tensor) writes the same bytes
+    as ssm_pack16q_weights per layer on the forward filter / on the materialised transposed + flipped filter."""
+    from ssm_amd import hipbind as hb
+    from ssm_amd.backward import transposed_filter
+    g = torch.Generator().manual_seed(77)
+    shapes = [(32, 16, 7, 128), (64, 32, 5, 64), (128, 96, 3, 32), (5, 32, 3, 128), (256, 512, 3, 16), (32, 6, 7, 128)]
+    entries_f, entries_t, want = [], [], []
+    for co, ci, k, W in shapes:
+        w = torch.randn(co, ci, k, k, generator=g).to(dev)
+        b = torch.randn(co, generator=g).to(dev)
+        ref_f = hb.PackedConv16(w, b, W, q8=True)
+        ref_t = hb.PackedConv16(transposed_filter(w), torch.zeros(ci, device=dev), W, q8=True, scale=ref_f.scale)
+        pf = hb.PackedConv16(None, None, W, q8=True, scale=ref_f.scale, shape=(co, ci, k), device=dev)
+        pt = hb.PackedConv16(None, None, W, q8=True, scale=ref_f.scale, shape=(ci, co, k), device=dev)
+        pf.w.fill_(0x5a), pt.w.fill_(0x5a), pf.b.fill_(3.0), pt.b.fill_(3.0)
+        entries_f.append((pf, w, b, False))
+        entries_t.append((pt, w, None, True))
+        want.append((ref_f, ref_t))
+    hb.PackBatch(entries_f + entries_t, dev).run()
+    torch.cuda.synchronize()
+    for (pf, _, _, _), (pt, _, _, _), (rf, rt), sh in zip(entries_f, entries_t, want, shapes):
+        assert (pf.bn, pf.kys, pt.bn, pt.kys) == (rf.bn, rf.kys, rt.bn, rt.kys)
+        assert torch.equal(pf.w, rf.w) and torch.equal(pf.b, rf.b), "forward filter %s" % (sh,)
+        assert torch.equal(pt.w, rt.w) and torch.equal(pt.b, rt.b), "data-gradient filter %s" % (sh,)
