@@ -63,6 +63,12 @@ def conv_flops_per_pair(h, w, n_t):
     return stage(1) + n_t * stage(2)
 
 
+TRAIN_DTYPE_NOTE = {
+    "f16f8": "f32 parameters/activations/gradients; products via 1x f16 + 2x block-scaled fp8 MFMA (forward, data gradients) and 3x bf16 "
+             "MFMA on hi/lo-split operands (weight gradients), f32 accumulate",
+    "f32": "f32 (fp32 MFMA)"}
+
+
 def train_bench(args):
     """BASELINE configs[2]: superslomo_original.ini training (FREEZE=FALSE), batch 16 = 2 samples per GPU x 8 of 352x352
     crops, t = i/8 per sample; forward + hand-written backward + gradient all-reduce (RCCL) + Adam.  A step = one
@@ -123,7 +129,7 @@ def train_bench(args):
     out = {"metric": "training samples/sec (352x352 crops, forward+backward+Adam)", "value": round(B * world * args.steps / elapsed, 3),
            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": TRAIN_DTYPE_NOTE.get(os.environ.get("SSM_TRAIN_PRECISION", "f16f8"), "f32"), "data": "synthetic",
            "config": {"workload": "superslomo_original.ini training, FREEZE=FALSE, %d samples/GPU of 352x352, %d GPU(s); "
                                   "losses: L1 reconstruction + 4 L1 warp terms + %s" % (B, world, "VGG16 conv4_3 perceptual term OFF" if args.no_perceptual else
                                                                                   "VGG16 conv4_3 perceptual term (synthetic VGG weights)"),

@@ -264,6 +264,70 @@ def test_training_step_with_adam_reduces_loss(dev):
     assert hist[-1] < hist[0]
 
 
+def _train_model(dev, seed_off=0):
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_state_dict
+    ov = synthetic_weight_overrides()
+    ov[("STAGE1", "FREEZE")] = "FALSE"
+    ov[("STAGE2", "FREEZE")] = "FALSE"
+    cfg = load_config("superslomo_original.ini", ov)
+    m = FullModel(cfg)
+    m.stage1_model.load_state_dict(synthetic_state_dict(1))
+    m.stage2_model.load_state_dict(synthetic_state_dict(2))
+    return m.to(dev).train(), cfg
+
+
+def test_gradients_accumulate_like_autograd(dev):
+    """The planned backward hands slices of its flat gradient buffers to `.grad` directly.  Semantics stay autograd's: a second
+    backward without zero_grad ADDS (the kept gradients are detached from the buffers first), zero_grad(set_to_none) restarts."""
+    from ssm_amd.weights import synthetic_frames
+    m, _ = _train_model(dev)
+    clips = torch.cat([synthetic_frames(3, 64, 64, seed=90), synthetic_frames(3, 64, 64, seed=91)], 0).to(dev)
+    xin, tgt = clips[:, [0, 2]], clips[:, 1:2]
+    t = torch.tensor([0.5, 0.25], device=dev).view(2, 1, 1, 1, 1)
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def backward_once():
+        _, losses = m(xin, t, tgt, None, False)
+        losses.mean(dim=0)[0].backward()
+
+    backward_once()
+    g1 = [p.grad.clone() for p in params]
+    backward_once()                                    # same batch again, no zero_grad: exactly twice the gradient (atomics aside)
+    for p, a in zip(params, g1):
+        assert float((p.grad - 2 * a).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-12
+    for p in params:
+        p.grad = None
+    backward_once()
+    for p, a in zip(params, g1):
+        assert float((p.grad - a).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-12
+
+
+def test_trainer_graph_replay_matches_eager_steps(dev):
+    """Trainer(graphs=True) (forward + backward replayed from a captured HIP graph, Adam outside) follows the eager trainer: same
+    losses over 3 steps on changing batches and the same parameters afterwards, up to the atomics' summation order."""
+    from ssm_amd.training import Trainer
+    from ssm_amd.weights import synthetic_frames
+    batches = []
+    for i in range(3):
+        clips = torch.cat([synthetic_frames(3, 64, 64, seed=100 + 2 * i), synthetic_frames(3, 64, 64, seed=101 + 2 * i)], 0).to(dev)
+        batches.append((clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous(),
+                        torch.tensor([0.5, 0.125 * (i + 1)], device=dev).view(2, 1, 1, 1, 1)))
+    hist, finals = {}, {}
+    for graphs in (False, True):
+        m, cfg = _train_model(dev)
+        tr = Trainer(m, cfg, graphs=graphs)
+        hist[graphs] = [tr.train_step(x, y, t).cpu() for x, y, t in batches]
+        finals[graphs] = [p.detach().clone() for p in m.parameters()]
+        assert (tr._graph is not None) == graphs
+    for a, b in zip(hist[False], hist[True]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+    for a, b in zip(finals[False], finals[True]):       # Adam normalises: a ~0 gradient whose sign flips with the atomics' order moves a weight by lr per step
+        assert float((a - b).abs().max()) <= 3 * 2 * tr.learning_rate + 1e-7
+        assert float((a - b).abs().mean()) <= 0.05 * tr.learning_rate
+
+
 def test_main_entry_point_trains_and_checkpoints(dev, tmp_path):
     """scripts/main.py (reference CLI flags): two epochs on synthetic batches, a checkpoint in the reference's layout
     that loads back through models.unetflow.get_model (strict)."""
