@@ -364,9 +364,17 @@ def main():
         wk = summ["warp"]
         wms = wk["ms"] / args.steps
         wach = wk["bytes"] / args.steps / (wms * 1e-3) / 1e9
+        wtraffic = None
+        if pmc and os.path.exists(pmc):   # same PMC passes as the conv figure: the two gather kernels' FETCH_SIZE x2 + WRITE_SIZE
+            pj = json.load(open(pmc))
+            wt = sum(v.get("hbm_bytes_per_step", 0.0) for k, v in pj.items() if k.startswith("flowinterp_inputs") or k.startswith("synthesize"))
+            wtraffic = wt or None
         out["roofline_warp"] = {"bound": "hbm", "kernel": "flowinterp_inputs_kernel + synthesize_kernel",
                                 "achieved": round(wach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round(wach / PEAK_HBM_GBS, 4), "traffic": None,
+                                "frac": round(wach / PEAK_HBM_GBS, 4), "traffic": wtraffic,
+                                "traffic_note": "HBM bytes per step of the two launches from the rocprofv3 --pmc passes (profiles/%s); above "
+                                                "bytes_per_step (algorithmic) by the bilinear taps that miss L2 and the 16-byte HL8 records "
+                                                "written for 10 of 16 channels" % (pmc_file or "-"),
                                 "bytes_per_step": wk["bytes"] / args.steps, "ms_per_step_in_kernel": round(wms, 3)}
         if args.detail:
             det = {fam: {n: {"ms_per_step": v[0] / args.steps, "tflops": (v[1] / v[0] / 1e9 if v[0] > 0 else 0.0)}
