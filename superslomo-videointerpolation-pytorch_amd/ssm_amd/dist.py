@@ -111,13 +111,49 @@ class GradientAllReduce:
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.bytes = 4 * n
+        self.last_runs = None
+
+    MAX_RUNS = 8     # in-place path: the gradients form at most this many contiguous memory runs
+
+    def runs(self):
+        """Contiguous memory runs of the gradients in parameter order, as 1-D tensors aliasing them - or None if some gradient
+        is missing / strided or there are more than MAX_RUNS runs.  The planned training step writes every gradient of a U-Net
+        into one flat buffer (ssm_amd.backward.UNetGrad.flat), so the two U-Nets are two runs."""
+        out, end = [], None
+        for p in self.params:
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+                return None
+            if out and g.untyped_storage().data_ptr() == out[-1][0].untyped_storage().data_ptr() and g.data_ptr() == end:
+                out[-1][1] += g.numel()
+            else:
+                out.append([g, g.numel()])
+                if len(out) > self.MAX_RUNS:
+                    return None
+            end = g.data_ptr() + 4 * g.numel()
+        return [torch.as_strided(g, (n,), (1,)) for g, n in out]
 
     def __call__(self):
         """Average the gradients over the ranks (no-op when not distributed).  Returns seconds spent (host clock
-        around an explicitly synchronised region when on a GPU)."""
+        around an explicitly synchronised region when on a GPU).  Gradients that already sit in a few flat buffers are
+        reduced in place (no gather / scatter copies: 2 x 96 launches per step); otherwise through one staging buffer."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return 0.0
         cuda = self.flat.is_cuda
+        runs = self.runs()
+        self.last_runs = None if runs is None else len(runs)
+        if runs is not None:
+            if cuda:
+                torch.cuda.synchronize(self.flat.device)
+            t0 = time.perf_counter()
+            for r in runs:
+                dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            if cuda:
+                torch.cuda.synchronize(self.flat.device)
+            el = time.perf_counter() - t0
+            for r in runs:
+                r.div_(dist.get_world_size())
+            return el
         off = 0
         for p in self.params:
             n = p.numel()

@@ -87,3 +87,32 @@ def test_gradient_allreduce_averages_over_ranks():
         assert torch.allclose(ret[r][0], torch.full((7, 3), 1.5))
         assert torch.allclose(ret[r][1], torch.arange(11, dtype=torch.float32) * 1.5)
         assert ret[r][2] == 4 * (21 + 11)
+
+
+def _ar_flat_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ssm_amd import dist as sd
+    sd.init("gloo")
+    shapes = [(4, 3, 3, 3), (4,), (2, 4, 3, 3), (2,)]
+    params = [torch.nn.Parameter(torch.zeros(sh)) for sh in shapes]
+    # the layout of the planned training step: one flat buffer per U-Net, .grad = slices of it (two buffers = two runs)
+    flats = [torch.arange(108 + 4, dtype=torch.float32) * (rank + 1), torch.arange(72 + 2, dtype=torch.float32) * (rank + 3)]
+    params[0].grad, params[1].grad = flats[0][:108].view(shapes[0]), flats[0][108:].view(shapes[1])
+    params[2].grad, params[3].grad = flats[1][:72].view(shapes[2]), flats[1][72:].view(shapes[3])
+    ar = sd.GradientAllReduce(params)
+    ar()
+    ret[rank] = (ar.last_runs, [f.clone() for f in flats], params[2].grad.data_ptr() == flats[1].data_ptr())
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_in_place_on_flat_buffers():
+    """Gradients that are slices of flat buffers (ssm_amd.backward.UNetGrad.flat) are all-reduced in place, one collective per
+    buffer, and stay slices of those buffers."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ar_flat_worker, args=(2, free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        runs, flats, aliased = ret[r]
+        assert runs == 2 and aliased
+        assert torch.allclose(flats[0], torch.arange(112, dtype=torch.float32) * 1.5)
+        assert torch.allclose(flats[1], torch.arange(74, dtype=torch.float32) * 3.5)

@@ -293,6 +293,9 @@ def test_gradients_accumulate_like_autograd(dev):
         losses.mean(dim=0)[0].backward()
 
     backward_once()
+    from ssm_amd.dist import GradientAllReduce
+    runs = GradientAllReduce(params).runs()            # the all-reduce works in place on the two U-Nets' flat buffers
+    assert runs is not None and len(runs) == 2 and sum(r.numel() for r in runs) == sum(p.numel() for p in params)
     g1 = [p.grad.clone() for p in params]
     backward_once()                                    # same batch again, no zero_grad: exactly twice the gradient (atomics aside)
     for p, a in zip(params, g1):
