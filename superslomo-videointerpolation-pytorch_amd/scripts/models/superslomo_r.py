@@ -65,6 +65,9 @@ class _TrainStep(torch.autograd.Function):
         sd2 = {k: v.detach() for k, v in model.stage2_model.state_dict().items()}
         eng.s1.refresh_weights(sd1)
         eng.s2.refresh_weights(sd2)
+        pt = model.loss.perceptual_term(B, H, W, img6.device)
+        if pt is not None and os.environ.get("SSM_VGG_OVERLAP", "1") != "0":
+            pt.begin_target(target)      # the target's VGG features do not depend on the forward: second stream, beside the U-Nets
         pred = eng.run(img6, t, want_aux=True).clone()
         f01, f10, e1, e0, _, _, _ = eng.intermediates()
         losses = model.loss.losses_from_parts(img6, torch.cat([f01, f10], 1), e1, e0, eng.s2.t["out"].interior, pred, target)

@@ -85,31 +85,34 @@ class VGGFeatures:
         e0.record()
         return e1
 
-    def forward(self, x):
-        """x: [B,3,H,W] device tensor -> Planes [B,512,H/8,W/8] (valid until the next forward)."""
+    def forward(self, x, b0=0):
+        """x: [nb,3,H,W] device tensor, written to batch entries [b0, b0+nb) of the plan (default: the whole batch)
+        -> Planes [B,512,H/8,W/8] (valid until the next forward over those entries)."""
         hb.require_device(x, "perceptual-loss input")
-        assert tuple(x.shape) == (self.B, 3, self.H, self.W), "VGG input has shape %s" % (tuple(x.shape),)
+        nb = x.shape[0]
+        assert tuple(x.shape[1:]) == (3, self.H, self.W) and 0 <= b0 and b0 + nb <= self.B, "VGG input has shape %s" % (tuple(x.shape),)
         lib, st = hb.load(), hb.stream_ptr()
         xs = x if x.stride(3) == 1 else x.contiguous()
-        hb.check(lib.ssm_copy_view(hb.view_of(xs), self.t["x"].view(), self.B, 3, self.H, self.W, st))
+        hb.check(lib.ssm_copy_view(hb.view_of(xs), self.t["x"].view(b0=b0), nb, 3, self.H, self.W, st))
         if self.q8:
-            self.q["x"].load(xs)
+            q = self.q["x"]
+            hb.check(lib.ssm_hq8_from_f32(hb.view_of(xs), q.view(b0=b0), nb, 3, q.G, self.H, self.W, st))
         for s in self.steps:
             if s[0] == "pool":
                 src, dst = self.t[s[1]], self.t[s[2]]
-                hb.check(lib.ssm_maxpool2_fwd(src.view(), dst.view(), self.B, src.C, src.H, src.W, st))
+                hb.check(lib.ssm_maxpool2_fwd(src.view(b0=b0), dst.view(b0=b0), nb, src.C, src.H, src.W, st))
                 if self.q8:          # the next convolution reads the pooled tensor in the Q8 form
                     q = self.q[s[2]]
-                    hb.check(lib.ssm_hq8_from_f32(dst.view(), q.view(), self.B, dst.C, q.G, dst.H, dst.W, st))
+                    hb.check(lib.ssm_hq8_from_f32(dst.view(b0=b0), q.view(b0=b0), nb, dst.C, q.G, dst.H, dst.W, st))
                 continue
             _, idx, cin, cout, sname, dname = s
             src, dst, pk = self.t[sname], self.t[dname], self.pk[idx]
-            e1 = self._span("vgg_fwd", "features.%d" % idx, 2.0 * self.B * src.H * src.W * cin * cout * 9)
+            e1 = self._span("vgg_fwd", "features.%d" % idx, 2.0 * nb * src.H * src.W * cin * cout * 9)
             if self.q8:
-                hb.conv2d_hl8(self.q[sname].view(), pk.cin_p, None, 0, pk, self.q[dname].view(), dst.view(), None, self.B, src.H, src.W,
-                              lrelu=True, slope=0.0)
+                hb.conv2d_hl8(self.q[sname].view(b0=b0), pk.cin_p, None, 0, pk, self.q[dname].view(b0=b0), dst.view(b0=b0), None, nb,
+                              src.H, src.W, lrelu=True, slope=0.0)
             else:
-                hb.conv2d(src.view(), pk.cin_p, None, 0, pk, dst.view(), None, self.B, src.H, src.W, lrelu=True, slope=0.0)
+                hb.conv2d(src.view(b0=b0), pk.cin_p, None, 0, pk, dst.view(b0=b0), None, nb, src.H, src.W, lrelu=True, slope=0.0)
             if e1 is not None:
                 e1.record()
         return self.t[self.out]
@@ -171,13 +174,30 @@ class PerceptualTerm:
         self.vgg = VGGFeatures(vgg_state_dict, 2 * B, H, W, device, mode)
         self.coef = torch.empty(B, dtype=torch.float32, device=device)
         self.both = torch.empty(2 * B, 3, H, W, dtype=torch.float32, device=device)
+        self._side, self._pending = None, None
+
+    def begin_target(self, target):
+        """Start the target's half of the VGG pass on a second stream (the training step calls this before the U-Net forward: the
+        target is known then, and the batch-2 U-Net leaves the GPU room).  forward(pred, target) with the SAME tensor then runs the
+        predicted frames only and joins."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=target.device)
+        self._side.wait_stream(torch.cuda.current_stream())      # the last step's readers of these buffers are queued before this
+        with torch.cuda.stream(self._side):
+            self.vgg.forward(target, b0=self.B)
+        self._pending = target
 
     def forward(self, pred, target):
         """-> [B] unweighted per-sample feature MSE."""
         B = self.B
-        self.both[:B].copy_(pred)
-        self.both[B:].copy_(target)
-        f = self.vgg.forward(self.both).interior
+        if self._pending is not None and self._pending is target:
+            f = self.vgg.forward(pred, b0=0).interior
+            torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            self.both[:B].copy_(pred)
+            self.both[B:].copy_(target)
+            f = self.vgg.forward(self.both).interior
+        self._pending = None
         return ((f[:B] - f[B:]) ** 2).reshape(B, -1).mean(dim=1)
 
     def grad_pred(self, weight):
