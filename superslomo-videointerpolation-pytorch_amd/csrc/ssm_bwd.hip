@@ -873,8 +873,7 @@ extern "C" int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, 
     const int ca = (Cout + 31) / 32, cb = (Cin + 31) / 32;
     // split of the image rows over gridDim.z: about two workgroups per CU, each walking >= 16 rows (shorter slices pay the ring
     // warm-up and the atomic epilogue more often: 2048 workgroups x 8 rows measured 40 % slower over the step's layers)
-    static const int tgt_wgs = getenv("SSM_WGRAD_WGS") ? atoi(getenv("SSM_WGRAD_WGS")) : 512;
-    static const int min_steps = getenv("SSM_WGRAD_MINSTEPS") ? atoi(getenv("SSM_WGRAD_MINSTEPS")) : 16;
+    const int tgt_wgs = 512, min_steps = 16;
     // tile configuration: (filter size, filter rows per workgroup, segment, cout tiles, cin tiles of the 4 waves)
 #define SSM_WGRAD16(KS_, TY_, SEG_, WAN_, WBN_)                                                                                   \
     {                                                                                                                             \
