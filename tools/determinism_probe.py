@@ -1,6 +1,7 @@
 """Bitwise determinism of a PairEngine: the same pair run (a) repeatedly on one stream and (b) on two engines on two
 concurrent HIP streams must leave identical bytes in every activation buffer.  Prints, per buffer in execution order,
-how many runs differed from the first.  Usage: python tools/determinism_probe.py [mode] [H] [W] [reps]"""
+how many runs differed from the first.  Usage: python tools/determinism_probe.py [mode] [H] [W] [reps] [mode of the 2nd stream's engine]
+$SSM_PROBE_LIB: load this build of libssm_hip.so instead (e.g. one compiled with the SLP vectoriser on, to reproduce the hazard)."""
 import os
 import sys
 
@@ -10,6 +11,10 @@ for p in (ROOT, PKG, os.path.join(PKG, "scripts")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 
+from ssm_amd import hipbind as _hb  # noqa: E402
+
+if os.environ.get("SSM_PROBE_LIB"):
+    _hb.LIB_PATH = os.path.abspath(os.environ["SSM_PROBE_LIB"])
 from ssm_amd.engine import PairEngine  # noqa: E402
 from ssm_amd.weights import synthetic_frames, synthetic_state_dict  # noqa: E402
 
@@ -52,6 +57,7 @@ def main():
     H = int(sys.argv[2]) if len(sys.argv) > 2 else 96
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 128
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    mode2 = sys.argv[5] if len(sys.argv) > 5 else mode       # what the OTHER stream runs beside engine 0
     dev = torch.device("cuda:0")
     sd1, sd2 = synthetic_state_dict(1), synthetic_state_dict(2)
     sd1 = {k: v.to(dev) for k, v in sd1.items()}
@@ -59,7 +65,7 @@ def main():
     x = synthetic_frames(2, H, W, seed=20).to(dev).reshape(1, 6, H, W)
     t = torch.tensor([0.25, 0.5, 0.75], device=dev)
     e0 = PairEngine(sd1, sd2, 1, 3, H, W, dev, True, mode)
-    e1 = PairEngine(sd1, sd2, 1, 3, H, W, dev, True, mode)
+    e1 = PairEngine(sd1, sd2, 1, 3, H, W, dev, True, mode2)
     torch.cuda.synchronize()
     e0.run(x, t, False)
     torch.cuda.synchronize()
@@ -82,7 +88,7 @@ def main():
                 with torch.cuda.stream(sb):
                     e1.run(x, t, False)
                 torch.cuda.synchronize()
-                snaps = [snapshot(e0), snapshot(e1)]
+                snaps = [snapshot(e0)] + ([snapshot(e1)] if mode2 == mode else [])
             for s in snaps:
                 for n in names:
                     bits = (lambda v: v.view(torch.int16) if v.dtype == torch.float16 else v.view(torch.int32))
@@ -116,7 +122,7 @@ def main():
                                 yy, r = divmod(r, pl.Wp * 8)
                                 xx, e = divmod(r, 8)
                                 print("     b*G+g %d plane %d y %d x %d e %d: got %04x ref %04x" % (bg, plane, yy, xx, e, int(bits(s[n])[i]) & 0xffff, int(bits(ref[n])[i]) & 0xffff))
-        print("== %s (%s, %dx%d, %d reps)" % (label, mode, H, W, reps))
+        print("== %s (%s%s, %dx%d, %d reps)" % (label, mode, "" if label == "one stream" else " beside " + mode2, H, W, reps))
         for n in names:
             if bad[n]:
                 print("  %-10s differed in %d snapshots, max |diff| %.3e" % (n, bad[n], worst[n]))
