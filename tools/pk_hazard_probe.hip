@@ -72,12 +72,31 @@ __global__ __launch_bounds__(256) void victim(const float *__restrict__ in, unsi
     if (nbad) atomicAdd(bad, nbad);
 }
 
-// co-runners: 0 = block-scaled fp8 MFMA (the f16f8 convolutions' instruction), 1 = fp16 MFMA, 2 = plain VALU fma
+// co-runners: 0 = block-scaled fp8 MFMA (the f16f8 convolutions' instruction), 1 = fp16 MFMA, 2 = plain VALU fma,
+// 3 = fp16 MFMA fed by ds_read_b128 (the convolutions' inner loop shape), 4 = ds_read_b128 only
 template <int KIND>
 __global__ __launch_bounds__(256) void corunner(float *__restrict__ out, int iters) {
     f16v acc0 = {0}, acc1 = {0};
     float s = threadIdx.x * 1e-3f;
-    if (KIND == 0) {
+    __shared__ __attribute__((aligned(16))) char lds[32768];
+    if (KIND >= 3) {
+        for (int i = threadIdx.x; i < 8192; i += 256) reinterpret_cast<int *>(lds)[i] = 0x3c003c00 + i;
+        __syncthreads();
+        h8 a = {0}, b = {0};
+        for (int i = 0; i < iters; ++i) {
+            const int off = ((i * 4096 + threadIdx.x * 16) & 32767) & ~15;
+            const h8 x0 = *reinterpret_cast<const h8 *>(lds + off);
+            const h8 x1 = *reinterpret_cast<const h8 *>(lds + ((off + 8192) & 32767));
+            if (KIND == 3) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, x0, acc1, 0, 0, 0);
+            } else {
+                a += x0;
+                b += x1;
+            }
+        }
+        s += (float)a[0] + (float)b[1];
+    } else if (KIND == 0) {
         i8v a, b;
         for (int e = 0; e < 8; ++e) { a[e] = 0x38383838 + threadIdx.x; b[e] = 0x30303030 + e; }
         for (int i = 0; i < iters; ++i) {
@@ -110,6 +129,8 @@ static void run_variant(const char *label, const float *din, unsigned *dbad, uns
         if (co_kind == 0) hipLaunchKernelGGL(corunner<0>, dim3(512), dim3(256), 0, sc, dout, 20000);
         if (co_kind == 1) hipLaunchKernelGGL(corunner<1>, dim3(512), dim3(256), 0, sc, dout, 40000);
         if (co_kind == 2) hipLaunchKernelGGL(corunner<2>, dim3(512), dim3(256), 0, sc, dout, 40000);
+        if (co_kind == 3) hipLaunchKernelGGL(corunner<3>, dim3(512), dim3(256), 0, sc, dout, 40000);
+        if (co_kind == 4) hipLaunchKernelGGL(corunner<4>, dim3(512), dim3(256), 0, sc, dout, 40000);
         for (int j = 0; j < 8; ++j) hipLaunchKernelGGL(victim<V>, dim3(1024), dim3(256), 0, sv, din, dbad, dlanes, 400);
         CHECK(hipDeviceSynchronize());
     }
@@ -136,8 +157,8 @@ int main() {
     hipStream_t sv, sc;
     CHECK(hipStreamCreate(&sv));
     CHECK(hipStreamCreate(&sc));
-    const char *co_names[4] = {"block-scaled fp8 MFMA", "fp16 MFMA", "VALU fma", "nothing"};
-    for (int co = 0; co < 4; ++co) {
+    const char *co_names[6] = {"block-scaled fp8 MFMA", "fp16 MFMA", "VALU fma", "fp16 MFMA fed by ds_read_b128", "ds_read_b128 only", "nothing"};
+    for (int co = 0; co < 6; ++co) {
         printf("co-runner on the second stream: %s\n", co_names[co]);
         run_variant<0>("pk_mul; s_nop 0; pk_add op_sel swap", din, dbad, dlanes, dout, sv, sc, co);
         run_variant<4>("pk_mul; pk_add op_sel swap (no nop)", din, dbad, dlanes, dout, sv, sc, co);
