@@ -146,6 +146,44 @@ int ssm_pack16q_weights(const float *w_oihw, const float *bias, void *w_packed, 
                         int Cin_padded, int k, int BN, int KYS, float scale, void *stream);
 int ssm_flowinterp_inputs_hq8_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_hview out16, ssm_view flows4, int B, int H,
                                   int W, void *stream);      /* ssm_flowinterp_inputs_hl8_fwd with a Q8 output */
+/* Sub-pixel form of the decoder's `F.upsample(cat([x, skip]), scale 2, bilinear)` + 3x3 conv (scripts/models/flow_computation.py:
+ * 215-289, flow_interpolation.py:220-281): conv3x3(upsample2x(X)) is a plain 3x3 convolution of the LOW-res tensors with 4*Cr
+ * outputs - one effective filter M_a * W * M_b^T per output parity (a, b), packed by the caller as channel (2a + b)*Cr + c - and a
+ * pixel-shuffle store: channel (2a + b)*Cr + c of low-res pixel (y, x) lands at pixel (2y + a, 2x + b) of channel c of y_hl8
+ * (transposed: (2x + b, 2y + a)).  y_hl8 points at the destination pixel of this launch's low-res pixel (0, 0); H, W = low-res
+ * extent of the launch.  The rows / columns 0 and last need their own effective filters (bilinear clamping vs the convolution's
+ * zero padding): the caller overwrites them from strip launches (H = 1 views; columns through ssm_hl8_gather_cols copies).
+ * Q8 operands only (flags must carry SSM_FLAG_Q8).                                                                          */
+int ssm_conv2d_hl8_subpixel_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, const void *w_packed, const float *bias_packed,
+                                float inv_wscale, ssm_hview y_hl8, int B, int H, int W, int Cr, int transposed, float slope, int flags,
+                                void *stream);
+/* The main problem, the four border strips and the four corners of a sub-pixel decoder level as ONE launch: every problem is one
+ * ssm_conv2d_hl8_subpixel_fwd call (all with the filter packing of ssm_conv16q_config(3, 4*Cr, wcfg)); skip_y / skip_x make a
+ * problem leave the first and last row / column of its extent to the problem that owns them, so the outputs are disjoint and the
+ * problems need no ordering.  ssm_conv16_subpixel_plan fills `table_host` (ssm_conv16_subpixel_table_bytes(n) bytes; copy it to
+ * device memory once - it holds the raw pointers of the views) and block_start[n+1]; ssm_conv16_subpixel_run launches it.     */
+typedef struct ssm_subpixel_problem {
+    ssm_hview x1;
+    int C1;
+    ssm_hview x2;
+    int C2;
+    const void *w_packed;
+    const float *bias_packed;
+    float inv_wscale;
+    ssm_hview y_hl8;
+    int H, W;
+    int transposed;
+    int skip_y, skip_x;
+} ssm_subpixel_problem;
+size_t ssm_conv16_subpixel_table_bytes(int n);
+int ssm_conv16_subpixel_plan(const ssm_subpixel_problem *problems, int n, int B, int Cr, int wcfg, float slope, int flags,
+                             void *table_host, size_t table_bytes, int *block_start);
+int ssm_conv16_subpixel_run(const void *table_device, int n, const int *block_start, int Cr, int wcfg, int Cin, void *stream);
+/* Image columns of the Ga + Gb groups of a two-source HL8 / Q8 tensor as the rows of a zero-framed tensor (record copies, both
+ * planes): dst rows 0..ncols-1 = columns col0.., and if col1 >= 0 dst rows ncols+1..2*ncols = columns col1.. (row ncols is left
+ * alone: the zero gap between the two column strips' neighbourhoods).                                                          */
+int ssm_hl8_gather_cols(ssm_hview a, int Ga, ssm_hview b, int Gb, ssm_hview dst, int B, int H, int col0, int ncols, int col1,
+                        void *stream);
 /* All filters of a U-Net packed (Q8 form) by ONE launch: the training step repacks every filter after each optimizer step
  * (scripts/main.py:188-197 updates the nn.Conv2d weights of scripts/models/layers.py:21-33 in place).  A job describes one
  * ssm_pack16q_weights call; transposed = 1 packs the data-gradient filter W'[co][ci][ky][kx] = w[ci][co][k-1-ky][k-1-kx] straight

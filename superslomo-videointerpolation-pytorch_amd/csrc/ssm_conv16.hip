@@ -65,6 +65,18 @@ struct Conv16Params {
     int tilesX, tilesY, NB;
     float slope;
     int lrelu;
+    int shuf;                  // 0, or Cr: the Cout = 4*Cr outputs are the four sub-pixel parities (pa, pb) of Cr channels; output
+                               // (y, x) of channel (2*pa + pb)*Cr + c is stored at pixel (2y + pa, 2x + pb) of channel c
+    int shuf_t;                // shuf with the kernel's axes swapped relative to the image: pixel (2x + pb, 2y + pa)
+    int skipy, skipx;          // shuf: do not store the first / last row (column) of this launch's extent (another problem owns them)
+};
+
+// several problems of one tile configuration in one launch (sub-pixel decoder level: main + border strips + corners, disjoint outputs)
+#define SSM_MULTI_MAX 12
+struct Conv16Multi {
+    const Conv16Params *table;     // device memory
+    int n;
+    int start[SSM_MULTI_MAX + 1];  // first workgroup of each problem; start[n] = grid size
 };
 
 // MODE_: 0 = plain fp16 (hi*hi), 1 = split (3 fp16 MFMAs per product), 2 = Q8 (1 fp16 MFMA + 2 block-scaled fp8 MFMAs per product)
@@ -373,6 +385,20 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
                     const int m = my * C::MTX + mx;
                     const int y = ybase + my, x = xbase + mx * 32;
                     if (y < p.H && x < p.W) {
+                        if (p.shuf) {          // sub-pixel form of conv(upsample2x(.)): pixel-shuffle store (Q8 / HL8 destination only)
+                            const bool owned = !((p.skipy && (y == 0 || y == p.H - 1)) || (p.skipx && (x == 0 || x == p.W - 1)));
+                            if (co0 < p.Cout && owned) {
+                                const int par = co0 / p.shuf, cr = co0 - par * p.shuf;
+                                const int Y = p.shuf_t ? 2 * x + (par & 1) : 2 * y + (par >> 1);
+                                const int X = p.shuf_t ? 2 * y + (par >> 1) : 2 * x + (par & 1);
+                                char *d = p.dh + (((long long)b * p.dhsb + (long long)(cr >> 3) * p.dhsg + (long long)Y * p.dhsh + X) * 16);
+                                if constexpr (C::Q8)
+                                    split_store_q8(d, p.dhsp * 16, p.dhsg * 16, cr >> 3, half, v[m][0], v[m][1], v[m][2], v[m][3]);
+                                else
+                                    split_store(d + half * 8, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
+                            }
+                            continue;
+                        }
                         if (p.dh && co0 < p.Cout) {
                             char *d = p.dh + (((long long)b * p.dhsb + (long long)(co0 >> 3) * p.dhsg + (long long)y * p.dhsh + x) * 16);
                             if constexpr (C::Q8)
@@ -416,7 +442,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP) + 3) / 4) void conv16_kernel(const Conv16Params p) {
+__device__ __forceinline__ void conv16_body(const Conv16Params &p, const int blk, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int KYS = C::KYS, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT, NW = C::NW, NL = C::NLOAD;
     char *const pbuf0 = lds;
@@ -430,7 +456,7 @@ __global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP
     const int lw = C::NP ? wid - NW : wid;                 // index among the loading waves
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
 
-    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    int id = ssm_xcd_tile(blk, nblk);
     const int nb = id % p.NB;
     id /= p.NB;
     const int tx = id % p.tilesX;
@@ -812,6 +838,20 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
             __syncthreads();
         }
     }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP) + 3) / 4) void conv16_kernel(const Conv16Params p) {
+    conv16_body<C>(p, blockIdx.x, gridDim.x);
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS_ALL, (C::BLOCKS_PER_CU * (C::NW + C::NP) + 3) / 4) void conv16_multi_kernel(const Conv16Multi m) {
+    int i = 0;
+    for (int j = 1; j < m.n; ++j)
+        if ((int)blockIdx.x >= m.start[j]) i = j;
+    const Conv16Params p = m.table[i];
+    conv16_body<C>(p, (int)blockIdx.x - m.start[i], m.start[i + 1] - m.start[i]);
 }
 
 // ---- tile configurations --------------------------------------------------------------------------
@@ -1275,6 +1315,9 @@ extern "C" int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, co
     p.H = H; p.W = W; p.Cout = Cout;
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.shuf = 0;
+    p.shuf_t = 0;
+    p.skipy = p.skipx = 0;
     hipStream_t st = (hipStream_t)stream;
     if (flags & SSM_FLAG_Q8) {
         SSM_REQUIRE((!y_hl8.ptr && !pool_hl8.ptr) || Cout % 16 == 0, "conv16: Q8 output needs Cout %% 16 == 0 (got %d)", Cout);
@@ -1282,6 +1325,167 @@ extern "C" int ssm_conv2d_hl8_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, co
     }
     if (flags & SSM_FLAG_FP16_FAST) return dispatch16<0>(p, B, k, st);
     return dispatch16<1>(p, B, k, st);
+}
+
+// Sub-pixel form of conv3x3(upsample2x(cat[x1, x2])): a plain 3x3 convolution of the LOW-res tensors with 4*Cr outputs (effective
+// filters per output parity, built by the caller) whose epilogue scatters channel (2*pa + pb)*Cr + c of low-res pixel (y, x) to
+// pixel (2y + pa, 2x + pb) of channel c of y_hl8 (transposed: (2x + pb, 2y + pa), for column strips run on transposed copies).
+// y_hl8 points at the destination pixel of low-res pixel (0, 0) of this launch.  Q8 form only.
+extern "C" int ssm_conv2d_hl8_subpixel_fwd(ssm_hview x1, int C1, ssm_hview x2, int C2, const void *w_packed, const float *bias_packed,
+                                           float wscale, ssm_hview y_hl8, int B, int H, int W, int Cr, int transposed, float slope,
+                                           int flags, void *stream) {
+    SSM_REQUIRE(B > 0 && H > 0 && W > 0 && Cr > 0 && C1 > 0 && C2 >= 0, "conv16 subpixel: bad sizes");
+    SSM_REQUIRE(x1.ptr && w_packed && bias_packed && y_hl8.ptr, "conv16 subpixel: null pointer");
+    SSM_REQUIRE((flags & SSM_FLAG_Q8) && Cr % 16 == 0, "conv16 subpixel: Q8 operands and Cr %% 16 == 0 (got %d)", Cr);
+    SSM_REQUIRE(C1 % 16 == 0 && C2 % 16 == 0, "conv16 subpixel: channel counts (%d,%d) must be multiples of 16", C1, C2);
+    SSM_REQUIRE(ssm::aligned16(x1.ptr) && ssm::aligned16(w_packed) && ssm::aligned16(y_hl8.ptr), "conv16 subpixel: 16-byte alignment");
+    if (C2 > 0) SSM_REQUIRE(x2.ptr && x2.sh == x1.sh && x2.sg == x1.sg && x2.sp == x1.sp, "conv16 subpixel: cat sources must share strides");
+    SSM_REQUIRE(x1.sg * 32 < 0x7fffffffLL, "conv16 subpixel: plane too large for 32-bit piece offsets");
+    Conv16Params p;
+    p.src1 = (const char *)x1.ptr;
+    p.src2 = C2 > 0 ? (const char *)x2.ptr : (const char *)x1.ptr;
+    p.sb1 = x1.sb;
+    p.sb2 = C2 > 0 ? x2.sb : 0;
+    p.sg = x1.sg;
+    p.sp = x1.sp;
+    p.sh = x1.sh;
+    p.C1 = C1;
+    p.Cin = C1 + C2;
+    p.wpk = (const char *)w_packed;
+    p.bias = bias_packed;
+    p.wscale = wscale;
+    p.dh = (char *)y_hl8.ptr;
+    p.dhsb = y_hl8.sb; p.dhsg = y_hl8.sg; p.dhsp = y_hl8.sp; p.dhsh = y_hl8.sh;
+    p.df = nullptr;
+    p.dfsb = p.dfsc = 0; p.dfsh = 0;
+    p.ph = nullptr;
+    p.phsb = p.phsg = p.phsp = 0; p.phsh = 0;
+    p.H = H; p.W = W; p.Cout = 4 * Cr;
+    p.slope = slope;
+    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.shuf = Cr;
+    p.shuf_t = transposed ? 1 : 0;
+    p.skipy = p.skipx = 0;
+    return dispatch16<2>(p, B, 3, (hipStream_t)stream);
+}
+
+// ---- the nine problems of a sub-pixel decoder level in ONE launch ------------------------------------------------------------------
+// All problems use the tile configuration of pick16(3, 4*Cr, wcfg) (their filters are packed for it) and own disjoint output pixels
+// (skip_y / skip_x), so they need no ordering: the strips' and corners' few workgroups run beside the main problem's instead of as
+// eight latency-bound launches behind it.
+template <class C>
+static int fill_problem(Conv16Params &p, int B, long long &blocks) {
+    p.tilesX = (p.W + C::TW - 1) / C::TW;
+    p.tilesY = (p.H + C::TH - 1) / C::TH;
+    p.NB = (p.Cout + C::BN - 1) / C::BN;
+    blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    return SSM_OK;
+}
+
+template <class C>
+static int launch16_multi(const Conv16Multi &m, hipStream_t st) {
+    if (!reserve_lds((const void *)conv16_multi_kernel<C>, C::LDS_BYTES)) return SSM_E_LAUNCH;
+    hipLaunchKernelGGL(conv16_multi_kernel<C>, dim3((unsigned)m.start[m.n]), dim3(C::NTHREADS_ALL), C::LDS_BYTES, st, m);
+    return ssm::check_launch("ssm_conv16_subpixel_run");
+}
+
+extern "C" size_t ssm_conv16_subpixel_table_bytes(int n) { return sizeof(Conv16Params) * (size_t)(n > 0 ? n : 0); }
+
+extern "C" int ssm_conv16_subpixel_plan(const ssm_subpixel_problem *pr, int n, int B, int Cr, int wcfg, float slope, int flags,
+                                        void *table_host, size_t table_bytes, int *block_start) {
+    SSM_REQUIRE(pr && table_host && block_start && n > 0 && n <= SSM_MULTI_MAX && B > 0 && Cr > 0 && Cr % 16 == 0, "subpixel_plan: bad arguments");
+    SSM_REQUIRE(table_bytes >= sizeof(Conv16Params) * (size_t)n, "subpixel_plan: table buffer too small");
+    SSM_REQUIRE(flags & SSM_FLAG_Q8, "subpixel_plan: Q8 operands only");
+    const int kind = pick16(3, 4 * Cr, wcfg);
+    Conv16Params *tab = (Conv16Params *)table_host;
+    long long off = 0;
+    for (int i = 0; i < n; ++i) {
+        const ssm_subpixel_problem &q = pr[i];
+        SSM_REQUIRE(q.x1.ptr && q.w_packed && q.bias_packed && q.y_hl8.ptr && q.H > 0 && q.W > 0 && q.C1 > 0 && q.C1 % 16 == 0 && q.C2 % 16 == 0,
+                    "subpixel_plan: problem %d malformed", i);
+        if (q.C2 > 0) SSM_REQUIRE(q.x2.ptr && q.x2.sh == q.x1.sh && q.x2.sg == q.x1.sg && q.x2.sp == q.x1.sp, "subpixel_plan: cat sources must share strides");
+        Conv16Params &p = tab[i];
+        p.src1 = (const char *)q.x1.ptr;
+        p.src2 = q.C2 > 0 ? (const char *)q.x2.ptr : (const char *)q.x1.ptr;
+        p.sb1 = q.x1.sb;
+        p.sb2 = q.C2 > 0 ? q.x2.sb : 0;
+        p.sg = q.x1.sg; p.sp = q.x1.sp; p.sh = q.x1.sh;
+        p.C1 = q.C1; p.Cin = q.C1 + q.C2;
+        p.wpk = (const char *)q.w_packed;
+        p.bias = q.bias_packed;
+        p.wscale = q.inv_wscale;
+        p.dh = (char *)q.y_hl8.ptr;
+        p.dhsb = q.y_hl8.sb; p.dhsg = q.y_hl8.sg; p.dhsp = q.y_hl8.sp; p.dhsh = q.y_hl8.sh;
+        p.df = nullptr; p.dfsb = p.dfsc = 0; p.dfsh = 0;
+        p.ph = nullptr; p.phsb = p.phsg = p.phsp = 0; p.phsh = 0;
+        p.H = q.H; p.W = q.W; p.Cout = 4 * Cr;
+        p.slope = slope;
+        p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+        p.shuf = Cr; p.shuf_t = q.transposed ? 1 : 0;
+        p.skipy = q.skip_y ? 1 : 0; p.skipx = q.skip_x ? 1 : 0;
+        long long blocks = 0;
+        switch (kind) {
+            case H3N32: fill_problem<C16K3N32<2>>(p, B, blocks); break;
+            case H3N32D: fill_problem<C16K3N32D<2>>(p, B, blocks); break;
+            case H3N64: fill_problem<C16K3N64<2>>(p, B, blocks); break;
+            case H3N128: fill_problem<C16K3N128<2>>(p, B, blocks); break;
+            case H3N128S: fill_problem<C16K3N128S<2>>(p, B, blocks); break;
+            default: ssm::set_error("subpixel_plan: no tile configuration"); return SSM_E_UNSUPPORTED;
+        }
+        block_start[i] = (int)off;
+        off += blocks;
+        SSM_REQUIRE(off < 0x7fffffffLL, "subpixel_plan: grid too large");
+    }
+    block_start[n] = (int)off;
+    return SSM_OK;
+}
+
+extern "C" int ssm_conv16_subpixel_run(const void *table_device, int n, const int *block_start, int Cr, int wcfg, int Cin, void *stream) {
+    SSM_REQUIRE(table_device && block_start && n > 0 && n <= SSM_MULTI_MAX, "subpixel_run: bad arguments");
+    Conv16Multi m;
+    m.table = (const Conv16Params *)table_device;
+    m.n = n;
+    for (int i = 0; i <= n; ++i) m.start[i] = block_start[i];
+    for (int i = n + 1; i <= SSM_MULTI_MAX; ++i) m.start[i] = block_start[n];
+    hipStream_t st = (hipStream_t)stream;
+    switch (pick16(3, 4 * Cr, wcfg, Cin)) {
+        case H3N32: return launch16_multi<C16K3N32<2>>(m, st);
+        case H3N32D: return launch16_multi<C16K3N32D<2>>(m, st);
+        case H3N64: return launch16_multi<C16K3N64<2>>(m, st);
+        case H3N128: return launch16_multi<C16K3N128<2>>(m, st);
+        case H3N128S: return launch16_multi<C16K3N128S<2>>(m, st);
+    }
+    return SSM_E_UNSUPPORTED;
+}
+
+// Image columns of a two-source HL8 / Q8 tensor as the rows of a (zero-framed) tensor with Ga + Gb groups - the input of the
+// sub-pixel convolution's column strips: dst rows 0..ncols-1 = columns col0.., and (col1 >= 0) dst rows ncols+1..2*ncols = columns
+// col1.. (row ncols stays untouched: the zero gap between the two strips' neighbourhoods).
+__global__ __launch_bounds__(256) void gather_cols_kernel(ssm_hview a, int Ga, ssm_hview bsrc, int Gb, ssm_hview dst, int H, int col0, int ncols,
+                                                          int col1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int G = Ga + Gb;
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;
+    const int r = blockIdx.y;
+    if (i >= H || r == ncols) return;
+    const int col = r < ncols ? col0 + r : col1 + (r - ncols - 1);
+    const ssm_hview &s = g < Ga ? a : bsrc;
+    const int gg = g < Ga ? g : g - Ga;
+    typedef int gi4 __attribute__((ext_vector_type(4)));
+    const char *sp = (const char *)s.ptr + ((long long)b * s.sb + (long long)gg * s.sg + (long long)i * s.sh + col) * 16;
+    char *dp = (char *)dst.ptr + ((long long)b * dst.sb + (long long)g * dst.sg + (long long)r * dst.sh + i) * 16;
+    *reinterpret_cast<gi4 *>(dp) = *reinterpret_cast<const gi4 *>(sp);
+    *reinterpret_cast<gi4 *>(dp + dst.sp * 16) = *reinterpret_cast<const gi4 *>(sp + s.sp * 16);
+}
+
+extern "C" int ssm_hl8_gather_cols(ssm_hview a, int Ga, ssm_hview b, int Gb, ssm_hview dst, int B, int H, int col0, int ncols, int col1,
+                                   void *stream) {
+    SSM_REQUIRE(a.ptr && dst.ptr && Ga > 0 && Gb >= 0 && (Gb == 0 || b.ptr) && B > 0 && H > 0 && ncols > 0 && col0 >= 0, "gather_cols: bad arguments");
+    SSM_REQUIRE((long long)B * (Ga + Gb) <= 65535 && ncols <= 1024, "gather_cols: grid too large");
+    const int rows = col1 >= 0 ? 2 * ncols + 1 : ncols;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((H + 255) / 256, rows, B * (Ga + Gb)), dim3(256), 0, (hipStream_t)stream, a, Ga, b, Gb, dst, H,
+                       col0, ncols, col1);
+    return ssm::check_launch("ssm_hl8_gather_cols");
 }
 
 // conv3x3(upsample2x(cat[a, b])) with a, b LOW-res HL8 tensors [B,C1|C2,H/2,W/2]; H, W = output (hi-res) size.
@@ -1341,6 +1545,9 @@ extern "C" int ssm_conv2d_ups_hl8_fwd(ssm_hview a, int C1, ssm_hview b, int C2, 
     p.H = H; p.W = W; p.Cout = Cout;
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.shuf = 0;
+    p.shuf_t = 0;
+    p.skipy = p.skipx = 0;
     hipStream_t st = (hipStream_t)stream;
     if (flags & SSM_FLAG_Q8) {
         SSM_REQUIRE(!y_hl8.ptr || Cout % 16 == 0, "conv16_ups: Q8 output needs Cout %% 16 == 0 (got %d)", Cout);

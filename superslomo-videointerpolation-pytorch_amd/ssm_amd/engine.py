@@ -14,6 +14,8 @@ several intermediates of one pair it runs ONCE and the t values are batched
 through stage 2 (the reference's eval loop recomputes it per t,
 scripts/evaluate_interpolation_results.py:234-242 - same numbers, fewer FLOPs).
 """
+import os
+
 import torch
 
 from . import hipbind as hb
@@ -142,6 +144,7 @@ class UNetPlan:
         t["t11a"], t["c11"] = D(32, 1), D(32, 1)
         t["tf"] = D(32, 1)
         t["out"] = hb.Planes(Bd, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
+        # (outer decoder levels run in the sub-pixel form on inference plans: _subpixel / ssm_amd.subpixel)
         self.f32 = {}
         if self.twins:
             assert bottleneck == "CONV" and dec is None, "fp32 twins are for the training plan"
@@ -153,6 +156,7 @@ class UNetPlan:
         """(Re)pack every filter from `state_dict` (training: the parameters change each optimizer step).  Mode f16f8 repacks all
         layers with ONE launch once the filters exist (hb.PackBatch over the parameters' storage); the first call, and any call
         with tensors at other addresses, goes layer by layer (it also chooses the power-of-two pre-scales on the host)."""
+        self.sp, self._sd_for_sp = {}, state_dict        # sub-pixel decoder levels are rebuilt from the new weights on first use
         tensors = []
         for name in self.layers:
             tensors += [state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")]]
@@ -219,11 +223,36 @@ class UNetPlan:
             return self.t[b], self._v(b)
         return None, None
 
+    SUBPIXEL = tuple(n for n in os.environ.get("SSM_SUBPIXEL", "conv11a,conv10a").split(",") if n not in ("", "0"))
+
+    def _subpixel(self, name, a, b):
+        """The layer's SubpixelUpConv, built on first use (None: layer not selected / plan not eligible)."""
+        if name not in self.SUBPIXEL or not self.q8 or self.twins or b is None:
+            return None
+        if name not in self.sp:
+            from .subpixel import SubpixelUpConv
+            A, Bp = self.t[a], self.t[b]
+            wt = self._sd_for_sp[param_key(name, "weight")]
+            assert wt.shape[1] == A.C + Bp.C == 8 * (A.G + Bp.G), "sub-pixel form expects whole channel groups"
+            self.sp[name] = SubpixelUpConv(wt, self._sd_for_sp[param_key(name, "bias")], A.G, Bp.G, self.Bd, A.H, A.W, self.device)
+        return self.sp[name]
+
     def _up_conv(self, name, a, b, u, dst, b_planes=None, b_broadcast=False, b_b0=0):
         """dst = conv(name)( upsample2x(cat[a, b]) ): fused in one kernel, or via the materialised tensor `u`."""
         if not self.fuse_up:
             self._up(a, b, u, b_planes=b_planes, b_broadcast=b_broadcast, b_b0=b_b0)
             return self._conv(name, u, dst)
+        sp = self._subpixel(name, a, b) if b_planes is None else None
+        if sp is not None:
+            tm = self.timer
+            if tm is not None:
+                d, pk0 = self.t[dst], self.pk[name]
+                e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * d.H * d.W * pk0.cout * pk0.cin * 9)
+                e0.record()
+            sp.run(lambda y0, x0: self._v(a, y0=y0, x0=x0), lambda y0, x0: self._v(b, y0=y0, x0=x0), self.t[dst])
+            if tm is not None:
+                e1.record()
+            return
         pk = self.pk[name]
         A = self.t[a]
         Bp, bview = self._bview(b, b_planes, b_broadcast, b_b0)

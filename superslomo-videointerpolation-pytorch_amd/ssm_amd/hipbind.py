@@ -77,6 +77,13 @@ SIGNATURES = {
     "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_lrelu_bwd_q8": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv2d_hl8_subpixel_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, ctypes.c_float, SsmHView, _c_int, _c_int, _c_int,
+                                              _c_int, _c_int, ctypes.c_float, _c_int, _vp]),
+    "ssm_hl8_gather_cols": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv16_subpixel_table_bytes": (ctypes.c_size_t, [_c_int]),
+    "ssm_conv16_subpixel_plan": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int, _vp, ctypes.c_size_t,
+                                          ctypes.POINTER(ctypes.c_int)]),
+    "ssm_conv16_subpixel_run": (_c_int, [_vp, _c_int, ctypes.POINTER(ctypes.c_int), _c_int, _c_int, _c_int, _vp]),
     "ssm_pack16q_job_blocks": (_c_int, [_c_int, _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ssm_pack16q_weights_batch": (_c_int, [_vp, _c_int, _c_int, _vp]),
     "ssm_bias_grad_acc": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -260,10 +267,11 @@ class HPlanes:
         n = B * self.G * 2 * self.Hp * self.Wp * 8
         self.buf = torch.zeros(n + 2 * SSM_TAIL_SLACK_FLOATS, dtype=torch.float16, device=device)
 
-    def view(self, g0=0, broadcast=False, b0=0):
-        """ssm_hview of channel groups g0.. of batch entries b0.. (broadcast: every batch index reads entry b0)."""
+    def view(self, g0=0, broadcast=False, b0=0, y0=0, x0=0):
+        """ssm_hview of channel groups g0.. of batch entries b0.. (broadcast: every batch index reads entry b0), starting at
+        pixel (y0, x0)."""
         pix = self.Hp * self.Wp
-        base = self.buf.data_ptr() + 16 * ((b0 * self.G + g0) * 2 * pix + SSM_PADY * self.Wp + SSM_PADX)
+        base = self.buf.data_ptr() + 16 * ((b0 * self.G + g0) * 2 * pix + (SSM_PADY + y0) * self.Wp + SSM_PADX + x0)
         return SsmHView(base, 0 if broadcast else self.G * 2 * pix, 2 * pix, pix, self.Wp)
 
     def load(self, x):
@@ -325,6 +333,13 @@ class PackedConv16:
         self.w = torch.empty(nh, dtype=torch.float16, device=weight.device)
         check(lib.ssm_pack16_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout,
                                      self.cin, self.cin_p, self.k, self.bn, self.kys, self.scale, stream_ptr()))
+
+
+class SsmSubpixelProblem(ctypes.Structure):
+    """ssm_subpixel_problem (include/ssm_hip.h)."""
+    _fields_ = [("x1", SsmHView), ("C1", ctypes.c_int), ("x2", SsmHView), ("C2", ctypes.c_int), ("w_packed", ctypes.c_void_p),
+                ("bias_packed", ctypes.c_void_p), ("inv_wscale", ctypes.c_float), ("y_hl8", SsmHView), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("transposed", ctypes.c_int), ("skip_y", ctypes.c_int), ("skip_x", ctypes.c_int)]
 
 
 class SsmPackJob(ctypes.Structure):

@@ -147,3 +147,35 @@ def test_batched_pack_matches_per_layer_pack(dev):
         assert (pf.bn, pf.kys, pt.bn, pt.kys) == (rf.bn, rf.kys, rt.bn, rt.kys)
         assert torch.equal(pf.w, rf.w) and torch.equal(pf.b, rf.b), "forward filter %s" % (sh,)
         assert torch.equal(pt.w, rt.w) and torch.equal(pt.b, rt.b), "data-gradient filter %s" % (sh,)
+
+
+@pytest.mark.parametrize("B,ca,cb,co,h,w", [(2, 64, 64, 32, 12, 40), (1, 32, 0, 64, 9, 70), (1, 128, 128, 128, 6, 33), (1, 16, 16, 16, 2, 2),
+                                            (1, 256, 256, 256, 5, 7)])
+def test_subpixel_upconv_matches_upsample_then_conv(dev, B, ca, cb, co, h, w):
+    """conv3x3(upsample2x(cat[a, b])) in the sub-pixel form (9 launches of the plain Q8 kernel: main + 4 border strips + 4 corners)
+    against the oracle's upsample + conv on the same Q8-representable inputs: interior, the two border rows / columns and the
+    corners all within 1e-4 of the output's scale."""
+    from ssm_amd import hipbind as hb
+    from ssm_amd.subpixel import SubpixelUpConv
+    g = torch.Generator().manual_seed(1000 * ca + co + h * w)
+    a = torch.randn(B, ca, h, w, generator=g)
+    b = torch.randn(B, cb, h, w, generator=g) if cb else None
+    wt = torch.randn(co, ca + cb, 3, 3, generator=g) / ((ca + cb) * 9) ** 0.5
+    bias = torch.randn(co, generator=g) * 0.1
+    A = hb.HPlanes(B, ca, h, w, dev, q8=True).load(a.to(dev))
+    Bp = hb.HPlanes(B, cb, h, w, dev, q8=True).load(b.to(dev)) if cb else None
+    aq = A.to_nchw().cpu()                       # what the kernel actually reads (fp16 hi + fp8 lo)
+    bq = Bp.to_nchw().cpu() if cb else None
+    up = O.upsample2x_bilinear(torch.cat([aq, bq], 1) if cb else aq)
+    want = O.conv2d_lrelu(up, wt, bias)
+    dst = hb.HPlanes(B, co, 2 * h, 2 * w, dev, q8=True)
+    sp = SubpixelUpConv(wt, bias, A.G, Bp.G if cb else 0, B, h, w, dev)
+    sp.run(lambda y0, x0: A.view(y0=y0, x0=x0), (lambda y0, x0: Bp.view(y0=y0, x0=x0)) if cb else None, dst)
+    got = dst.to_nchw().cpu()
+    err = (got - want).abs()
+    scale = float(want.abs().max())
+    ring = torch.ones_like(err, dtype=torch.bool)
+    ring[:, :, 2:-2, 2:-2] = False
+    print("sub-pixel upconv %s: max err interior %.2e, border ring %.2e (scale %.2f)" % ((B, ca, cb, co, h, w), float(err[~ring].max()) if (~ring).any() else 0.0,
+                                                                                         float(err[ring].max()), scale))
+    assert float(err.max()) < 1e-4 * max(scale, 1.0) + 2e-4
