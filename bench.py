@@ -337,20 +337,20 @@ def main():
         traffic = None
         pmc_file, pmc_key = {"f32": ("r1b_pmc_traffic_summary.json", "conv_mfma_kernel"),
                              "f16x3": ("r1k_pmc_traffic_summary.json", "conv16_kernel"),
-                             "f16f8": ("r1l_pmc_traffic_summary.json", "conv16_kernel")}.get(precision, (None, None))
+                             "f16f8": ("r1q_pmc_traffic_summary.json", "conv16_kernel")}.get(precision, (None, None))
         pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
         if pmc and os.path.exists(pmc):   # HBM bytes per step from rocprofv3 --pmc passes (tools/pmc_traffic.sh), not live
             pj = json.load(open(pmc))
-            traffic = pj.get(pmc_key, {}).get("hbm_bytes_per_step", 0.0) + pj.get("conv16_ups_kernel", {}).get("hbm_bytes_per_step", 0.0)
+            traffic = sum(pj.get(k, {}).get("hbm_bytes_per_step", 0.0) for k in (pmc_key, "conv16_ups_kernel", "conv16_multi_kernel"))
         if precision == "f32":
             kname, peak, mfma_per_prod = "conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS, 1
         else:
-            kname, peak = "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
+            kname, peak = "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)", PEAK_F16_MFMA_TFLOPS
             # fp16-MFMA units per algorithmic product: f16x3 = 3; f16f8 = 1 fp16 + 2 block-scaled fp8 steps that cover 4x the K in the
             # cycles of one fp16 step (= 1/4 unit each, up to 4/3 padding on 3-tap rows)
             mfma_per_prod = {"f16x3": 3, "f16f8": 1.5}.get(precision, 1)
             if precision == "f16f8":
-                kname = "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4)"
+                kname = "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4)"
         out["roofline"] = {"bound": "mfma", "kernel": kname + ", all %d launches of a step" % (conv["launches"] // args.steps),
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "mfma_issue_frac": round(mfma_per_prod * ach / peak, 4),
