@@ -179,3 +179,29 @@ def test_subpixel_upconv_matches_upsample_then_conv(dev, B, ca, cb, co, h, w):
     print("sub-pixel upconv %s: max err interior %.2e, border ring %.2e (scale %.2f)" % ((B, ca, cb, co, h, w), float(err[~ring].max()) if (~ring).any() else 0.0,
                                                                                          float(err[ring].max()), scale))
     assert float(err.max()) < 1e-4 * max(scale, 1.0) + 2e-4
+
+
+def test_subpixel_levels_match_fused_upsample_plan(dev, monkeypatch):
+    """Whole pair engines at 96x160, 3 intermediates: the plan with conv11a / conv10a in the sub-pixel form against the plan with
+    the fused-upsample kernel everywhere - the two levels' outputs (both stages) and the frames agree to the fp8-compensation
+    noise (2e-4 of the tensors' scale), borders included."""
+    from ssm_amd.engine import PairEngine, UNetPlan
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    sd1 = {k: v.to(dev) for k, v in synthetic_state_dict(1).items()}
+    sd2 = {k: v.to(dev) for k, v in synthetic_state_dict(2).items()}
+    x = synthetic_frames(2, 96, 160, seed=5).to(dev).reshape(1, 6, 96, 160)
+    t = torch.tensor([0.25, 0.5, 0.875], device=dev)
+    outs = {}
+    for label, levels in (("fused", ()), ("subpixel", ("conv11a", "conv10a"))):
+        monkeypatch.setattr(UNetPlan, "SUBPIXEL", levels)
+        eng = PairEngine(sd1, sd2, 1, 3, 96, 160, dev, True, "f16f8")
+        img = eng.run(x, t, False).clone()
+        assert (len(eng.s1.sp), len(eng.s2.sp)) == ((2, 2) if levels else (0, 0))
+        outs[label] = (img, {"%s.%s" % (st, n): pl.t[n].to_nchw() for st, pl in (("s1", eng.s1), ("s2", eng.s2)) for n in ("t11a", "t10a")})
+    for n, a in outs["fused"][1].items():
+        b = outs["subpixel"][1][n]
+        err = (a - b).abs()
+        assert float(err.max()) < 2e-4 * max(float(a.abs().max()), 1.0), n
+        ring = float(torch.cat([err[:, :, :2].flatten(), err[:, :, -2:].flatten(), err[:, :, :, :2].flatten(), err[:, :, :, -2:].flatten()]).max())
+        assert ring < 2e-4 * max(float(a.abs().max()), 1.0), n + " border"
+    assert float((outs["fused"][0] - outs["subpixel"][0]).abs().max()) < 5e-4
