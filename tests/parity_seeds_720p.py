@@ -1,5 +1,6 @@
 """Study (GPU box, not collected by pytest): parity of the two split-precision modes against the CPU oracle at 736x1280 on
-further synthetic pairs / t values than the bench uses.  r1l: f16f8 3.1e-4 ... 4.2e-4, f16x3 2.0e-4 ... 2.8e-4 (bar 1e-3).
+further synthetic pairs / t values than the bench uses.  r1l: f16f8 3.1e-4 ... 4.2e-4, f16x3 2.0e-4 ... 2.8e-4 (bar 1e-3);
+r1q (two decoder levels in the sub-pixel form): f16f8 3.9e-4 ... 4.3e-4, f16x3 2.0e-4 ... 2.8e-4.
 
     python tests/parity_seeds_720p.py          (about 30 s of CPU oracle per pair)
 """
