@@ -70,6 +70,7 @@ class SubpixelUpConv:
         # image columns 0, 1 (rows 0, 1) and w-2, w-1 (rows 3, 4) as rows; row 2 stays zero
         self.cols = hb.HPlanes(B, 8 * G, 5, h, device, groups=G, q8=True)
         self._plan = None
+        self.wcfg = w      # width hint of the tile configuration all nine problems share (the 32-wide 2-workgroup tile measured the same)
 
     def _build(self, a_view, b_view, dst, slope):
         lib = hb.load()
@@ -91,7 +92,7 @@ class SubpixelUpConv:
         host = (ctypes.c_char * nbytes)()
         starts = (ctypes.c_int * (n + 1))()
         flags = hb.SSM_FLAG_LRELU | hb.SSM_FLAG_Q8
-        hb.check(lib.ssm_conv16_subpixel_plan(ctypes.cast(arr, ctypes.c_void_p), n, self.B, self.co, self.w, slope, flags,
+        hb.check(lib.ssm_conv16_subpixel_plan(ctypes.cast(arr, ctypes.c_void_p), n, self.B, self.co, self.wcfg, slope, flags,
                                               ctypes.cast(host, ctypes.c_void_p), nbytes, starts))
         table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
         return table, starts, n
@@ -106,4 +107,4 @@ class SubpixelUpConv:
             self._plan = (key,) + self._build(a_view, b_view, dst, slope)
         _, table, starts, n = self._plan
         hb.check(lib.ssm_hl8_gather_cols(a0, self.Ga, b0, self.Gb, self.cols.view(), self.B, self.h, 0, 2, self.w - 2, st))
-        hb.check(lib.ssm_conv16_subpixel_run(table.data_ptr(), n, starts, self.co, self.w, self.cin_p, st))
+        hb.check(lib.ssm_conv16_subpixel_run(table.data_ptr(), n, starts, self.co, self.wcfg, self.cin_p, st))
