@@ -860,6 +860,10 @@ template <int S> using C16K7 = Cfg16<7, 1, 1, 1, 2, 1, 4, 1, 1, S>;       //  4 
 template <int S> using C16K5 = Cfg16<5, 1, 2, 1, 2, 1, 4, 2, 2, S>;       //  8   64    8  64   145 KB   1
 template <int S> using C16K3N32 = Cfg16<3, (S == 2 ? 1 : 3), 1, 1, 2, 2, 4, 1, 1, S>;    //  4   32    8  64    80 KB   2   (short K)
 template <int S> using C16K3N32D = Cfg16<3, (S == 2 ? 1 : 3), 1, 1, 2, 1, 4, 2, 2, S>;   //  8   32    8  64   121 KB   1   (Cin >= 64)
+// narrow maps (W <= 48): all three filter rows per stage also in the Q8 form - a third of the barrier-separated iterations per
+// workgroup, which is what a layer with fewer workgroups than CUs pays for (0.07 ms per 512-channel layer at 22x22 regardless of FLOPs)
+template <int S> using C16K3N32V = Cfg16<3, 3, 1, 1, 2, 2, 4, 1, 1, S>;      //  4   32    8  64   (Cin < 128)
+template <int S> using C16K3N32W = Cfg16<3, 3, 1, 1, 2, 1, 4, 2, 2, S>;      //  8   32    8  64   (Cin >= 128)
 template <int S> using C16K3N64 = Cfg16<3, (S == 2 ? 1 : 3), 2, 1, 2, 1, 4, 2, 2, S>;    //  8   64    8  64   158 KB   1
 template <int S> using C16K3N128 = Cfg16<3, 1, 2, 2, 2, 1, 2, 2, 2, S>;   //  8  128    4  64    99 KB   1   //  8  128    4  64    99 KB   1
 template <int S> using C16K3N128S = Cfg16<3, 1, 2, 2, 2, 1, 2, 1, (S == 2 ? 1 : 2), S>;   // Q8: single patch buffer, 2 workgroups per CU  //  4  128    4  32    83 KB   1
@@ -870,7 +874,7 @@ template <int S> using U3N64 = CfgUps<1, 2, 1, 2, 1, 4, 2, 4, S>;    //  8 + 4  
 template <int S> using U3N128 = CfgUps<1, 2, 2, 2, 1, 2, 2, 4, S>;   //  8 + 4  128   4  64  116 KB   conv9a
 template <int S> using U3N128S = CfgUps<1, 2, 2, 2, 1, 2, 1, 4, S>;  //  4 + 4  128   4  32   84 KB   conv7a, conv8a
 
-enum Kind16 { H7 = 0, H5, H3N32, H3N32D, H3N64, H3N128, H3N128S };
+enum Kind16 { H7 = 0, H5, H3N32, H3N32D, H3N64, H3N128, H3N128S, H3N32V, H3N32W };
 
 int pick16(int k, int Cout, int W, int Cin = 0) {
     if (k == 7) return H7;
@@ -880,7 +884,8 @@ int pick16(int k, int Cout, int W, int Cin = 0) {
     // workgroups, each streaming a quarter of the layer's filter through one CU (0.10 ms per layer regardless of its FLOPs);
     // 32-cout tiles give 4x the workgroups and a quarter of the filter bytes each.
     // (measured: training step 140 -> 147 samples/s, 720p inference unchanged; a threshold of 96 costs the 720p 1/16 level 4 %)
-    if (Cout <= 32 || W <= 48) return Cin >= 128 ? H3N32D : H3N32;      // same BN / KYS: the packed filter does not depend on it
+    if (W <= 48) return Cin >= 128 ? H3N32W : H3N32V;                   // same BN / KYS: the packed filter does not depend on Cin
+    if (Cout <= 32) return Cin >= 128 ? H3N32D : H3N32;
     if (Cout <= 64) return H3N64;
     const int w64 = (W + 63) / 64 * 64, w32 = (W + 31) / 32 * 32;
     return w32 < w64 ? H3N128S : H3N128;
@@ -943,7 +948,9 @@ template <int S>
 int dispatch16_ups(Conv16Params &p, int B, hipStream_t st) {
     switch (pick16(3, p.Cout, p.W, p.Cin)) {
         case H3N32:
-        case H3N32D: return launch16_ups<U3N32<S>>(p, B, st);
+        case H3N32D:
+        case H3N32V:
+        case H3N32W: return launch16_ups<U3N32<S>>(p, B, st);
         case H3N64: return launch16_ups<U3N64<S>>(p, B, st);
         case H3N128: return launch16_ups<U3N128<S>>(p, B, st);
         case H3N128S: return launch16_ups<U3N128S<S>>(p, B, st);
@@ -958,6 +965,8 @@ int dispatch16(Conv16Params &p, int B, int k, hipStream_t st) {
         case H5: return launch16<C16K5<S>>(p, B, st);
         case H3N32: return launch16<C16K3N32<S>>(p, B, st);
         case H3N32D: return launch16<C16K3N32D<S>>(p, B, st);
+        case H3N32V: return launch16<C16K3N32V<S>>(p, B, st);
+        case H3N32W: return launch16<C16K3N32W<S>>(p, B, st);
         case H3N64: return launch16<C16K3N64<S>>(p, B, st);
         case H3N128: return launch16<C16K3N128<S>>(p, B, st);
         case H3N128S: return launch16<C16K3N128S<S>>(p, B, st);
@@ -1164,6 +1173,8 @@ extern "C" int ssm_conv16_config(int k, int Cout, int W, int *BN, int *KYS) {
         case H5: dims16<C16K5<1>>(BN, KYS); break;
         case H3N32:
         case H3N32D: dims16<C16K3N32<1>>(BN, KYS); break;
+        case H3N32V:
+        case H3N32W: dims16<C16K3N32W<1>>(BN, KYS); break;
         case H3N64: dims16<C16K3N64<1>>(BN, KYS); break;
         case H3N128: dims16<C16K3N128<1>>(BN, KYS); break;
         case H3N128S: dims16<C16K3N128S<1>>(BN, KYS); break;
@@ -1211,6 +1222,8 @@ extern "C" int ssm_conv16q_config(int k, int Cout, int W, int *BN, int *KYS) {
         case H5: dims16<C16K5<2>>(BN, KYS); break;
         case H3N32:
         case H3N32D: dims16<C16K3N32<2>>(BN, KYS); break;
+        case H3N32V:
+        case H3N32W: dims16<C16K3N32W<2>>(BN, KYS); break;
         case H3N64: dims16<C16K3N64<2>>(BN, KYS); break;
         case H3N128: dims16<C16K3N128<2>>(BN, KYS); break;
         case H3N128S: dims16<C16K3N128S<2>>(BN, KYS); break;
@@ -1427,6 +1440,8 @@ extern "C" int ssm_conv16_subpixel_plan(const ssm_subpixel_problem *pr, int n, i
         switch (kind) {
             case H3N32: fill_problem<C16K3N32<2>>(p, B, blocks); break;
             case H3N32D: fill_problem<C16K3N32D<2>>(p, B, blocks); break;
+            case H3N32V: fill_problem<C16K3N32V<2>>(p, B, blocks); break;
+            case H3N32W: fill_problem<C16K3N32W<2>>(p, B, blocks); break;
             case H3N64: fill_problem<C16K3N64<2>>(p, B, blocks); break;
             case H3N128: fill_problem<C16K3N128<2>>(p, B, blocks); break;
             case H3N128S: fill_problem<C16K3N128S<2>>(p, B, blocks); break;
@@ -1451,6 +1466,8 @@ extern "C" int ssm_conv16_subpixel_run(const void *table_device, int n, const in
     switch (pick16(3, 4 * Cr, wcfg, Cin)) {
         case H3N32: return launch16_multi<C16K3N32<2>>(m, st);
         case H3N32D: return launch16_multi<C16K3N32D<2>>(m, st);
+        case H3N32V: return launch16_multi<C16K3N32V<2>>(m, st);
+        case H3N32W: return launch16_multi<C16K3N32W<2>>(m, st);
         case H3N64: return launch16_multi<C16K3N64<2>>(m, st);
         case H3N128: return launch16_multi<C16K3N128<2>>(m, st);
         case H3N128S: return launch16_multi<C16K3N128S<2>>(m, st);
@@ -1493,7 +1510,9 @@ extern "C" int ssm_hl8_gather_cols(ssm_hview a, int Ga, ssm_hview b, int Gb, ssm
 extern "C" int ssm_conv16_ups_config(int Cout, int W, int *BN, int *KYS) {
     switch (pick16(3, Cout, W, 0)) {
         case H3N32:
-        case H3N32D: *BN = U3N32<1>::BN; *KYS = U3N32<1>::KYS; break;
+        case H3N32D:
+        case H3N32V:
+        case H3N32W: *BN = U3N32<1>::BN; *KYS = U3N32<1>::KYS; break;
         case H3N64: *BN = U3N64<1>::BN; *KYS = U3N64<1>::KYS; break;
         case H3N128: *BN = U3N128<1>::BN; *KYS = U3N128<1>::KYS; break;
         case H3N128S: *BN = U3N128S<1>::BN; *KYS = U3N128S<1>::KYS; break;
@@ -1505,7 +1524,9 @@ extern "C" int ssm_conv16_ups_config(int Cout, int W, int *BN, int *KYS) {
 extern "C" int ssm_conv16q_ups_config(int Cout, int W, int *BN, int *KYS) {
     switch (pick16(3, Cout, W, 0)) {
         case H3N32:
-        case H3N32D: *BN = U3N32<2>::BN; *KYS = U3N32<2>::KYS; break;
+        case H3N32D:
+        case H3N32V:
+        case H3N32W: *BN = U3N32<2>::BN; *KYS = U3N32<2>::KYS; break;
         case H3N64: *BN = U3N64<2>::BN; *KYS = U3N64<2>::KYS; break;
         case H3N128: *BN = U3N128<2>::BN; *KYS = U3N128<2>::KYS; break;
         case H3N128S: *BN = U3N128S<2>::BN; *KYS = U3N128S<2>::KYS; break;
