@@ -116,3 +116,35 @@ def test_gradient_allreduce_in_place_on_flat_buffers():
         assert runs == 2 and aliased
         assert torch.allclose(flats[0], torch.arange(112, dtype=torch.float32) * 1.5)
         assert torch.allclose(flats[1], torch.arange(74, dtype=torch.float32) * 3.5)
+
+
+def _run_bench(*flags):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_bare_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun): the parent starts 2 rank processes, relays exactly one JSON line with
+    n_gpus = 2; the real argument path with the per-pair work stubbed (--stub, gloo) since this container has no GPU."""
+    import json
+    r = _run_bench("--gpus", "2", "--stub", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    # rank 1 sleeps 2 ms per pair, rank 0 1 ms: the line must carry the max over ranks (8 pairs x 2 ms)
+    assert out["ms_per_step"] >= 16.0
+    assert "stub" in out["data"]
+
+
+def test_bench_launcher_fails_loudly_when_a_rank_fails():
+    """Without a GPU the real ranks assert; the parent must exit non-zero and print no JSON line."""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a GPU-less host")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

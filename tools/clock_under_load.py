@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: shader clock while one conv layer runs back to back (is the matrix pipe clock- or issue-limited?).
-usage: python tools/clock_under_load.py [layer ...]   (default: a few stage-2 layers at B=7, 736x1280)"""
+usage: python tools/clock_under_load.py [--f32] [--b N] [layer ...]   (default: a few stage-2 layers at B=7, 736x1280;
+--f32: the fp32-MFMA kernel of ssm_conv.hip instead of the fp16 split kernels)"""
 import ctypes
 import os
 import sys
@@ -41,8 +42,16 @@ def measure(fn, ms=30.0):
 
 
 def main():
-    names = sys.argv[1:] or ["conv1b", "conv2b", "conv4b", "conv8b", "conv9b", "conv10b", "conv11b"]
-    B, H, W = 7, 736, 1280
+    argv = sys.argv[1:]
+    f32 = "--f32" in argv
+    argv = [a for a in argv if a != "--f32"]
+    B = 7
+    if "--b" in argv:
+        i = argv.index("--b")
+        B = int(argv[i + 1])
+        del argv[i:i + 2]
+    names = argv or ["conv1b", "conv2b", "conv4b", "conv8b", "conv9b", "conv10b", "conv11b"]
+    H, W = 736, 1280
     dev = torch.device("cuda:0")
     ghz, _ = measure(lambda: None, 10.0)
     print("idle: %.3f GHz" % ghz)
@@ -51,6 +60,17 @@ def main():
             continue
         s = layer_scale(name)
         h, w = H // s, W // s
+        if f32:
+            pk = hb.PackedConv(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5, torch.zeros(cout, device=dev), B, h, w)
+            x = hb.Planes(B, cin, h, w, dev)
+            x.interior.normal_()
+            y = hb.Planes(B, cout, h, w, dev)
+            fn = lambda: hb.conv2d(x.view(), cin, None, 0, pk, y.view(), None, B, h, w)  # noqa: E731
+            ghz, ms = measure(fn)
+            gf = 2.0 * B * h * w * cout * cin * k * k / 1e9
+            print("%-8s f32    %.3f ms  %6.1f TF  clock %.3f GHz  -> MFMA busy %.0f %% of the pipe at that clock"
+                  % (name, ms, gf / ms, ghz, 100 * (gf / ms) / (157.3 * ghz / 2.4)))
+            continue
         pk = hb.PackedConv16(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5, torch.zeros(cout, device=dev), w)
         x = hb.HPlanes(B, cin, h, w, dev, groups=pk.cin_p // 8)
         x.buf.normal_()
