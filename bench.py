@@ -416,10 +416,11 @@ def infer_bench(args):
     model = model.to(dev).eval()
     headline = args.precision or HEADLINE_PRECISION
     h_in, w_in = (H_IN, W_IN) if args.size == "720p" else (2160, 3840)
-    P = args.pairs_per_step
+    P, PB = args.pairs_per_step, args.pairs_per_batch
+    assert P % PB == 0, "--pairs-per-step must be a multiple of --pairs-per-batch"
     xs = [synthetic_frames(2, h_in, w_in, seed=42 + rank * P + i) for i in range(P)]     # [1,2,3,Hp,Wp] each
     Hp, Wp = xs[0].shape[-2:]
-    pairs = [x.reshape(1, 6, Hp, Wp).to(dev) for x in xs]
+    pairs = [torch.cat([x.reshape(1, 6, Hp, Wp) for x in xs[i:i + PB]], 0).to(dev) for i in range(0, P, PB)]    # batches of PB pairs
     t_dev = torch.tensor([i / 8.0 for i in range(1, N_T + 1)], dtype=torch.float32, device=dev)
     sd1d = {k: v.detach() for k, v in model.stage1_model.state_dict().items()}
     sd2d = {k: v.detach() for k, v in model.stage2_model.state_dict().items()}
@@ -429,9 +430,9 @@ def infer_bench(args):
         torch.cuda.synchronize(dev)
 
     def run_mode(precision, steps, warmup, timers):
-        pipe = PairPipeline(sd1d, sd2d, N_T, Hp, Wp, dev, True, precision, args.streams, graphs=bool(args.graphs))
+        pipe = PairPipeline(sd1d, sd2d, N_T, Hp, Wp, dev, True, precision, args.streams, graphs=bool(args.graphs), pairs_per_batch=PB)
 
-        def step():                 # P pairs -> 7 frames each; consecutive pairs alternate between the streams
+        def step():                 # P pairs -> 7 frames each; consecutive batches of PB pairs alternate between the streams
             for img6 in pairs:
                 pipe.submit(img6, t_dev, want_aux=False)
 
@@ -452,8 +453,8 @@ def infer_bench(args):
         traffic = sum(pj.get(k, {}).get("hbm_bytes_per_step", 0.0) for k in pmc_keys) if pj else None
         res["roofline"] = {"bound": "mfma", "kernel": kname + ", the conv launches of a pair", "achieved": round(ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "region": "the timed region: algorithmic conv FLOP of %d pairs / its wall time (%d pair(s) in flight; "
-                                     "non-conv kernels and gaps count against it)" % (P * steps, args.streams),
+                           "region": "the timed region: algorithmic conv FLOP of %d pairs / its wall time (%d batch(es) of %d pair(s) in "
+                                     "flight; non-conv kernels and gaps count against it)" % (P * steps, args.streams, PB),
                            "flop_per_pair": flops_pair, "traffic": traffic or None,
                            "traffic_note": "HBM bytes per pair of the conv launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from "
                                            "separate rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/%s" % (pmc_file or "-")}
@@ -465,9 +466,10 @@ def infer_bench(args):
             sync()
             timer = KernelTimer()
             UNetPlan.timer = timer
-            n_solo = max(2, min(P, 8))
+            nb_solo = max(1, min(len(pairs), 8 // PB))
+            n_solo = nb_solo * PB
             t0 = time.perf_counter()
-            for img6 in pairs[:n_solo]:
+            for img6 in pairs[:nb_solo]:
                 solo.run(img6, t_dev, want_aux=False)
             sync()
             solo_ms = 1e3 * (time.perf_counter() - t0) / n_solo
@@ -479,7 +481,7 @@ def infer_bench(args):
             mfma_per_prod = {"f16x3": 3, "f16f8": 1.5}.get(precision, 1)
             res["roofline"]["detail"] = {"region": "%d single-stream pairs run right after the timed region, HIP-event brackets around every "
                                                    "launch on the launch stream" % n_solo,
-                                         "launches_per_pair": conv["launches"] // n_solo, "ms_per_pair_in_kernel": round(conv_ms, 3),
+                                         "launches_per_batch": conv["launches"] // nb_solo, "pairs_per_batch": PB, "ms_per_pair_in_kernel": round(conv_ms, 3),
                                          "achieved_in_kernel": round(kach, 2), "frac_in_kernel": round(kach / peak, 4),
                                          "mfma_issue_frac_in_kernel": round(mfma_per_prod * kach / peak, 4),
                                          "wall_ms_per_pair_single_stream": round(solo_ms, 3)}
@@ -516,9 +518,10 @@ def infer_bench(args):
         "config": {"precision": headline,
                    "workload": "superslomo_original.ini inference: synthetic %dx%d pairs (padded %dx%d) -> 7 intermediates t=i/8 each, "
                                "stage 1 once per pair, random-init (deterministic) weights" % (w_in, h_in, Wp, Hp),
-                   "pairs_per_step": P, "frames_per_step": N_T * P, "ms_per_pair": round(main_res["ms_per_pair"], 3),
+                   "pairs_per_step": P, "pairs_per_batch": PB, "frames_per_step": N_T * P, "ms_per_pair": round(main_res["ms_per_pair"], 3),
                    "streams_per_gpu": args.streams,
-                   "parallelism": "pairs sharded, %d rank(s); %d pair(s) in flight per GPU on separate HIP streams" % (world, args.streams)},
+                   "parallelism": "pairs sharded, %d rank(s); %d batch(es) of %d pair(s) in flight per GPU on separate HIP streams"
+                                  % (world, args.streams, PB)},
     }
     for k in ("roofline", "roofline_warp", "time_split_ms_per_pair"):
         if k in main_res:
@@ -563,6 +566,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-step", type=int, default=8, help="frame pairs per step (infer mode); 20 steps x 8 = 160 pairs")
+    ap.add_argument("--pairs-per-batch", type=int, default=2,
+                    help="pairs taken through one engine pass (stage 1 at this batch, stage 2 at 7x it): more workgroups per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-io", action="store_true", help="skip the measured H2D / D2H legs")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (no roofline.detail)")

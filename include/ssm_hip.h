@@ -84,6 +84,14 @@ int ssm_copy_view(ssm_view src, ssm_view dst, int B, int C, int H, int W, void *
  * BN = output-channel block the weights must be packed for, CK = input-channel
  * chunk (Cin and the first cat source must be multiples of it).             */
 int ssm_conv_config(int k, int Cout, int B, int H, int W, int pool, int *BN, int *CK);
+/* The same with the input channel count and the fused-upsample form taken into account (what ssm_conv2d_fwd /
+ * ssm_conv2d_ups_fwd evaluate at launch: an estimate of the launch duration per tile configuration from the
+ * workgroup count against the 512 resident slots of the chip, the MFMAs per workgroup and the tile overshoot).
+ * kind = index of the configuration (diagnostics).  Pack filters for the BN / CK returned HERE.               */
+int ssm_conv_plan(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups, int *kind, int *BN, int *CK);
+/* Tests / tuning only: force tile configuration `kind` for its kernel size (-1 = automatic).  Process-wide.
+ * Returns the number of configurations.                                                                     */
+int ssm_conv_force_kind(int kind);
 
 /* Number of floats of the packed filter / packed bias for that configuration. */
 size_t ssm_packed_weight_floats(int Cout, int Cin_padded, int k, int BN);
@@ -108,6 +116,16 @@ int ssm_pack_weights(const float *w_oihw, const float *bias, float *w_packed, fl
 int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed,
                    const float *bias_packed, ssm_view y, ssm_view pool, int B, int H, int W,
                    int Cout, int k, float slope, int flags, void *stream);
+
+/* Fused  conv3x3( F.upsample(torch.cat([a, b], 1), size=(2h,2w), mode="bilinear") )  - the decoder step of
+ * scripts/models/flow_computation.py:244-247 (lambdas :92-137; flow_interpolation.py:92-141,224-231) - in exact
+ * fp32 (v_mfma_f32_32x32x2_f32).  a [B,C1,H/2,W/2], b [B,C2,H/2,W/2] LOW-res padded-plane views (C2 may be 0, b may
+ * be batch-broadcast), H, W = OUTPUT size (even).  The concatenated, upsampled tensor is never materialised: each
+ * workgroup expands the low-res chunk it staged into the hi-res patch in LDS (align_corners=False half-pixel rule,
+ * edge-clamped sources, zeros outside the image = the convolution's padding).  Filters: ssm_pack_weights for the
+ * BN / CK of ssm_conv_plan(3, C1+C2, Cout, B, H, W, 0, 1, ...).                                                  */
+int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
+                       ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 
 /* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------
  * Same operator as ssm_conv2d_fwd.  Default mode evaluates a*b as a_hi*b_hi + a_hi*b_lo +
@@ -242,6 +260,17 @@ int ssm_flowinterp_inputs_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm
  * the intermediates FullModel returns (scripts/models/superslomo_r.py:142-150). */
 int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, const float *t, ssm_view y3,
                        ssm_view aux, int B, int H, int W, void *stream);
+
+/* final_conv [+ synthesis]: Conv2d(32 -> NC, k3, pad 1, bias), no activation (scripts/models/flow_computation.py:145-153,
+ * flow_interpolation.py:149-157) on v_mfma_f32_4x4x1_16B_f32 (4 couts x 64 pixels per instruction: nothing padded for the
+ * 4 flow channels of stage 1, 8 for the 5 of stage 2), exact fp32.  x [B,32,H,W] padded-plane view; w_oihw / bias the
+ * reference's state-dict tensors as they are (device fp32), NC <= 8.
+ *   out (ptr NULL = off): [B,NC,H,W].
+ *   y3 (ptr NULL = plain convolution): with NC = 5, extract_outputs + compute_output_image (flow_interpolation.py:374-429)
+ *   run on the five sums in registers - arguments as ssm_synthesize_fwd, the 5-channel map is never written unless `out`
+ *   is given too.                                                                                                       */
+int ssm_final_conv_fwd(ssm_view x, const float *w_oihw, const float *bias, int NC, ssm_view out, ssm_view img6, ssm_view in16,
+                       const float *t, ssm_view y3, ssm_view aux, int B, int H, int W, void *stream);
 
 /* ---- frame formats either side of the path (uint8 HWC RGB on the device) ----------------
  * ssm_frames_from_u8_fwd: [N,H,W,3] uint8 -> normalised fp32 [N,3,Hp,Wp], image at (top,left),

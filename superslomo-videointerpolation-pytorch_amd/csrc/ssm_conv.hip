@@ -3,13 +3,16 @@
 // Replaces layers.conv / final_conv of the reference (scripts/models/layers.py:21-33,
 // scripts/models/flow_computation.py:145-153): stride-1 'same' cross-correlation,
 // zero padding, bias, optional LeakyReLU, optional fused 2x2 average pool
-// (scripts/models/layers.py:60-63) and optional two-source input (torch.cat on C).
+// (scripts/models/layers.py:60-63), optional two-source input (torch.cat on C) and - the
+// decoder step of scripts/models/flow_computation.py:244-247 - optional fused
+// F.upsample(torch.cat([a, b], 1), bilinear x2) in front of the convolution.
 //
 // GEMM view, per batch element:  D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],
 // k = (cin, ky, kx).  The MFMA A operand is the filter (32 couts x 2 k), the B
 // operand is the activation (2 k x 32 pixels), so the accumulator has the pixel
-// on the lane: consecutive lanes own consecutive x of one output row and every
-// store instruction writes whole 128-byte row segments of NCHW planes.
+// on the lane.  A 32-pixel group is 32x1 (consecutive x of one row: every store
+// instruction writes whole 128-byte row segments of NCHW planes) or, for maps
+// whose width is not near a multiple of 32 (80, 40, 22, 11 ...), 8x4.
 //
 // Data movement: the input lives in the padded-plane layout (include/ssm_hip.h),
 // so a tile's halo is just a bigger rectangle - no bounds tests.  Per chunk of CK
@@ -20,7 +23,19 @@
 // its two k from two consecutive input channels at the same tap (lanes 0-31 /
 // 32-63), so each operand fetch is one conflict-free ds_read_b32 at a
 // compile-time offset from a per-lane base.
+//
+// Fused upsample (UPS): the DMA brings the LOW-res [CK][TH/2+2][TW/2+8] patch of
+// the chunk instead; the workgroup expands it in LDS to the hi-res patch the MFMA
+// loop reads (ATen's half-pixel rule with edge-clamped source indices, exact zeros
+// outside the image = the convolution's zero padding).  fp32 MFMA is 16x slower
+// than the fp16 matrix path, so the ~10 VALU operations per patch element vanish
+// beside the chunk's MFMAs (the other workgroup of the CU keeps the pipe busy
+// meanwhile), and the concatenated, upsampled tensor - the largest activation of
+// every decoder level - never touches HBM.
 #include "ssm_common.h"
+
+#include <atomic>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -41,79 +56,112 @@ struct ConvParams {
     float *pool;
     long long psb, psc;
     int psh;
-    int H, W, Cout;
+    int H, W, Cout;      // OUTPUT map
+    int hs, ws;          // UPS: source map (H/2, W/2)
     int tilesX, tilesY, NB;
     float slope;
     int lrelu;
+    int nb_slow;         // tile order inside an XCD's share: 1 = cout block slowest (big filters), 0 = fastest
+    int B;
+    int abl;             // diagnostics build only (make ablate): 1 = no LDS-DMA after the second chunk, 2 = no stores
 };
 
-template <int KS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int CK_>
+template <int KS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int CK_, int GW_ = 32>
 struct Cfg {
     static constexpr int KS = KS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_, CK = CK_;
+    static constexpr int GW = GW_, GH = 32 / GW_;   // a 32-pixel group = GH rows x GW columns
     static constexpr int KS2 = KS * KS, PAD = (KS - 1) / 2;
     static constexpr int BN = 32 * NT * WN;       // output channels per workgroup
-    static constexpr int TH = MTY * WY;           // output rows per workgroup
-    static constexpr int TW = 32 * MTX * WX;      // output columns per workgroup
-    static constexpr int MT = MTY * MTX;          // 32-pixel tiles per wave
+    static constexpr int TH = MTY * GH * WY;      // output rows per workgroup
+    static constexpr int TW = MTX * GW * WX;      // output columns per workgroup
+    static constexpr int MT = MTY * MTX;          // 32-pixel groups per wave
     static constexpr int PH = TH + KS - 1;        // patch rows
     static constexpr int PW = TW + 8;             // patch columns (16-byte aligned both ends)
     static constexpr int PW4 = PW / 4;
     static constexpr int WSZ = CK * KS2 * BN;     // filter floats per chunk
     static constexpr int PSZ = CK * PH * PW;      // patch floats per chunk
-    static constexpr int NWQ = WSZ / 4, NPQ = PSZ / 4, NQ = NWQ + NPQ;  // 16-byte pieces
+    // fused upsample: low-res raw patch rows y0/2-1 .. (y0+TH)/2, columns x0/2-4 .. x0/2+TW/2+3
+    static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;
+    static constexpr int RSZ = CK * LH * LW;
+    static constexpr bool POOL_OK = (GW == 32) ? (MTY % 2 == 0) : true;
+    static constexpr bool UPS_OK = (KS == 3) && (TH % 2 == 0);
+    static_assert(GW == 32 || GW == 8, "pixel group is 32x1 or 8x4");
+    static_assert(WN * WY * WX == 4, "4 waves per workgroup");
+    static_assert(CK % 2 == 0, "one MFMA k-step = two input channels");
+    static_assert(TW % 16 == 0, "patch rows must keep the 8x4 groups on distinct LDS banks");
+};
+
+// LDS plan of one kernel variant: two DMA stages [filter | patch or raw patch] (+ the expanded patch)
+template <class C, bool UPS>
+struct Lds {
+    static constexpr int DSZ = UPS ? C::RSZ : C::PSZ;            // DMA'd activation floats per chunk
+    static constexpr int DH = UPS ? C::LH : C::PH, DW4 = UPS ? C::LW4 : C::PW4;
+    static constexpr int NWQ = C::WSZ / 4, NDQ = DSZ / 4, NQ = NWQ + NDQ;  // 16-byte pieces
     static constexpr int NG = (NQ + 63) / 64;     // 1-KiB wave-instructions per chunk
     static constexpr int STAGE = NG * 256;        // floats per LDS stage
     static constexpr int NI = (NG + 3) / 4;       // LDS-DMA instructions per wave per chunk
-    static constexpr int LDS_BYTES = 2 * STAGE * 4;
-    static_assert(WN * WY * WX == 4, "4 waves per workgroup");
-    static_assert(CK % 2 == 0, "one MFMA k-step = two input channels");
-    static_assert(LDS_BYTES <= 65536, "LDS budget");
+    static constexpr int HIP = 2 * STAGE;         // offset of the expanded patch (UPS)
+    static constexpr int BYTES = (2 * STAGE + (UPS ? C::PSZ : 0)) * 4;
+    static_assert(BYTES <= 65536, "LDS budget (two workgroups per CU)");
 };
 
 #define SSM_GLDS16(gp, lp)                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
                                      (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
 
-template <class C>
+template <class C, bool UPS>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    using L = Lds<C, UPS>;
     constexpr int KS = C::KS, KS2 = C::KS2, BN = C::BN, PH = C::PH, PW = C::PW, NT = C::NT, MT = C::MT;
+    constexpr int GW = C::GW, GH = C::GH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int gy = l31 / GW, gx = l31 % GW;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
 
     int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
-    const int nb = id % p.NB;
-    id /= p.NB;
-    const int tx = id % p.tilesX;
-    id /= p.tilesX;
-    const int ty = id % p.tilesY;
-    const int b = id / p.tilesY;
+    int nb, tx, ty, b;
+    if (p.nb_slow) {
+        tx = id % p.tilesX;
+        id /= p.tilesX;
+        ty = id % p.tilesY;
+        id /= p.tilesY;
+        b = id % p.B;
+        nb = id / p.B;
+    } else {
+        nb = id % p.NB;
+        id /= p.NB;
+        tx = id % p.tilesX;
+        id /= p.tilesX;
+        ty = id % p.tilesY;
+        b = id / p.tilesY;
+    }
     const int x0 = tx * C::TW, y0 = ty * C::TH;
 
-    // patch origin = element (c, y0-PAD, x0-4) of the padded planes
-    const long long porg = (long long)(y0 - C::PAD) * p.sh + (x0 - 4);
+    // DMA origin: element (c, y0-PAD, x0-4) of the padded planes, or (c, y0/2-1, x0/2-4) of the low-res source
+    const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - C::PAD) * p.sh + (x0 - 4);
     const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
     const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
     const float *wbase = p.wpk + (long long)nb * p.Cin * (KS2 * BN);
 
     // per-lane source offset of each LDS-DMA piece this wave issues (same for every chunk)
-    int off[C::NI];
-    bool isw[C::NI];
+    int off[L::NI];
+    bool isw[L::NI];
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
+    for (int i = 0; i < L::NI; ++i) {
         const int q = (i * 4 + wid) * 64 + lane;
-        if (q < C::NWQ) {
+        if (q < L::NWQ) {
             isw[i] = true;
             off[i] = q * 4;
-        } else if (q < C::NQ) {
-            const int qq = q - C::NWQ;
-            const int c = qq / (PH * C::PW4);
-            const int rem = qq - c * (PH * C::PW4);
-            const int r = rem / C::PW4;
-            const int j = rem - r * C::PW4;
+        } else if (q < L::NQ) {
+            const int qq = q - L::NWQ;
+            const int c = qq / (L::DH * L::DW4);
+            const int rem = qq - c * (L::DH * L::DW4);
+            const int r = rem / L::DW4;
+            const int j = rem - r * L::DW4;
             isw[i] = false;
             off[i] = (int)(c * p.sc) + r * p.sh + 4 * j;
         } else {  // tail of the last 1-KiB piece: lands in the stage's padding
@@ -126,11 +174,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         const int c0 = ch * C::CK;
         const float *pb = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
         const float *wb = wbase + (long long)c0 * (KS2 * BN);
-        float *ls = lds + stage * C::STAGE;
+        float *ls = lds + stage * L::STAGE;
 #pragma unroll
-        for (int i = 0; i < C::NI; ++i) {
+        for (int i = 0; i < L::NI; ++i) {
             const int g = i * 4 + wid;
-            if (g < C::NG) {
+            if (g < L::NG) {
                 const float *gp = (isw[i] ? wb : pb) + off[i];
                 SSM_GLDS16(gp, ls + g * 256);
             }
@@ -145,9 +193,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
-    // per-lane operand bases inside a stage (floats)
+    // per-lane operand bases (floats): filter inside a stage, activation inside the patch
     const int aBase = half * (KS2 * BN) + wn * (NT * 32) + l31;
-    const int bBase = C::WSZ + half * (PH * PW) + (wy * C::MTY) * PW + wx * (C::MTX * 32) + l31 + (4 - C::PAD);
+    const int bBase = half * (PH * PW) + (wy * C::MTY * GH + gy) * PW + wx * (C::MTX * GW) + gx + (4 - C::PAD);
 
     const int nchunks = p.Cin / C::CK;
     issue(0, 0);
@@ -155,38 +203,102 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         // chunk ch has landed for every wave; every wave is done reading chunk ch-1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef SSM_CONV_ABLATE
+        if (ch + 1 < nchunks && !((p.abl & 1) && ch >= 1)) issue(ch + 1, (ch + 1) & 1);
+#else
         if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
+#endif
 
-        const float *sa = lds + (ch & 1) * C::STAGE + aBase;
-        const float *sb = lds + (ch & 1) * C::STAGE + bBase;
+        const float *stg = lds + (ch & 1) * L::STAGE;
+        if constexpr (UPS) {
+            // expand the low-res chunk: one work unit = the 2x2 hi-res block between low-res pixels (i,j)..(i+1,j+1)
+            constexpr int PRH = C::TH / 2 + 1, PRW = C::TW / 2 + 1, NU = C::CK * PRH * PRW;
+            constexpr int LH = C::LH, LW = C::LW;
+            const float *raw = stg + C::WSZ;
+            float *hip = lds + L::HIP;
+            const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+            for (int u = tid; u < NU; u += 256) {
+                const int c = u / (PRH * PRW);
+                const int rem = u - c * (PRH * PRW);
+                const int pi = rem / PRW, pj = rem - pi * PRW;
+                const int i = ly0 + pi, j = lx0 + pj;
+                const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
+                const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
+                const float *r0 = raw + (c * LH + (i0 - ly0)) * LW + 3 - lx0;
+                const float *r1 = raw + (c * LH + (i1 - ly0)) * LW + 3 - lx0;
+                const float v00 = r0[j0], v01 = r0[j1], v10 = r1[j0], v11 = r1[j1];
+                // clamped pairs (image border) take the single source value exactly, like ATen's lambda = 0
+                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;
+                const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
+                const float h00 = xa * v00 + xb * v01, h01 = xb * v00 + xa * v01;   // columns 2j+1, 2j+2 of low row i
+                const float h10 = xa * v10 + xb * v11, h11 = xb * v10 + xa * v11;   // ... of low row i+1
+                const int Y = 2 * i + 1, X = 2 * j + 1;
+                const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
+                float *d = hip + (c * PH + 2 * pi) * PW + 2 * pj + 3;
+                d[0] = (yt && xl) ? ya * h00 + yb * h10 : 0.f;
+                d[1] = (yt && xr) ? ya * h01 + yb * h11 : 0.f;
+                d[PW] = (yb2 && xl) ? yb * h00 + ya * h10 : 0.f;
+                d[PW + 1] = (yb2 && xr) ? yb * h01 + ya * h11 : 0.f;
+            }
+            __syncthreads();
+        }
+        const float *sa = stg + aBase;
+        const float *sb = (UPS ? lds + L::HIP : stg + C::WSZ) + bBase;
+        // Operand fetches are software-pipelined in a second register set: a macro-step = G k-steps (>= 4 MFMAs); the
+        // fetches of macro-step i+1 are issued right after the FIRST MFMA of macro-step i, so when the wave waits for
+        // them (the compiler's s_waitcnt lgkmcnt(0) in front of macro-step i+1) they have had >= 3 MFMA times to land and
+        // nothing younger is outstanding.  (Left to itself the compiler sinks every ds_read next to its use and exposes
+        // the LDS latency two or three times per k-step.)  sched_barrier pins source order = issue order.
+        constexpr int S = (C::CK / 2) * KS2;          // k-steps per chunk (2 input channels x 1 tap each)
+        constexpr int G = NT * MT >= 4 ? 1 : (NT * MT == 2 ? 2 : 4);
+        constexpr int NM = (S + G - 1) / G;
+        float a[2][G][NT], bv[2][G][MT];
+        auto fetch = [&](int ms, int buf) {
 #pragma unroll
-        for (int cp = 0; cp < C::CK / 2; ++cp) {
+            for (int g = 0; g < G; ++g) {
+                const int s = ms * G + g;
+                if (s < S) {
+                    const int cp = s / KS2, t = s % KS2, ky = t / KS, kx = t % KS;
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    float a[NT], bv[MT];
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) a[n] = sa[(2 * cp * KS2 + ky * KS + kx) * BN + n * 32];
+                    for (int n = 0; n < NT; ++n) a[buf][g][n] = sa[(2 * cp * KS2 + t) * BN + n * 32];
 #pragma unroll
                     for (int my = 0; my < C::MTY; ++my)
 #pragma unroll
                         for (int mx = 0; mx < C::MTX; ++mx)
-                            bv[my * C::MTX + mx] = sb[(2 * cp * PH + my + ky) * PW + mx * 32 + kx];
+                            bv[buf][g][my * C::MTX + mx] = sb[(2 * cp * PH + my * GH + ky) * PW + mx * GW + kx];
+                }
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int ms = 0; ms < NM; ++ms) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (ms * G + g < S) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n], bv[m], acc[n][m], 0, 0, 0);
+                        for (int m = 0; m < MT; ++m) {
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms & 1][g][n], bv[ms & 1][g][m], acc[n][m], 0, 0, 0);
+                            if (g == 0 && n == 0 && m == 0) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (ms + 1 < NM) fetch(ms + 1, (ms + 1) & 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---- epilogue: bias, LeakyReLU, store (and fused 2x2 mean) -------------------------
-    // accumulator register r of lane (l31, half) = cout (r&3) + 8*(r>>2) + 4*half, pixel l31
-    const int xbase = x0 + wx * (C::MTX * 32) + l31;
-    const int ybase = y0 + wy * C::MTY;
+    // accumulator register r of lane (l31, half) = cout (r&3) + 8*(r>>2) + 4*half, pixel l31 of the group
+    const int xbase = x0 + wx * (C::MTX * GW) + gx;
+    const int ybase = y0 + wy * (C::MTY * GH) + gy;
+#ifdef SSM_CONV_ABLATE
+    if ((p.abl & 2) && acc[0][0][0] != 12345.678f) return;
+#endif
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
 #pragma unroll
@@ -208,21 +320,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
             for (int my = 0; my < C::MTY; ++my)
 #pragma unroll
                 for (int mx = 0; mx < C::MTX; ++mx) {
-                    const int y = ybase + my, x = xbase + mx * 32;
+                    const int y = ybase + my * GH, x = xbase + mx * GW;
                     if (cok && y < p.H && x < p.W) dstb[(long long)co * p.dsc + (long long)y * p.dsh + x] = v[my * C::MTX + mx];
                 }
             if (poolb) {
-                if constexpr (C::MTY % 2 == 0) {
+                if constexpr (GW == 32) {
+                    if constexpr (C::MTY % 2 == 0) {
 #pragma unroll
-                    for (int my = 0; my < C::MTY; my += 2)
+                        for (int my = 0; my < C::MTY; my += 2)
 #pragma unroll
-                        for (int mx = 0; mx < C::MTX; ++mx) {
-                            float s = v[my * C::MTX + mx] + v[(my + 1) * C::MTX + mx];
-                            s += __shfl_xor(s, 1);
-                            const int y = ybase + my, x = xbase + mx * 32;
-                            if (cok && !(l31 & 1) && y < p.H && x < p.W)
-                                poolb[(long long)co * p.psc + (long long)(y >> 1) * p.psh + (x >> 1)] = s * 0.25f;
-                        }
+                            for (int mx = 0; mx < C::MTX; ++mx) {
+                                float s = v[my * C::MTX + mx] + v[(my + 1) * C::MTX + mx];
+                                s += __shfl_xor(s, 1);
+                                const int y = ybase + my, x = xbase + mx * 32;
+                                if (cok && !(l31 & 1) && y < p.H && x < p.W)
+                                    poolb[(long long)co * p.psc + (long long)(y >> 1) * p.psh + (x >> 1)] = s * 0.25f;
+                            }
+                    }
+                } else {   // 8x4 group: the 2x2 neighbours are lanes ^1 (x) and ^GW (y)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float s = v[m] + __shfl_xor(v[m], 1);
+                        s += __shfl_xor(s, GW);
+                        const int y = ybase + (m / C::MTX) * GH, x = xbase + (m % C::MTX) * GW;
+                        if (cok && !(gx & 1) && !(gy & 1) && y < p.H && x < p.W)
+                            poolb[(long long)co * p.psc + (long long)(y >> 1) * p.psh + (x >> 1)] = s * 0.25f;
+                    }
                 }
             }
         }
@@ -230,62 +353,145 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 }
 
 // ---- tile configurations ------------------------------------------------------------
-//            KS NT WN MTY MTX WY WX CK        BN   TH  TW
-using CfgK7 = Cfg<7, 1, 1, 2, 2, 4, 1, 2>;  //  32    8  64   conv1a / conv1b
-using CfgK5 = Cfg<5, 2, 1, 2, 2, 4, 1, 2>;  //  64    8  64   conv2a / conv2b
-using CfgK3N32 = Cfg<3, 1, 1, 2, 2, 4, 1, 4>;   //  32    8  64   conv11a/b, fuse, final
-using CfgK3N64 = Cfg<3, 2, 1, 2, 2, 4, 1, 4>;   //  64    8  64   conv10a/b
-using CfgK3N128 = Cfg<3, 2, 2, 2, 2, 2, 1, 4>;  // 128    4  64   conv3..conv9 (wide maps)
-using CfgK3N128S = Cfg<3, 2, 2, 2, 1, 2, 1, 4>;  // 128   4  32   same, maps where 64-wide tiles waste columns
-// small maps (1/16, 1/32 resolution at batch 1): more, smaller workgroups to cover 256 CUs
-using CfgK3N64T = Cfg<3, 1, 2, 2, 1, 2, 1, 4>;   //  64    4  32
-using CfgK3N32T = Cfg<3, 1, 1, 1, 1, 4, 1, 8>;   //  32    4  32   (odd row tile: no fused pool)
+//                  KS NT WN MTY MTX WY WX CK GW      BN   TH  TW
+using CfgK7 = Cfg<7, 1, 1, 2, 2, 4, 1, 2>;        //  32    8  64   conv1a / conv1b
+using CfgK5 = Cfg<5, 2, 1, 2, 2, 4, 1, 2>;        //  64    8  64   conv2a / conv2b
+using CfgK3N32 = Cfg<3, 1, 1, 2, 2, 4, 1, 4>;     //  32    8  64   conv11a/b, fuse, final
+using CfgK3N64 = Cfg<3, 2, 1, 2, 2, 4, 1, 4>;     //  64    8  64   conv10a/b
+using CfgK3N128 = Cfg<3, 2, 2, 2, 2, 2, 1, 4>;    // 128    4  64   conv3..conv9 (wide maps)
+using CfgK3N128S = Cfg<3, 2, 2, 2, 1, 2, 1, 4>;   // 128    4  32   same, maps where 64-wide tiles waste columns
+// small maps (1/16, 1/32 resolution): more, smaller workgroups to cover 256 CUs
+using CfgK3N64T = Cfg<3, 1, 2, 2, 1, 2, 1, 4>;    //  64    4  32
+using CfgK3N32T = Cfg<3, 1, 1, 1, 1, 4, 1, 8>;    //  32    4  32   (odd row tile: no fused pool / upsample)
+// 8x4 pixel groups: maps 80 / 40 / 22 / 11 ... wide, where 32-wide row segments waste a third of the MFMA columns
+using CfgK3N128G = Cfg<3, 2, 2, 2, 2, 2, 1, 4, 8>;   // 128   16  16
+using CfgK3N64G = Cfg<3, 2, 1, 1, 2, 2, 2, 4, 8>;    //  64    8  32
+using CfgK3N64GS = Cfg<3, 2, 1, 1, 2, 4, 1, 4, 8>;   //  64   16  16
+using CfgK3N32G = Cfg<3, 1, 1, 1, 2, 2, 2, 8, 8>;    //  32    8  32
+using CfgK3N32GS = Cfg<3, 1, 1, 1, 1, 2, 2, 8, 8>;   //  32    8  16
+using CfgK5G = Cfg<5, 2, 1, 1, 2, 2, 2, 2, 8>;       //  64    8  32
+using CfgK7G = Cfg<7, 1, 1, 1, 2, 2, 2, 2, 8>;       //  32    8  32
 
-enum ConvKind { K7 = 0, K5, K3N32, K3N64, K3N128, K3N128S, K3N64T, K3N32T, NKIND };
+#define SSM_CONV_KINDS(X)                                                                                      \
+    X(K7, CfgK7) X(K5, CfgK5) X(K3N32, CfgK3N32) X(K3N64, CfgK3N64) X(K3N128, CfgK3N128) X(K3N128S, CfgK3N128S) \
+    X(K3N64T, CfgK3N64T) X(K3N32T, CfgK3N32T) X(K3N128G, CfgK3N128G) X(K3N64G, CfgK3N64G) X(K3N64GS, CfgK3N64GS) \
+    X(K3N32G, CfgK3N32G) X(K3N32GS, CfgK3N32GS) X(K5G, CfgK5G) X(K7G, CfgK7G)
 
-constexpr int kFillBlocks = 256;   // one workgroup per CU
+enum ConvKind {
+#define X(name, cfg) name,
+    SSM_CONV_KINDS(X)
+#undef X
+        NKIND
+};
+
+struct KindInfo {
+    int ks, bn, th, tw, ck, nt, mt;
+    bool pool_ok, ups_ok;
+};
 
 template <class C>
-long long grid_blocks(int B, int H, int W, int Cout) {
-    return (long long)B * ((W + C::TW - 1) / C::TW) * ((H + C::TH - 1) / C::TH) * ((Cout + C::BN - 1) / C::BN);
+constexpr KindInfo info_of() {
+    return KindInfo{C::KS, C::BN, C::TH, C::TW, C::CK, C::NT, C::MT, C::POOL_OK, C::UPS_OK};
 }
 
-int pick_kind(int k, int Cout, int B, int H, int W, int pool) {
-    if (k == 7) return K7;
-    if (k == 5) return K5;
-    if (k != 3) return -1;
-    if (Cout <= 32) return K3N32;
-    if (Cout <= 64) return K3N64;
-    const int w64 = (W + 63) / 64 * 64, w32 = (W + 31) / 32 * 32;
-    const bool narrow = w32 < w64;
-    const long long nb = narrow ? grid_blocks<CfgK3N128S>(B, H, W, Cout) : grid_blocks<CfgK3N128>(B, H, W, Cout);
-    if (nb >= kFillBlocks) return narrow ? K3N128S : K3N128;
-    if (pool || grid_blocks<CfgK3N64T>(B, H, W, Cout) >= kFillBlocks) return K3N64T;
-    return K3N32T;
+constexpr KindInfo kInfo[NKIND] = {
+#define X(name, cfg) info_of<cfg>(),
+    SSM_CONV_KINDS(X)
+#undef X
+};
+
+std::atomic<int> g_force_kind{-1};    // tests / tuning only (ssm_conv_force_kind)
+
+// Estimated duration (MFMA cycles) of a launch with tile configuration `ki`: 512 workgroup slots (2 per CU); a
+// workgroup alone on its CU issues one MFMA per 64 cycles per wave, two co-resident ones share the pipe; the
+// last round runs under-filled (its workgroups at full speed), and every workgroup pays a fixed prologue
+// (first DMA round trip) + epilogue (stores).
+double estimate_cycles(const KindInfo &ki, int cin8, int Cout, int B, int H, int W) {
+    const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
+    const long long nwg = tiles * ((Cout + ki.bn - 1) / ki.bn);
+    // operand fetches per MFMA cost issue slots and power: (NT + MT) ds_reads per NT*MT MFMAs
+    const double per_mfma = 64.0 + 4.0 * (ki.nt + ki.mt) / (double)(ki.nt * ki.mt);
+    const double wg = (double)ki.nt * ki.mt * (cin8 * ki.ks * ki.ks / 2) * per_mfma + 9000.0;
+    const long long slots = 512;
+    if (nwg <= 256) return wg;
+    if (nwg <= slots) return 2.0 * wg;
+    const long long full = nwg / slots, rest = nwg % slots;
+    return 2.0 * wg * full + (rest == 0 ? 0.0 : rest <= 256 ? wg : 2.0 * wg);
 }
 
-template <class C>
+int pick_kind(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups) {
+    if (k != 3 && k != 5 && k != 7) return -1;
+    const int forced = g_force_kind.load();
+    if (forced >= 0 && forced < NKIND && kInfo[forced].ks == k) return forced;
+    const int cin8 = (Cin + 7) / 8 * 8;
+    int best = -1;
+    double bt = 0.0;
+    for (int i = 0; i < NKIND; ++i) {
+        const KindInfo &ki = kInfo[i];
+        if (ki.ks != k) continue;
+        if (pool && !ki.pool_ok) continue;
+        if (ups && !ki.ups_ok) continue;
+        if (ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;   // more than half of the cout block would be padding
+        const double t = estimate_cycles(ki, cin8, Cout, B, H, W);
+        if (best < 0 || t < bt * 0.999) {
+            best = i;
+            bt = t;
+        }
+    }
+    return best;
+}
+
+// Tile order inside an XCD's contiguous share of the grid.  Cout block fastest: the NB workgroups that read one input
+// patch run together (patch shared in the XCD's L2) - but then every cout block's filter is live in that L2 at once,
+// and the filters of the deep layers (9.4 MB for 512x512x3x3, 18.9 MB for conv7a of stage 2) do not fit its 4 MB: the
+// filter stream of every workgroup then comes from the Infinity Cache.  Cout block slowest: an XCD works through the
+// pixel tiles of ONE cout block at a time (its filter slice stays in L2, the activations stream).  $SSM_CONV_ORDER
+// forces 0 / 1 (tuning).
+int pick_order(const ConvParams &p, int ks2) {
+    static const int forced = [] {
+        const char *e = getenv("SSM_CONV_ORDER");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced == 0 || forced == 1) return forced;
+    return p.NB > 1 && (long long)p.Cout * p.Cin * ks2 * 4 > (3LL << 20);
+}
+
+template <class C, bool UPS>
 int launch(ConvParams &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
     p.NB = (p.Cout + C::BN - 1) / C::BN;
-    if (p.pool && (C::MTY % 2 != 0)) {
+    if (p.pool && !C::POOL_OK) {
         ssm::set_error("conv: fused pool needs an even row tile");
         return SSM_E_UNSUPPORTED;
     }
+    p.B = B;
+    p.nb_slow = pick_order(p, C::KS2);
     const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
-    hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)blocks), dim3(256), C::LDS_BYTES, st, p);
-    return ssm::check_launch("ssm_conv2d_fwd");
+    if constexpr (UPS && !C::UPS_OK) {
+        ssm::set_error("conv: this tile configuration has no fused-upsample form");
+        return SSM_E_UNSUPPORTED;
+    } else {
+        constexpr int lds_bytes = Lds<C, UPS>::BYTES;
+        auto kern = conv_mfma_kernel<C, UPS>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+        return ssm::check_launch(UPS ? "ssm_conv2d_ups_fwd" : "ssm_conv2d_fwd");
+    }
 }
 
-template <class C>
-void cfg_dims(int *BN, int *CK) {
-    *BN = C::BN;
-    *CK = C::CK;
+template <bool UPS>
+int dispatch(int kind, ConvParams &p, int B, hipStream_t st) {
+    switch (kind) {
+#define X(name, cfg) \
+    case name: return launch<cfg, UPS>(p, B, st);
+        SSM_CONV_KINDS(X)
+#undef X
+    }
+    return SSM_E_UNSUPPORTED;
 }
 
 __global__ void pack_weights_kernel(const float *__restrict__ w, const float *__restrict__ bias,
@@ -309,24 +515,73 @@ __global__ void pack_weights_kernel(const float *__restrict__ w, const float *__
     if (i < nbias) bp[i] = (i < Cout) ? bias[i] : 0.f;
 }
 
+int fill_common(ConvParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed,
+                ssm_view y, int H, int W, int Cout, float slope, int flags, int CK, int srcW) {
+    SSM_REQUIRE(H > 0 && W > 0 && Cout > 0 && C1 > 0 && C2 >= 0, "conv: bad sizes");
+    SSM_REQUIRE(x1.ptr && y.ptr && w_packed && bias_packed, "conv: null pointer");
+    SSM_REQUIRE(C1 % CK == 0 && C2 % CK == 0, "conv: channel counts (%d,%d) must be multiples of %d", C1, C2, CK);
+    SSM_REQUIRE(ssm::aligned16(x1.ptr) && x1.sh % 4 == 0 && x1.sc % 4 == 0 && x1.sb % 4 == 0,
+                "conv: input 1 is not a padded-plane view (16-byte alignment)");
+    SSM_REQUIRE(x1.sh >= srcW + 2 * SSM_PADX, "conv: input 1 row stride %d leaves no zero frame for W=%d", x1.sh, srcW);
+    SSM_REQUIRE(ssm::aligned16(w_packed), "conv: packed filter must be 16-byte aligned");
+    if (C2 > 0) {
+        SSM_REQUIRE(x2.ptr && ssm::aligned16(x2.ptr) && x2.sb % 4 == 0, "conv: input 2 is not a padded-plane view");
+        SSM_REQUIRE(x2.sh == x1.sh && x2.sc == x1.sc, "conv: cat sources must share row/channel strides");
+    }
+    SSM_REQUIRE((long long)CK * x1.sc < 0x7fffffffLL, "conv: channel stride too large");
+    p.src1 = x1.ptr;
+    p.src2 = C2 > 0 ? x2.ptr : x1.ptr;
+    p.sb1 = x1.sb;
+    p.sb2 = C2 > 0 ? x2.sb : 0;
+    p.sc = x1.sc;
+    p.sh = x1.sh;
+    p.C1 = C1;
+    p.Cin = C1 + C2;
+    p.wpk = w_packed;
+    p.bias = bias_packed;
+    p.dst = y.ptr;
+    p.dsb = y.sb;
+    p.dsc = y.sc;
+    p.dsh = y.sh;
+    p.pool = nullptr;
+    p.psb = p.psc = 0;
+    p.psh = 0;
+    p.H = H;
+    p.W = W;
+    p.hs = H / 2;
+    p.ws = W / 2;
+    p.Cout = Cout;
+    p.slope = slope;
+    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.abl = 0;
+#ifdef SSM_CONV_ABLATE
+    if (const char *e = getenv("SSM_CONV_ABL")) p.abl = atoi(e);
+#endif
+    return SSM_OK;
+}
+
 }  // namespace
 
-extern "C" int ssm_conv_config(int k, int Cout, int B, int H, int W, int pool, int *BN, int *CK) {
-    const int kind = pick_kind(k, Cout, B, H, W, pool);
-    switch (kind) {
-        case K7: cfg_dims<CfgK7>(BN, CK); break;
-        case K5: cfg_dims<CfgK5>(BN, CK); break;
-        case K3N32: cfg_dims<CfgK3N32>(BN, CK); break;
-        case K3N64: cfg_dims<CfgK3N64>(BN, CK); break;
-        case K3N128: cfg_dims<CfgK3N128>(BN, CK); break;
-        case K3N128S: cfg_dims<CfgK3N128S>(BN, CK); break;
-        case K3N64T: cfg_dims<CfgK3N64T>(BN, CK); break;
-        case K3N32T: cfg_dims<CfgK3N32T>(BN, CK); break;
-        default:
-            ssm::set_error("conv: kernel size %d unsupported (3, 5, 7 are)", k);
-            return SSM_E_UNSUPPORTED;
+extern "C" int ssm_conv_plan(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups, int *kind, int *BN, int *CK) {
+    const int kd = pick_kind(k, Cin, Cout, B, H, W, pool, ups);
+    if (kd < 0) {
+        ssm::set_error("conv: no tile configuration for kernel size %d (3, 5, 7 are supported%s)", k, ups ? "; fused upsample: 3" : "");
+        return SSM_E_UNSUPPORTED;
     }
+    if (kind) *kind = kd;
+    if (BN) *BN = kInfo[kd].bn;
+    if (CK) *CK = kInfo[kd].ck;
     return SSM_OK;
+}
+
+extern "C" int ssm_conv_force_kind(int kind) {
+    g_force_kind.store(kind >= 0 && kind < NKIND ? kind : -1);
+    return NKIND;
+}
+
+extern "C" int ssm_conv_config(int k, int Cout, int B, int H, int W, int pool, int *BN, int *CK) {
+    // historical form (no Cin): the plan of a filter with as many input as output channels
+    return ssm_conv_plan(k, Cout, Cout, B, H, W, pool, 0, nullptr, BN, CK);
 }
 
 extern "C" size_t ssm_packed_weight_floats(int Cout, int CinP, int k, int BN) {
@@ -351,57 +606,32 @@ extern "C" int ssm_pack_weights(const float *w, const float *bias, float *wp, fl
 extern "C" int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed,
                               const float *bias_packed, ssm_view y, ssm_view pool, int B, int H, int W, int Cout,
                               int k, float slope, int flags, void *stream) {
-    int BN = 0, CK = 0;
-    const int rc = ssm_conv_config(k, Cout, B, H, W, pool.ptr ? 1 : 0, &BN, &CK);
+    int kind = 0, BN = 0, CK = 0;
+    SSM_REQUIRE(B > 0, "conv: bad batch");
+    const int rc = ssm_conv_plan(k, C1 + C2, Cout, B, H, W, pool.ptr ? 1 : 0, 0, &kind, &BN, &CK);
     if (rc != SSM_OK) return rc;
-    SSM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && C1 > 0 && C2 >= 0, "conv: bad sizes");
-    SSM_REQUIRE(x1.ptr && y.ptr && w_packed && bias_packed, "conv: null pointer");
-    SSM_REQUIRE(C1 % CK == 0 && C2 % CK == 0, "conv: channel counts (%d,%d) must be multiples of %d", C1, C2, CK);
-    SSM_REQUIRE(ssm::aligned16(x1.ptr) && x1.sh % 4 == 0 && x1.sc % 4 == 0 && x1.sb % 4 == 0,
-                "conv: input 1 is not a padded-plane view (16-byte alignment)");
-    SSM_REQUIRE(x1.sh >= W + 2 * SSM_PADX, "conv: input 1 row stride %d leaves no zero frame for W=%d", x1.sh, W);
-    SSM_REQUIRE(ssm::aligned16(w_packed), "conv: packed filter must be 16-byte aligned");
-    if (C2 > 0) {
-        SSM_REQUIRE(x2.ptr && ssm::aligned16(x2.ptr) && x2.sb % 4 == 0, "conv: input 2 is not a padded-plane view");
-        SSM_REQUIRE(x2.sh == x1.sh && x2.sc == x1.sc, "conv: cat sources must share row/channel strides");
-    }
-    SSM_REQUIRE((long long)CK * x1.sc < 0x7fffffffLL, "conv: channel stride too large");
-    if (pool.ptr) SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv: fused pool needs even H, W");
-
     ConvParams p;
-    p.src1 = x1.ptr;
-    p.src2 = C2 > 0 ? x2.ptr : x1.ptr;
-    p.sb1 = x1.sb;
-    p.sb2 = C2 > 0 ? x2.sb : 0;
-    p.sc = x1.sc;
-    p.sh = x1.sh;
-    p.C1 = C1;
-    p.Cin = C1 + C2;
-    p.wpk = w_packed;
-    p.bias = bias_packed;
-    p.dst = y.ptr;
-    p.dsb = y.sb;
-    p.dsc = y.sc;
-    p.dsh = y.sh;
-    p.pool = pool.ptr;
-    p.psb = pool.sb;
-    p.psc = pool.sc;
-    p.psh = pool.sh;
-    p.H = H;
-    p.W = W;
-    p.Cout = Cout;
-    p.slope = slope;
-    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
-    hipStream_t st = (hipStream_t)stream;
-    switch (pick_kind(k, Cout, B, H, W, pool.ptr ? 1 : 0)) {
-        case K7: return launch<CfgK7>(p, B, st);
-        case K5: return launch<CfgK5>(p, B, st);
-        case K3N32: return launch<CfgK3N32>(p, B, st);
-        case K3N64: return launch<CfgK3N64>(p, B, st);
-        case K3N128: return launch<CfgK3N128>(p, B, st);
-        case K3N128S: return launch<CfgK3N128S>(p, B, st);
-        case K3N64T: return launch<CfgK3N64T>(p, B, st);
-        case K3N32T: return launch<CfgK3N32T>(p, B, st);
+    const int rf = fill_common(p, x1, C1, x2, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W);
+    if (rf != SSM_OK) return rf;
+    if (pool.ptr) {
+        SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv: fused pool needs even H, W");
+        p.pool = pool.ptr;
+        p.psb = pool.sb;
+        p.psc = pool.sc;
+        p.psh = pool.sh;
     }
-    return SSM_E_UNSUPPORTED;
+    return dispatch<false>(kind, p, B, (hipStream_t)stream);
+}
+
+extern "C" int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
+                                  ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    int kind = 0, BN = 0, CK = 0;
+    SSM_REQUIRE(B > 0, "conv_ups: bad batch");
+    SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_ups: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
+    const int rc = ssm_conv_plan(3, C1 + C2, Cout, B, H, W, 0, 1, &kind, &BN, &CK);
+    if (rc != SSM_OK) return rc;
+    ConvParams p;
+    const int rf = fill_common(p, a, C1, b, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W / 2);
+    if (rf != SSM_OK) return rf;
+    return dispatch<true>(kind, p, B, (hipStream_t)stream);
 }

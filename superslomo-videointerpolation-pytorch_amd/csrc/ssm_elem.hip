@@ -100,18 +100,18 @@ __global__ __launch_bounds__(256) void flowinterp_inputs_kernel(ssm_view img6, s
     vp(out16, b, 9, y)[x] = ft0v;
 }
 
-// extract_outputs + compute_output_image, scripts/models/flow_interpolation.py:374-429
-__global__ __launch_bounds__(256) void synthesize_kernel(ssm_view img6, ssm_view in16, ssm_view out5, const float *__restrict__ tarr,
-                                                         ssm_view y3, ssm_view aux, int H, int W) {
-    SSM_PIXEL_INDEX();
-    const float t = tarr[b];
+// extract_outputs + compute_output_image, scripts/models/flow_interpolation.py:374-429, for one pixel: o5 = the five
+// channels of stage 2's final_conv at (b, y, x).  Shared by synthesize_kernel and final_conv_kernel<.., SYNTH> so the
+// two paths round identically.
+__device__ __forceinline__ void synth_pixel(const ssm_view &img6, const ssm_view &in16, const float (&o5)[5], float t, const ssm_view &y3,
+                                            const ssm_view &aux, int b, int y, int x, int H, int W) {
     const float omt = 1.0f - t;
-    const float v1 = 1.0f / (1.0f + expf(-vp(out5, b, 0, y)[x]));
+    const float v1 = 1.0f / (1.0f + expf(-o5[0]));
     const float v0 = 1.0f - v1;
-    const float ft1u = vp(in16, b, 6, y)[x] + vp(out5, b, 1, y)[x];
-    const float ft1v = vp(in16, b, 7, y)[x] + vp(out5, b, 2, y)[x];
-    const float ft0u = vp(in16, b, 8, y)[x] + vp(out5, b, 3, y)[x];
-    const float ft0v = vp(in16, b, 9, y)[x] + vp(out5, b, 4, y)[x];
+    const float ft1u = vp(in16, b, 6, y)[x] + o5[1];
+    const float ft1v = vp(in16, b, 7, y)[x] + o5[2];
+    const float ft0u = vp(in16, b, 8, y)[x] + o5[3];
+    const float ft0v = vp(in16, b, 9, y)[x] + o5[4];
     const Taps t0 = make_taps(x, y, ft0u, ft0v, H, W, img6.sh);
     const Taps t1 = make_taps(x, y, ft1u, ft1v, H, W, img6.sh);
     const float den = omt * v0 + t * v1;
@@ -127,6 +127,135 @@ __global__ __launch_bounds__(256) void synthesize_kernel(ssm_view img6, ssm_view
         vp(aux, b, 2, y)[x] = ft0u;
         vp(aux, b, 3, y)[x] = ft0v;
         vp(aux, b, 4, y)[x] = v0;
+    }
+}
+
+__global__ __launch_bounds__(256) void synthesize_kernel(ssm_view img6, ssm_view in16, ssm_view out5, const float *__restrict__ tarr,
+                                                         ssm_view y3, ssm_view aux, int H, int W) {
+    SSM_PIXEL_INDEX();
+    float o5[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) o5[c] = vp(out5, b, c, y)[x];
+    synth_pixel(img6, in16, o5, tarr[b], y3, aux, b, y, x, H, W);
+}
+
+// ---- final_conv (32 -> 4 or 5 channels, no activation) [+ synthesis] ------------------------------------------------
+// flow_computation.py:145-153 / flow_interpolation.py:149-157 (+ :374-429).  A 32-cout MFMA tile wastes 84 % of the
+// matrix work on these layers (20 TFLOP/s, 1.1 ms of a 46 ms pair); v_mfma_f32_4x4x1_16B_f32 fits them: 16 blocks of
+// (4 couts x 1 k) x (1 k x 4 pixels) - with the filter replicated over the blocks one instruction is 4 couts x 64
+// pixels x 1 k, the pixel on the lane, full fp32-MFMA rate, nothing padded for 4 couts (8 for the 5 of stage 2).
+// Exact fp32 (an fmaf chain per output like the 32x32x2 form).  Stage 2 never writes its 5-channel map: the lane that
+// holds a pixel's five sums runs the synthesis arithmetic on them directly.
+// Tile 8 rows x 64 columns, 4 waves x 2 rows; per chunk of 4 input channels the [4][10][72] patch arrives by LDS-DMA
+// (double-buffered), each wave keeps the chunk's 36 x NG4 filter values in registers for both of its rows.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define SSM_GLDS16(gp, lp)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
+                                     (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
+
+struct FinalParams {
+    ssm_view x;               // [B,32,H,W] padded planes
+    const float *w, *bias;    // OIHW [NC][32][3][3], [NC]
+    int NC;
+    ssm_view out;             // [B,NC,H,W] (ptr NULL with SYNTH)
+    ssm_view img6, in16, y3, aux;
+    const float *t;
+    int H, W, tilesX, tilesY;
+};
+
+template <int NG4, bool SYNTH>
+__global__ __launch_bounds__(256, 2) void final_conv_kernel(const FinalParams p) {
+    constexpr int CIN = 32, CK = 4, TH = 8, TW = 64, PH = TH + 2, PW = TW + 8, PSZ = CK * PH * PW;
+    constexpr int NPQ = PSZ / 4, NG = (NPQ + 63) / 64, STAGE = NG * 256, NI = (NG + 3) / 4;
+    constexpr int WFL = CIN * 9 * NG4 * 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + WFL];
+    float *wl = lds + 2 * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    // filter -> LDS as [cin][tap][group][4 couts], zero beyond NC
+    for (int i = tid; i < WFL; i += 256) {
+        const int co = i % (NG4 * 4), ct = i / (NG4 * 4);       // ct = cin*9 + tap
+        wl[i] = co < p.NC ? p.w[(long long)co * (CIN * 9) + ct] : 0.f;
+    }
+    const float *pbase = p.x.ptr + (long long)b * p.x.sb + (long long)(y0 - 1) * p.x.sh + (x0 - 4);
+    int off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = (i * 4 + wid) * 64 + lane;
+        if (q < NPQ) {
+            const int c = q / (PH * (PW / 4)), rem = q - c * (PH * (PW / 4));
+            const int r = rem / (PW / 4), j = rem - r * (PW / 4);
+            off[i] = (int)(c * p.x.sc) + r * p.x.sh + 4 * j;
+        } else {
+            off[i] = 0;       // tail of the last 1-KiB piece: lands in the stage's padding
+        }
+    }
+    auto issue = [&](int ch, int stage) {
+        const float *pb = pbase + (long long)(ch * CK) * p.x.sc;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int g = i * 4 + wid;
+            if (g < NG) SSM_GLDS16(pb + off[i], lds + stage * STAGE + g * 256);
+        }
+    };
+    f32x4 acc[2][NG4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int g = 0; g < NG4; ++g) acc[r][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // chunk ch (and, first time, the filter) is in LDS; chunk ch-1 is consumed
+        if (ch + 1 < CIN / CK) issue(ch + 1, (ch + 1) & 1);
+        float wr[CK * 9][NG4];
+#pragma unroll
+        for (int i = 0; i < CK * 9; ++i)
+#pragma unroll
+            for (int g = 0; g < NG4; ++g) wr[i][g] = wl[((ch * CK * 9 + i) * NG4 + g) * 4 + (lane & 3)];
+        const float *sb = lds + (ch & 1) * STAGE + (2 * wid) * PW + lane + 3;
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const float xv = sb[(c * PH + r + ky) * PW + kx];
+#pragma unroll
+                        for (int g = 0; g < NG4; ++g)
+                            acc[r][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[c * 9 + ky * 3 + kx][g], xv, acc[r][g], 0, 0, 0);
+                    }
+    }
+    const int x = x0 + lane;
+    if (x >= p.W) return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int y = y0 + 2 * wid + r;
+        if (y >= p.H) continue;
+        float o[NG4 * 4];
+#pragma unroll
+        for (int g = 0; g < NG4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[g * 4 + i] = acc[r][g][i] + (g * 4 + i < p.NC ? p.bias[g * 4 + i] : 0.f);
+        if constexpr (SYNTH) {
+            const float o5[5] = {o[0], o[1], o[2], o[3], o[4]};
+            synth_pixel(p.img6, p.in16, o5, p.t[b], p.y3, p.aux, b, y, x, p.H, p.W);
+        }
+        if (p.out.ptr) {
+#pragma unroll
+            for (int c = 0; c < NG4 * 4; ++c)
+                if (c < p.NC) vp(p.out, b, c, y)[x] = o[c];
+        }
     }
 }
 
@@ -459,6 +588,33 @@ extern "C" int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, c
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "synthesize: plane too large");
     hipLaunchKernelGGL(synthesize_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, in16, out5, t, y3, aux, H, W);
     return ssm::check_launch("ssm_synthesize_fwd");
+}
+
+extern "C" int ssm_final_conv_fwd(ssm_view x, const float *w_oihw, const float *bias, int NC, ssm_view out, ssm_view img6, ssm_view in16,
+                                  const float *t, ssm_view y3, ssm_view aux, int B, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("final_conv");
+    SSM_REQUIRE(x.ptr && w_oihw && bias && NC >= 1 && NC <= 8, "final_conv: null pointer / 1..8 output channels");
+    SSM_REQUIRE(ssm::aligned16(x.ptr) && x.sh % 4 == 0 && x.sc % 4 == 0 && x.sb % 4 == 0 && x.sh >= W + 2 * SSM_PADX,
+                "final_conv: input is not a padded-plane view");
+    SSM_REQUIRE(4LL * x.sc < 0x7fffffffLL, "final_conv: channel stride too large");
+    const bool synth = y3.ptr != nullptr;
+    if (synth) {
+        SSM_REQUIRE(NC == 5 && img6.ptr && in16.ptr && t, "final_conv: the synthesis epilogue needs the 5-channel stage-2 filter, img6, in16, t");
+        SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "final_conv: plane too large");
+    } else {
+        SSM_REQUIRE(out.ptr, "final_conv: no output");
+    }
+    FinalParams p;
+    p.x = x; p.w = w_oihw; p.bias = bias; p.NC = NC; p.out = out; p.img6 = img6; p.in16 = in16; p.y3 = y3; p.aux = aux; p.t = t;
+    p.H = H; p.W = W; p.tilesX = (W + 63) / 64; p.tilesY = (H + 7) / 8;
+    const long long blocks = (long long)p.tilesX * p.tilesY * B;
+    SSM_REQUIRE(blocks > 0 && blocks <= 0x7fffffffLL, "final_conv: grid out of range");
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (synth) hipLaunchKernelGGL((final_conv_kernel<2, true>), grid, blk, 0, st, p);
+    else if (NC <= 4) hipLaunchKernelGGL((final_conv_kernel<1, false>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((final_conv_kernel<2, false>), grid, blk, 0, st, p);
+    return ssm::check_launch("ssm_final_conv_fwd");
 }
 
 extern "C" int ssm_upsample2x_cat_hl8_fwd(ssm_hview a, int Ga, ssm_hview b, int Gb, ssm_hview y, int B, int H, int W, void *stream) {

@@ -21,7 +21,7 @@ def _packed_for(conv_mod, B, H, W):
     problem size selects another tile configuration."""
     w, b = conv_mod.weight, conv_mod.bias
     stamp = (w.data_ptr(), w._version, b.data_ptr(), b._version,
-             hb.conv_config(w.shape[2], w.shape[0], B, H, W, False))
+             hb.conv_plan(w.shape[2], w.shape[1], w.shape[0], B, H, W, False))
     cache = conv_mod.__dict__.get("_ssm_packed")
     if cache is None or cache[0] != stamp:
         cache = (stamp, hb.PackedConv(w, b, B, H, W, False))

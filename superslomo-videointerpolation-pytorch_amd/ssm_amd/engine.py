@@ -2,7 +2,7 @@
 
 A `UNetPlan` is one U-Net (stage 1 = flow computation, stage 2 = arbitrary-time
 flow interpolation) at a fixed (batch, H, W) and precision mode: every activation
-pre-allocated (HL8 hi/lo-fp16 planes by default, fp32 padded planes in mode f32),
+pre-allocated (fp32 padded planes in mode f32, HL8 hi/lo-fp16 planes in the split modes),
 every filter repacked once, and a fixed sequence of C-ABI calls: 24 convolutions
 with fused LeakyReLU / 2x2 mean / two-source concat, the five decoder "a"
 convolutions with the concat + bilinear x2 upsample fused into their loader.  Topology restates scripts/models/flow_computation.py:155-289 and
@@ -84,7 +84,7 @@ class UNetPlan:
                 "t10a", "c10", "t11a", "c11", "tf")
 
     def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True,
-                 bottleneck="CONV", seq_len=1, dec=None, twins=False):
+                 bottleneck="CONV", seq_len=1, dec=None, twins=False, final4=None):
         """B = encoder batch.  With a recurrent bottleneck the batch holds `seq_len` windows of B/seq_len
         sequences in time-major order (index = window * S + sequence).  dec = (b0, Bd): the decoder runs on
         encoder batch entries [b0, b0+Bd) only (inference returns the middle window); None = all."""
@@ -101,7 +101,10 @@ class UNetPlan:
         self._b0 = 0            # batch offset applied to ENCODER_T views (set while the decoder runs)
         self._Bcur = B
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
-        self.fuse_up = bool(fuse_upsample) and self.hl8      # concat+upsample fused into the consumer conv's loader
+        self.fuse_up = bool(fuse_upsample)      # concat+upsample fused into the consumer conv's loader (every mode)
+        # final_conv (32 -> 4 / 5 channels) on the 4x4x1-MFMA kernel instead of a 32-cout tile (mode f32, inference plans);
+        # stage 2 can then run the synthesis in its epilogue (run_decoder(synth=...))
+        self.final4 = (mode == "f32" and self.fuse_up) if final4 is None else (bool(final4) and mode == "f32")
         if self.q8:
             assert self.fuse_up, "mode f16f8 covers the plan with the concat+upsample fused into the convolutions"
         if H % 32 or W % 32:
@@ -172,13 +175,16 @@ class UNetPlan:
             if check_shapes:
                 assert tuple(w.shape) == (co, ci, k, k), "%s: weight shape %s != %s" % (name, tuple(w.shape), (co, ci, k, k))
             s = layer_scale(name)
+            if name == "final_conv":
+                self.final_wb = (w.contiguous(), b.contiguous())
             if self.hl8:
                 self.pk[name] = hb.PackedConv16(w, b, self.W // s, q8=self.q8, ups=self.fuse_up and name in self.UPS,
                                                 scale=self.scales.get(name))
                 self.scales.setdefault(name, self.pk[name].scale)      # later repacks (training) skip the host-side max|w|
             else:
                 nb = self.Bd if name in self.DECODER else self.B
-                self.pk[name] = hb.PackedConv(w, b, nb, self.H // s, self.W // s, pool=name in POOLED)
+                self.pk[name] = hb.PackedConv(w, b, nb, self.H // s, self.W // s, pool=name in POOLED,
+                                              ups=self.fuse_up and name in self.UPS)
         self._pack = None
         if batchable:
             entries = [(self.pk[name], state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")], False)
@@ -261,9 +267,12 @@ class UNetPlan:
         if tm is not None:
             e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * d.H * d.W * pk.cout * pk.cin * 9)
             e0.record()
-        hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
-                          d.view(), self.f32[dst].view() if self.twins else None, self._Bcur, d.H, d.W, lrelu=True,
-                          fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
+        if self.hl8:
+            hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
+                              d.view(), self.f32[dst].view() if self.twins else None, self._Bcur, d.H, d.W, lrelu=True,
+                              fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
+        else:
+            hb.conv2d_ups(self._v(a), A.C, bview, Bp.C if Bp else 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True)
         if tm is not None:
             e1.record()
 
@@ -287,13 +296,13 @@ class UNetPlan:
         if tm is not None:
             e1.record()
 
-    def run(self, cross_planes=None, cross_broadcast=False, cross_b0=0):
+    def run(self, cross_planes=None, cross_broadcast=False, cross_b0=0, synth=None):
         """Input must already be in self.t['in'].  Returns the Planes of final_conv's output (decoder batch).
         cross_planes: stage-1 conv6 output; its entries [cross_b0, cross_b0+Bd) pair with the decoder's batch
-        (cross_broadcast: entry cross_b0 serves the whole batch)."""
+        (cross_broadcast: entry cross_b0 serves the whole batch).  synth: see run_decoder."""
         self.run_encoder()
         self.run_bottleneck()
-        return self.run_decoder(cross_planes, cross_broadcast, cross_b0)
+        return self.run_decoder(cross_planes, cross_broadcast, cross_b0, synth)
 
     def run_encoder(self):
         c = self._conv
@@ -323,15 +332,39 @@ class UNetPlan:
         self._conv("conv6.0", "p6", "t6a")
         self._conv("conv6.1", "t6a", "c6")
 
-    def run_decoder(self, cross_planes=None, cross_broadcast=False, cross_b0=0):
+    def run_decoder(self, cross_planes=None, cross_broadcast=False, cross_b0=0, synth=None):
+        """synth (plans with final4 only): callable(tf_planes, w, b) that launches final_conv fused with the synthesis
+        (ssm_final_conv_fwd with y3) - then the 5-channel map is not written and None is returned."""
         c, uc = self._conv, self._up_conv
         self._b0, self._Bcur = self.dec_b0, self.Bd
         try:
-            return self._decode(c, uc, cross_planes, cross_broadcast, cross_b0)
+            return self._decode(c, uc, cross_planes, cross_broadcast, cross_b0, synth)
         finally:
             self._b0, self._Bcur = 0, self.B
 
-    def _decode(self, c, uc, cross_planes, cross_broadcast, cross_b0):
+    def _final(self, synth):
+        """final_conv: flow_computation.py:145-153 / flow_interpolation.py:149-157."""
+        if not self.final4:
+            assert synth is None
+            self._conv("final_conv", "tf", "out", lrelu=False)
+            return self.t["out"]
+        tf, out = self.t["tf"], self.t["out"]
+        w, b = self.final_wb
+        tm = self.timer
+        if tm is not None:
+            e0, e1 = tm.span("conv", "s%d.final_conv" % self.stage, 2.0 * self._Bcur * tf.H * tf.W * out.C * tf.C * 9)
+            e0.record()
+        if synth is not None:
+            synth(tf, w, b)
+        else:
+            nv = hb.NULL_VIEW
+            hb.check(hb.load().ssm_final_conv_fwd(tf.view(), w.data_ptr(), b.data_ptr(), out.C, out.view(), nv, nv, None, nv, nv,
+                                                  self._Bcur, tf.H, tf.W, hb.stream_ptr()))
+        if tm is not None:
+            e1.record()
+        return None if synth is not None else out
+
+    def _decode(self, c, uc, cross_planes, cross_broadcast, cross_b0, synth=None):
         if self.cross:
             if cross_planes is None:
                 raise RuntimeError("stage 2 was built with CROSS_SKIP but no stage-1 encoding was given")
@@ -348,8 +381,7 @@ class UNetPlan:
         uc("conv11a", "c10", "c2", "u11", "t11a")
         c("conv11b", "t11a", "c11")
         c("fuse_conv", "c11", "tf", src2="c1")
-        c("final_conv", "tf", "out", lrelu=False)
-        return self.t["out"]
+        return self._final(synth)
 
 
 class RecurrentBottleneck:
@@ -466,24 +498,32 @@ class RecurrentBottleneck:
 
 
 class PairEngine:
-    """stage 1 (batch B1) -> compute_inputs -> stage 2 (batch B2) -> synthesis.
-    Either B2 == B1 (one t per sample: FullModel.forward) or B1 == 1 and B2 = number
-    of intermediates of that pair (stage-1 tensors broadcast over the t batch)."""
+    """stage 1 (batch B1 = pairs) -> compute_inputs -> stage 2 (batch B2 = B1 * G) -> synthesis; stage-2 entry p*G + i is
+    pair p at its i-th interpolation time.  G = 1: one t per sample (FullModel.forward).  B1 = 1: the t values of one pair
+    (stage-1 tensors batch-broadcast).  B1 > 1 and G > 1: several pairs per pass - the convolutions then see 2-4x the
+    workgroups per launch (less tail, fuller small maps) while the three kernels that mix stage-1 and stage-2 tensors run
+    once per pair on batch-offset views."""
 
-    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True, twins=False):
-        assert B2 == B1 or B1 == 1, "stage-2 batch must equal stage-1 batch, or stage-1 batch must be 1"
+    def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True, twins=False, fuse_final=None):
+        assert B2 % B1 == 0, "stage-2 batch must be a multiple of the stage-1 batch (pairs x times)"
         self.twins = bool(twins) and mode != "f32"
-        self.B1, self.B2, self.H, self.W, self.device = B1, B2, H, W, device
+        self.B1, self.B2, self.G, self.H, self.W, self.device = B1, B2, B2 // B1, H, W, device
         self.cross = bool(cross_skip)
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.bcast = (B1 == 1 and B2 > 1)
-        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode, fuse_upsample, twins=twins)
-        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode, fuse_upsample, twins=twins)
+        self.grouped = B1 > 1 and self.G > 1
+        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode, fuse_upsample, twins=twins, final4=fuse_final)
+        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode, fuse_upsample, twins=twins, final4=fuse_final)
+        self.fuse_final = self.s2.final4          # stage 2: final_conv + synthesis in one kernel (no 5-channel map)
         self.t_dev = torch.empty(B2, dtype=torch.float32, device=device)
         self.img = torch.empty(B2, 3, H, W, dtype=torch.float32, device=device)
         self.aux = torch.empty(B2, 5, H, W, dtype=torch.float32, device=device)
-        self.img6 = None        # the caller's [B1,6,H,W] pair, read in place by the two gather kernels
+        self.img6 = None        # the caller's [B1,6,H,W] pairs, read in place by the gather kernels
         self.est = torch.empty(B2, 4, H, W, dtype=torch.float32, device=device) if self.hl8 else None   # Ft1^ | Ft0^
+        self.c6x = None
+        if self.grouped and self.cross:     # stage-1 bottleneck output repeated G times per pair: conv7a's second source
+            c6 = self.s1.t["c6"]
+            self.c6x = (hb.HPlanes(B2, c6.C, c6.H, c6.W, device, q8=self.q8) if self.hl8 else hb.Planes(B2, c6.C, c6.H, c6.W, device))
 
     def load_pair(self, img6):
         """img6: [B1,6,H,W] device tensor (I0 | I1 on the channel axis)."""
@@ -496,49 +536,87 @@ class PairEngine:
     def run_stage1(self):
         return self.s1.run()
 
-    def _img6_view(self):
-        v = hb.view_of(self.img6)
-        if self.bcast:
+    def _groups(self):
+        """(pair index or None, first stage-2 entry, entries, stage-1 tensors broadcast?) per launch of a mixing kernel."""
+        if self.grouped:
+            return [(p, p * self.G, self.G, True) for p in range(self.B1)]
+        return [(None, 0, self.B2, self.bcast)]
+
+    def _img6_view(self, p=None, bc=None):
+        v = hb.view_of(self.img6 if p is None else self.img6[p:p + 1])
+        if self.bcast if bc is None else bc:
             v.sb = 0
         return v
 
+    def _cross_planes(self):
+        """(planes, broadcast) of conv7a's cross-skip source for the stage-2 batch."""
+        if not self.cross:
+            return None, False
+        if not self.grouped:
+            return self.s1.t["c6"], self.bcast
+        c6, x, B1, G = self.s1.t["c6"], self.c6x, self.B1, self.G      # whole padded entries (frame included), one strided copy
+        if self.hl8:
+            E = c6.G * 2 * c6.Hp * c6.Wp * 8
+            x.buf[:self.B2 * E].view(B1, G, E).copy_(c6.buf[:B1 * E].view(B1, 1, E).expand(-1, G, -1))
+        else:
+            x.full.view(B1, G, c6.C, c6.Hp, c6.Wp).copy_(c6.full.unsqueeze(1).expand(-1, G, -1, -1, -1))
+        return self.c6x, False
+
     def run_stage2(self, t, want_aux=True):
-        """t: [B2] device tensor of interpolation times in (0,1)."""
+        """t: [B2] device tensor of interpolation times in (0,1) (or [G]: the same times for every pair)."""
         lib = hb.load()
         st = hb.stream_ptr()
-        self.t_dev.copy_(t.reshape(-1), non_blocking=True)
+        t = t.reshape(-1)
+        if t.numel() == self.G and self.B1 > 1:
+            self.t_dev.view(self.B1, self.G).copy_(t.view(1, self.G).expand(self.B1, self.G), non_blocking=True)
+        else:
+            self.t_dev.copy_(t, non_blocking=True)
         flow4 = self.s1.t["out"]
         in16 = self.s2.t["in"]
-        bc = self.bcast
         tm = UNetPlan.timer
         px = float(self.B2 * self.H * self.W)
+        tptr = self.t_dev.data_ptr()
         if tm is not None:   # SURVEY 8d: 104 B/px (read 10 ch, write 16 ch)
             e0, e1 = tm.span("warp", "flowinterp_inputs", nbytes=104.0 * px)
             e0.record()
-        if self.hl8:
-            fn = lib.ssm_flowinterp_inputs_hq8_fwd if self.q8 else lib.ssm_flowinterp_inputs_hl8_fwd
-            hb.check(fn(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
-                        in16.view(), hb.view_of(self.est), self.B2, self.H, self.W, st))
-            if self.twins:      # fp32 copy of the 16-channel stage-2 input for the weight gradient of conv1a
-                hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
-                                                       self.s2.f32["in"].view(), self.B2, self.H, self.W, st))
-        else:
-            hb.check(lib.ssm_flowinterp_inputs_fwd(self._img6_view(), flow4.view(broadcast=bc), self.t_dev.data_ptr(),
-                                                   in16.view(), self.B2, self.H, self.W, st))
+        for p, b0, n, bc in self._groups():
+            i6 = self._img6_view(p, bc)
+            f4 = flow4.view(broadcast=bc, b0=p or 0)
+            if self.hl8:
+                fn = lib.ssm_flowinterp_inputs_hq8_fwd if self.q8 else lib.ssm_flowinterp_inputs_hl8_fwd
+                hb.check(fn(i6, f4, tptr + 4 * b0, in16.view(b0=b0), hb.view_of(self.est[b0:]), n, self.H, self.W, st))
+                if self.twins:      # fp32 copy of the 16-channel stage-2 input for the weight gradient of conv1a
+                    hb.check(lib.ssm_flowinterp_inputs_fwd(i6, f4, tptr + 4 * b0, self.s2.f32["in"].view(b0=b0), n, self.H, self.W, st))
+            else:
+                hb.check(lib.ssm_flowinterp_inputs_fwd(i6, f4, tptr + 4 * b0, in16.view(b0=b0), n, self.H, self.W, st))
         if tm is not None:
             e1.record()
-        out5 = self.s2.run(cross_planes=self.s1.t["c6"] if self.cross else None, cross_broadcast=bc)
-        if self.hl8:    # the kernel reads channels 6..9 of its `in16` argument: alias them onto the 4 est-flow planes
-            ev = hb.view_of(self.est)
-            in16_view = hb.SsmView(ev.ptr - 4 * 6 * ev.sc, ev.sb, ev.sc, ev.sh)
-        else:
-            in16_view = in16.view()
+        cross, cbc = self._cross_planes()
+
+        def in16_view(b0):     # the synthesis reads channels 6..9 of its `in16` argument: in the split modes they alias the 4 est-flow planes
+            if self.hl8:
+                ev = hb.view_of(self.est[b0:])
+                return hb.SsmView(ev.ptr - 4 * 6 * ev.sc, ev.sb, ev.sc, ev.sh)
+            return in16.view(b0=b0)
+
+        def aux_view(b0):
+            return hb.view_of(self.aux[b0:]) if want_aux else hb.NULL_VIEW
+
+        if self.fuse_final:
+            def synth(tf, w, b):      # final_conv + synthesis in one kernel, per group of entries that share a pair
+                for p, b0, n, bc in self._groups():
+                    hb.check(lib.ssm_final_conv_fwd(tf.view(b0=b0), w.data_ptr(), b.data_ptr(), 5, hb.NULL_VIEW, self._img6_view(p, bc),
+                                                    in16_view(b0), tptr + 4 * b0, hb.view_of(self.img[b0:]), aux_view(b0), n,
+                                                    self.H, self.W, st))
+            self.s2.run(cross_planes=cross, cross_broadcast=cbc, synth=synth)
+            return self.img
+        out5 = self.s2.run(cross_planes=cross, cross_broadcast=cbc)
         if tm is not None:   # SURVEY 8d: 72 B/px (read 6+4+5 ch, write 3 ch)
             e0, e1 = tm.span("warp", "synthesize", nbytes=72.0 * px)
             e0.record()
-        hb.check(lib.ssm_synthesize_fwd(self._img6_view(), in16_view, out5.view(), self.t_dev.data_ptr(),
-                                        hb.view_of(self.img), hb.view_of(self.aux) if want_aux else hb.NULL_VIEW,
-                                        self.B2, self.H, self.W, st))
+        for p, b0, n, bc in self._groups():
+            hb.check(lib.ssm_synthesize_fwd(self._img6_view(p, bc), in16_view(b0), out5.view(b0=b0), tptr + 4 * b0,
+                                            hb.view_of(self.img[b0:]), aux_view(b0), n, self.H, self.W, st))
         if tm is not None:
             e1.record()
         return self.img
@@ -552,8 +630,8 @@ class PairEngine:
         """(F01, F10, Ft1^, Ft0^, Ft1, Ft0, V0) as FullModel returns them
         (scripts/models/superslomo_r.py:108-150); torch views/copies on the device."""
         flow = self.s1.t["out"].interior
-        if self.bcast:
-            flow = flow.expand(self.B2, -1, -1, -1)
+        if self.G > 1:
+            flow = flow.repeat_interleave(self.G, 0) if self.B1 > 1 else flow.expand(self.B2, -1, -1, -1)
         if self.hl8:
             e1, e0 = self.est[:, 0:2], self.est[:, 2:4]
         else:
@@ -669,8 +747,11 @@ class PairPipeline:
     MFMA-bound convolutions use the idle matrix cores / CUs.  Each engine owns its activations; the input
     pair is read in place.  Results of `submit` stay valid until that slot is reused (N pairs later)."""
 
-    def __init__(self, sd1, sd2, n_t, H, W, device, cross_skip=True, mode="f16f8", n_streams=2, graphs=False):
-        self.engines = [PairEngine(sd1, sd2, 1, n_t, H, W, device, cross_skip, mode) for _ in range(n_streams)]
+    def __init__(self, sd1, sd2, n_t, H, W, device, cross_skip=True, mode="f32", n_streams=2, graphs=False, pairs_per_batch=1):
+        """pairs_per_batch = P: every submit() takes P pairs [P,6,H,W] through one PairEngine pass (stage 1 at batch P,
+        stage 2 at batch P * n_t) and returns [P * n_t,3,H,W], pair-major."""
+        self.P = P = int(pairs_per_batch)
+        self.engines = [PairEngine(sd1, sd2, P, P * n_t, H, W, device, cross_skip, mode) for _ in range(n_streams)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
         self.n = n_streams
         self._i = 0
@@ -679,7 +760,7 @@ class PairPipeline:
         self.graphs = bool(graphs)
         self._g = [dict() for _ in range(n_streams)]
         if self.graphs:
-            self._in = [torch.empty(1, 6, H, W, dtype=torch.float32, device=device) for _ in range(n_streams)]
+            self._in = [torch.empty(P, 6, H, W, dtype=torch.float32, device=device) for _ in range(n_streams)]
             self._t = [torch.empty(n_t, dtype=torch.float32, device=device) for _ in range(n_streams)]
 
     def _graph(self, k, want_aux):
@@ -695,13 +776,15 @@ class PairPipeline:
         return g
 
     def submit(self, img6, t, want_aux=False, clone=False):
-        """Queue one pair [1,6,H,W] with its t vector on the next stream.  Returns the [n_t,3,H,W] frames:
+        """Queue one batch of pairs [P,6,H,W] with the t vector [n_t] on the next stream.  Returns the [P*n_t,3,H,W] frames:
         the slot's own output buffer (valid until the slot is reused, N pairs later) or, with clone=True, a
         private copy made on the slot's stream.  Filled asynchronously: call sync() before reading."""
         k = self._i % self.n
         self._i += 1
         st = self.streams[k]
-        st.wait_stream(torch.cuda.current_stream())        # inputs produced on the caller's stream
+        caller = torch.cuda.current_stream()
+        st.wait_stream(caller)        # inputs produced on the caller's stream
+        img6.record_stream(st)        # ... and read on this one: keep the allocator from recycling them early
         with torch.cuda.stream(st):
             if self.graphs:
                 self._in[k].copy_(img6.reshape(self._in[k].shape), non_blocking=True)
@@ -712,7 +795,7 @@ class PairPipeline:
                 out = self.engines[k].run(img6, t, want_aux)
             if clone:
                 out = out.clone()
-                out.record_stream(torch.cuda.current_stream())
+                out.record_stream(caller)
         return out
 
     def sync(self):

@@ -77,6 +77,10 @@ SIGNATURES = {
     "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_lrelu_bwd_q8": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv_plan": (_c_int, [_c_int] * 8 + [ctypes.POINTER(ctypes.c_int)] * 3),
+    "ssm_conv_force_kind": (_c_int, [_c_int]),
+    "ssm_conv2d_ups_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
+                                    _c_int, _vp]),
     "ssm_conv2d_hl8_subpixel_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, ctypes.c_float, SsmHView, _c_int, _c_int, _c_int,
                                               _c_int, _c_int, ctypes.c_float, _c_int, _vp]),
     "ssm_hl8_gather_cols": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -108,6 +112,7 @@ SIGNATURES = {
     "ssm_upsample2x_cat_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_flowinterp_inputs_fwd": (_c_int, [SsmView, SsmView, _vp, SsmView, _c_int, _c_int, _c_int, _vp]),
+    "ssm_final_conv_fwd": (_c_int, [SsmView, _vp, _vp, _c_int, SsmView, SsmView, SsmView, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_synthesize_fwd": (_c_int, [SsmView, SsmView, SsmView, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _vp]),
 }
 
@@ -213,7 +218,17 @@ class Planes:
         return out
 
 
+def conv_plan(k, cin, cout, B, H, W, pool=False, ups=False):
+    """(kind, BN, CK) of the tile configuration ssm_conv2d_fwd / ssm_conv2d_ups_fwd will use for this problem."""
+    lib = load()
+    kind, bn, ck = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.ssm_conv_plan(k, cin, cout, B, H, W, 1 if pool else 0, 1 if ups else 0, ctypes.byref(kind), ctypes.byref(bn),
+                            ctypes.byref(ck)))
+    return kind.value, bn.value, ck.value
+
+
 def conv_config(k, cout, B, H, W, pool=False):
+    """(BN, CK) of ssm_conv_config: the plan of a filter with as many input as output channels (historical form)."""
     lib = load()
     bn, ck = ctypes.c_int(0), ctypes.c_int(0)
     check(lib.ssm_conv_config(k, cout, B, H, W, 1 if pool else 0, ctypes.byref(bn), ctypes.byref(ck)))
@@ -226,11 +241,13 @@ class PackedConv:
     handle owned by the Python side (packed-weight caches are
     created/destroyed by the caller)."""
 
-    def __init__(self, weight, bias, B, H, W, pool=False):
+    def __init__(self, weight, bias, B, H, W, pool=False, ups=False):
+        """B, H, W: batch and OUTPUT map of the launches this filter serves; ups: it feeds ssm_conv2d_ups_fwd."""
         require_device(weight, "conv weight")
         require_device(bias, "conv bias")
         self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
-        self.bn, self.ck = conv_config(self.k, self.cout, B, H, W, pool)
+        self.ups = bool(ups)
+        _, self.bn, self.ck = conv_plan(self.k, self.cin, self.cout, B, H, W, pool, ups)
         self.cin_p = (self.cin + self.ck - 1) // self.ck * self.ck
         lib = load()
         nw = lib.ssm_packed_weight_floats(self.cout, self.cin_p, self.k, self.bn)
@@ -245,11 +262,21 @@ class PackedConv:
 def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1):
     lib = load()
     assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
-    assert (pk.bn, pk.ck) == conv_config(pk.k, pk.cout, B, H, W, pool is not None), \
+    assert (pk.bn, pk.ck) == conv_plan(pk.k, c1 + c2, pk.cout, B, H, W, pool is not None)[1:], \
         "filter was packed for another tile configuration (batch/size/pool changed)"
     check(lib.ssm_conv2d_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                              pool if pool is not None else NULL_VIEW, B, H, W, pk.cout, pk.k, slope,
                              SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
+def conv2d_ups(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1):
+    """conv3x3(upsample2x(cat[a, b])) in exact fp32: a, b LOW-res padded-plane views, H, W the OUTPUT size."""
+    lib = load()
+    assert pk.k == 3 and pk.cin_p == c1 + c2, "packed 3x3 filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
+    assert (pk.bn, pk.ck) == conv_plan(3, c1 + c2, pk.cout, B, H, W, False, True)[1:], \
+        "filter was packed for another tile configuration (batch/size changed, or not packed with ups=True)"
+    check(lib.ssm_conv2d_ups_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y, B, H, W,
+                                 pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
 # ---- HL8 (fp16 hi/lo) tensors and the fp16-MFMA convolution ------------------------------------

@@ -36,17 +36,28 @@ def test_plane_dims_and_conv_config():
         lib.ssm_plane_dims(h, w, ctypes.byref(hp), ctypes.byref(wp))
         assert (hp.value, wp.value) == hb.plane_dims(h, w)
         assert wp.value % 4 == 0 and wp.value >= w + 8 and hp.value == h + 6
-    for k, cout, bn in ((7, 32, 32), (5, 64, 64), (3, 32, 32), (3, 5, 32), (3, 64, 64), (3, 128, 128), (3, 512, 128)):
+    for k, cout, bns in ((7, 32, (32,)), (5, 64, (32, 64)), (3, 32, (32,)), (3, 5, (32,)), (3, 64, (32, 64)), (3, 128, (32, 64, 128)),
+                         (3, 512, (32, 64, 128))):
         b, ck = hb.conv_config(k, cout, 7, 736, 1280)
-        assert b == bn and ck in (2, 4)
+        assert b in bns and ck in (2, 4, 8)
         assert lib.ssm_packed_weight_floats(cout, 8, k, b) == (cout + b - 1) // b * 8 * k * k * b
-    # low-parallelism maps get smaller workgroup tiles (more workgroups); fused pool keeps an even row tile
-    assert hb.conv_config(3, 512, 1, 46, 80) == (64, 4)
-    assert hb.conv_config(3, 512, 1, 23, 40) == (32, 8)
-    assert hb.conv_config(3, 512, 1, 4, 4, pool=True) == (64, 4)
-    assert hb.conv_config(3, 512, 7, 23, 40) == (64, 4)
-    assert hb.conv_config(3, 512, 7, 46, 80) == (128, 4)
-    with pytest.raises(RuntimeError, match="unsupported"):
+    # the plan (cost model over the tile configurations) is a pure function of the problem; low-parallelism maps get small
+    # workgroup tiles (more workgroups); a fused pool / fused upsample never selects a configuration without that form
+    assert hb.conv_plan(3, 512, 512, 1, 23, 40) == hb.conv_plan(3, 512, 512, 1, 23, 40)
+    assert hb.conv_plan(3, 512, 512, 1, 23, 40)[1] == 32
+    assert hb.conv_plan(3, 509, 512, 1, 23, 40) == hb.conv_plan(3, 512, 512, 1, 23, 40), "Cin is rounded up to 8 before planning"
+    n_kinds = lib.ssm_conv_force_kind(-1)
+    names = ["K7", "K5", "K3N32", "K3N64", "K3N128", "K3N128S", "K3N64T", "K3N32T", "K3N128G", "K3N64G", "K3N64GS", "K3N32G", "K3N32GS",
+             "K5G", "K7G"]
+    assert n_kinds == len(names)
+    for B, h, w in ((1, 4, 4), (1, 22, 22), (7, 46, 80), (2, 352, 352), (1, 736, 1280)):
+        for cout in (5, 32, 64, 128, 512):
+            assert names[hb.conv_plan(3, 64, cout, B, h, w, pool=True)[0]] != "K3N32T"
+            kd = hb.conv_plan(3, 64, cout, B, h, w, ups=True)[0]
+            assert names[kd].startswith("K3")
+    with pytest.raises(RuntimeError, match="fused upsample"):
+        hb.conv_plan(5, 64, 64, 1, 64, 64, ups=True)
+    with pytest.raises(RuntimeError, match="no tile configuration for kernel size 1"):
         hb.conv_config(1, 32, 1, 64, 64)
 
 
