@@ -58,7 +58,7 @@ DTYPE_NOTE = {"f32": "f32",
               "f16f8": "split f16+e4m3: 1x f16 MFMA + 2x block-scaled e4m3 MFMA for the compensation products (~15-bit products, "
                        "activations stored as f16 hi + e4m3 lo, f32 accumulate) - narrower than f32"}
 # rocprofv3 --pmc traffic summaries (tools/pmc_traffic.sh) per mode: (file under profiles/, conv kernel family keys)
-PMC_FILES = {"f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "conv_ups_kernel", "final_synth_kernel")),
+PMC_FILES = {"f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "final_conv_kernel")),
              "f16x3": ("r1k_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel")),
              "f16f8": ("r1q_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel"))}
 
@@ -335,7 +335,7 @@ def cpu_baseline(sd1, sd2, pair, budget_s=120.0):
     from oracle import ssm_oracle as O
     from ssm_amd.weights import synthetic_frames
     logical, phys = usable_cpus(), physical_cores()
-    cand = sorted({n for n in (8, 16, 32, 64, phys, logical) if 1 <= n <= logical})
+    cand = sorted({n for n in (8, 16, 32, 64, phys) if 1 <= n <= min(phys, logical)})     # SMT siblings only slow the oracle down
     x1 = synthetic_frames(2, 256, 256, seed=42)
     pair1 = torch.cat([x1[:, 0], x1[:, 1]], 1)
     sweep = {}
@@ -444,7 +444,7 @@ def infer_bench(args):
         res = {"value": N_T * P * world * steps / elapsed, "ms_per_step": ms_step, "ms_per_pair": ms_step / P, "elapsed_s": elapsed}
         peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
-        kname = {"f32": "conv_mfma_kernel<*> / conv_ups_kernel<*> (v_mfma_f32_32x32x2_f32)",
+        kname = {"f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "
                           "v_mfma_scale_f32_32x32x64_f8f6f4)"}.get(precision, "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)")
         pmc_file, pmc_keys = PMC_FILES.get(precision, (None, ()))

@@ -61,8 +61,6 @@ struct ConvParams {
     int tilesX, tilesY, NB;
     float slope;
     int lrelu;
-    int nb_slow;         // tile order inside an XCD's share: 1 = cout block slowest (big filters), 0 = fastest
-    int B;
     int abl;             // diagnostics build only (make ablate): 1 = no LDS-DMA after the second chunk, 2 = no stores
 };
 
@@ -123,22 +121,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
 
     int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
-    int nb, tx, ty, b;
-    if (p.nb_slow) {
-        tx = id % p.tilesX;
-        id /= p.tilesX;
-        ty = id % p.tilesY;
-        id /= p.tilesY;
-        b = id % p.B;
-        nb = id / p.B;
-    } else {
-        nb = id % p.NB;
-        id /= p.NB;
-        tx = id % p.tilesX;
-        id /= p.tilesX;
-        ty = id % p.tilesY;
-        b = id / p.tilesY;
-    }
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
     const int x0 = tx * C::TW, y0 = ty * C::TH;
 
     // DMA origin: element (c, y0-PAD, x0-4) of the padded planes, or (c, y0/2-1, x0/2-4) of the low-res source
@@ -441,21 +429,6 @@ int pick_kind(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups) 
     return best;
 }
 
-// Tile order inside an XCD's contiguous share of the grid.  Cout block fastest: the NB workgroups that read one input
-// patch run together (patch shared in the XCD's L2) - but then every cout block's filter is live in that L2 at once,
-// and the filters of the deep layers (9.4 MB for 512x512x3x3, 18.9 MB for conv7a of stage 2) do not fit its 4 MB: the
-// filter stream of every workgroup then comes from the Infinity Cache.  Cout block slowest: an XCD works through the
-// pixel tiles of ONE cout block at a time (its filter slice stays in L2, the activations stream).  $SSM_CONV_ORDER
-// forces 0 / 1 (tuning).
-int pick_order(const ConvParams &p, int ks2) {
-    static const int forced = [] {
-        const char *e = getenv("SSM_CONV_ORDER");
-        return e ? atoi(e) : -1;
-    }();
-    if (forced == 0 || forced == 1) return forced;
-    return p.NB > 1 && (long long)p.Cout * p.Cin * ks2 * 4 > (3LL << 20);
-}
-
 template <class C, bool UPS>
 int launch(ConvParams &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
@@ -465,8 +438,6 @@ int launch(ConvParams &p, int B, hipStream_t st) {
         ssm::set_error("conv: fused pool needs an even row tile");
         return SSM_E_UNSUPPORTED;
     }
-    p.B = B;
-    p.nb_slow = pick_order(p, C::KS2);
     const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("conv: grid of %lld workgroups out of range", blocks);

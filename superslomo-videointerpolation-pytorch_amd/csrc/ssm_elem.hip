@@ -216,25 +216,40 @@ __global__ __launch_bounds__(256, 2) void final_conv_kernel(const FinalParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                      // chunk ch (and, first time, the filter) is in LDS; chunk ch-1 is consumed
         if (ch + 1 < CIN / CK) issue(ch + 1, (ch + 1) & 1);
-        float wr[CK * 9][NG4];
-#pragma unroll
-        for (int i = 0; i < CK * 9; ++i)
-#pragma unroll
-            for (int g = 0; g < NG4; ++g) wr[i][g] = wl[((ch * CK * 9 + i) * NG4 + g) * 4 + (lane & 3)];
+        // macro-step = one filter row of one input channel (3 taps x 2 rows x NG4 MFMAs); its operands are fetched into the
+        // other register set right after the first MFMA of the step before (the compiler, left alone, re-reads the filter
+        // value from LDS immediately in front of every group of MFMAs and waits for it)
+        const float *sw = wl + (ch * CK * 9 * NG4) * 4 + (lane & 3);
         const float *sb = lds + (ch & 1) * STAGE + (2 * wid) * PW + lane + 3;
+        float wv[2][3][NG4], xv[2][2][3];
+        auto fetch = [&](int m, int buf) {
+            const int c = m / 3, ky = m % 3;
 #pragma unroll
-        for (int c = 0; c < CK; ++c)
+            for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int g = 0; g < NG4; ++g) wv[buf][kx][g] = sw[((c * 9 + ky * 3 + kx) * NG4 + g) * 4];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int r = 0; r < 2; ++r) xv[buf][r][kx] = sb[(c * PH + r + ky) * PW + kx];
+            }
+        };
+        fetch(0, 0);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const float xv = sb[(c * PH + r + ky) * PW + kx];
+        for (int m = 0; m < CK * 3; ++m) {
 #pragma unroll
-                        for (int g = 0; g < NG4; ++g)
-                            acc[r][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[c * 9 + ky * 3 + kx][g], xv, acc[r][g], 0, 0, 0);
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int g = 0; g < NG4; ++g) {
+                        acc[r][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[m & 1][kx][g], xv[m & 1][r][kx], acc[r][g], 0, 0, 0);
+                        if (kx == 0 && r == 0 && g == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (m + 1 < CK * 3) fetch(m + 1, (m + 1) & 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     const int x = x0 + lane;
     if (x >= p.W) return;

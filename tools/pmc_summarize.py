@@ -2,7 +2,8 @@
 """Sum FETCH_SIZE / WRITE_SIZE per kernel family from the rocprofv3 --pmc CSVs written by
 tools/pmc_traffic.sh and apply the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact.
-Counter unit: KiB (rocprofv3 derived counter, TCC_EA0_*REQ based)."""
+Counter unit: KiB (rocprofv3 derived counter, TCC_EA0_*REQ based).
+usage: pmc_summarize.py <outdir> [pairs that went through the kernels, default 3]; figures are per frame pair."""
 import csv
 import glob
 import json
@@ -20,14 +21,14 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             name = row.get("Kernel_Name", "")
             if row.get("Counter_Name") != ctr:
                 continue
-            fam = next((k for k in ("conv16_ups_kernel", "conv16_multi_kernel", "conv16_kernel", "conv_mfma_kernel", "upsample2x_cat_hl8_kernel", "upsample2x_cat_kernel",
+            fam = next((k for k in ("final_conv_kernel", "conv16_ups_kernel", "conv16_multi_kernel", "conv16_kernel", "conv_mfma_kernel", "upsample2x_cat_hl8_kernel", "upsample2x_cat_kernel",
                                     "flowinterp_inputs_hl8_kernel", "flowinterp_inputs_kernel", "to_hl8_kernel", "to_hq8_kernel", "gather_cols_kernel", "pack16_kernel",
                                     "synthesize_kernel", "copy_view_kernel", "pack_weights_kernel", "FillFunctor",
                                     "copyBuffer") if k in name), "other")
             res[fam][ctr] += float(row["Counter_Value"])
             if ctr == "FETCH_SIZE":
                 calls[fam] += 1
-STEPS = 3   # bench.py --steps 2 --warmup 1
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3   # frame pairs processed (bench.py --steps 2 --warmup 1 x pairs per step)
 summ = {}
 for fam, d in res.items():
     rd = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024.0      # gfx950: x2

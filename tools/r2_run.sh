@@ -1,8 +1,8 @@
 set -x
 mkdir -p gpurun_out
-for sg in 0 1; do
-SSM_CONV_STAGGER=$sg timeout 600 python tools/bench_layers.py 7 > gpurun_out/r2g_layers_b7_stag$sg.log 2>&1; tail -n 1 gpurun_out/r2g_layers_b7_stag$sg.log
-SSM_CONV_STAGGER=$sg timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-io --modes '' --streams 3 --pairs-per-batch 2 --detail gpurun_out/r2g_detail_stag$sg.json > gpurun_out/r2g_f32_stag$sg.json 2>> gpurun_out/r2g_err.log
-cut -c1-200 gpurun_out/r2g_f32_stag$sg.json
-done
-timeout 1500 python -m pytest tests/test_hip_conv_f32.py tests/test_hip_model.py -x -q -m gpu > gpurun_out/r2g_tests.log 2>&1; tail -n 5 gpurun_out/r2g_tests.log
+timeout 2400 python bench.py --steps 20 --warmup 3 --streams 3 --detail gpurun_out/r2k_detail.json > gpurun_out/r2k_bench_line.json 2> gpurun_out/r2k_bench_err.log
+cut -c1-300 gpurun_out/r2k_bench_line.json; tail -n 3 gpurun_out/r2k_bench_err.log
+bash tools/pmc_traffic.sh gpurun_out/r2k_pmc_f32 f32 > gpurun_out/r2k_pmc_f32.log 2>&1; tail -n 12 gpurun_out/r2k_pmc_f32.log
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2k_prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --pairs-per-step 4 --no-cpu-baseline --no-io --no-kernel-timers --modes '' --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/r2k_prof.log 2>&1
+cd $GRAFT_REPO_ROOT; ls gpurun_out/r2k_prof | head; find gpurun_out/r2k_prof -name "*kernel_stats.csv" | head -2
