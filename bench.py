@@ -124,8 +124,8 @@ def conv_flops_per_pair(h, w, n_t):
 
 
 TRAIN_DTYPE_NOTE = {
-    "f16f8": "f32 parameters/activations/gradients; products via 1x f16 + 2x block-scaled fp8 MFMA (forward, data gradients) and 3x bf16 "
-             "MFMA on hi/lo-split operands (weight gradients), f32 accumulate",
+    "f16f8": "f32 parameters/activations/gradients; products via 1x f16 + 2x block-scaled e4m3 MFMA (forward, data gradients) and 3x bf16 "
+             "MFMA on hi/lo-split operands (weight gradients), f32 accumulate - narrower than f32",
     "f32": "f32 (fp32 MFMA)"}
 
 
@@ -152,6 +152,9 @@ def train_bench(args):
         from ssm_amd.perceptual import VGGFeatures, synthetic_vgg_state_dict      # pretrained net the reference downloads
         model.loss.load_vgg16(synthetic_vgg_state_dict())
     model = model.to(dev).train()
+    train_mode = args.precision or os.environ.get("SSM_TRAIN_PRECISION", "f32")
+    assert train_mode in ("f32", "f16f8"), "--mode train: --precision f32 (default, exact) or f16f8"
+    model.train_precision = train_mode
     trainer = Trainer(model, cfg)
     B, S = 2, 352
     clips = torch.cat([synthetic_frames(3, S, S, seed=100 + 2 * rank + i) for i in range(B)], 0).to(dev)   # [B,3,3,S,S]
@@ -185,7 +188,7 @@ def train_bench(args):
     out = {"metric": "training samples/sec (352x352 crops, forward+backward+Adam)", "value": round(B * world * args.steps / elapsed, 3),
            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": TRAIN_DTYPE_NOTE.get(os.environ.get("SSM_TRAIN_PRECISION", "f16f8"), "f32"), "data": "synthetic",
+           "dtype": TRAIN_DTYPE_NOTE[train_mode], "data": "synthetic",
            "config": {"workload": "superslomo_original.ini training, FREEZE=FALSE, %d samples/GPU of 352x352, %d GPU(s); "
                                   "losses: L1 reconstruction + 4 L1 warp terms + %s" % (B, world, "VGG16 conv4_3 perceptual term OFF" if args.no_perceptual else
                                                                                   "VGG16 conv4_3 perceptual term (synthetic VGG weights)"),
@@ -224,7 +227,7 @@ def recurrent_bench(args):
     p1, p2 = synthetic_state_dict(1, bottleneck=kind), synthetic_state_dict(2, bottleneck=kind)
     model.stage1_model.load_state_dict(p1)
     model.stage2_model.load_state_dict(p2)
-    model.precision = args.precision or "f16f8"
+    model.precision = args.precision or HEADLINE_PRECISION
     model = model.to(dev).eval()
     n_frames = cfg.getint("TRAIN", "N_FRAMES")
     clips = [synthetic_frames(n_frames, H_IN, W_IN, seed=42 + 2 * rank + i).to(dev) for i in range(2)]

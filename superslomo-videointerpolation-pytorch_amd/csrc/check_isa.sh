@@ -1,0 +1,24 @@
+#!/bin/bash
+# Build-time fence for the packed-fp32 hazard: no v_pk_*_f32 instruction may appear in the gfx950 code of any
+# object of libssm_hip.so.  (Vectoriser-generated v_pk_mul_f32 -> v_pk_add_f32 with swapped op_sel halves gave wrong lanes
+# 48..63 in rare waves while another queue ran the block-scaled MFMA convolutions; every file is therefore compiled with
+# -fno-slp-vectorize, and this check fails the build if a compiler or flag change brings packed fp32 back.)
+#   usage: check_isa.sh a.o b.o ...
+set -e
+LLVM=${LLVM_BIN:-/opt/rocm/lib/llvm/bin}
+tmp=$(mktemp -d)
+trap 'rm -rf $tmp' EXIT
+bad=0
+for o in "$@"; do
+    objcopy -O binary --only-section=.hip_fatbin "$o" $tmp/fat.bin 2>/dev/null || continue
+    [ -s $tmp/fat.bin ] || continue                     # host-only object
+    $LLVM/clang-offload-bundler --unbundle --type=o --input=$tmp/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$tmp/dev.co
+    n=$($LLVM/llvm-objdump -d $tmp/dev.co | grep -c 'v_pk_[a-z0-9]*_f32' || true)
+    if [ "$n" != "0" ]; then
+        echo "check_isa: $o contains $n packed-fp32 instructions (v_pk_*_f32):" >&2
+        $LLVM/llvm-objdump -d $tmp/dev.co | grep 'v_pk_[a-z0-9]*_f32' | head -5 >&2
+        bad=1
+    fi
+done
+[ $bad = 0 ] && echo "check_isa: no packed-fp32 instructions in $# object(s)"
+exit $bad

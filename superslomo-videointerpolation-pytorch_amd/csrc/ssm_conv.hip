@@ -325,11 +325,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                                     poolb[(long long)co * p.psc + (long long)(y >> 1) * p.psh + (x >> 1)] = s * 0.25f;
                             }
                     }
-                } else {   // 8x4 group: the 2x2 neighbours are lanes ^1 (x) and ^GW (y)
+                } else {   // 8x4 group: the 2x2 neighbours are lanes ^GW (y) and ^1 (x); same association as the 32x1 form
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        float s = v[m] + __shfl_xor(v[m], 1);
-                        s += __shfl_xor(s, GW);
+                        float s = v[m] + __shfl_xor(v[m], GW);
+                        s += __shfl_xor(s, 1);
                         const int y = ybase + (m / C::MTX) * GH, x = xbase + (m % C::MTX) * GW;
                         if (cok && !(gx & 1) && !(gy & 1) && y < p.H && x < p.W)
                             poolb[(long long)co * p.psc + (long long)(y >> 1) * p.psh + (x >> 1)] = s * 0.25f;
@@ -414,16 +414,18 @@ int pick_kind(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups) 
     const int cin8 = (Cin + 7) / 8 * 8;
     int best = -1;
     double bt = 0.0;
-    for (int i = 0; i < NKIND; ++i) {
-        const KindInfo &ki = kInfo[i];
-        if (ki.ks != k) continue;
-        if (pool && !ki.pool_ok) continue;
-        if (ups && !ki.ups_ok) continue;
-        if (ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;   // more than half of the cout block would be padding
-        const double t = estimate_cycles(ki, cin8, Cout, B, H, W);
-        if (best < 0 || t < bt * 0.999) {
-            best = i;
-            bt = t;
+    for (int pass = 0; pass < 2 && best < 0; ++pass) {      // second pass: kernel sizes without a narrow cout block (k = 5, Cout <= 32)
+        for (int i = 0; i < NKIND; ++i) {
+            const KindInfo &ki = kInfo[i];
+            if (ki.ks != k) continue;
+            if (pool && !ki.pool_ok) continue;
+            if (ups && !ki.ups_ok) continue;
+            if (pass == 0 && ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;   // over half of the cout block = padding
+            const double t = estimate_cycles(ki, cin8, Cout, B, H, W);
+            if (best < 0 || t < bt * 0.999) {
+                best = i;
+                bt = t;
+            }
         }
     }
     return best;

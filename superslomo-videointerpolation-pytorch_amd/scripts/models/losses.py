@@ -58,7 +58,8 @@ class SSMLosses(nn.Module):
         """The HIP VGG16 plan for this batch geometry (None without weights)."""
         if self._vgg_sd is None:
             return None
-        mode = os.environ.get("SSM_TRAIN_PRECISION", "f16f8")
+        # the model's training precision (FullModel._train_engine stores it here), else $SSM_TRAIN_PRECISION, else exact fp32
+        mode = self.__dict__.get("train_precision") or os.environ.get("SSM_TRAIN_PRECISION", "f32")
         key = (B, H, W, str(device), mode)
         if self._pterm is None or self._pterm[0] != key:
             from ssm_amd.perceptual import PerceptualTerm

@@ -19,11 +19,13 @@ import torch.nn as nn
 from ssm_amd import hipbind as hb
 from ssm_amd.engine import PairEngine, WindowEngine
 
-# Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f16f8" evaluates every fp32 product
-# as one fp16 MFMA on the hi parts plus two block-scaled fp8 MFMAs for the compensation terms; "f16x3" as three fp16
-# MFMAs on hi/lo-split operands (both fp32-accumulated, fp32-grade, held to the same 1e-3 bar by the tests); "f32" is
-# the plain fp32-MFMA kernel; "f16" is reduced precision.
-DEFAULT_PRECISION = "f16f8"
+# Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f32" (default) = the reference's arithmetic:
+# every product on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32).  Opt-in split modes, narrower than fp32: "f16x3"
+# evaluates a product as three fp16 MFMAs on hi/lo-split operands (~22-bit operands), "f16f8" as one fp16 MFMA on the hi
+# parts plus two block-scaled e4m3 MFMAs for the compensation terms (~15-bit products); both accumulate in fp32 and meet
+# the 1e-3 frame bar in the tests at 2.5x / 2.9x the frame rate.  "f16" is plain fp16 inputs (config 5).
+DEFAULT_PRECISION = "f32"
+DEFAULT_TRAIN_PRECISION = "f32"
 
 from . import unetflow as unet
 from .losses import SSMLosses
@@ -68,7 +70,7 @@ class _TrainStep(torch.autograd.Function):
         pt = model.loss.perceptual_term(B, H, W, img6.device)
         if pt is not None and os.environ.get("SSM_VGG_OVERLAP", "1") != "0":
             pt.begin_target(target)      # the target's VGG features do not depend on the forward: second stream, beside the U-Nets
-        pred = eng.run(img6, t, want_aux=True).clone()
+        pred = eng.run(img6, t, want_aux=True, want_out5=True).clone()
         f01, f10, e1, e0, _, _, _ = eng.intermediates()
         losses = model.loss.losses_from_parts(img6, torch.cat([f01, f10], 1), e1, e0, eng.s2.t["out"].interior, pred, target)
         ctx.model, ctx.pg, ctx.sd, ctx.target = model, pg, (sd1, sd2), target
@@ -85,15 +87,16 @@ class _TrainStep(torch.autograd.Function):
         dy_extra = None
         B, _, H, W = ctx.target.shape
         pt = model.loss.perceptual_term(B, H, W, ctx.target.device)
+        S = ctx.pg.loss_scale(max(lambda_r, lambda_w, lambda_p))      # power-of-two gradient scale of the f16f8 plan (1 for f32)
         if pt is not None:        # VGG activations of this step's forward are still in the plan's buffers
-            dy_extra = pt.grad_pred((d_losses[:, 0] + d_losses[:, 3]) * lambda_p).view()
+            dy_extra = pt.grad_pred((d_losses[:, 0] + d_losses[:, 3]) * (S * lambda_p)).view()
         named = [(stage + name, p) for stage, mod in (("stage1.", model.stage1_model), ("stage2.", model.stage2_model))
                  for name, p in mod.named_parameters()]
         for _, p in named:          # a gradient kept from an earlier backward lives in the buffers this backward rewrites: detach it
             if p.grad is not None and ctx.pg.owns(p.grad):
                 p.grad = p.grad.clone()
         grads = ctx.pg.backward(ctx.sd[0], ctx.sd[1], ctx.target, d_losses, lambda_r, lambda_w, train_s1, train_s2,
-                                dy_extra=dy_extra)
+                                dy_extra=dy_extra, lambda_p=lambda_p)
         # The gradients are handed to `.grad` directly (what AccumulateGrad would do, minus 96 clone launches per step): slices of the
         # per-U-Net flat buffers, valid until this model's next backward; an existing .grad is accumulated into, as autograd does.
         for key, p in named:
@@ -116,6 +119,16 @@ class FullModel(nn.Module):
         self.freeze_weights()
         self.loss = SSMLosses(cfg)
         self._engine = None
+        # a load_state_dict into the stage modules (checkpoint resume, main.py:263-284) writes the parameters IN PLACE: same
+        # addresses, so the training plan would keep the power-of-two filter pre-scales it chose for the old values - drop the
+        # plans, the next step rebuilds them from the loaded weights
+        for m in (self.stage1_model, self.stage2_model):
+            m.register_load_state_dict_post_hook(lambda module, incompatible_keys: self._drop_plans())
+
+    def _drop_plans(self):
+        self._engine = None
+        self._pipe = None
+        self._train = None
 
     def load_weights(self):
         # quirk kept for drop-in behaviour: BOTH paths are gated on STAGE1.LOADPREV (superslomo_r.py:46-52)
@@ -220,15 +233,16 @@ class FullModel(nn.Module):
         return outs
 
     # ---- training step ------------------------------------------------------------------------------------------
-    train_precision = None      # "f16f8" (default; $SSM_TRAIN_PRECISION) | "f32"
+    train_precision = None      # "f32" (default; $SSM_TRAIN_PRECISION) | "f16f8" (opt-in: split forward / data gradients, bf16x3 weight gradients)
 
     def _train_engine(self, B, H, W, device):
         """The training plan + its PairGrad.  f16f8: the inference plan (fused upsample, fp16 + fp8 matrix path) writing fp32
         twins of every conv output for the backward, data gradients on the same kernels; f32: exact-fp32 MFMA plan with
         materialised upsample tensors."""
         from ssm_amd.backward import PairGrad
-        mode = self.train_precision or os.environ.get("SSM_TRAIN_PRECISION", "f16f8")
+        mode = self.train_precision or os.environ.get("SSM_TRAIN_PRECISION", DEFAULT_TRAIN_PRECISION)
         assert mode in ("f16f8", "f32"), "training precision must be f16f8 or f32"
+        self.loss.__dict__["train_precision"] = mode        # the VGG16 term runs in the same arithmetic
         key = (B, H, W, str(device), mode)
         if getattr(self, "_train", None) is None or self._train[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
@@ -272,7 +286,7 @@ class FullModel(nn.Module):
             for k in range(T):
                 img6 = image_pairs[:, k].contiguous()
                 eng = self.engine_for(B, B, img6.shape[2], img6.shape[3], img6.device)
-                pred = eng.run(img6, t_interp[:, k].reshape(B).to(torch.float32), want_aux=True)
+                pred = eng.run(img6, t_interp[:, k].reshape(B).to(torch.float32), want_aux=True, want_out5=True)
                 f01, f10, e1, e0, _, _, _ = eng.intermediates()
                 out5 = eng.s2.t["out"].interior
                 losses = losses + self.loss.losses_from_parts(img6, torch.cat([f01, f10], 1), e1, e0, out5, pred,

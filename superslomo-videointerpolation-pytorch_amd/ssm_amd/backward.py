@@ -10,6 +10,7 @@ planes (the training plan runs in precision mode "f32"):
   ssm_synthesize_bwd
 """
 import contextlib
+import math
 import os
 
 import torch
@@ -155,8 +156,11 @@ class UNetGrad:
         if self.hl8:
             ws = [state_dict[param_key(n, "weight")] for n in names]
             if all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in ws):
-                key = (tuple(names), hb.PackBatch.key(ws))
+                scales = tuple(self.plan.scales[n] for n in names)
+                key = (tuple(names), hb.PackBatch.key(ws), scales)
                 if getattr(self, "_pack", None) is None or self._pack[0] != key:
+                    if getattr(self, "_pack", None) is not None and self._pack[0][2] != scales:
+                        self.pk_t = {}          # the forward plan re-chose its filter pre-scales: repack with them
                     entries = []
                     for n, w in zip(names, ws):
                         ci, co, k = self.plan.layers[n]
@@ -310,17 +314,32 @@ class PairGrad:
                 return True
         return False
 
-    def backward(self, sd1, sd2, target, g_losses, lambda_r, lambda_w, train_s1, train_s2, n_windows=1, dy_extra=None):
+    def loss_scale(self, lambda_max, n_windows=1):
+        """Power-of-two scale S applied to the loss gradient at the top of the backward and divided out of the parameter
+        gradients at its end (exact in fp32, the chain is linear in dZ).  Only the f16f8 plan needs it: there dZ is carried as
+        fp16 hi + e4m3(lo * 2^11), and the per-pixel loss gradient lambda / (3 H W) - 1.2e-5 for the shipped config at 224x224
+        with batch 32 - is below fp16's smallest normal (6.1e-5): hi would be subnormal and the compensation part flush to zero.
+        S brings the top-level coefficient to ~4 x the upstream gradient (4/B for a batch mean): the e4m3 compensation parts
+        (lo * 2^11 ~ dZ/2) then sit in e4m3's normal range for the gradients that matter, while 448 (the clamp of the fp8(dZ)
+        operand) and fp16's 65504 stay 2 and 4 orders of magnitude away."""
+        if not self.e.hl8:
+            return 1.0
+        n = 3.0 * self.e.H * self.e.W * n_windows
+        return 4.0 * 2.0 ** math.floor(math.log2(n / max(float(lambda_max), 1e-30)))
+
+    def backward(self, sd1, sd2, target, g_losses, lambda_r, lambda_w, train_s1, train_s2, n_windows=1, dy_extra=None, lambda_p=0.0):
         """target [B,3,H,W]; g_losses [B,4] = upstream gradient of the [B,4] loss tensor (columns total, recon, warp,
         perceptual); returns {state-dict key: gradient} for the stages that train.  The warp-loss terms follow the
-        FREEZE gating of scripts/models/losses.py:159-167.  dy_extra: ssm_view of d(perceptual term)/d(frame), or None."""
+        FREEZE gating of scripts/models/losses.py:159-167.  dy_extra: ssm_view of d(perceptual term)/d(frame) ALREADY times
+        loss_scale(max(lambda_r, lambda_w, lambda_p)), or None."""
         e = self.e
         lib = hb.load()
         st = hb.stream_ptr()
         B, H, W = e.B2, e.H, e.W
         n = 3.0 * H * W * n_windows
-        self.cr.copy_((g_losses[:, 0] + g_losses[:, 1]) * (lambda_r / n))
-        self.cw.copy_((g_losses[:, 0] + g_losses[:, 2]) * (lambda_w / n))
+        S = self.loss_scale(max(lambda_r, lambda_w, lambda_p), n_windows)
+        self.cr.copy_((g_losses[:, 0] + g_losses[:, 1]) * (S * lambda_r / n))
+        self.cw.copy_((g_losses[:, 0] + g_losses[:, 2]) * (S * lambda_w / n))
         target = target.contiguous()
         img6 = hb.view_of(e.img6)
         in16, out5, flow4 = e.s2.t["in"], e.s2.t["out"], e.s1.t["out"]
@@ -353,4 +372,8 @@ class PairGrad:
             self.u1.backward(d_flow4, need_wgrad=True, c6_grad_init=dcross)
             grads.update({"stage1." + k: v for k, v in self.u1.grads.items()})
         self.u2.join()
+        if S != 1.0:
+            for u, on in ((self.u2, train_s2), (self.u1, need_s1)):
+                if on:
+                    u.flat.mul_(1.0 / S)
         return grads

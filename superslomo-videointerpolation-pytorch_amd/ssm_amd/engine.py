@@ -73,6 +73,7 @@ def layer_scale(name):
 
 class UNetPlan:
     timer = None     # a KernelTimer, or None
+    RESCALE_EVERY = int(os.environ.get("SSM_RESCALE_EVERY", "256"))
     fast_layers = frozenset()    # diagnostics: "s<stage>.<layer>" names that run hi*hi only inside an f16x3 plan (tools/precision_scan.py)
 
     DECODER = ("conv7a", "conv7b", "conv8a", "conv8b", "conv9a", "conv9b", "conv10a", "conv10b", "conv11a", "conv11b",
@@ -164,6 +165,12 @@ class UNetPlan:
         for name in self.layers:
             tensors += [state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")]]
         batchable = self.q8 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
+        # the one-launch repack reuses the power-of-two pre-scales chosen at the first pack; every RESCALE_EVERY-th refresh goes
+        # the slow way and chooses them again from the current max|w| (one host sync), so filters that grew or shrank by a few
+        # octaves during training get their fp16 / e4m3 range back
+        self._refreshes = getattr(self, "_refreshes", 0) + 1
+        if self._refreshes % self.RESCALE_EVERY == 0:
+            self.scales, self._pack = {}, None
         if batchable and getattr(self, "_pack", None) is not None and self._pack[0] == hb.PackBatch.key(tensors):
             self._pack[1].run()
             if getattr(self, "rnn", None) is not None:
@@ -562,8 +569,10 @@ class PairEngine:
             x.full.view(B1, G, c6.C, c6.Hp, c6.Wp).copy_(c6.full.unsqueeze(1).expand(-1, G, -1, -1, -1))
         return self.c6x, False
 
-    def run_stage2(self, t, want_aux=True):
-        """t: [B2] device tensor of interpolation times in (0,1) (or [G]: the same times for every pair)."""
+    def run_stage2(self, t, want_aux=True, want_out5=False):
+        """t: [B2] device tensor of interpolation times in (0,1) (or [G]: the same times for every pair).  want_out5: the
+        caller reads stage 2's raw 5-channel map (s2.t["out"], the loss terms do) - the fused final_conv + synthesis kernel
+        then writes it as well."""
         lib = hb.load()
         st = hb.stream_ptr()
         t = t.reshape(-1)
@@ -605,7 +614,8 @@ class PairEngine:
         if self.fuse_final:
             def synth(tf, w, b):      # final_conv + synthesis in one kernel, per group of entries that share a pair
                 for p, b0, n, bc in self._groups():
-                    hb.check(lib.ssm_final_conv_fwd(tf.view(b0=b0), w.data_ptr(), b.data_ptr(), 5, hb.NULL_VIEW, self._img6_view(p, bc),
+                    o5 = self.s2.t["out"].view(b0=b0) if want_out5 else hb.NULL_VIEW
+                    hb.check(lib.ssm_final_conv_fwd(tf.view(b0=b0), w.data_ptr(), b.data_ptr(), 5, o5, self._img6_view(p, bc),
                                                     in16_view(b0), tptr + 4 * b0, hb.view_of(self.img[b0:]), aux_view(b0), n,
                                                     self.H, self.W, st))
             self.s2.run(cross_planes=cross, cross_broadcast=cbc, synth=synth)
@@ -621,10 +631,10 @@ class PairEngine:
             e1.record()
         return self.img
 
-    def run(self, img6, t, want_aux=True):
+    def run(self, img6, t, want_aux=True, want_out5=False):
         self.load_pair(img6)
         self.run_stage1()
-        return self.run_stage2(t, want_aux)
+        return self.run_stage2(t, want_aux, want_out5)
 
     def intermediates(self):
         """(F01, F10, Ft1^, Ft0^, Ft1, Ft0, V0) as FullModel returns them

@@ -188,7 +188,94 @@ def _oracle_training_loss(p1, p2, img6, t, target, lr, lw, vgg=None, lp=0.0):
 # forward activations carry ~3e-5 of fp8-compensation noise, which flips the LeakyReLU branch of the few elements that sit within
 # that distance of zero - the gradient is exact for the perturbed network, so single tensors (the 2x2-pixel bottleneck at 64x64)
 # can differ by several per cent in max-abs while the direction stays put.
-GRAD_BARS = {"f32": (0.9999, 2e-2), "f16f8": (0.999, 1e-1)}
+GRAD_BARS = {"f32": (0.99999, 1e-4), "f16f8": (0.999, 1e-1)}
+# measured at 64x64: f32 2.0e-6, f16f8 1.9e-2 (7.1e-2 with the VGG term on: 2x2-pixel bottleneck maps); with the VGG term the exact
+# plan sits at 6.6e-4 (bar below); at 352x352 (config 3's shape): f32 6.8e-4 - reassociation noise amplified by the net -, f16f8 3.0e-3
+GRAD_BARS_VGG = {"f32": (0.99999, 2e-3), "f16f8": (0.999, 1e-1)}
+GRAD_BARS_352 = {"f32": (0.99999, 2e-3), "f16f8": (0.9995, 1.5e-2)}
+
+
+def _train_model_p(dev, precision):
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_state_dict
+    ov = synthetic_weight_overrides()
+    ov[("STAGE1", "FREEZE")] = "FALSE"
+    ov[("STAGE2", "FREEZE")] = "FALSE"
+    m = FullModel(load_config("superslomo_original.ini", ov))
+    sd1, sd2 = synthetic_state_dict(1), synthetic_state_dict(2)
+    m.stage1_model.load_state_dict(sd1)
+    m.stage2_model.load_state_dict(sd2)
+    m = m.to(dev).train()
+    m.train_precision = precision
+    return m, sd1, sd2
+
+
+@pytest.fixture(scope="module")
+def oracle_352():
+    """BASELINE config 3's per-GPU shape (2 samples of 352x352, t per sample): loss, frame and all 96 parameter gradients from
+    CPU autograd of the oracle, once per session."""
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    sd1, sd2 = synthetic_state_dict(1), synthetic_state_dict(2)
+    clips = torch.cat([synthetic_frames(3, 352, 352, seed=170), synthetic_frames(3, 352, 352, seed=171)], 0)      # [2,3,3,352,352]
+    xin, tgt = clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous()
+    t = torch.tensor([0.625, 0.25]).view(2, 1, 1, 1, 1)
+    p1 = {k: v.clone().requires_grad_() for k, v in sd1.items()}
+    p2 = {k: v.clone().requires_grad_() for k, v in sd2.items()}
+    img6 = torch.cat([xin[:, 0], xin[:, 1]], 1)
+    L, pred = _oracle_training_loss(p1, p2, img6, t.view(2, 1, 1, 1), tgt[:, 0], 60.0, 10.0)
+    L.backward()
+    grads = {"s1." + k: v.grad for k, v in p1.items()}
+    grads.update({"s2." + k: v.grad for k, v in p2.items()})
+    return xin, tgt, t, float(L), pred.detach(), grads
+
+
+@pytest.mark.parametrize("train_precision", ["f32", "f16f8"])
+def test_training_step_at_config3_size_vs_oracle(dev, oracle_352, train_precision):
+    """BASELINE config 3 at its workload size: one training step on 2 x 352x352 (the per-GPU share of batch 16), both training
+    precisions: loss and frame against the oracle's forward, all 96 parameter gradients against CPU autograd of the oracle."""
+    xin, tgt, t, L, pred, want = oracle_352
+    m, _, _ = _train_model_p(dev, train_precision)
+    img, losses = m(xin.to(dev), t.to(dev), tgt.to(dev), None, False)
+    losses.mean(dim=0)[0].backward()
+    assert float((img.cpu() - pred).abs().max()) < (3e-4 if train_precision == "f32" else 6e-4)
+    assert abs(float(losses.mean(0)[0]) - L) < 1e-4 * abs(L)
+    worst = []
+    for stage, mod in (("s1", m.stage1_model), ("s2", m.stage2_model)):
+        for name, p in mod.named_parameters():
+            g, w = p.grad.cpu().flatten(), want[stage + "." + name].flatten()
+            worst.append((float((g - w).abs().max() / (w.abs().max() + 1e-30)),
+                          float(torch.dot(g, w) / (g.norm() * w.norm() + 1e-30)), stage + "." + name))
+    worst.sort(reverse=True)
+    print("352x352 worst gradients [%s] (rel max err, cosine):" % train_precision, worst[:4])
+    cos_bar, rel_bar = GRAD_BARS_352[train_precision]
+    assert all(c > cos_bar for _, c, _ in worst), sorted(worst, key=lambda w: w[1])[:4]
+    assert worst[0][0] < rel_bar, worst[:4]
+
+
+def test_f16f8_gradients_survive_small_loss_gradients(dev, oracle_352):
+    """with the shipped config (batch 32, LAMBDA_R = 60, 224x224 crops) the per-pixel loss gradient is ~1.2e-5,
+    below fp16's smallest normal; dZ of the f16f8 plan (fp16 hi + e4m3 lo) would lose its compensation part and deep layers
+    flush to zero.  With the power-of-two loss scale (PairGrad.loss_scale) the backward at batch-32 magnitude (this 1-sample
+    224x224 crop with the loss times 1/32) gives the gradients of the unscaled loss to 1e-4, and even 128x below that
+    (loss / 4096) it degrades gracefully (< 1e-3, nothing flushed) and stays as close to the exact-fp32 plan as at full size."""
+    xin, tgt, t, _, _, _ = oracle_352
+    xin, tgt, t = xin[:1, :, :, :224, :224].contiguous().to(dev), tgt[:1, :, :, :224, :224].contiguous().to(dev), t[:1].to(dev)
+    grads = {}
+    for tag, precision, k in (("f32", "f32", 1.0), ("q8", "f16f8", 1.0), ("q8_b32", "f16f8", 1.0 / 32), ("q8_tiny", "f16f8", 1.0 / 4096)):
+        m, _, _ = _train_model_p(dev, precision)
+        _, losses = m(xin, t, tgt, None, False)
+        (losses.mean(dim=0)[0] * k).backward()
+        grads[tag] = torch.cat([p.grad.flatten() / k for mod in (m.stage1_model, m.stage2_model) for p in mod.parameters()]).cpu()
+    a, b, c, ref = grads["q8"], grads["q8_b32"], grads["q8_tiny"], grads["f32"]
+    d_b32, d_tiny = float((a - b).abs().max() / a.abs().max()), float((a - c).abs().max() / a.abs().max())
+    cos = lambda x, y: float(torch.dot(x, y) / (x.norm() * y.norm()))      # noqa: E731
+    print("f16f8 gradients vs loss magnitude: x1/32 -> %.2e, x1/4096 -> %.2e of max|g|; cos vs f32: %.6f %.6f %.6f"
+          % (d_b32, d_tiny, cos(a, ref), cos(b, ref), cos(c, ref)))
+    assert d_b32 < 1e-4, "the f16f8 backward depends on the magnitude of the loss gradient at batch-32 scaling"
+    assert d_tiny < 1e-3
+    assert min(cos(a, ref), cos(b, ref), cos(c, ref)) > 0.9995
+    assert float((c == 0).float().mean()) <= float((ref == 0).float().mean()) + 1e-6, "gradients flushed to zero"
 
 
 @pytest.mark.parametrize("train_precision", ["f16f8", "f32"])
@@ -475,7 +562,7 @@ def test_training_step_with_perceptual_term_vs_oracle_autograd(dev, train_precis
             worst.append((rel, cos, stage + "." + name))
     worst.sort(reverse=True)
     print("worst gradients with the perceptual term [%s] (rel max err, cosine):" % train_precision, worst[:4])
-    cos_bar, rel_bar = GRAD_BARS[train_precision]
+    cos_bar, rel_bar = GRAD_BARS_VGG[train_precision]
     assert all(c > cos_bar for _, c, _ in worst), worst[:4]
     assert worst[0][0] < rel_bar, worst[:4]
 

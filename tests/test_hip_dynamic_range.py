@@ -1,0 +1,137 @@
+"""Dynamic-range suite of the split precision modes (f16x3 = 3 fp16 MFMAs on hi/lo-split operands, f16f8 = fp16 hi + e4m3
+compensation) against the exact-fp32 mode - the evidence behind their labels "narrower than f32".  What is asserted is where
+each mode IS fp32-grade, where it degrades to fp16-grade, and where it breaks (so nobody mistakes it for a drop-in fp32):
+
+  activations / weights in 2^-4 .. 2^4   : f16x3 <= 5e-6, f16f8 <= 5e-4 of the output scale (2.4e-6 / 2.1e-4 measured)
+  activations down to 2^-10 / 2^-14      : lo parts go subnormal in fp16 -> fp16-grade (documented in DESIGN 3.1)
+  |activation| in (448, 65504)           : f16f8's e4m3 copies clamp (pack4_fp8) -> compensation lost, fp16-grade; f16x3 unaffected
+  |activation| > 65504                   : fp16 hi overflows -> non-finite output in BOTH split modes; mode f32 is exact
+  large motion (flows of 30-120 px)      : f16x3 frames within 1e-3 of mode f32 (1.1e-4 measured); f16f8 EXCEEDS the 1e-3
+                                           bar (1.4e-3 measured) - it is not an fp32 replacement under large motion
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def conv_modes(dev, x, w, b):
+    """conv + LeakyReLU of the same tensors in mode f32, f16x3 and f16f8 (through the C ABI); fp32 NCHW results on the host."""
+    from ssm_amd import hipbind as hb
+    B, cin, H, W = x.shape
+    cout, k = w.shape[0], w.shape[2]
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    out = {}
+    pk = hb.PackedConv(wd, bd, B, H, W)
+    xp = hb.Planes(B, pk.cin_p, H, W, dev)
+    xp.interior[:, :cin] = xd
+    y = hb.Planes(B, cout, H, W, dev)
+    hb.conv2d(xp.view(), pk.cin_p, None, 0, pk, y.view(), None, B, H, W)
+    out["f32"] = y.to_nchw().cpu()
+    for mode, q8 in (("f16x3", False), ("f16f8", True)):
+        pk16 = hb.PackedConv16(wd, bd, W, q8=q8)
+        xh = hb.HPlanes(B, cin, H, W, dev, groups=pk16.cin_p // 8, q8=q8).load(xd)
+        yh = hb.HPlanes(B, cout, H, W, dev, q8=q8)
+        hb.conv2d_hl8(xh.view(), pk16.cin_p, None, 0, pk16, yh.view(), None, None, B, H, W)
+        out[mode] = yh.to_nchw().cpu()
+    return out
+
+
+def rel(a, ref):
+    return float((a - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("sx,sw", [(1.0, 1.0), (2.0 ** -4, 2.0 ** 4), (2.0 ** 4, 2.0 ** -4), (2.0 ** 4, 2.0 ** 4), (2.0 ** -4, 2.0 ** -4)])
+def test_in_range_scales_are_fp32_grade(dev, sx, sw):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 24, 40, generator=g) * sx
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0 * sw
+    b = torch.randn(64, generator=g) * 0.1 * sx * sw
+    o = conv_modes(dev, x, w, b)
+    assert rel(o["f16x3"], o["f32"]) < 5e-6, rel(o["f16x3"], o["f32"])
+    assert rel(o["f16f8"], o["f32"]) < 5e-4, rel(o["f16f8"], o["f32"])
+
+
+@pytest.mark.parametrize("sx", [2.0 ** -10, 2.0 ** -14])
+def test_tiny_activations_degrade_to_fp16_grade(dev, sx):
+    """x ~ 2^-10: hi = fp16(x) is still normal, lo = x - hi ~ 2^-21 x is a subnormal fp16 with few bits (2^-14: none):
+    the split modes then deliver fp16-grade (2^-11), not fp32-grade, products.  The U-Nets' activations are O(1) by
+    construction (ImageNet-normalised frames, He-scaled filters), which is why the frame tests pass."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, 64, 16, 32, generator=g) * sx
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.zeros(64)
+    o = conv_modes(dev, x, w, b)
+    for mode in ("f16x3", "f16f8"):
+        r = rel(o[mode], o["f32"])
+        assert bool(torch.isfinite(o[mode]).all()) and r < 2.0 ** -9, (mode, r)
+
+
+def test_activations_beyond_the_e4m3_clamp(dev):
+    """|x| in (448, 65504): pack4_fp8 clamps the e4m3 copy of x, so f16f8 loses its compensation products for those
+    elements (fp16-grade, <= 2^-10 of the output scale) - f16x3 carries lo in fp16 and stays fp32-grade."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(1, 64, 16, 32, generator=g) * 2000.0
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.zeros(64)
+    o = conv_modes(dev, x, w, b)
+    assert rel(o["f16x3"], o["f32"]) < 5e-6
+    r = rel(o["f16f8"], o["f32"])
+    assert bool(torch.isfinite(o["f16f8"]).all()) and 1e-6 < r < 2.0 ** -9, r     # measurably worse than in range, still fp16-grade
+
+
+def test_activations_beyond_fp16_break_the_split_modes(dev):
+    """|x| > 65504: fp16(x) = inf.  Known limitation of BOTH split modes (mode f32 is exact) - asserted so that it stays
+    documented: results are non-finite, never silently wrong finite numbers."""
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(1, 64, 8, 32, generator=g)
+    x[0, 3, 4, 10] = 1.0e5
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.zeros(64)
+    o = conv_modes(dev, x, w, b)
+    assert bool(torch.isfinite(o["f32"]).all())
+    hit = o["f32"][0, :, 3:6, 9:12]                      # outputs whose receptive field holds the big value
+    assert float(hit.abs().max()) > 100.0
+    for mode in ("f16x3", "f16f8"):
+        bad = ~torch.isfinite(o[mode])
+        assert bool(bad.any()), "%s returned finite values for an input beyond fp16" % mode
+        ok = ~bad
+        assert float((o[mode][ok] - o["f32"][ok]).abs().max()) < 1e-3, "finite outputs away from the overflow must still be right"
+
+
+@pytest.mark.parametrize("gain", [6.0])
+def test_large_motion_frames_vs_mode_f32(dev, gain):
+    """Flows of 30-120 px (stage 1's final_conv scaled up so the synthetic network predicts large motion): every warp tap
+    moves by tens of pixels per unit of flow error x image gradient.  f16x3 stays within the 1e-3 bar of the exact-fp32
+    mode; f16f8 does NOT (1.4e-3 measured) - asserted as a documented limitation of that mode, with a ceiling."""
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    sd1, sd2 = synthetic_state_dict(1), synthetic_state_dict(2)
+    sd1 = dict(sd1)
+    sd1["final_conv.weight"] = sd1["final_conv.weight"] * gain
+    sd1["final_conv.bias"] = sd1["final_conv.bias"] * gain
+    m = FullModel(load_config("superslomo_original.ini", synthetic_weight_overrides()))
+    m.stage1_model.load_state_dict(sd1)
+    m.stage2_model.load_state_dict(sd2)
+    m = m.to(dev).eval()
+    x = synthetic_frames(2, 352, 352, seed=5).to(dev)
+    ts = [0.25, 0.5, 0.875]
+    frames = {}
+    for mode in ("f32", "f16x3", "f16f8"):
+        m.precision = mode
+        img, inter = m(x, torch.full((1, 1, 1, 1, 1), 0.5, device=dev), inference_mode=True)
+        if mode == "f32":
+            fmax = float(torch.cat([inter[0], inter[1]], 1).abs().max())
+            assert 30.0 < fmax < 120.0, "stage-1 flows reach %.1f px" % fmax
+        frames[mode] = m.interpolate(x, ts).clone()
+    for mode in ("f16x3", "f16f8"):
+        err = float((frames[mode] - frames["f32"]).abs().max())
+        print("large motion, %s vs f32: %.3e" % (mode, err))
+        assert err < (1e-3 if mode == "f16x3" else 3e-3), (mode, err)

@@ -237,3 +237,30 @@ def test_recurrent_full_model_trains(dev):
         opt.step()
         hist.append(float(loss.detach()))
     assert hist[-1] < hist[0], hist
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16f8"])
+def test_recurrent_config4_at_720p(dev, precision):
+    """BASELINE config 4 at its workload size: superslomo_recurrent.ini (N_FRAMES = 4, ConvBLSTM bottleneck) on a
+    1280x720 clip (padded 736x1280): (a) deterministic, (b) the hoisted 7-t evaluation (stage 1 + its BLSTM once per clip,
+    t values batched) equals one forward per t, (c) one t against the CPU oracle (restated cells: parity with the
+    un-vendored upstream module is unpinned, oracle/ssm_oracle.py)."""
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    m = _model("CLSTM", dev, precision)
+    x = synthetic_frames(4, 720, 1280, seed=42)
+    assert tuple(x.shape) == (1, 4, 3, 736, 1280)
+    xd = x.to(dev)
+    ts = [i / 8.0 for i in range(1, 8)]
+    a = m.interpolate_windows(xd, ts).clone()
+    b = m.interpolate_windows(xd, ts)
+    assert torch.isfinite(a).all() and torch.equal(a, b), "same clip must give bit-identical frames"
+    for j in (0, 3, 6):
+        one, _ = m(xd, torch.full((1, 3, 1, 1, 1), ts[j], device=dev), inference_mode=True)
+        # other batch -> other tile configurations -> other rounding in places (fp32 noise amplified ~1000x by the network)
+        assert float((one[0] - a[j]).abs().max()) < 3e-4, "hoisted != per-t at t=%.3f" % ts[j]
+    p1, p2 = synthetic_state_dict(1, bottleneck="CLSTM"), synthetic_state_dict(2, bottleneck="CLSTM")
+    with torch.no_grad():
+        want, _ = O.full_model_infer_windows(p1, p2, x, torch.full((1, 3, 1, 1, 1), 0.5), True, "CLSTM")
+    err = float((a[3:4].cpu() - want).abs().max())
+    print("recurrent 720p [%s]: max|HIP - oracle| at t=0.5 = %.3e" % (precision, err))
+    assert err < (5e-4 if precision == "f32" else 6e-4), err
