@@ -69,7 +69,7 @@ def main(argv=None, model=None):
     n_epochs, save_every = cfg.getint("TRAIN", "N_EPOCHS"), cfg.getint("TRAIN", "SAVE_EVERY")
     ckpt_dir = os.path.join(cfg.get("TRAIN", "CKPT_DIR"), args.expt)
     last = None
-    for epoch in range(1, n_epochs + 1):
+    for epoch in range(trainer.start, n_epochs + 1):          # trainer.start: 1, or the checkpoint's epoch when resuming (main.py:263-284)
         trainer.train(synthetic_batches(cfg, args.synthetic_batches, dev, rank), n_epochs=1,
                       on_step=lambda e, it, losses: log.info("epoch %d it %d losses %s", epoch, it, losses.tolist()))
         if rank == 0 and epoch % save_every == 0:

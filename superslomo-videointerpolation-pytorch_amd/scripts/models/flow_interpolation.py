@@ -6,6 +6,7 @@ import logging
 import torch
 
 from ssm_amd import hipbind as hb
+from ssm_amd import ops as _ops  # noqa: F401  (torch.ops.ssm.*)
 
 from .unet_common import StageUNet
 
@@ -19,63 +20,6 @@ def _t_vector(t, B, device):
         t = t.expand(B)
     assert t.numel() == B, "one interpolation time per sample expected"
     return t.contiguous()
-
-
-class _InputsFn(torch.autograd.Function):
-    """compute_inputs with its adjoint wrt the stage-1 flows (the images are data: no gradient)."""
-
-    @staticmethod
-    def forward(ctx, img, flow, tv):
-        img, flow = img.detach().contiguous(), flow.detach().contiguous()
-        B, _, H, W = img.shape
-        out = torch.empty(B, 16, H, W, dtype=torch.float32, device=img.device)
-        hb.check(hb.load().ssm_flowinterp_inputs_fwd(hb.view_of(img), hb.view_of(flow), tv.data_ptr(), hb.view_of(out),
-                                                     B, H, W, hb.stream_ptr()))
-        ctx.save_for_backward(img, flow, tv)
-        return out
-
-    @staticmethod
-    def backward(ctx, d16):
-        img, flow, tv = ctx.saved_tensors
-        B, _, H, W = img.shape
-        d16 = d16.contiguous()
-        zero4 = torch.zeros(B, 4, H, W, dtype=torch.float32, device=img.device)
-        zb = torch.zeros(B, dtype=torch.float32, device=img.device)
-        dflow = torch.empty_like(flow)
-        hb.check(hb.load().ssm_flowinterp_inputs_bwd(hb.view_of(img), hb.view_of(flow), hb.view_of(d16), hb.view_of(zero4),
-                                                     tv.data_ptr(), zb.data_ptr(), hb.view_of(dflow), B, H, W, 0, hb.stream_ptr()))
-        return None, dflow, None
-
-
-class _SynthFn(torch.autograd.Function):
-    """compute_output_image with its adjoint wrt the stage-2 output (5 ch) and the approximated flows (channels 6:10 of
-    the 16-channel input)."""
-
-    @staticmethod
-    def forward(ctx, img, xin, xout, tv):
-        img, xin, xout = img.detach().contiguous(), xin.detach().contiguous(), xout.detach().contiguous()
-        B, _, H, W = img.shape
-        y = torch.empty(B, 3, H, W, dtype=torch.float32, device=img.device)
-        hb.check(hb.load().ssm_synthesize_fwd(hb.view_of(img), hb.view_of(xin), hb.view_of(xout), tv.data_ptr(), hb.view_of(y),
-                                              hb.NULL_VIEW, B, H, W, hb.stream_ptr()))
-        ctx.save_for_backward(img, xin, xout, tv)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        img, xin, xout, tv = ctx.saved_tensors
-        B, _, H, W = img.shape
-        dy = dy.contiguous()
-        zb = torch.zeros(B, dtype=torch.float32, device=img.device)
-        est = xin[:, 6:10].contiguous()
-        dout5 = torch.empty_like(xout)
-        dxin = torch.zeros_like(xin)
-        dest = torch.empty(B, 4, H, W, dtype=torch.float32, device=img.device)
-        hb.check(hb.load().ssm_synthesize_bwd(hb.view_of(img), hb.view_of(est), hb.view_of(xout), hb.view_of(dy), tv.data_ptr(),
-                                              zb.data_ptr(), zb.data_ptr(), hb.view_of(dy), hb.view_of(dout5), hb.view_of(dest),
-                                              B, H, W, 0, hb.stream_ptr()))
-        dxin[:, 6:10] = dest
-        return None, dxin, dout5, None
 
 
 class FlowInterpolationModel(StageUNet):
@@ -107,11 +51,7 @@ class FlowInterpolationModel(StageUNet):
         B, _, H, W = img_tensor.shape
         img, flow = img_tensor.contiguous(), flow_pred_tensor.contiguous()
         tv = _t_vector(t, B, img.device)
-        if torch.is_grad_enabled() and flow.requires_grad:
-            return _InputsFn.apply(img, flow, tv)
-        out = torch.empty(B, 16, H, W, dtype=torch.float32, device=img.device)
-        hb.check(hb.load().ssm_flowinterp_inputs_fwd(hb.view_of(img), hb.view_of(flow), tv.data_ptr(), hb.view_of(out),
-                                                     B, H, W, hb.stream_ptr()))
+        out = torch.ops.ssm.flowinterp_inputs(img, flow, tv)      # dispatcher op; its autograd = the HIP adjoint wrt the flows
         if self.verbose:
             log.info("Generated Input tensor of shape: %s", str(out.shape))
         return out
@@ -127,8 +67,8 @@ class FlowInterpolationModel(StageUNet):
         B, _, H, W = img_tensor.shape
         img, xin, xout = img_tensor.contiguous(), input_tensor.contiguous(), output_tensor.contiguous()
         tv = _t_vector(t, B, img.device)
-        if torch.is_grad_enabled() and (xin.requires_grad or xout.requires_grad) and not return_aux:
-            return _SynthFn.apply(img, xin, xout, tv)
+        if not return_aux:
+            return torch.ops.ssm.synthesize(img, xin, xout, tv)
         y = torch.empty(B, 3, H, W, dtype=torch.float32, device=img.device)
         aux = torch.empty(B, 5, H, W, dtype=torch.float32, device=img.device) if return_aux else None
         hb.check(hb.load().ssm_synthesize_fwd(hb.view_of(img), hb.view_of(xin), hb.view_of(xout), tv.data_ptr(),

@@ -233,6 +233,7 @@ class FullModel(nn.Module):
         return outs
 
     # ---- training step ------------------------------------------------------------------------------------------
+    grad_sync = None            # a ssm_amd.dist.GradientAllReduce (set by the Trainer), or None
     train_precision = None      # "f32" (default; $SSM_TRAIN_PRECISION) | "f16f8" (opt-in: split forward / data gradients, bf16x3 weight gradients)
 
     def _train_engine(self, B, H, W, device):
@@ -253,6 +254,8 @@ class FullModel(nn.Module):
             else:
                 eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, "f16f8", fuse_upsample=True, twins=True)
             self._train = (key, eng, PairGrad(eng))
+        if self.grad_sync is not None:        # ssm_amd.training.Trainer: bucketed gradient all-reduce overlapped with the backward
+            self.grad_sync.attach(self._train[2])
         return self._train[1], self._train[2]
 
     def _forward_with_losses(self, image_tensor, t_interp, target_images):

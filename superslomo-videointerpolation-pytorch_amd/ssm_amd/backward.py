@@ -106,10 +106,58 @@ class UNetGrad:
             sizes += [(param_key(name, "weight"), (co, ci, k, k)), (param_key(name, "bias"), (co,))]
         self.flat = torch.empty(sum(int(torch.Size(sh).numel()) for _, sh in sizes), dtype=torch.float32, device=self.dev)
         off = 0
+        span = {}
         for key, sh in sizes:
             n = int(torch.Size(sh).numel())
             self.grads[key] = self.flat[off:off + n].view(sh)
+            lname = key[:-len(".weight")] if key.endswith(".weight") else key[:-len(".bias")]
+            a, _ = span.get(lname, (off, off))
+            span[lname] = (a, off + n)
             off += n
+        # Buckets of the flat buffer (SURVEY 8e: "bucketed and overlapped with backward").  The backward walks the layers in
+        # reverse state-dict order, so the buffer completes from its tail: a bucket = a run of consecutive layers of roughly
+        # 1/N_BUCKETS of the bytes; when the weight-gradient kernels of its last layer have been queued (side stream), the bucket
+        # is post-scaled (loss scale of the f16f8 plan, 1/world) and handed to `sync.reduce` - the RCCL all-reduce of the
+        # decoder's gradients then runs while the encoder's (and the other U-Net's) backward is still computing.
+        self.sync, self.post_scale = None, 1.0
+        self.layer_span = {param_layer: se for param_layer, se in span.items()}
+        names = list(plan.layers)
+        target = self.flat.numel() / float(self.N_BUCKETS)
+        self.buckets, cur, size = [], [], 0
+        for name in names:
+            a, b = self._span_of(name)
+            cur.append(name)
+            size += b - a
+            if size >= target and len(self.buckets) < self.N_BUCKETS - 1:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._pending = []
+
+    N_BUCKETS = int(os.environ.get("SSM_GRAD_BUCKETS", "4"))
+
+    def _span_of(self, name):
+        """[a, b) of layer `name`'s weight + bias inside the flat buffer."""
+        return self.layer_span[param_key(name, "weight")[:-len(".weight")]]
+
+    def _arm(self):
+        self._pending = [set(b) for b in self.buckets]
+
+    def _layer_done(self, name):
+        """Called in the context (stream) that queued the layer's parameter-gradient kernels."""
+        for i, pend in enumerate(self._pending):
+            if name in pend:
+                pend.discard(name)
+                if not pend:
+                    a = self._span_of(self.buckets[i][0])[0]
+                    b = self._span_of(self.buckets[i][-1])[1]
+                    view = self.flat[a:b]
+                    if self.post_scale != 1.0:
+                        view.mul_(self.post_scale)
+                    if self.sync is not None:
+                        self.sync.reduce(view)
+                return
 
     def join(self):
         """The caller's stream waits for the parameter gradients queued on the side stream."""
@@ -226,6 +274,7 @@ class UNetGrad:
                 bias_grad(dz, self.grads[bk], zero_first=False)
                 if tm is not None:
                     e1.record()
+                self._layer_done(name)
         if dx is not None:
             if tm is not None:
                 e0, e1 = tm.span("dgrad", "s%d.%s" % (plan.stage, name), flops)
@@ -249,6 +298,7 @@ class UNetGrad:
                 self.side.wait_stream(torch.cuda.current_stream())       # last step's consumers of the gradients are done
             with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
                 self.flat.zero_()
+            self._arm()
         L("final_conv", d_out, None, G("tf"), need_wgrad, act=False)
         cat = G("cat_fuse", like="tf", C=plan.t["c11"].C + plan.t["c1"].C)
         L("fuse_conv", G("tf"), None, cat, need_wgrad)
@@ -302,6 +352,8 @@ class PairGrad:
         if os.environ.get("SSM_WGRAD_STREAM", "1") != "0":
             self.u1.side = self.u2.side = torch.cuda.Stream(device=engine.device)
         B, H, W, dev = engine.B2, engine.H, engine.W, engine.device
+        # gradient exchange (ssm_amd.dist.GradientAllReduce.attach): buckets are scaled by sync_scale (1/world) and reduced as they complete
+        self.sync, self.sync_scale = None, 1.0
         self.dest = torch.empty(B, 4, H, W, dtype=torch.float32, device=dev)
         self.cr = torch.empty(B, dtype=torch.float32, device=dev)
         self.cw = torch.empty(B, dtype=torch.float32, device=dev)
@@ -344,6 +396,8 @@ class PairGrad:
         img6 = hb.view_of(e.img6)
         in16, out5, flow4 = e.s2.t["in"], e.s2.t["out"], e.s1.t["out"]
         need_s1 = train_s1
+        for u in (self.u1, self.u2):          # every bucket of the flat gradient buffers is multiplied by this when it completes
+            u.post_scale, u.sync = self.sync_scale / S, self.sync
         self.u2.refresh(sd2, need_input_grad=need_s1)
         self.u2.prepare(cross=e.s1.f32.get("c6") if e.hl8 else None)
         d_out5 = self.u2._G("out", C=self.u2.pk_t["final_conv"].cin_p)
@@ -372,8 +426,4 @@ class PairGrad:
             self.u1.backward(d_flow4, need_wgrad=True, c6_grad_init=dcross)
             grads.update({"stage1." + k: v for k, v in self.u1.grads.items()})
         self.u2.join()
-        if S != 1.0:
-            for u, on in ((self.u2, train_s2), (self.u1, need_s1)):
-                if on:
-                    u.flat.mul_(1.0 / S)
         return grads

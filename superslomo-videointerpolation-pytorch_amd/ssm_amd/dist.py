@@ -102,8 +102,8 @@ class GradientAllReduce:
     """Sum-then-average all-reduce of every trainable parameter's gradient in ONE flat fp32 buffer (38,848,553
     floats = 155.4 MB for the two U-Nets) over RCCL/xGMI.  Replaces DataParallel's per-iteration parameter
     broadcast + reduce_add + output gather (scripts/main.py:74-76).  One large collective per step suits xGMI's
-    point-to-point links better than many small buckets; the hand-written backward produces all gradients at the
-    end of the step anyway, so there is nothing to overlap with yet."""
+    point-to-point links better than many small buckets.  This flat form serves gradients that arrive all at once
+    (op-by-op autograd, foreign layouts); the planned training step uses the bucketed, overlapped form (attach)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -112,6 +112,37 @@ class GradientAllReduce:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.bytes = 4 * n
         self.last_runs = None
+        self._works, self._bucket_bytes, self.last_buckets = [], 0, 0
+
+    # ---- bucketed, overlapped form ----------------------------------------------------------------------
+    def attach(self, pair_grad):
+        """Hook into the planned backward (ssm_amd.backward.PairGrad): every bucket of a U-Net's flat gradient buffer is
+        pre-scaled by 1/world and all-reduced (async, on the collective's own stream, ordered after the weight-gradient
+        kernels that were queued before it) the moment its last layer's kernels are queued - the decoder's gradients
+        travel over xGMI while the encoder's and the other U-Net's backward still computes.  Few, large buckets (4 per
+        U-Net, ~20 MB): xGMI is point-to-point, ring steps are per-link bound, small messages waste it."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        pair_grad.sync = self if world > 1 else None
+        pair_grad.sync_scale = 1.0 / world
+
+    def reduce(self, view):
+        """One completed bucket (already scaled by 1/world): start its sum all-reduce, in place."""
+        self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        self._bucket_bytes += 4 * view.numel()
+
+    def _finish_buckets(self):
+        """Wait for the bucket all-reduces of this step; returns the seconds the caller was blocked (the exposed part)."""
+        cuda = self.flat.is_cuda
+        t0 = time.perf_counter()
+        for w in self._works:
+            w.wait()
+        if cuda:
+            torch.cuda.current_stream().synchronize()
+        el = time.perf_counter() - t0
+        self.last_buckets, self._works = len(self._works), []
+        covered, self._bucket_bytes = self._bucket_bytes, 0
+        assert covered == self.bytes, "bucketed all-reduce covered %d of %d gradient bytes" % (covered, self.bytes)
+        return el
 
     MAX_RUNS = 8     # in-place path: the gradients form at most this many contiguous memory runs
 
@@ -139,6 +170,8 @@ class GradientAllReduce:
         reduced in place (no gather / scatter copies: 2 x 96 launches per step); otherwise through one staging buffer."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return 0.0
+        if self._works:          # the backward handed its buckets over as they completed (attach): only wait
+            return self._finish_buckets()
         cuda = self.flat.is_cuda
         runs = self.runs()
         self.last_runs = None if runs is None else len(runs)

@@ -37,7 +37,35 @@ class Trainer:
         self.optimizer = torch.optim.Adam(params, lr=self.learning_rate, **({"fused": True} if fused else {}))
         self.lr_scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=self.lr_period, gamma=self.lr_decay)
         self.allreduce = GradientAllReduce(params)
+        # the planned backward hands its gradient buckets over as they complete (not under graph capture: the collective stays outside)
+        model.grad_sync = None if self.graphs else self.allreduce
         self.last_allreduce_s = 0.0
+        self.start = 1
+        self.configure_resume()
+
+    def configure_resume(self):
+        """Resume of scripts/main.py:263-284: when a stage is loaded from a checkpoint (LOADPREV) AND trains (not FREEZE), the
+        optimizer state, the scheduler state and the epoch counter come from that checkpoint ("self.optimizer", "scheduler",
+        "epoch" of the dict save_model writes); stage 1's checkpoint wins when both qualify.  The weights themselves were
+        loaded by FullModel.load_weights (models.unetflow.get_model)."""
+        cfg = self.cfg
+        load_1, load_2 = cfg.getboolean("STAGE1", "LOADPREV"), cfg.getboolean("STAGE2", "LOADPREV")
+        freeze_1, freeze_2 = cfg.getboolean("STAGE1", "FREEZE"), cfg.getboolean("STAGE2", "FREEZE")
+        if load_1 and not freeze_1:
+            ckpt_path = cfg.get("STAGE1", "WEIGHTS")
+        elif load_2 and not freeze_2:
+            ckpt_path = cfg.get("STAGE2", "WEIGHTS")
+        else:
+            return
+        device = next(p for p in self.model.parameters()).device
+        checkpoint = torch.load(ckpt_path, map_location=device)
+        self.optimizer.load_state_dict(checkpoint["self.optimizer"])
+        self.lr_scheduler.load_state_dict(checkpoint["scheduler"])
+        self.start = max(checkpoint["epoch"], 1)
+        log.info("Starting training from: %s", self.start)
+        log.info("Scheduler: %s", self.lr_scheduler.get_last_lr())
+        for param_group in self.optimizer.param_groups:
+            log.info("Learning rate: %s", param_group["lr"])
 
     def train_step(self, input_images, target_images, t_interp, iteration=None):
         """forward_pass + backward + optimizer step (scripts/main.py:116-145,188-197).  Returns the [4] loss vector

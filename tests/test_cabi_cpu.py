@@ -122,3 +122,27 @@ def test_product_path_never_touches_the_oracle():
                     if pat.search(text):
                         offenders.append(os.path.join(dirpath, f))
     assert not offenders, offenders
+
+
+def test_torch_library_operators_are_registered():
+    """north_star: "PyTorch-ROCm custom ops over a thin C-ABI".  The operator surface is registered with the dispatcher
+    (namespace ssm): schemas, fake (meta) kernels for shape inference; there is no CPU kernel, so a CPU tensor is refused."""
+    import torch
+    from ssm_amd import ops  # noqa: F401
+    want = {"conv2d": "ssm::conv2d(Tensor x, Tensor weight, Tensor bias, bool lrelu, float slope) -> Tensor",
+            "avg_pool2": "ssm::avg_pool2(Tensor x) -> Tensor",
+            "upsample2x_cat": "ssm::upsample2x_cat(Tensor a, Tensor? b) -> Tensor",
+            "warp": "ssm::warp(Tensor x, Tensor flo) -> Tensor",
+            "flowinterp_inputs": "ssm::flowinterp_inputs(Tensor img6, Tensor flow4, Tensor t) -> Tensor",
+            "synthesize": "ssm::synthesize(Tensor img6, Tensor in16, Tensor out5, Tensor t) -> Tensor"}
+    for name, schema in want.items():
+        assert str(getattr(torch.ops.ssm, name).default._schema) == schema
+    m = lambda *s: torch.empty(*s, device="meta")      # noqa: E731
+    assert tuple(torch.ops.ssm.conv2d(m(2, 6, 16, 24), m(32, 6, 7, 7), m(32), True, 0.1).shape) == (2, 32, 16, 24)
+    assert tuple(torch.ops.ssm.avg_pool2(m(2, 6, 16, 24)).shape) == (2, 6, 8, 12)
+    assert tuple(torch.ops.ssm.upsample2x_cat(m(2, 6, 16, 24), m(2, 3, 16, 24)).shape) == (2, 9, 32, 48)
+    assert tuple(torch.ops.ssm.warp(m(2, 3, 16, 24), m(2, 2, 16, 24)).shape) == (2, 3, 16, 24)
+    assert tuple(torch.ops.ssm.flowinterp_inputs(m(2, 6, 16, 24), m(2, 4, 16, 24), m(2)).shape) == (2, 16, 16, 24)
+    assert tuple(torch.ops.ssm.synthesize(m(2, 6, 16, 24), m(2, 16, 16, 24), m(2, 5, 16, 24), m(2)).shape) == (2, 3, 16, 24)
+    with pytest.raises(RuntimeError):
+        torch.ops.ssm.warp(torch.zeros(1, 3, 4, 4), torch.zeros(1, 2, 4, 4))

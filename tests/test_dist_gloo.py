@@ -148,3 +148,52 @@ def test_bench_launcher_fails_loudly_when_a_rank_fails():
     r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _ar_bucket_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ssm_amd import dist as sd
+    sd.init("gloo")
+    shapes = [(4, 3, 3, 3), (4,), (2, 4, 3, 3), (2,), (5, 2, 3, 3), (5,)]
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(sum(int(torch.Size(s).numel()) for s in shapes), generator=g)
+
+    def make():
+        params, flat, off = [torch.nn.Parameter(torch.zeros(s)) for s in shapes], local.clone(), 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        return params, flat
+    # flat form: one in-place all-reduce of the whole buffer after the backward
+    params, flat = make()
+    sd.GradientAllReduce(params)()
+    # bucketed form: the backward hands over buckets tail-first (decoder before encoder), each pre-scaled by 1/world
+    params2, flat2 = make()
+    ar = sd.GradientAllReduce(params2)
+
+    class FakePairGrad:
+        sync, sync_scale = None, 1.0
+    pg = FakePairGrad()
+    ar.attach(pg)
+    assert pg.sync is ar and pg.sync_scale == 1.0 / world
+    bounds = [0, 112, 186, flat2.numel()]
+    for a, b in reversed(list(zip(bounds[:-1], bounds[1:]))):
+        v = flat2[a:b]
+        v.mul_(pg.sync_scale)
+        pg.sync.reduce(v)
+    ar()
+    ret[rank] = (flat.clone(), flat2.clone(), ar.last_buckets, params2[4].grad.data_ptr() == flat2[186:].data_ptr())
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_equals_flat():
+    """the gradient exchange in buckets started during the backward (GradientAllReduce.attach / reduce) gives
+    the same averaged gradients as one flat all-reduce after it, in place, and refuses to finish if a bucket is missing."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ar_bucket_worker, args=(2, free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        flat, bucketed, n, aliased = ret[r]
+        assert n == 3 and aliased
+        assert torch.allclose(flat, bucketed, rtol=0, atol=1e-7)
+    assert torch.equal(ret[0][1], ret[1][1])

@@ -227,7 +227,7 @@ def oracle_352():
     L.backward()
     grads = {"s1." + k: v.grad for k, v in p1.items()}
     grads.update({"s2." + k: v.grad for k, v in p2.items()})
-    return xin, tgt, t, float(L), pred.detach(), grads
+    return xin, tgt, t, float(L.detach()), pred.detach(), grads
 
 
 @pytest.mark.parametrize("train_precision", ["f32", "f16f8"])
@@ -269,7 +269,7 @@ def test_f16f8_gradients_survive_small_loss_gradients(dev, oracle_352):
         grads[tag] = torch.cat([p.grad.flatten() / k for mod in (m.stage1_model, m.stage2_model) for p in mod.parameters()]).cpu()
     a, b, c, ref = grads["q8"], grads["q8_b32"], grads["q8_tiny"], grads["f32"]
     d_b32, d_tiny = float((a - b).abs().max() / a.abs().max()), float((a - c).abs().max() / a.abs().max())
-    cos = lambda x, y: float(torch.dot(x, y) / (x.norm() * y.norm()))      # noqa: E731
+    cos = lambda x, y: float(torch.dot(x.double(), y.double()) / (x.double().norm() * y.double().norm()))      # noqa: E731
     print("f16f8 gradients vs loss magnitude: x1/32 -> %.2e, x1/4096 -> %.2e of max|g|; cos vs f32: %.6f %.6f %.6f"
           % (d_b32, d_tiny, cos(a, ref), cos(b, ref), cos(c, ref)))
     assert d_b32 < 1e-4, "the f16f8 backward depends on the magnitude of the loss gradient at batch-32 scaling"
@@ -448,6 +448,101 @@ def test_main_entry_point_trains_and_checkpoints(dev, tmp_path):
     init = synthetic_state_dict(1)
     # the model started from torch's default init (LOADPREV=FALSE), trained 4 steps: weights are finite and loadable
     assert all(torch.isfinite(v).all() for v in s1.state_dict().values()) and set(s1.state_dict()) == set(init)
+
+
+def test_main_resumes_optimizer_scheduler_and_epoch(dev, tmp_path):
+    """scripts/main.py:263-284: a stage with LOADPREV=TRUE and FREEZE=FALSE resumes - optimizer state (Adam moments, step
+    count), StepLR state and the epoch counter come from the checkpoint that also supplied the weights; training continues at
+    that epoch and writes the next checkpoint."""
+    import configparser
+    import main as M
+    from ssm_amd.config import CONFIG_DIR
+    cfg = configparser.RawConfigParser()
+    cfg.read(f"{CONFIG_DIR}/superslomo_original.ini")
+    for sec in ("STAGE1", "STAGE2"):
+        cfg.set(sec, "LOADPREV", "FALSE")
+        cfg.set(sec, "FREEZE", "FALSE")
+    for k, v in (("BATCH_SIZE", "2"), ("CROP_IMH", "64"), ("CROP_IMW", "64"), ("N_EPOCHS", "2"), ("SAVE_EVERY", "1"), ("LR_PERIOD", "1"),
+                 ("CKPT_DIR", str(tmp_path / "ckpt"))):
+        cfg.set("TRAIN", k, v)
+    ini = tmp_path / "a.ini"
+    with open(ini, "w") as f:
+        cfg.write(f)
+    first = M.main(["-c", str(ini), "--expt", "e", "--log", str(tmp_path / "a.log"), "--synthetic_batches", "2"])
+    assert first.endswith("e_EPOCH_0002.pt")
+    saved = torch.load(first, map_location="cpu")
+    assert saved["epoch"] == 2 and saved["scheduler"]["last_epoch"] == 2
+    steps = {int(v["step"]) for v in saved["self.optimizer"]["state"].values()}
+    assert steps == {4}                                   # 2 epochs x 2 batches
+    # resume: both stages load that checkpoint and keep training, 4 epochs in total
+    for sec in ("STAGE1", "STAGE2"):
+        cfg.set(sec, "LOADPREV", "TRUE")
+        cfg.set(sec, "WEIGHTS", first)
+    cfg.set("TRAIN", "N_EPOCHS", "4")
+    ini2 = tmp_path / "b.ini"
+    with open(ini2, "w") as f:
+        cfg.write(f)
+    from ssm_amd.training import Trainer
+    from models.superslomo_r import FullModel
+    m = FullModel(cfg).to(dev).train()
+    tr = Trainer(m, cfg)
+    assert tr.start == 2 and tr.lr_scheduler.last_epoch == 2
+    lr0 = cfg.getfloat("TRAIN", "LEARNING_RATE") * cfg.getfloat("TRAIN", "LR_DECAY") ** 2
+    assert abs(tr.optimizer.param_groups[0]["lr"] - lr0) < 1e-12 * max(1.0, lr0) + 1e-15
+    assert {int(v["step"]) for v in tr.optimizer.state_dict()["state"].values()} == {4}
+    w_saved = saved["stage2_state_dict"]["conv1a.0.weight"]
+    assert torch.equal(m.stage2_model.state_dict()["conv1a.0.weight"].cpu(), w_saved)
+    last = M.main(["-c", str(ini2), "--expt", "e", "--log", str(tmp_path / "b.log"), "--synthetic_batches", "2"])
+    assert last.endswith("e_EPOCH_0004.pt")
+    data = torch.load(last, map_location="cpu")
+    # epochs 2, 3, 4 ran (the reference restarts AT the saved epoch): 3 x 2 more optimizer steps
+    assert data["epoch"] == 4 and {int(v["step"]) for v in data["self.optimizer"]["state"].values()} == {10}
+
+
+def test_gradient_buckets_cover_the_flat_buffers_tail_first(dev):
+    """The planned backward hands each U-Net's flat gradient buffer over in buckets as they complete: decoder
+    (tail of the buffer) first, disjoint, covering everything, every bucket scaled exactly once - and the gradients equal a
+    run without a sync object."""
+    ref_m, _, _ = _train_model_p(dev, "f32")
+    from ssm_amd.weights import synthetic_frames
+    clips = torch.cat([synthetic_frames(3, 64, 64, seed=70), synthetic_frames(3, 64, 64, seed=71)], 0).to(dev)
+    xin, tgt = clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous()
+    t = torch.tensor([0.5, 0.375], device=dev).view(2, 1, 1, 1, 1)
+    _, losses = ref_m(xin, t, tgt, None, False)
+    losses.mean(dim=0)[0].backward()
+    want = torch.cat([p.grad.flatten() for p in ref_m.parameters()])
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def attach(self, pg):
+            pg.sync, pg.sync_scale = self, 0.5          # as if world = 2
+
+        def reduce(self, view):
+            self.calls.append((view.data_ptr(), view.numel()))
+            view.mul_(2.0)                               # stand-in for the sum over 2 identical ranks
+
+    m, _, _ = _train_model_p(dev, "f32")
+    rec = Recorder()
+    m.grad_sync = rec
+    _, losses = m(xin, t, tgt, None, False)
+    losses.mean(dim=0)[0].backward()
+    torch.cuda.synchronize()
+    got = torch.cat([p.grad.flatten() for p in m.parameters()])
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    pg = m._train[2]
+    for u, n_params in ((pg.u2, 20611909), (pg.u1, 18236644)):
+        base = u.flat.data_ptr()
+        mine = [((p - base) // 4, n) for p, n in rec.calls if base <= p < base + 4 * u.flat.numel()]
+        assert len(mine) == len(u.buckets) >= 2
+        assert sum(n for _, n in mine) == u.flat.numel() == n_params
+        starts = [a for a, _ in mine]
+        assert starts == sorted(starts, reverse=True), "buckets must complete from the tail (decoder) to the head (encoder)"
+        assert sorted(mine)[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(sorted(mine), sorted(mine)[1:]))
+    # stage 2's buckets were all handed over before stage 1's first one (its backward runs first): that is the overlap window
+    first_s1 = next(i for i, (p, _) in enumerate(rec.calls) if pg.u1.flat.data_ptr() <= p < pg.u1.flat.data_ptr() + 4 * pg.u1.flat.numel())
+    assert first_s1 == len(pg.u2.buckets)
 
 
 def test_maxpool_and_feature_mse_kernels(dev):

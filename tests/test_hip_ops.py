@@ -191,3 +191,25 @@ def test_cpu_tensor_is_refused():
     from models import layers
     with pytest.raises(RuntimeError):
         layers.warp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+
+
+def test_dispatcher_ops_pass_opcheck(dev):
+    """torch.library.opcheck on the registered operators: schema, fake-tensor agreement and autograd registration of
+    torch.ops.ssm.* on real device inputs."""
+    from ssm_amd import ops  # noqa: F401
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 8, 12, 20, generator=g).to(dev)
+    w = (torch.randn(16, 8, 3, 3, generator=g) / 8.0).to(dev)
+    b = torch.randn(16, generator=g).to(dev)
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration")
+    torch.library.opcheck(torch.ops.ssm.conv2d.default, (x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_(), True, 0.1),
+                          test_utils=tests)
+    torch.library.opcheck(torch.ops.ssm.avg_pool2.default, (x.clone().requires_grad_(),), test_utils=tests)
+    torch.library.opcheck(torch.ops.ssm.upsample2x_cat.default, (x.clone().requires_grad_(), None), test_utils=tests)
+    img, flo = torch.randn(1, 3, 12, 20, generator=g).to(dev), (torch.randn(1, 2, 12, 20, generator=g) * 2).to(dev)
+    torch.library.opcheck(torch.ops.ssm.warp.default, (img.clone().requires_grad_(), flo.clone().requires_grad_()), test_utils=tests)
+    img6, flow4, t = torch.randn(1, 6, 12, 20, generator=g).to(dev), torch.randn(1, 4, 12, 20, generator=g).to(dev), torch.tensor([0.25], device=dev)
+    torch.library.opcheck(torch.ops.ssm.flowinterp_inputs.default, (img6, flow4.clone().requires_grad_(), t), test_utils=tests)
+    in16 = torch.ops.ssm.flowinterp_inputs(img6, flow4, t)
+    out5 = torch.randn(1, 5, 12, 20, generator=g).to(dev)
+    torch.library.opcheck(torch.ops.ssm.synthesize.default, (img6, in16.clone().requires_grad_(), out5.clone().requires_grad_(), t), test_utils=tests)
