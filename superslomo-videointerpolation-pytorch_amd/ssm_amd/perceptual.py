@@ -48,6 +48,7 @@ class VGGFeatures:
         self.q8 = mode == "f16f8"
         self.steps = []          # ("conv", idx, cin, cout, src, dst) | ("pool", src, dst)
         self.t, self.pk, self.w, self.q = {}, {}, {}, {}        # q: Q8 twins of the conv inputs (mode f16f8)
+        self.b, self.pk_nb = {}, {}
         h, w, c, name = H, W, 3, "x"
         for item in VGG16_CONV4_3:
             if item == "M":
@@ -63,9 +64,10 @@ class VGGFeatures:
             bs = state_dict["features.%d.bias" % idx].to(device=device, dtype=torch.float32)
             assert tuple(wt.shape) == (cout, cin, 3, 3), "features.%d.weight has shape %s" % (idx, tuple(wt.shape))
             self.w[idx] = wt
+            self.b[idx] = bs
             self.pk[idx] = hb.PackedConv16(wt, bs, w, q8=True) if self.q8 else hb.PackedConv(wt, bs, B, h, w)
             if name == "x":
-                self.t["x"] = hb.Planes(B, self.pk[idx].cin_p, h, w, device)     # 3 channels padded to the conv's chunk
+                self.t["x"] = hb.Planes(B, max(8, self.pk[idx].cin_p), h, w, device)     # 3 channels padded to the largest conv chunk
                 if self.q8:
                     self.q["x"] = hb.HPlanes(B, 3, h, w, device, groups=self.pk[idx].cin_p // 8, q8=True)
             dst = "a%d" % idx
@@ -76,6 +78,19 @@ class VGGFeatures:
             c, name = cout, dst
         self.out = name
         self.g, self.pk_t = {}, {}
+
+    def _pk(self, idx, nb, src):
+        """Packed filter of conv `idx` for a launch over nb batch entries: the fp32 kernel's tile plan (and with it the packing)
+        depends on the batch, and forward() runs on sub-batches (prediction and target separately)."""
+        if self.q8:
+            return self.pk[idx]
+        pk = self.pk[idx]
+        if hb.conv_plan(3, pk.cin_p, pk.cout, nb, src.H, src.W)[1:] == (pk.bn, pk.ck):
+            return pk
+        key = (idx, nb)
+        if key not in self.pk_nb:
+            self.pk_nb[key] = hb.PackedConv(self.w[idx], self.b[idx], nb, src.H, src.W)
+        return self.pk_nb[key]
 
     def _span(self, fam, name, flops):
         tm = VGGFeatures.timer
@@ -106,7 +121,7 @@ class VGGFeatures:
                     hb.check(lib.ssm_hq8_from_f32(dst.view(b0=b0), q.view(b0=b0), nb, dst.C, q.G, dst.H, dst.W, st))
                 continue
             _, idx, cin, cout, sname, dname = s
-            src, dst, pk = self.t[sname], self.t[dname], self.pk[idx]
+            src, dst, pk = self.t[sname], self.t[dname], self._pk(idx, nb, self.t[sname])
             e1 = self._span("vgg_fwd", "features.%d" % idx, 2.0 * nb * src.H * src.W * cin * cout * 9)
             if self.q8:
                 hb.conv2d_hl8(self.q[sname].view(b0=b0), pk.cin_p, None, 0, pk, self.q[dname].view(b0=b0), dst.view(b0=b0), None, nb,

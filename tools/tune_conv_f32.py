@@ -23,6 +23,7 @@ def main():
     stage = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 736
     W = int(sys.argv[4]) if len(sys.argv) > 4 else 1280
+    only = os.environ.get("TUNE_ONLY", "").split(",") if os.environ.get("TUNE_ONLY") else None
     dev = torch.device("cuda:0")
     lib = hb.load()
     tot_auto = tot_best = tot_f = 0.0
@@ -41,6 +42,8 @@ def main():
         res = {}
         for ki, kn in enumerate(KINDS):
             if KS.get(kn, 3) != k or (kn == "K3N32T" and pool):
+                continue
+            if only and kn not in only:
                 continue
             if kn in ("K3N64", "K3N64T", "K3N64G", "K3N64GS") and cout <= 32:
                 continue
@@ -69,7 +72,7 @@ def main():
             res[kn] = e0.elapsed_time(e1) / n
             del x, pk
         best = min(res, key=res.get)
-        an = KINDS[auto]
+        an = KINDS[auto] if KINDS[auto] in res else best
         tot_auto += res[an]
         tot_best += res[best]
         tot_f += gf
