@@ -303,6 +303,31 @@ def stub_bench(args):
         torch.distributed.destroy_process_group()
 
 
+def start_clock_probe(dev, seconds):
+    """Diagnostic (optional: needs tools/libclockprobe.so, built by __graft_entry__.build()): one wave on a side stream spins
+    for `seconds` and records shader-clock ticks against the 100 MHz reference."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "libclockprobe.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p]
+        out = torch.zeros(2, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        lib.clock_probe_launch(out.data_ptr(), int(seconds * 1e8), ctypes.c_void_p(side.cuda_stream))
+        return out, side
+    except OSError:
+        return None
+
+
+def read_clock_probe(probe):
+    out, side = probe
+    side.synchronize()
+    c, r = [int(v) for v in out.cpu()]
+    return c / (r / 100e6) / 1e9 if r > 0 else None
+
+
 def physical_cores():
     try:
         seen = set()
@@ -442,6 +467,7 @@ def infer_bench(args):
         for _ in range(warmup):
             step()
         sync()
+        clk = start_clock_probe(dev, 2.0) if (rank == 0 and precision == headline) else None
         elapsed = sdist.timed_steps(step, steps, 0, sync)
         ms_step = 1e3 * elapsed / steps
         res = {"value": N_T * P * world * steps / elapsed, "ms_per_step": ms_step, "ms_per_pair": ms_step / P, "elapsed_s": elapsed}
@@ -461,6 +487,14 @@ def infer_bench(args):
                            "flop_per_pair": flops_pair, "traffic": traffic or None,
                            "traffic_note": "HBM bytes per pair of the conv launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from "
                                            "separate rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/%s" % (pmc_file or "-")}
+        if clk is not None:
+            ghz = read_clock_probe(clk)
+            if ghz:
+                res["roofline"]["shader_clock"] = {
+                    "ghz": round(ghz, 3), "peak_at_clock": round(peak * ghz / 2.4, 1), "frac_at_clock": round(ach / (peak * ghz / 2.4), 4),
+                    "note": "average shader clock over the first 2 s of the timed region (one resident wave comparing s_memtime with the "
+                            "100 MHz s_memrealtime, tools/clock_probe.hip): the chip is power-managed below its 2.4 GHz peak clock "
+                            "under this load, peak_at_clock = peak x ghz / 2.4"}
         if timers and rank == 0:
             # per-kernel brackets: ONE stream (with several pairs in flight the spans overlap and cannot be attributed)
             solo = pipe.engines[0]
@@ -583,7 +617,7 @@ def main():
                          "(N_FRAMES=4, ConvBLSTM bottleneck) at 720p")
     ap.add_argument("--size", default="720p", choices=["720p", "4k"],
                     help="720p = BASELINE configs[1] (the headline); 4k = configs[4] shape (3840x2160, use --precision f16)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams (= frame pairs in flight) per GPU")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams (= engine passes in flight) per GPU")
     ap.add_argument("--no-perceptual", action="store_true", help="--mode train: leave the VGG16 perceptual loss term out")
     ap.add_argument("--graphs", type=int, default=0, help="1: replay each pair's launch sequence from a captured HIP graph")
     ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")

@@ -211,26 +211,38 @@ class FullModel(nn.Module):
         return eng.run(img6, t, want_aux=False).clone()
 
     @torch.no_grad()
-    def interpolate_many(self, pairs, t_values, n_streams=2):
+    def interpolate_many(self, pairs, t_values, n_streams=2, pairs_per_batch=1):
         """Throughput form of interpolate(): a list of pairs ([1,2,3,H,W] each, same size) -> list of
-        [len(t_values),3,H,W] tensors.  Pairs are dealt round-robin to `n_streams` engines on separate HIP
-        streams (ssm_amd.engine.PairPipeline) so HBM-bound and MFMA-bound kernels of different pairs overlap."""
+        [len(t_values),3,H,W] tensors.  Passes of `pairs_per_batch` pairs are dealt round-robin to `n_streams` engines on
+        separate HIP streams (ssm_amd.engine.PairPipeline) so under-filled and tail phases of one pass overlap the
+        MFMA-bound convolutions of another; pairs_per_batch > 1 also gives every convolution launch that many times the
+        workgroups (bench.py's configuration: 3 streams x 2 pairs).  A remainder that does not fill a pass goes through
+        the one-pair engine."""
         from ssm_amd.engine import PairPipeline
         first = pairs[0]
         hb.require_device(first, "image pair")
         H, W = first.shape[-2:]
         t = _t_vector(t_values, first.device)
+        P = max(1, int(pairs_per_batch))
         mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)
-        key = ("pipe", n_streams, t.numel(), H, W, str(first.device), mode, self._stamp())
+        key = ("pipe", n_streams, P, t.numel(), H, W, str(first.device), mode, self._stamp())
         if getattr(self, "_pipe", None) is None or self._pipe[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
             sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
             self._pipe = None
-            self._pipe = (key, PairPipeline(sd1, sd2, t.numel(), H, W, first.device, self.cross_skip, mode, n_streams))
+            self._pipe = (key, PairPipeline(sd1, sd2, t.numel(), H, W, first.device, self.cross_skip, mode, n_streams,
+                                            pairs_per_batch=P))
         pipe = self._pipe[1]
-        outs = [pipe.submit(pr.reshape(1, 6, H, W), t, clone=True) for pr in pairs]
+        full = len(pairs) // P * P
+        outs = []
+        for i in range(0, full, P):
+            batch = pairs[i].reshape(1, 6, H, W) if P == 1 else torch.cat([pr.reshape(1, 6, H, W) for pr in pairs[i:i + P]], 0)
+            outs.append(pipe.submit(batch, t, clone=True))
         pipe.sync()
-        return outs
+        res = [o for out in outs for o in (out.split(t.numel()) if P > 1 else (out,))]
+        for pr in pairs[full:]:
+            res.append(self.interpolate(pr, t_values).clone())
+        return res
 
     # ---- training step ------------------------------------------------------------------------------------------
     grad_sync = None            # a ssm_amd.dist.GradientAllReduce (set by the Trainer), or None

@@ -239,7 +239,7 @@ def test_training_step_at_config3_size_vs_oracle(dev, oracle_352, train_precisio
     img, losses = m(xin.to(dev), t.to(dev), tgt.to(dev), None, False)
     losses.mean(dim=0)[0].backward()
     assert float((img.cpu() - pred).abs().max()) < (3e-4 if train_precision == "f32" else 6e-4)
-    assert abs(float(losses.mean(0)[0]) - L) < 1e-4 * abs(L)
+    assert abs(float(losses.detach().mean(0)[0]) - L) < 1e-4 * abs(L)
     worst = []
     for stage, mod in (("s1", m.stage1_model), ("s2", m.stage2_model)):
         for name, p in mod.named_parameters():

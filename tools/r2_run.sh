@@ -1,5 +1,4 @@
 set -x
 mkdir -p gpurun_out
-timeout 900 python bench.py --mode train --steps 20 --warmup 3 --detail gpurun_out/r2p_train_f32_detail.json > gpurun_out/r2p_train_f32.json 2> gpurun_out/r2p_err.log; cut -c1-250 gpurun_out/r2p_train_f32.json; tail -n 3 gpurun_out/r2p_err.log
-timeout 900 python bench.py --mode train --steps 20 --warmup 3 --no-perceptual > gpurun_out/r2p_train_f32_noperc.json 2>> gpurun_out/r2p_err.log; cut -c1-250 gpurun_out/r2p_train_f32_noperc.json
-timeout 1200 python -m pytest tests/test_hip_backward.py -q -m gpu -x > gpurun_out/r2p_tests.log 2>&1; tail -n 3 gpurun_out/r2p_tests.log
+timeout 3400 python -m pytest tests/ -q -m gpu > gpurun_out/r2q_full_tests.log 2>&1; tail -n 6 gpurun_out/r2q_full_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2q_smoke.log 2>&1; tail -n 4 gpurun_out/r2q_smoke.log
