@@ -493,8 +493,8 @@ def infer_bench(args):
                 res["roofline"]["shader_clock"] = {
                     "ghz": round(ghz, 3), "peak_at_clock": round(peak * ghz / 2.4, 1), "frac_at_clock": round(ach / (peak * ghz / 2.4), 4),
                     "note": "average shader clock over the first 2 s of the timed region (one resident wave comparing s_memtime with the "
-                            "100 MHz s_memrealtime, tools/clock_probe.hip): the chip is power-managed below its 2.4 GHz peak clock "
-                            "under this load, peak_at_clock = peak x ghz / 2.4"}
+                            "100 MHz s_memrealtime, tools/clock_probe.hip); peak_at_clock = peak x ghz / 2.4 (single 7x7 / 5x5 layers run "
+                            "back to back are power-managed down to 2.2 GHz, the mix of a whole pair holds the clock)"}
         if timers and rank == 0:
             # per-kernel brackets: ONE stream (with several pairs in flight the spans overlap and cannot be attributed)
             solo = pipe.engines[0]
