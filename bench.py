@@ -372,7 +372,7 @@ def cpu_baseline(sd1, sd2, pair, budget_s=120.0):
             torch.set_num_threads(n)
             O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)      # warm-up at this thread count
             t0 = time.perf_counter()
-            O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)
+            want1 = O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)
             sweep[n] = time.perf_counter() - t0
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
@@ -397,7 +397,7 @@ def cpu_baseline(sd1, sd2, pair, budget_s=120.0):
            "c1_256x256": {"value": round(1.0 / sweep[best], 3), "unit": "frames/s", "seconds": round(sweep[best], 3)},
            "thread_sweep_c1_seconds": {str(k): round(v, 3) for k, v in sweep.items()},
            "host": {"logical_cpus_usable": logical, "physical_cores": phys}}
-    return out, want
+    return out, want, (x1, want1[0])
 
 
 def io_legs(dev, h, w, reps=10):
@@ -575,8 +575,21 @@ def infer_bench(args):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.size == "720p":
         pair = torch.cat([xs[0][:, 0], xs[0][:, 1]], 1)
-        base, want = cpu_baseline(sd1, sd2, pair)
+        base, want, (x1, want1) = cpu_baseline(sd1, sd2, pair)
         out["cpu_baseline"] = base
+        # BASELINE configs[0] (plumbing): superslomo_eval.ini shape, one 256x256 pair, t = 0.5, HIP (headline mode) beside the CPU oracle
+        model.precision = headline
+        x1d = x1.to(dev)
+        got1 = model.interpolate(x1d, [0.5])
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            model.interpolate(x1d, [0.5])
+        sync()
+        hip1 = 20.0 / (time.perf_counter() - t0)
+        out["config1_256x256"] = {"hip_frames_per_s": round(hip1, 1), "cpu_frames_per_s": base["c1_256x256"]["value"],
+                                  "max_abs_vs_oracle": float((got1.cpu() - want1).abs().max()), "mode": headline,
+                                  "note": "one pair, one t, stage 1 not hoisted, one stream (latency, not throughput)"}
         ts = [i / 8.0 for i in range(1, N_T + 1)]
         par = {}
         for m in results:
