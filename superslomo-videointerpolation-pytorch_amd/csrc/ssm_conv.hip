@@ -35,6 +35,7 @@
 #include "ssm_common.h"
 
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -173,13 +174,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
+    // The accumulators start from the bias (register r of a lane = cout (r&3) + 8*(r>>2) + 4*half of the wave's 32-cout block):
+    // its loads ride the first DMA round trip of the prologue.  (Loading it in the epilogue put a vector load + s_waitcnt
+    // vmcnt(0) in front of each of the 16 register rounds of stores - every round then waited for the previous round's stores:
+    // 16 serialized memory round trips per tile; keeping 16 x NT bias values in registers across the k-loop instead would cost
+    // resident workgroups.)
     f32x16 acc[NT][MT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int r = 0; r < 16; ++r) {
+            const float bv0 = p.bias[nb * BN + (wn * NT + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
+            for (int m = 0; m < MT; ++m) acc[n][m][r] = bv0;
+        }
 
     // per-lane operand bases (floats): filter inside a stage, activation inside the patch
     const int aBase = half * (KS2 * BN) + wn * (NT * 32) + l31;
@@ -287,57 +295,72 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #ifdef SSM_CONV_ABLATE
     if ((p.abl & 2) && acc[0][0][0] != 12345.678f) return;
 #endif
+    // Lean store loop: one wave-uniform 64-bit base per (cout, batch) + one 32-bit per-lane offset per pixel group (saddr form
+    // of global_store), the in-image predicate evaluated once per pixel group, LeakyReLU as max(t, t*slope) (slope 1 = off).
+    // The first version recomputed a 64-bit address and three predicates per store: ~16 vector instructions per store, 1600 per
+    // wave and tile - a fifth of the MFMA time of a 32->32 3x3 tile.
+    const float sl = p.lrelu ? p.slope : 1.f;
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
+    const int cu0 = nb * BN + wn * (NT * 32);                    // first cout of this wave's block (uniform)
+    const bool full = cu0 + NT * 32 <= p.Cout;                   // uniform: no cout padding in this wave's block
+    // per lane: ONE offset into a cout plane (and one into a pooled plane); the pixel groups of the wave differ by uniform amounts
+    // (BYTE offsets, < 2^31: one batch entry of a 32-cout block; the stores use the saddr form: 64-bit SGPR base + 32-bit VGPR offset)
+    const unsigned pbase = 4u * ((unsigned)(4 * half) * (unsigned)p.dsc + (unsigned)ybase * (unsigned)p.dsh + (unsigned)xbase);
+    const unsigned qbase = 4u * ((unsigned)(4 * half) * (unsigned)p.psc + (unsigned)(ybase >> 1) * (unsigned)p.psh + (unsigned)(xbase >> 1));
+    auto st = [](const float *base, unsigned off_bytes, float val) {
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+    };
+    const bool even = (GW == 32) ? !(l31 & 1) : (!(gx & 1) && !(gy & 1));      // the lane that writes a 2x2 mean
+    bool pok[MT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
+    for (int m = 0; m < MT; ++m) pok[m] = ybase + (m / C::MTX) * GH < p.H && xbase + (m % C::MTX) * GW < p.W;
+    auto store_all = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cl = (wn * NT + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // within the cout block
-            const int co = nb * BN + cl;
-            const float bias = p.bias[co];
-            const bool cok = co < p.Cout;
-            float v[MT];
+        for (int n = 0; n < NT; ++n) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float t = acc[n][m][r] + bias;
-                if (p.lrelu) t = t > 0.f ? t : t * p.slope;
-                v[m] = t;
-            }
+            for (int r = 0; r < 16; ++r) {
+                const int cu = cu0 + n * 32 + (r & 3) + 8 * (r >> 2);       // uniform; this lane's cout = cu + 4*half
+                const bool cok = FULL || cu + 4 * half < p.Cout;
+                float *bp = dstb + (long long)cu * p.dsc;
+                float v[MT];
 #pragma unroll
-            for (int my = 0; my < C::MTY; ++my)
-#pragma unroll
-                for (int mx = 0; mx < C::MTX; ++mx) {
-                    const int y = ybase + my * GH, x = xbase + mx * GW;
-                    if (cok && y < p.H && x < p.W) dstb[(long long)co * p.dsc + (long long)y * p.dsh + x] = v[my * C::MTX + mx];
+                for (int m = 0; m < MT; ++m) {
+                    const float t = acc[n][m][r];          // the bias is already in: the accumulators start from it
+                    v[m] = fmaxf(t, t * sl);
+                    float *bpm = bp + ((m / C::MTX) * GH) * p.dsh + (m % C::MTX) * GW;        // uniform
+                    if (pok[m] && cok) st(bpm, pbase, v[m]);
                 }
-            if (poolb) {
-                if constexpr (GW == 32) {
-                    if constexpr (C::MTY % 2 == 0) {
+                if (poolb) {
+                    float *qp = poolb + (long long)cu * p.psc;
+                    if constexpr (GW == 32) {
+                        if constexpr (C::MTY % 2 == 0) {
 #pragma unroll
-                        for (int my = 0; my < C::MTY; my += 2)
+                            for (int my = 0; my < C::MTY; my += 2)
 #pragma unroll
-                            for (int mx = 0; mx < C::MTX; ++mx) {
-                                float s = v[my * C::MTX + mx] + v[(my + 1) * C::MTX + mx];
-                                s += __shfl_xor(s, 1);
-                                const int y = ybase + my, x = xbase + mx * 32;
-                                if (cok && !(l31 & 1) && y < p.H && x < p.W)
-                                    poolb[(long long)co * p.psc + (long long)(y >> 1) * p.psh + (x >> 1)] = s * 0.25f;
-                            }
-                    }
-                } else {   // 8x4 group: the 2x2 neighbours are lanes ^GW (y) and ^1 (x); same association as the 32x1 form
+                                for (int mx = 0; mx < C::MTX; ++mx) {
+                                    float sm = v[my * C::MTX + mx] + v[(my + 1) * C::MTX + mx];
+                                    sm += __shfl_xor(sm, 1);
+                                    float *qpm = qp + (my / 2) * p.psh + mx * (GW / 2);
+                                    if (pok[my * C::MTX + mx] && even && cok) st(qpm, qbase, sm * 0.25f);
+                                }
+                        }
+                    } else {   // 8x4 group: the 2x2 neighbours are lanes ^GW (y) and ^1 (x); same association as the 32x1 form
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        float s = v[m] + __shfl_xor(v[m], GW);
-                        s += __shfl_xor(s, 1);
-                        const int y = ybase + (m / C::MTX) * GH, x = xbase + (m % C::MTX) * GW;
-                        if (cok && !(gx & 1) && !(gy & 1) && y < p.H && x < p.W)
-                            poolb[(long long)co * p.psc + (long long)(y >> 1) * p.psh + (x >> 1)] = s * 0.25f;
+                        for (int m = 0; m < MT; ++m) {
+                            float sm = v[m] + __shfl_xor(v[m], GW);
+                            sm += __shfl_xor(sm, 1);
+                            float *qpm = qp + ((m / C::MTX) * GH / 2) * p.psh + (m % C::MTX) * (GW / 2);
+                            if (pok[m] && even && cok) st(qpm, qbase, sm * 0.25f);
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (full) store_all(std::true_type{});
+    else store_all(std::false_type{});
 }
 
 // ---- tile configurations ------------------------------------------------------------
