@@ -159,19 +159,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         }
     }
 
-    auto issue = [&](int ch, int stage) {
+    // LDS-DMA of one chunk.  A 1-KiB wave-instruction (group g) whose 64 pieces all come from the filter, or all from the
+    // activation patch, uses the saddr form - wave-uniform 64-bit base in SGPRs + the per-lane 32-bit byte offset computed once -
+    // and costs no vector instruction; only the one group that straddles the filter | patch boundary selects its base per lane.
+    // (The builtin's 64-bit per-lane address cost 7 VALU instructions per DMA, every chunk.)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+    // issue_k(ch, stage, k): this wave's k-th DMA instruction of chunk `ch` (group g = 4k + wave), k < NI.
+    auto issue_k = [&](int ch, int stage, int k) {
         const int c0 = ch * C::CK;
         const float *pb = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
         const float *wb = wbase + (long long)c0 * (KS2 * BN);
         float *ls = lds + stage * L::STAGE;
+        const unsigned lsb = lds0 + (unsigned)(stage * L::STAGE) * 4u;
 #pragma unroll
-        for (int i = 0; i < L::NI; ++i) {
-            const int g = i * 4 + wid;
-            if (g < L::NG) {
-                const float *gp = (isw[i] ? wb : pb) + off[i];
-                SSM_GLDS16(gp, ls + g * 256);
+        for (int w = 0; w < 4; ++w) {
+            const int g = 4 * k + w;
+            if (w == wid && g < L::NG) {          // wave-uniform
+                const bool pure_w = g * 64 + 63 < L::NWQ, pure_p = g * 64 >= L::NWQ;
+#ifndef SSM_DMA_SADDR
+#define SSM_DMA_SADDR 1
+#endif
+                if (SSM_DMA_SADDR && (pure_w || pure_p)) {
+                    const float *base = pure_w ? wb : pb;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 :: "v"(off[k] * 4), "s"(base), "s"(lsb + (unsigned)g * 1024u) : "memory", "m0");
+                } else {
+                    const float *gp = (isw[k] ? wb : pb) + off[k];
+                    SSM_GLDS16(gp, ls + g * 256);
+                }
             }
         }
+    };
+    auto issue = [&](int ch, int stage) {
+#pragma unroll
+        for (int k = 0; k < L::NI; ++k) issue_k(ch, stage, k);
     };
 
     // The accumulators start from the bias (register r of a lane = cout (r&3) + 8*(r>>2) + 4*half of the wave's 32-cout block):
@@ -199,11 +220,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         // chunk ch has landed for every wave; every wave is done reading chunk ch-1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#ifdef SSM_CONV_ABLATE
-        if (ch + 1 < nchunks && !((p.abl & 1) && ch >= 1)) issue(ch + 1, (ch + 1) & 1);
-#else
-        if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
+        // the DMA of chunk ch+1 is issued from inside the MFMA loop below, one instruction per macro-step (SSM_DMA_SPREAD): the
+        // requests do not hit the memory system as one burst behind the barrier, and the first MFMA does not wait for their issue
+#ifndef SSM_DMA_SPREAD
+#define SSM_DMA_SPREAD 1
 #endif
+#ifdef SSM_CONV_ABLATE
+        const bool dma_next = ch + 1 < nchunks && !((p.abl & 1) && ch >= 1);
+#else
+        const bool dma_next = ch + 1 < nchunks;
+#endif
+        if (!SSM_DMA_SPREAD && dma_next) issue(ch + 1, (ch + 1) & 1);
 
         const float *stg = lds + (ch & 1) * L::STAGE;
         if constexpr (UPS) {
@@ -279,12 +306,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                             if (g == 0 && n == 0 && m == 0) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 if (ms + 1 < NM) fetch(ms + 1, (ms + 1) & 1);
+                                if (SSM_DMA_SPREAD && ms < L::NI && dma_next) issue_k(ch + 1, (ch + 1) & 1, ms);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (SSM_DMA_SPREAD && L::NI > NM) {
+            if (dma_next) {
+#pragma unroll
+                for (int k = NM; k < L::NI; ++k) issue_k(ch + 1, (ch + 1) & 1, k);
+            }
         }
     }
 
