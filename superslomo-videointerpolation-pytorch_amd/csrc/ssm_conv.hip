@@ -181,8 +181,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #endif
                 if (SSM_DMA_SADDR && (pure_w || pure_p)) {
                     const float *base = pure_w ? wb : pb;
+                    const unsigned m0v = lsb + (unsigned)g * 1024u;
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                                 :: "v"(off[k] * 4), "s"(base), "s"(lsb + (unsigned)g * 1024u) : "memory", "m0");
+                                 :: "v"(off[k] * 4), "s"(base), "s"(m0v) : "memory", "m0");
                 } else {
                     const float *gp = (isw[k] ? wb : pb) + off[k];
                     SSM_GLDS16(gp, ls + g * 256);
@@ -195,20 +196,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         for (int k = 0; k < L::NI; ++k) issue_k(ch, stage, k);
     };
 
-    // The accumulators start from the bias (register r of a lane = cout (r&3) + 8*(r>>2) + 4*half of the wave's 32-cout block):
-    // its loads ride the first DMA round trip of the prologue.  (Loading it in the epilogue put a vector load + s_waitcnt
-    // vmcnt(0) in front of each of the 16 register rounds of stores - every round then waited for the previous round's stores:
-    // 16 serialized memory round trips per tile; keeping 16 x NT bias values in registers across the k-loop instead would cost
-    // resident workgroups.)
+    // (Bias: added AFTER the k-loop, see the epilogue.)
     f32x16 acc[NT][MT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bv0 = p.bias[nb * BN + (wn * NT + n) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[n][m][r] = bv0;
-        }
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
     // per-lane operand bases (floats): filter inside a stage, activation inside the patch
     const int aBase = half * (KS2 * BN) + wn * (NT * 32) + l31;
@@ -323,6 +318,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     }
 
     // ---- epilogue: bias, LeakyReLU, store (and fused 2x2 mean) -------------------------
+    // Bias: added after the k-loop like the reference's Conv2d (sum of products, then + bias: the same single rounding, so
+    // LeakyReLU branches agree with the reference also for outputs that cancel to ~0) - as one extra MFMA k-step per
+    // accumulator with A = the bias column (k = 0) and B = a row of ones: NT vector loads and ONE wait per tile.  (A vector
+    // load of the bias inside the store loop put an s_waitcnt vmcnt(0) - which also waits for the previous STORES - in front
+    // of each of the 16 register rounds; starting the accumulators from the bias changes the rounding order.)
+    {
+        float abias[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const float bv0 = p.bias[nb * BN + (wn * NT + n) * 32 + l31];       // every lane loads (no divergent branch), half 1 drops it
+            abias[n] = half ? 0.f : bv0;
+        }
+        const float ones = half ? 0.f : 1.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(abias[n], ones, acc[n][m], 0, 0, 0);
+    }
     // accumulator register r of lane (l31, half) = cout (r&3) + 8*(r>>2) + 4*half, pixel l31 of the group
     const int xbase = x0 + wx * (C::MTX * GW) + gx;
     const int ybase = y0 + wy * (C::MTY * GH) + gy;
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
                 float v[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const float t = acc[n][m][r];          // the bias is already in: the accumulators start from it
+                    const float t = acc[n][m][r];
                     v[m] = fmaxf(t, t * sl);
                     float *bpm = bp + ((m / C::MTX) * GH) * p.dsh + (m % C::MTX) * GW;        // uniform
                     if (pok[m] && cok) st(bpm, pbase, v[m]);
