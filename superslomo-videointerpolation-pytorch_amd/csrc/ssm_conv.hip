@@ -35,6 +35,7 @@
 #include "ssm_common.h"
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <cstdlib>
 
@@ -82,6 +83,10 @@ struct Cfg {
     // fused upsample: low-res raw patch rows y0/2-1 .. (y0+TH)/2, columns x0/2-4 .. x0/2+TW/2+3
     static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;
     static constexpr int RSZ = CK * LH * LW;
+    // fused-upsample expander: positions of 2x2 hi-res blocks per tile, channel groups over the 256 threads, channels per thread
+    static constexpr int NPOS = (TH / 2 + 1) * (TW / 2 + 1);
+    static constexpr int CG = (2 * NPOS <= 256 && CK >= 2) ? ((4 * NPOS <= 256 && CK >= 4) ? ((8 * NPOS <= 256 && CK >= 8) ? 8 : 4) : 2) : 1;
+    static constexpr int CPT = CK / CG;
     static constexpr bool POOL_OK = (GW == 32) ? (MTY % 2 == 0) : true;
     static constexpr bool UPS_OK = (KS == 3) && (TH % 2 == 0);
     static_assert(GW == 32 || GW == 8, "pixel group is 32x1 or 8x4");
@@ -229,34 +234,46 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 
         const float *stg = lds + (ch & 1) * L::STAGE;
         if constexpr (UPS) {
-            // expand the low-res chunk: one work unit = the 2x2 hi-res block between low-res pixels (i,j)..(i+1,j+1)
-            constexpr int PRH = C::TH / 2 + 1, PRW = C::TW / 2 + 1, NU = C::CK * PRH * PRW;
+            // expand the low-res chunk: one work unit = the 2x2 hi-res block between low-res pixels (i,j)..(i+1,j+1).  A thread
+            // owns ONE position (pi, pj) of the tile - its clamps, weights, in-image flags and LDS offsets are computed once per
+            // chunk - and walks CPT of the chunk's channels with constant strides (the first version did the index arithmetic,
+            // two divisions included, per unit: 3x the vector instructions on the 8x64 tiles).
+            constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, CG = C::CG, CPT = C::CPT;
             constexpr int LH = C::LH, LW = C::LW;
+            static_assert(NPOS <= 256 && C::CK % CG == 0, "expander mapping");
             const float *raw = stg + C::WSZ;
             float *hip = lds + L::HIP;
-            const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
-            for (int u = tid; u < NU; u += 256) {
-                const int c = u / (PRH * PRW);
-                const int rem = u - c * (PRH * PRW);
-                const int pi = rem / PRW, pj = rem - pi * PRW;
+            int tl = tid;
+            // big tiles (several channels per thread) recompute the geometry per chunk: hoisted out of the k-loop it would hold ~12
+            // VGPRs across the MFMAs = one resident workgroup less per CU; the small tiles have the registers and let it hoist
+            if constexpr (CPT > 1) asm volatile("" : "+v"(tl));
+            const int cg = tl / NPOS, pos = tl - cg * NPOS;
+            if (cg < CG) {
+                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+                const int pi = pos / PRW, pj = pos - pi * PRW;
                 const int i = ly0 + pi, j = lx0 + pj;
                 const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
                 const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
-                const float *r0 = raw + (c * LH + (i0 - ly0)) * LW + 3 - lx0;
-                const float *r1 = raw + (c * LH + (i1 - ly0)) * LW + 3 - lx0;
-                const float v00 = r0[j0], v01 = r0[j1], v10 = r1[j0], v11 = r1[j1];
                 // clamped pairs (image border) take the single source value exactly, like ATen's lambda = 0
                 const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;
                 const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
-                const float h00 = xa * v00 + xb * v01, h01 = xb * v00 + xa * v01;   // columns 2j+1, 2j+2 of low row i
-                const float h10 = xa * v10 + xb * v11, h11 = xb * v10 + xa * v11;   // ... of low row i+1
                 const int Y = 2 * i + 1, X = 2 * j + 1;
                 const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
-                float *d = hip + (c * PH + 2 * pi) * PW + 2 * pj + 3;
-                d[0] = (yt && xl) ? ya * h00 + yb * h10 : 0.f;
-                d[1] = (yt && xr) ? ya * h01 + yb * h11 : 0.f;
-                d[PW] = (yb2 && xl) ? yb * h00 + ya * h10 : 0.f;
-                d[PW + 1] = (yb2 && xr) ? yb * h01 + ya * h11 : 0.f;
+                const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
+                const float *r0 = raw + (cg * CPT * LH + (i0 - ly0)) * LW + 3 - lx0;
+                const float *r1 = raw + (cg * CPT * LH + (i1 - ly0)) * LW + 3 - lx0;
+                float *d = hip + (cg * CPT * PH + 2 * pi) * PW + 2 * pj + 3;
+#pragma unroll 1
+                for (int cc = 0; cc < CPT; ++cc) {
+                    const float v00 = r0[cc * LH * LW + j0], v01 = r0[cc * LH * LW + j1];
+                    const float v10 = r1[cc * LH * LW + j0], v11 = r1[cc * LH * LW + j1];
+                    const float h00 = xa * v00 + xb * v01, h01 = xb * v00 + xa * v01;   // columns 2j+1, 2j+2 of low row i
+                    const float h10 = xa * v10 + xb * v11, h11 = xb * v10 + xa * v11;   // ... of low row i+1
+                    d[cc * PH * PW] = m00 * (ya * h00 + yb * h10);
+                    d[cc * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
+                    d[cc * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
+                    d[cc * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
+                }
             }
             __syncthreads();
         }
@@ -443,13 +460,13 @@ enum ConvKind {
 };
 
 struct KindInfo {
-    int ks, bn, th, tw, ck, nt, mt;
+    int ks, bn, th, tw, ck, nt, mt, cpt;
     bool pool_ok, ups_ok;
 };
 
 template <class C>
 constexpr KindInfo info_of() {
-    return KindInfo{C::KS, C::BN, C::TH, C::TW, C::CK, C::NT, C::MT, C::POOL_OK, C::UPS_OK};
+    return KindInfo{C::KS, C::BN, C::TH, C::TW, C::CK, C::NT, C::MT, C::CPT, C::POOL_OK, C::UPS_OK};
 }
 
 constexpr KindInfo kInfo[NKIND] = {
@@ -460,21 +477,56 @@ constexpr KindInfo kInfo[NKIND] = {
 
 std::atomic<int> g_force_kind{-1};    // tests / tuning only (ssm_conv_force_kind)
 
-// Estimated duration (MFMA cycles) of a launch with tile configuration `ki`: 512 workgroup slots (2 per CU); a
-// workgroup alone on its CU issues one MFMA per 64 cycles per wave, two co-resident ones share the pipe; the
-// last round runs under-filled (its workgroups at full speed), and every workgroup pays a fixed prologue
-// (first DMA round trip) + epilogue (stores).
-double estimate_cycles(const KindInfo &ki, int cin8, int Cout, int B, int H, int W) {
+// Resident workgroups per CU of every kernel instance (registers / LDS), asked from the runtime once; 2 where there is no device
+// (the plan then is still a pure function of the problem - nothing is launched there).
+template <class C, bool UPS>
+int query_occupancy() {
+    if constexpr (UPS && !C::UPS_OK) {
+        return 1;
+    } else {
+        int n = 0;
+        auto kern = conv_mfma_kernel<C, UPS>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, Lds<C, UPS>::BYTES) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 2;
+        }
+        return n > 8 ? 8 : n;
+    }
+}
+
+const int (*occupancy_table())[2] {
+    static int occ[NKIND][2];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int i = 0;
+#define X(name, cfg)                        \
+    occ[i][0] = query_occupancy<cfg, false>(); \
+    occ[i][1] = query_occupancy<cfg, true>();  \
+    ++i;
+        SSM_CONV_KINDS(X)
+#undef X
+    });
+    return occ;
+}
+
+// Estimated duration (cycles) of a launch with tile configuration `ki`.  A workgroup needs `mf` cycles of matrix pipe (NT*MT
+// MFMAs of 64 cycles per k-step) plus `oth` cycles that are not MFMA (per chunk: barrier + DMA wait, the upsample expansion - more
+// per chunk where a thread walks several channels -; per workgroup: prologue + epilogue).  k co-resident workgroups share the pipe
+// of their CU: a round of them takes max(k*mf + oth, mf + oth); the launch is its full rounds (k = occupancy) plus one round of
+// the remainder spread over the 256 CUs.  Constants fitted to per-layer sweeps of every configuration at batch 1 ... 28
+// (tools/tune_conv_f32.py; the picks are within 0.4 % of the per-layer best on average, 1.1 % at worst).
+double estimate_cycles(const KindInfo &ki, int occ, int cin8, int Cout, int B, int H, int W, int ups) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * ((Cout + ki.bn - 1) / ki.bn);
-    // operand fetches per MFMA cost issue slots and power: (NT + MT) ds_reads per NT*MT MFMAs
-    const double per_mfma = 64.0 + 4.0 * (ki.nt + ki.mt) / (double)(ki.nt * ki.mt);
-    const double wg = (double)ki.nt * ki.mt * (cin8 * ki.ks * ki.ks / 2) * per_mfma + 9000.0;
-    const long long slots = 512;
-    if (nwg <= 256) return wg;
-    if (nwg <= slots) return 2.0 * wg;
-    const long long full = nwg / slots, rest = nwg % slots;
-    return 2.0 * wg * full + (rest == 0 ? 0.0 : rest <= 256 ? wg : 2.0 * wg);
+    const double mf = (double)ki.nt * ki.mt * (cin8 * ki.ks * ki.ks / 2) * 64.0;
+    const double chunks = (double)cin8 / ki.ck;
+    const double oth = chunks * (800.0 + (ups ? 400.0 + 400.0 * ki.cpt : 0.0)) + 20000.0;
+    const long long slots = 256LL * occ;
+    const long long full = nwg / slots, rem = nwg % slots;
+    auto round_time = [&](double k) { return (k * mf + oth > mf + oth) ? k * mf + oth : mf + oth; };
+    double t = (double)full * round_time((double)occ);
+    if (rem) t += round_time((double)((rem + 255) / 256));
+    return t;
 }
 
 int pick_kind(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups) {
@@ -491,7 +543,7 @@ int pick_kind(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups) 
             if (pool && !ki.pool_ok) continue;
             if (ups && !ki.ups_ok) continue;
             if (pass == 0 && ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;   // over half of the cout block = padding
-            const double t = estimate_cycles(ki, cin8, Cout, B, H, W);
+            const double t = estimate_cycles(ki, occupancy_table()[i][ups ? 1 : 0], cin8, Cout, B, H, W, ups);
             if (best < 0 || t < bt * 0.999) {
                 best = i;
                 bt = t;
