@@ -127,6 +127,24 @@ int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_pack
 int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
                        ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 
+/* ---- the same 3x3 convolution as Winograd F(2x2,3x3), all arithmetic fp32 (v_mfma_f32_32x32x2_f32) ---------------
+ * Same operator and operand layout as ssm_conv2d_fwd / ssm_conv2d_ups_fwd for k = 3 (layers.conv,
+ * scripts/models/layers.py:21-33; decoder step scripts/models/flow_computation.py:244-247), evaluated as
+ * Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A per 2x2 output tile: 16 instead of 36 multiplies per (cin, cout, 4 outputs),
+ * i.e. 2.25x fewer matrix-core cycles; in fp32 the result differs from the direct form by rounding only (about as much as
+ * a different summation order).  W must be even; Cin and the first cat source multiples of CK.
+ * ssm_wino_plan: tile configuration for the problem (BN = cout block to pack for, CK = channel chunk).
+ * ssm_wino_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/BN][Cin][4][BN][4] (+ bias padded to BN).          */
+int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int *kind, int *BN, int *CK);
+int ssm_wino_force_kind(int kind);       /* tests / tuning only (-1 = automatic); returns the number of configurations */
+size_t ssm_wino_packed_weight_floats(int Cout, int Cin, int BN);
+int ssm_wino_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin,
+                          int BN, void *stream);
+int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed,
+                        ssm_view y, ssm_view pool, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
+                            ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+
 /* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------
  * Same operator as ssm_conv2d_fwd.  Default mode evaluates a*b as a_hi*b_hi + a_hi*b_lo +
  * a_lo*b_hi with fp32 accumulation (fp32-grade products at 16/3 x the fp32-MFMA rate);

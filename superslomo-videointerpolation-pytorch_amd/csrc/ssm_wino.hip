@@ -1,0 +1,615 @@
+// 3x3 convolution as Winograd F(2x2,3x3) on the CDNA4 fp32 matrix cores (v_mfma_f32_32x32x2_f32), all arithmetic fp32.
+//
+// Same operator as ssm_conv.hip for k = 3 (layers.conv of the reference, scripts/models/layers.py:21-33: stride-1 'same'
+// cross-correlation, zero padding, bias, LeakyReLU; fused 2x2 mean, scripts/models/layers.py:60-63; two-source input =
+// torch.cat on C; fused F.upsample(torch.cat([a, b], 1), bilinear x2), scripts/models/flow_computation.py:244-247), evaluated as
+//
+//      Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A          per 2x2 output tile (d = its 4x4 input patch, g = the 3x3 filter)
+//
+// i.e. 16 multiplies per (cin, cout, 4 outputs) instead of 36: 2.25x fewer matrix-core cycles than the direct form for the same
+// result in exact arithmetic.  In fp32 the rounding differs from the direct fmaf chain by about as much as a different summation
+// order does (transform entries are 0, +-1, +-1/2 only): tests/emulate_winograd_precision.py measures both forms 2.3e-4 from a
+// float64 evaluation of the whole pair -> frame path at 736x1280.
+//
+// GEMM view: for each of the 16 "frequencies" f,  M_f[cout][tile] = sum_cin U_f[cout][cin] * V_f[cin][tile].  A wave owns a
+// 32-cout x 32-tile block for ALL 16 frequencies: 16 accumulators of 16 registers (the 256 accumulation VGPRs of a wave that has
+// the SIMD to itself - one 4-wave workgroup per CU).  With every frequency of a tile on the same lane, both transforms are
+// lane-local: the input transform B^T d B (32 add/sub per k-step, from 16 LDS values of the activation patch) feeds the B operands,
+// the output transform A^T M A (24 add/sub per cout) runs on the accumulators in the epilogue, and each lane stores 2x2 pixel blocks
+// (8-byte stores, a wave writes 256-byte row segments).  The filter is pre-transformed once per plan (U = G g G^T, 16 floats per
+// (cout, cin), ssm_wino_pack_weights) in the order the A operands are read: [cin][f/4][cout][f%4] -> one ds_read_b128 per 4 frequencies.
+//
+// Data movement: as in ssm_conv.hip the input is the padded-plane layout, a tile's halo is a bigger rectangle; per chunk of CK input
+// channels the workgroup stages [CK][16][BN] filter values and the [CK][TH+2][TW+8] patch with LDS-DMA, double-buffered.  The one
+// barrier per chunk sits inside the LAST k-step of the chunk: by then all LDS reads of the chunk are complete (the last k-step's
+// operands are in registers), so its stage is handed to the DMA of chunk c+2 at once, chunk c+1 (issued a chunk ago) becomes visible,
+// and the operands of its first k-step are fetched and transformed behind the remaining MFMAs - the matrix pipe never waits for LDS.
+#include "ssm_common.h"
+
+#include <atomic>
+#include <mutex>
+#include <type_traits>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct WinoParams {
+    const float *src1;
+    const float *src2;
+    long long sb1, sb2;  // batch strides
+    long long sc;        // channel stride (both sources)
+    int sh;              // row stride (both sources)
+    int C1, Cin;         // channels of source 1, total
+    const float *wpk;    // U, [Cout/BN][Cin][4][BN][4]
+    const float *bias;
+    float *dst;
+    long long dsb, dsc;
+    int dsh;
+    float *pool;
+    long long psb, psc;
+    int psh;
+    int H, W, Cout;      // OUTPUT map
+    int hs, ws;          // UPS: source map (H/2, W/2)
+    int tilesX, tilesY, NB;
+    float slope;
+    int lrelu;
+};
+
+// WN cout blocks x (WTY x WTX) tile groups = 4 waves; a tile group = GTW x (32/GTW) Winograd tiles of 2x2 pixels
+template <int WN_, int WTY_, int WTX_, int GTW_, int CK_>
+struct WCfg {
+    static constexpr int WN = WN_, WTY = WTY_, WTX = WTX_, GTW = GTW_, GTH = 32 / GTW_, CK = CK_;
+    static constexpr int BN = 32 * WN;
+    static constexpr int TH = 2 * GTH * WTY, TW = 2 * GTW * WTX;      // output pixels per workgroup
+    static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;       // patch rows y0-1 .. y0+TH, columns x0-4 .. x0+TW+3
+    static constexpr int USZ = CK * 16 * BN, PSZ = CK * PH * PW;
+    static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;   // fused upsample: low-res raw patch
+    static constexpr int RSZ = CK * LH * LW;
+    static constexpr int NPOS = (TH / 2 + 1) * (TW / 2 + 1);
+    static constexpr int CG = (2 * NPOS <= 256 && CK >= 2) ? ((4 * NPOS <= 256 && CK >= 4) ? ((8 * NPOS <= 256 && CK >= 8) ? 8 : 4) : 2) : 1;
+    static constexpr int CPT = CK / CG;
+    static_assert(WN * WTY * WTX == 4, "4 waves per workgroup");
+    static_assert(GTW == 8 || GTW == 16 || GTW == 32, "tile group is 32x1, 16x2 or 8x4 tiles");
+    static_assert(CK % 4 == 0 && USZ % 256 == 0, "even number of k-steps per chunk; filter stage = whole 1-KiB DMA groups");
+    static_assert(NPOS <= 256, "fused-upsample expander: one position per thread");
+};
+
+template <class C, bool UPS>
+struct WLds {
+    static constexpr int DSZ = UPS ? C::RSZ : C::PSZ;
+    static constexpr int DH = UPS ? C::LH : C::PH, DW4 = UPS ? C::LW4 : C::PW4;
+    static constexpr int NGU = C::USZ / 256;                    // 1-KiB groups of filter per chunk
+    static constexpr int NDQ = DSZ / 4;                         // 16-byte pieces of activation per chunk
+    static constexpr int NGP = (NDQ + 63) / 64;
+    static constexpr int NG = NGU + NGP;
+    static constexpr int STAGE = NG * 256;                      // floats per stage
+    static constexpr int NIU = (NGU + 3) / 4, NIP = (NGP + 3) / 4, NI = NIU + NIP;   // DMA instructions per wave per chunk
+    static constexpr int NST = 2;                               // stages (double buffer)
+    static constexpr int HIP = NST * STAGE;                     // expanded patch (UPS)
+    static constexpr int BYTES = (NST * STAGE + (UPS ? C::PSZ : 0)) * 4;
+    static_assert(BYTES <= 160 * 1024, "LDS budget (one workgroup per CU)");
+};
+
+template <class C, bool UPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_kernel(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using L = WLds<C, UPS>;
+    constexpr int BN = C::BN, PH = C::PH, PW = C::PW, CK = C::CK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid % C::WN, wty = (wid / C::WN) % C::WTY, wtx = wid / (C::WN * C::WTY);
+    const int tyl = l31 / C::GTW, txl = l31 % C::GTW;
+
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
+    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
+    const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
+    const float *wbase = p.wpk + (long long)nb * p.Cin * (16 * BN);
+
+    // per-lane source offsets (bytes) of the activation pieces this wave brings per chunk; the filter pieces are linear
+    int poff[L::NIP];
+#pragma unroll
+    for (int i = 0; i < L::NIP; ++i) {
+        const int qq = (i * 4 + wid) * 64 + lane;
+        if (qq < L::NDQ) {
+            const int c = qq / (L::DH * L::DW4);
+            const int rem = qq - c * (L::DH * L::DW4);
+            const int r = rem / L::DW4;
+            const int j = rem - r * L::DW4;
+            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+        } else {
+            poff[i] = 0;          // tail of the last 1-KiB piece: lands in the stage's padding
+        }
+    }
+    const int uoff = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+
+    // k-th DMA instruction of this wave for chunk `ch` into ring stage `stage`: k < NIU filter group 4k + wave, else activation
+    auto issue_k = [&](int ch, int stage, int k) {
+        const int c0 = ch * CK;
+        const unsigned lsb = lds0 + (unsigned)(stage * L::STAGE) * 4u;
+        if (k < L::NIU) {
+            const int g = 4 * k + wid;
+            if (g < L::NGU) {
+                const float *base = wbase + (long long)c0 * (16 * BN) + g * 256;
+                const unsigned m0v = lsb + (unsigned)g * 1024u;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
+            }
+        } else {
+            const int kk = k - L::NIU;
+            const int g = 4 * kk + wid;
+            if (g < L::NGP) {
+                const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
+                const unsigned m0v = lsb + (unsigned)(L::NGU + g) * 1024u;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
+            }
+        }
+    };
+    auto issue = [&](int ch, int stage) {
+#pragma unroll
+        for (int k = 0; k < L::NI; ++k) issue_k(ch, stage, k);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // per-lane operand bases (floats) inside a stage: U of (cin = 2cp + half, cout = wn*32 + l31), patch of the lane's tile
+    const int aBase = half * (16 * BN) + (wn * 32 + l31) * 4;
+    const int bBase = half * (PH * PW) + ((wty * C::GTH + tyl) * 2) * PW + (wtx * C::GTW + txl) * 2 + 3;
+
+    constexpr int S = CK / 2;                  // k-steps per chunk
+    const int nchunks = p.Cin / CK;
+
+    f32x4 a[2][4];
+    float d[16], v[2][16];
+    auto fetchA = [&](const float *stg, int cp, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[buf][q] = *(const f32x4 *)(stg + aBase + cp * (32 * BN) + q * (4 * BN));
+    };
+    auto fetchD = [&](const float *pat, int cp) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[4 * i + j] = pat[bBase + cp * (2 * PH * PW) + i * PW + j];
+    };
+    // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], in two halves of 16 add/sub that go into separate MFMA gaps
+    float t[16];
+    auto transform_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = d[j] - d[8 + j];
+            t[4 + j] = d[4 + j] + d[8 + j];
+            t[8 + j] = d[8 + j] - d[4 + j];
+            t[12 + j] = d[4 + j] - d[12 + j];
+        }
+    };
+    auto transform_cols = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[buf][4 * i] = t[4 * i] - t[4 * i + 2];
+            v[buf][4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+            v[buf][4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
+            v[buf][4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+        }
+    };
+
+    // fused upsample: low-res raw chunk -> hi-res patch; one thread = one 2x2 hi-res block position, walking CPT channels (ssm_conv.hip)
+    auto expand = [&](const float *stg) {
+        if constexpr (UPS) {
+            constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, CG = C::CG, CPT = C::CPT;
+            constexpr int LH = C::LH, LW = C::LW;
+            const float *raw = stg + C::USZ;
+            float *hip = lds + L::HIP;
+            const int cg = tid / NPOS, pos = tid - cg * NPOS;
+            if (cg < CG) {
+                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+                const int pi = pos / PRW, pj = pos - pi * PRW;
+                const int i = ly0 + pi, j = lx0 + pj;
+                const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
+                const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
+                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;
+                const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
+                const int Y = 2 * i + 1, X = 2 * j + 1;
+                const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
+                const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
+                const float *r0 = raw + (cg * CPT * LH + (i0 - ly0)) * LW + 3 - lx0;
+                const float *r1 = raw + (cg * CPT * LH + (i1 - ly0)) * LW + 3 - lx0;
+                float *dd = hip + (cg * CPT * PH + 2 * pi) * PW + 2 * pj + 3;
+#pragma unroll 1
+                for (int cc = 0; cc < CPT; ++cc) {
+                    const float v00 = r0[cc * LH * LW + j0], v01 = r0[cc * LH * LW + j1];
+                    const float v10 = r1[cc * LH * LW + j0], v11 = r1[cc * LH * LW + j1];
+                    const float h00 = xa * v00 + xb * v01, h01 = xb * v00 + xa * v01;
+                    const float h10 = xa * v10 + xb * v11, h11 = xb * v10 + xa * v11;
+                    dd[cc * PH * PW] = m00 * (ya * h00 + yb * h10);
+                    dd[cc * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
+                    dd[cc * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
+                    dd[cc * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    // ---- prologue: chunks 0 and 1 in flight, operands of the first k-step ------------------------------------------
+    issue(0, 0);
+    if (nchunks > 1) issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    expand(lds);
+    fetchA(lds, 0, 0);
+    fetchD(UPS ? lds + L::HIP : lds + C::USZ, 0);
+    transform_rows();
+    transform_cols(0);
+
+    // Chunk loop.  The barrier sits INSIDE the last k-step of a chunk (after its first MFMAs are queued): at that point every LDS
+    // read of chunk ch has been issued and has completed (the last k-step's operands are in registers), so the stage of chunk ch is
+    // free for the DMA of chunk ch+2, and chunk ch+1 - issued one chunk ago - is waited for and becomes visible to all waves; the
+    // operands of its first k-step are then fetched and transformed behind the remaining MFMAs of chunk ch.
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float *stg = lds + (ch & 1) * L::STAGE;
+        const float *pat = UPS ? lds + L::HIP : stg + C::USZ;
+        const float *stg_n = lds + ((ch + 1) & 1) * L::STAGE;
+        const float *pat_n = UPS ? lds + L::HIP : stg_n + C::USZ;
+        const bool dma = ch + 2 < nchunks;
+        const bool more = ch + 1 < nchunks;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            const bool last = s == S - 1;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][f >> 2][f & 3], v[cur][f], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!last) {
+                    if (f == 0) {
+                        fetchA(stg, s + 1, nxt);
+                        fetchD(pat, s + 1);
+                    }
+                } else if (more) {
+                    if (f == 1) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        fetchA(stg_n, 0, nxt);
+                        if constexpr (!UPS) fetchD(pat_n, 0);
+                    }
+                    if (f >= 2 && f < 8) {                                  // DMA of chunk ch+2 into the stage just freed
+                        constexpr int PER = (L::NI + 5) / 6;
+#pragma unroll
+                        for (int j = 0; j < PER; ++j) {
+                            const int k = (f - 2) * PER + j;
+                            if (k < L::NI && dma) issue_k(ch + 2, ch & 1, k);
+                        }
+                    }
+                }
+                if (!last || (more && !UPS)) {
+                    if (f == 9) transform_rows();
+                    if (f == 11) transform_cols(nxt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (UPS) {
+            if (more) {
+                __syncthreads();           // every wave is done with the expanded patch of chunk ch
+                expand(stg_n);
+                fetchD(pat_n, 0);
+                transform_rows();
+                transform_cols(0);
+            }
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // Bias: A^T M A adds M[1][1] to all four outputs of the tile, so one extra k-step into accumulator 5 with A = the bias column and
+    // B = a row of ones adds the bias (one vector load per lane).
+    {
+        const float bv0 = p.bias[nb * BN + wn * 32 + l31];
+        const float ab = half ? 0.f : bv0, ones = half ? 0.f : 1.f;
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, ones, acc[5], 0, 0, 0);
+    }
+    const int px = x0 + (wtx * C::GTW + txl) * 2, py = y0 + (wty * C::GTH + tyl) * 2;
+    const float sl = p.lrelu ? p.slope : 1.f;
+    float *dstb = p.dst + (long long)b * p.dsb;
+    float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
+    const int cu0 = nb * BN + wn * 32;
+    const bool full = cu0 + 32 <= p.Cout;
+    const unsigned pb0 = 4u * ((unsigned)(4 * half) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
+    const unsigned pb1 = pb0 + 4u * (unsigned)p.dsh;
+    const unsigned qb = 4u * ((unsigned)(4 * half) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
+    const bool ok0 = py < p.H && px < p.W, ok1 = py + 1 < p.H && px < p.W;
+    auto st2 = [](const float *base, unsigned off_bytes, f32x2 val) {
+        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+    };
+    auto st1 = [](const float *base, unsigned off_bytes, float val) {
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+    };
+    auto store_all = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cu = cu0 + (r & 3) + 8 * (r >> 2);      // uniform; this lane's cout = cu + 4*half
+            const bool cok = FULL || cu + 4 * half < p.Cout;
+            // Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+                s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+            }
+            float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+            float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            y00 = fmaxf(y00, y00 * sl);
+            y01 = fmaxf(y01, y01 * sl);
+            y10 = fmaxf(y10, y10 * sl);
+            y11 = fmaxf(y11, y11 * sl);
+            float *bp = dstb + (long long)cu * p.dsc;
+            f32x2 r0 = {y00, y01}, r1 = {y10, y11};
+            if (ok0 && cok) st2(bp, pb0, r0);
+            if (ok1 && cok) st2(bp, pb1, r1);
+            if (poolb) {
+                float *qp = poolb + (long long)cu * p.psc;
+                const float sm = ((y00 + y10) + (y01 + y11)) * 0.25f;
+                if (ok1 && cok) st1(qp, qb, sm);
+            }
+        }
+    };
+    if (full) store_all(std::true_type{});
+    else store_all(std::false_type{});
+}
+
+// ---- tile configurations ------------------------------------------------------------------------------------------
+//                     WN WTY WTX GTW CK        BN   TH  TW (pixels)
+using W64A = WCfg<2, 2, 1, 32, 8>;        //    64    4  64
+using W32A = WCfg<1, 4, 1, 32, 8>;        //    32    8  64
+using W128A = WCfg<4, 1, 1, 32, 4>;       //   128    2  64
+using W64G = WCfg<2, 2, 1, 8, 8>;         //    64   16  16
+using W128G = WCfg<4, 1, 1, 8, 4>;        //   128    8  16
+using W64H = WCfg<2, 2, 1, 16, 8>;        //    64    8  32
+using W128H = WCfg<4, 1, 1, 16, 4>;       //   128    4  32
+
+#define SSM_WINO_KINDS(X) X(W64A_, W64A) X(W32A_, W32A) X(W128A_, W128A) X(W64G_, W64G) X(W128G_, W128G) X(W64H_, W64H) X(W128H_, W128H)
+
+enum WinoKind {
+#define X(name, cfg) name,
+    SSM_WINO_KINDS(X)
+#undef X
+        NWKIND
+};
+
+struct WKindInfo {
+    int bn, th, tw, ck;
+};
+
+template <class C>
+constexpr WKindInfo winfo_of() {
+    return WKindInfo{C::BN, C::TH, C::TW, C::CK};
+}
+
+constexpr WKindInfo kWInfo[NWKIND] = {
+#define X(name, cfg) winfo_of<cfg>(),
+    SSM_WINO_KINDS(X)
+#undef X
+};
+
+std::atomic<int> g_force_wkind{-1};
+
+// Estimated matrix-pipe cycles of a launch: one workgroup per CU, every workgroup Cin/2 k-steps of 16 MFMAs (64 cycles each) plus a
+// fixed prologue/epilogue; rounds of 256 workgroups.
+double estimate_wino(const WKindInfo &ki, int Cin, int Cout, int B, int H, int W) {
+    const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
+    const long long nwg = tiles * ((Cout + ki.bn - 1) / ki.bn);
+    const double per = (double)(Cin / 2) * 16.0 * 64.0 + 12000.0;
+    return (double)((nwg + 255) / 256) * per;
+}
+
+int pick_wkind(int Cin, int Cout, int B, int H, int W) {
+    const int forced = g_force_wkind.load();
+    if (forced >= 0 && forced < NWKIND) return forced;
+    int best = -1;
+    double bt = 0.0;
+    for (int i = 0; i < NWKIND; ++i) {
+        const WKindInfo &ki = kWInfo[i];
+        if (ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;      // over half of the cout block would be padding
+        if (Cin % ki.ck) continue;
+        const double t = estimate_wino(ki, Cin, Cout, B, H, W);
+        if (best < 0 || t < bt * 0.999) {
+            best = i;
+            bt = t;
+        }
+    }
+    return best;
+}
+
+template <class C, bool UPS>
+int wlaunch(WinoParams &p, int B, hipStream_t st) {
+    p.tilesX = (p.W + C::TW - 1) / C::TW;
+    p.tilesY = (p.H + C::TH - 1) / C::TH;
+    p.NB = (p.Cout + C::BN - 1) / C::BN;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        ssm::set_error("wino conv: grid of %lld workgroups out of range", blocks);
+        return SSM_E_ARG;
+    }
+    constexpr int lds_bytes = WLds<C, UPS>::BYTES;
+    auto kern = wino_kernel<C, UPS>;
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    if (attr_rc != hipSuccess) {
+        ssm::set_error("wino conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
+        return SSM_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+    return ssm::check_launch(UPS ? "ssm_wino_conv2d_ups_fwd" : "ssm_wino_conv2d_fwd");
+}
+
+template <bool UPS>
+int wdispatch(int kind, WinoParams &p, int B, hipStream_t st) {
+    switch (kind) {
+#define X(name, cfg) \
+    case name: return wlaunch<cfg, UPS>(p, B, st);
+        SSM_WINO_KINDS(X)
+#undef X
+    }
+    return SSM_E_UNSUPPORTED;
+}
+
+// U = G g G^T,  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; packed index -> (nb, cin, q, n, e), frequency f = 4q + e = 4i + j
+__global__ void wino_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ wp,
+                                 float *__restrict__ bp, int Cout, int Cin, int BN, long long total, int nbias) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        long long r = i;
+        const int e = (int)(r % 4);
+        r /= 4;
+        const int n = (int)(r % BN);
+        r /= BN;
+        const int q = (int)(r % 4);
+        r /= 4;
+        const int cin = (int)(r % Cin);
+        const int nb = (int)(r / Cin);
+        const int co = nb * BN + n;
+        float val = 0.f;
+        if (co < Cout) {
+            const float *g = w + ((long long)co * Cin + cin) * 9;
+            float row[3];      // row q of G g
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+                row[c] = q == 0 ? g0 : (q == 1 ? 0.5f * (g0 + g1 + g2) : (q == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+            }
+            val = e == 0 ? row[0] : (e == 1 ? 0.5f * (row[0] + row[1] + row[2]) : (e == 2 ? 0.5f * (row[0] - row[1] + row[2]) : row[2]));
+        }
+        wp[i] = val;
+    }
+    if (i < nbias) bp[i] = (i < Cout) ? bias[i] : 0.f;
+}
+
+int wfill(WinoParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y, int H,
+          int W, int Cout, float slope, int flags, int CK, int srcW) {
+    SSM_REQUIRE(H > 0 && W > 0 && Cout > 0 && C1 > 0 && C2 >= 0, "wino conv: bad sizes");
+    SSM_REQUIRE(W % 2 == 0, "wino conv: the map width must be even (got %d)", W);
+    SSM_REQUIRE(x1.ptr && y.ptr && w_packed && bias_packed, "wino conv: null pointer");
+    SSM_REQUIRE(C1 % CK == 0 && C2 % CK == 0, "wino conv: channel counts (%d,%d) must be multiples of %d", C1, C2, CK);
+    SSM_REQUIRE(ssm::aligned16(x1.ptr) && x1.sh % 4 == 0 && x1.sc % 4 == 0 && x1.sb % 4 == 0,
+                "wino conv: input 1 is not a padded-plane view (16-byte alignment)");
+    SSM_REQUIRE(x1.sh >= srcW + 2 * SSM_PADX, "wino conv: input 1 row stride %d leaves no zero frame for W=%d", x1.sh, srcW);
+    SSM_REQUIRE(ssm::aligned16(w_packed), "wino conv: packed filter must be 16-byte aligned");
+    SSM_REQUIRE((reinterpret_cast<size_t>(y.ptr) & 7) == 0 && y.sh % 2 == 0 && y.sc % 2 == 0 && y.sb % 2 == 0,
+                "wino conv: output view must be 8-byte aligned (2x2 pixel blocks are stored as row pairs)");
+    if (C2 > 0) {
+        SSM_REQUIRE(x2.ptr && ssm::aligned16(x2.ptr) && x2.sb % 4 == 0, "wino conv: input 2 is not a padded-plane view");
+        SSM_REQUIRE(x2.sh == x1.sh && x2.sc == x1.sc, "wino conv: cat sources must share row/channel strides");
+    }
+    SSM_REQUIRE((long long)CK * x1.sc * 4 < 0x7fffffffLL, "wino conv: channel stride too large");
+    p.src1 = x1.ptr;
+    p.src2 = C2 > 0 ? x2.ptr : x1.ptr;
+    p.sb1 = x1.sb;
+    p.sb2 = C2 > 0 ? x2.sb : 0;
+    p.sc = x1.sc;
+    p.sh = x1.sh;
+    p.C1 = C1;
+    p.Cin = C1 + C2;
+    p.wpk = w_packed;
+    p.bias = bias_packed;
+    p.dst = y.ptr;
+    p.dsb = y.sb;
+    p.dsc = y.sc;
+    p.dsh = y.sh;
+    p.pool = nullptr;
+    p.psb = p.psc = 0;
+    p.psh = 0;
+    p.H = H;
+    p.W = W;
+    p.hs = H / 2;
+    p.ws = W / 2;
+    p.Cout = Cout;
+    p.slope = slope;
+    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    return SSM_OK;
+}
+
+}  // namespace
+
+extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int *kind, int *BN, int *CK) {
+    const int kd = (W % 2 == 0) ? pick_wkind(Cin, Cout, B, H, W) : -1;
+    if (kd < 0) {
+        ssm::set_error("wino conv: no tile configuration for Cin=%d Cout=%d on a %dx%d map (needs even W, Cin a multiple of 8)", Cin, Cout, H, W);
+        return SSM_E_UNSUPPORTED;
+    }
+    if (kind) *kind = kd;
+    if (BN) *BN = kWInfo[kd].bn;
+    if (CK) *CK = kWInfo[kd].ck;
+    return SSM_OK;
+}
+
+extern "C" int ssm_wino_force_kind(int kind) {
+    g_force_wkind.store(kind >= 0 && kind < NWKIND ? kind : -1);
+    return NWKIND;
+}
+
+extern "C" size_t ssm_wino_packed_weight_floats(int Cout, int Cin, int BN) {
+    const size_t nb = (size_t)(Cout + BN - 1) / BN;
+    return nb * (size_t)Cin * 16 * BN;
+}
+
+extern "C" int ssm_wino_pack_weights(const float *w, const float *bias, float *wp, float *bp, int Cout, int Cin, int BN, void *stream) {
+    SSM_REQUIRE(w && bias && wp && bp, "wino pack_weights: null pointer");
+    SSM_REQUIRE(Cout > 0 && Cin > 0 && BN > 0 && BN % 32 == 0, "wino pack_weights: bad sizes");
+    const long long total = (long long)ssm_wino_packed_weight_floats(Cout, Cin, BN);
+    const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
+    const long long n = total > nbias ? total : nbias;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
+                       BN, total, nbias);
+    return ssm::check_launch("ssm_wino_pack_weights");
+}
+
+extern "C" int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                   ssm_view pool, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    int kind = 0, BN = 0, CK = 0;
+    SSM_REQUIRE(B > 0, "wino conv: bad batch");
+    const int rc = ssm_wino_plan(C1 + C2, Cout, B, H, W, &kind, &BN, &CK);
+    if (rc != SSM_OK) return rc;
+    WinoParams p;
+    const int rf = wfill(p, x1, C1, x2, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W);
+    if (rf != SSM_OK) return rf;
+    if (pool.ptr) {
+        SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino conv: fused pool needs even H, W");
+        p.pool = pool.ptr;
+        p.psb = pool.sb;
+        p.psc = pool.sc;
+        p.psh = pool.sh;
+    }
+    return wdispatch<false>(kind, p, B, (hipStream_t)stream);
+}
+
+extern "C" int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                       int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    int kind = 0, BN = 0, CK = 0;
+    SSM_REQUIRE(B > 0, "wino conv_ups: bad batch");
+    SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino conv_ups: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
+    const int rc = ssm_wino_plan(C1 + C2, Cout, B, H, W, &kind, &BN, &CK);
+    if (rc != SSM_OK) return rc;
+    WinoParams p;
+    const int rf = wfill(p, a, C1, b, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W / 2);
+    if (rf != SSM_OK) return rf;
+    return wdispatch<true>(kind, p, B, (hipStream_t)stream);
+}
