@@ -53,6 +53,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 HEADLINE_PRECISION = "f32"
 DTYPE_NOTE = {"f32": "f32",
+              "f32w": "f32",
               "f16": "f16 (f32 accumulate) - reduced precision",
               "f16x3": "split f16: 3x f16 MFMA on hi/lo-split f32 operands (~22-bit operands, f32 accumulate) - narrower than f32",
               "f16f8": "split f16+e4m3: 1x f16 MFMA + 2x block-scaled e4m3 MFMA for the compensation products (~15-bit products, "
@@ -471,7 +472,7 @@ def infer_bench(args):
         elapsed = sdist.timed_steps(step, steps, 0, sync)
         ms_step = 1e3 * elapsed / steps
         res = {"value": N_T * P * world * steps / elapsed, "ms_per_step": ms_step, "ms_per_pair": ms_step / P, "elapsed_s": elapsed}
-        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
         kname = {"f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "
@@ -621,7 +622,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-io", action="store_true", help="skip the measured H2D / D2H legs")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (no roofline.detail)")
-    ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16", "f16f8"],
+    ap.add_argument("--precision", default=None, choices=["f32", "f32w", "f16x3", "f16", "f16f8"],
                     help="headline conv arithmetic (default f32 = the reference's arithmetic)")
     ap.add_argument("--modes", default="f16x3,f16f8", help="comma list of further modes reported under `modes` (N=1, 720p only); '' = none")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "recurrent"],

@@ -57,6 +57,7 @@ struct WinoParams {
     int tilesX, tilesY, NB;
     float slope;
     int lrelu;
+    int abl;             // diagnostics build only (make wabl): 1 no LDS-DMA in the loop, 2 no stores, 4 no B fetch/transform, 8 no A fetch, 16 no barrier
 };
 
 // WN cout blocks x (WTY x WTX) tile groups = 4 waves; a tile group = GTW x (32/GTW) Winograd tiles of 2x2 pixels
@@ -93,6 +94,12 @@ struct WLds {
     static constexpr int BYTES = (NST * STAGE + (UPS ? C::PSZ : 0)) * 4;
     static_assert(BYTES <= 160 * 1024, "LDS budget (one workgroup per CU)");
 };
+
+#ifdef SSM_WINO_ABLATE
+#define WABL(bit) (p.abl & (bit))
+#else
+#define WABL(bit) 0
+#endif
 
 template <class C, bool UPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_kernel(const WinoParams p) {
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float *pat = UPS ? lds + L::HIP : stg + C::USZ;
         const float *stg_n = lds + ((ch + 1) & 1) * L::STAGE;
         const float *pat_n = UPS ? lds + L::HIP : stg_n + C::USZ;
-        const bool dma = ch + 2 < nchunks;
+        const bool dma = ch + 2 < nchunks && !WABL(1);
         const bool more = ch + 1 < nchunks;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -280,15 +287,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_sched_barrier(0);
                 if (!last) {
                     if (f == 0) {
-                        fetchA(stg, s + 1, nxt);
-                        fetchD(pat, s + 1);
+                        if (!WABL(8)) fetchA(stg, s + 1, nxt);
+                        if (!WABL(4)) fetchD(pat, s + 1);
                     }
                 } else if (more) {
                     if (f == 1) {
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        fetchA(stg_n, 0, nxt);
-                        if constexpr (!UPS) fetchD(pat_n, 0);
+                        if (!WABL(16)) {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            __syncthreads();
+                        }
+                        if (!WABL(8)) fetchA(stg_n, 0, nxt);
+                        if constexpr (!UPS) {
+                            if (!WABL(4)) fetchD(pat_n, 0);
+                        }
                     }
                     if (f >= 2 && f < 8) {                                  // DMA of chunk ch+2 into the stage just freed
                         constexpr int PER = (L::NI + 5) / 6;
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         }
                     }
                 }
-                if (!last || (more && !UPS)) {
+                if ((!last || (more && !UPS)) && !WABL(4)) {
                     if (f == 9) transform_rows();
                     if (f == 11) transform_cols(nxt);
                 }
@@ -326,6 +337,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, ones, acc[5], 0, 0, 0);
     }
     const int px = x0 + (wtx * C::GTW + txl) * 2, py = y0 + (wty * C::GTH + tyl) * 2;
+#ifdef SSM_WINO_ABLATE
+    if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
+#endif
     const float sl = p.lrelu ? p.slope : 1.f;
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
@@ -544,6 +558,10 @@ int wfill(WinoParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *
     p.Cout = Cout;
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.abl = 0;
+#ifdef SSM_WINO_ABLATE
+    if (const char *e = getenv("SSM_WINO_ABL")) p.abl = atoi(e);
+#endif
     return SSM_OK;
 }
 

@@ -52,12 +52,24 @@ class KernelTimer:
         return out
 
 
-MODES = ("f32", "f16x3", "f16", "f16f8")
-# f32   : fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 padded planes
+MODES = ("f32", "f32w", "f16x3", "f16", "f16f8")
+# f32   : fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 padded planes, every convolution in the direct form (an fmaf chain per output)
+# f32w  : the same fp32 planes and kernels, but the 3x3 convolutions run as Winograd F(2x2,3x3) on the fp32 MFMA (csrc/ssm_wino.hip):
+#         all arithmetic fp32, 2.25x fewer matrix-core cycles for those layers; 7x7 / 5x5 / final convs stay direct
 # f16x3 : fp16 MFMA on hi/lo-split operands, 3 MFMAs per product, fp32 accumulate (fp32-grade results)
 # f16   : fp16 MFMA, hi*hi only (reduced precision; 4K / config 5)
 # f16f8 : fp16 MFMA for hi*hi + two block-scaled fp8 MFMAs (K = 4 taps x 16 channels) for the compensation products, on the
 #         Q8 form of the HL8 layout (fp32-grade results at half the matrix cost of f16x3)
+
+
+def base_mode(mode):
+    """Layout / kernel family of a precision mode: "f32w" shares everything with "f32" except the algorithm of the 3x3 layers."""
+    return "f32" if mode == "f32w" else mode
+
+
+# layers of an f32w plan that stay on the direct kernel ($SSM_WINO_SKIP=conv11b,...; "all" = none in Winograd form)
+WINO_SKIP = frozenset(n for n in os.environ.get("SSM_WINO_SKIP", "").split(",") if n)
+
 POOLED = ("conv1b", "conv2b", "conv3b", "conv4b", "conv5b")      # 2x2 mean fused into these convs
 _SCALE = (("conv10", 2), ("conv11", 1), ("conv1", 1), ("conv2", 2), ("conv3", 4), ("conv4", 8), ("conv5", 16),
           ("conv6", 32), ("conv7", 16), ("conv8", 8), ("conv9", 4), ("fuse_conv", 1), ("final_conv", 1))
@@ -90,6 +102,8 @@ class UNetPlan:
         sequences in time-major order (index = window * S + sequence).  dec = (b0, Bd): the decoder runs on
         encoder batch entries [b0, b0+Bd) only (inference returns the middle window); None = all."""
         assert mode in MODES, "precision mode must be one of %s" % (MODES,)
+        self.wino = mode == "f32w"          # 3x3 layers in the Winograd form where the kernel supports the problem
+        self.mode_name, mode = mode, base_mode(mode)
         assert bottleneck in ("CONV", "CLSTM", "CGRU"), "Unknown bottleneck type: %s" % bottleneck
         assert B % seq_len == 0
         self.bottleneck = bottleneck
@@ -118,7 +132,7 @@ class UNetPlan:
         self.refresh_weights(state_dict, check_shapes=True)
         self.rnn = None
         if bottleneck != "CONV":
-            self.rnn = RecurrentBottleneck(bottleneck, state_dict, B // seq_len, seq_len, H // 32, W // 32, device, mode)
+            self.rnn = RecurrentBottleneck(bottleneck, state_dict, B // seq_len, seq_len, H // 32, W // 32, device, mode)   # gate convs: direct form
         Bd = self.Bd
         if self.hl8:
             P = lambda c, s: hb.HPlanes(B, c, H // s, W // s, device, q8=self.q8)  # noqa: E731
@@ -190,8 +204,11 @@ class UNetPlan:
                 self.scales.setdefault(name, self.pk[name].scale)      # later repacks (training) skip the host-side max|w|
             else:
                 nb = self.Bd if name in self.DECODER else self.B
-                self.pk[name] = hb.PackedConv(w, b, nb, self.H // s, self.W // s, pool=name in POOLED,
-                                              ups=self.fuse_up and name in self.UPS)
+                ups = self.fuse_up and name in self.UPS
+                use_w = (self.wino and name != "final_conv" and name not in WINO_SKIP and "all" not in WINO_SKIP
+                         and hb.wino_supported(ci, co, self.H // s, self.W // s, k))
+                cls = hb.PackedWino if use_w else hb.PackedConv
+                self.pk[name] = cls(w, b, nb, self.H // s, self.W // s, pool=name in POOLED, ups=ups)
         self._pack = None
         if batchable:
             entries = [(self.pk[name], state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")], False)
@@ -223,8 +240,8 @@ class UNetPlan:
                           y32, v(pool) if pool else None, self._Bcur, s.H, s.W,
                           lrelu=lrelu, fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         else:
-            hb.conv2d(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst),
-                      v(pool) if pool else None, self._Bcur, s.H, s.W, lrelu=lrelu)
+            fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
+            fn(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst), v(pool) if pool else None, self._Bcur, s.H, s.W, lrelu=lrelu)
         if tm is not None:
             e1.record()
 
@@ -279,7 +296,8 @@ class UNetPlan:
                               d.view(), self.f32[dst].view() if self.twins else None, self._Bcur, d.H, d.W, lrelu=True,
                               fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         else:
-            hb.conv2d_ups(self._v(a), A.C, bview, Bp.C if Bp else 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True)
+            fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
+            fn(self._v(a), A.C, bview, Bp.C if Bp else 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True)
         if tm is not None:
             e1.record()
 
@@ -407,6 +425,7 @@ class RecurrentBottleneck:
     def __init__(self, kind, state_dict, S, T, h, w, device, mode="f32", prefix="conv6."):
         assert kind in ("CLSTM", "CGRU")
         self.kind, self.S, self.T, self.h, self.w, self.device = kind, S, T, h, w, device
+        mode = base_mode(mode)
         self.mode, self.hl8, self.prefix = mode, mode != "f32", prefix
         self.q8 = mode == "f16f8"
         self.flags = hb.SSM_FLAG_Q8 if self.q8 else 0
@@ -513,14 +532,15 @@ class PairEngine:
 
     def __init__(self, sd1, sd2, B1, B2, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True, twins=False, fuse_final=None):
         assert B2 % B1 == 0, "stage-2 batch must be a multiple of the stage-1 batch (pairs x times)"
+        full_mode, mode = mode, base_mode(mode)
         self.twins = bool(twins) and mode != "f32"
         self.B1, self.B2, self.G, self.H, self.W, self.device = B1, B2, B2 // B1, H, W, device
         self.cross = bool(cross_skip)
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.bcast = (B1 == 1 and B2 > 1)
         self.grouped = B1 > 1 and self.G > 1
-        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, mode, fuse_upsample, twins=twins, final4=fuse_final)
-        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, mode, fuse_upsample, twins=twins, final4=fuse_final)
+        self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, full_mode, fuse_upsample, twins=twins, final4=fuse_final)
+        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, full_mode, fuse_upsample, twins=twins, final4=fuse_final)
         self.fuse_final = self.s2.final4          # stage 2: final_conv + synthesis in one kernel (no 5-channel map)
         self.t_dev = torch.empty(B2, dtype=torch.float32, device=device)
         self.img = torch.empty(B2, 3, H, W, dtype=torch.float32, device=device)
@@ -665,12 +685,13 @@ class WindowEngine:
         assert S2 == S1 or S1 == 1, "stage-2 sequences must equal stage-1 clips, or there must be one clip"
         self.T, self.S1, self.S2, self.H, self.W, self.device = T, S1, S2, H, W, device
         self.mid = T // 2
+        full_mode, mode = mode, base_mode(mode)
         self.cross, self.mode, self.hl8, self.q8 = bool(cross_skip), mode, mode != "f32", mode == "f16f8"
         self.bcast = S1 == 1 and S2 > 1
         self.decode_all = decode_all
         b1, b2 = bottleneck if isinstance(bottleneck, (tuple, list)) else (bottleneck, bottleneck)
-        self.s1 = UNetPlan(1, sd1, T * S1, H, W, device, cross_skip, mode, True, b1, seq_len=T)
-        self.s2 = UNetPlan(2, sd2, T * S2, H, W, device, cross_skip, mode, True, b2, seq_len=T,
+        self.s1 = UNetPlan(1, sd1, T * S1, H, W, device, cross_skip, full_mode, True, b1, seq_len=T)
+        self.s2 = UNetPlan(2, sd2, T * S2, H, W, device, cross_skip, full_mode, True, b2, seq_len=T,
                            dec=None if decode_all else (self.mid * S2, S2))
         nd = T * S2 if decode_all else S2
         self.t_dev = torch.empty(T * S2, dtype=torch.float32, device=device)

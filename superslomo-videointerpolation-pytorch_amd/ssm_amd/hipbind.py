@@ -249,6 +249,8 @@ class PackedConv:
     handle owned by the Python side (packed-weight caches are
     created/destroyed by the caller)."""
 
+    algo = "direct"
+
     def __init__(self, weight, bias, B, H, W, pool=False, ups=False):
         """B, H, W: batch and OUTPUT map of the launches this filter serves; ups: it feeds ssm_conv2d_ups_fwd."""
         require_device(weight, "conv weight")
