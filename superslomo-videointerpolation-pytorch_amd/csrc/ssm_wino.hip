@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
     // per-lane operand bases (floats) inside a stage: U of (cin = 2cp + half, cout = wn*32 + l31), patch of the lane's tile
-    const int aBase = half * (16 * BN) + (wn * 32 + l31) * 4;
+    const int aBase = half * (4 * BN) + (wn * 32 + l31);          // in f32x4 units
     const int bBase = half * (PH * PW) + ((wty * C::GTH + tyl) * 2) * PW + (wtx * C::GTW + txl) * 2 + 3;
 
     constexpr int S = CK / 2;                  // k-steps per chunk
@@ -186,15 +186,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     f32x4 a[2][4];
     float d[16], v[2][16];
-    auto fetchA = [&](const float *stg, int cp, int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[buf][q] = *(const f32x4 *)(stg + aBase + cp * (32 * BN) + q * (4 * BN));
+    // Operand fetches, ONE LDS instruction per call so that the k-loop can place them one per MFMA gap: with a single wave per SIMD
+    // nothing else fills the issue slots, and tools/wave1_sched_probe.py shows an LDS instruction costs the in-order stream ~40
+    // cycles - one fits under a 64-cycle MFMA, a burst of 12 behind one MFMA stalls the matrix pipe for ~450 cycles per k-step.
+    // ai / bi: float index of the k-step's operands inside lds[] (one VGPR each, opaque to the optimizer so that the 4 + 8 reads of a
+    // k-step use immediate offsets instead of one address computation per read).
+    const f32x4 *lds4 = (const f32x4 *)lds;       // A operands: 16-byte units (ai counts f32x4)
+    auto ldA = [&](int ai, int q, int buf) { a[buf][q] = lds4[ai + q * BN]; };
+    auto ldB = [&](int bi, int h) {
+        const int i = h >> 1, j = (h & 1) * 2;
+        d[4 * i + j] = lds[bi + i * PW + j];
+        d[4 * i + j + 1] = lds[bi + i * PW + j + 1];
     };
-    auto fetchD = [&](const float *pat, int cp) {
+    auto fetchA = [&](int ai, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < 4; ++q) ldA(ai, q, buf);
+    };
+    auto fetchD = [&](int bi) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[4 * i + j] = pat[bBase + cp * (2 * PH * PW) + i * PW + j];
+        for (int h = 0; h < 8; ++h) ldB(bi, h);
     };
     // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], in two halves of 16 add/sub that go into separate MFMA gaps
     float t[16];
@@ -215,6 +225,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             v[buf][4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
             v[buf][4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
         }
+        // pin the results here: without this the optimizer sinks each subtraction next to the MFMA that consumes it (a dependent
+        // VALU -> MFMA pair with wait states in front of every matrix instruction of the next k-step)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(v[buf][i]));
     };
 
     // fused upsample: low-res raw chunk -> hi-res patch; one thread = one 2x2 hi-res block position, walking CPT channels (ssm_conv.hip)
@@ -258,61 +272,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- prologue: chunks 0 and 1 in flight, operands of the first k-step ------------------------------------------
     issue(0, 0);
     if (nchunks > 1) issue(1, 1);
+    // Bias: A^T M A adds M[1][1] to all four outputs of the tile, so accumulator 5 starts from the bias - one MFMA k-step with A =
+    // the bias column and B = a row of ones (one vector load per lane), issued while the first chunks are still in flight.
+    {
+        const float bv0 = p.bias[nb * BN + wn * 32 + l31];
+        const float ab = half ? 0.f : bv0, ones = half ? 0.f : 1.f;
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, ones, acc[5], 0, 0, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     expand(lds);
-    fetchA(lds, 0, 0);
-    fetchD(UPS ? lds + L::HIP : lds + C::USZ, 0);
+    constexpr int PO = UPS ? L::HIP : C::USZ;          // patch offset: inside the stage, or the expanded patch
+    fetchA(aBase, 0);
+    fetchD(PO + bBase);
     transform_rows();
     transform_cols(0);
 
-    // Chunk loop.  The barrier sits INSIDE the last k-step of a chunk (after its first MFMAs are queued): at that point every LDS
+    // Chunk loop.  The barrier sits INSIDE the last k-step of a chunk (after its first MFMA is queued): at that point every LDS
     // read of chunk ch has been issued and has completed (the last k-step's operands are in registers), so the stage of chunk ch is
     // free for the DMA of chunk ch+2, and chunk ch+1 - issued one chunk ago - is waited for and becomes visible to all waves; the
     // operands of its first k-step are then fetched and transformed behind the remaining MFMAs of chunk ch.
+#ifndef WS_TR0
+#define WS_TR0 13      // MFMA gap that takes the row half of the input transform (16 VALU)
+#endif
+#ifndef WS_TR1
+#define WS_TR1 13      // ... the column half (same gap: the probe prefers the VALU work in ONE gap)
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
-        const float *stg = lds + (ch & 1) * L::STAGE;
-        const float *pat = UPS ? lds + L::HIP : stg + C::USZ;
-        const float *stg_n = lds + ((ch + 1) & 1) * L::STAGE;
-        const float *pat_n = UPS ? lds + L::HIP : stg_n + C::USZ;
+        const int so = (ch & 1) * L::STAGE, so_n = ((ch + 1) & 1) * L::STAGE;
         const bool dma = ch + 2 < nchunks && !WABL(1);
         const bool more = ch + 1 < nchunks;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
             const bool last = s == S - 1;
+            int ai = (last ? so_n : so + (s + 1) * (32 * BN)) / 4 + aBase;
+            int bi = (UPS ? L::HIP : (last ? so_n : so) + C::USZ) + (last ? 0 : (s + 1) * (2 * PH * PW)) + bBase;
+            asm volatile("" : "+v"(ai), "+v"(bi));
 #pragma unroll
             for (int f = 0; f < 16; ++f) {
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][f >> 2][f & 3], v[cur][f], acc[f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!last) {
-                    if (f == 0) {
-                        if (!WABL(8)) fetchA(stg, s + 1, nxt);
-                        if (!WABL(4)) fetchD(pat, s + 1);
+                    if (f < 4) {
+                        if (!WABL(8)) ldA(ai, f, nxt);
+                    } else if (f < 12) {
+                        if (!WABL(4)) ldB(bi, f - 4);
+                    }
+                    if (!WABL(4)) {
+                        if (f == WS_TR0) transform_rows();
+                        if (f == WS_TR1) transform_cols(nxt);
                     }
                 } else if (more) {
-                    if (f == 1) {
-                        if (!WABL(16)) {
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                            __syncthreads();
-                        }
-                        if (!WABL(8)) fetchA(stg_n, 0, nxt);
+                    if (f == 0 && !WABL(16)) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __syncthreads();
+                    }
+                    if (f >= 1 && f < 5) {
+                        if (!WABL(8)) ldA(ai, f - 1, nxt);
+                    } else if (f >= 5 && f < 13) {
                         if constexpr (!UPS) {
-                            if (!WABL(4)) fetchD(pat_n, 0);
+                            if (!WABL(4)) ldB(bi, f - 5);
                         }
                     }
-                    if (f >= 2 && f < 8) {                                  // DMA of chunk ch+2 into the stage just freed
-                        constexpr int PER = (L::NI + 5) / 6;
+                    if (f >= 1) {                                           // DMA of chunk ch+2 into the stage just freed, one per gap
+                        constexpr int PER = (L::NI + 14) / 15;
 #pragma unroll
                         for (int j = 0; j < PER; ++j) {
-                            const int k = (f - 2) * PER + j;
+                            const int k = (f - 1) * PER + j;
                             if (k < L::NI && dma) issue_k(ch + 2, ch & 1, k);
                         }
                     }
-                }
-                if ((!last || (more && !UPS)) && !WABL(4)) {
-                    if (f == 9) transform_rows();
-                    if (f == 11) transform_cols(nxt);
+                    if constexpr (!UPS) {
+                        if (f == 14 && !WABL(4)) {
+                            transform_rows();
+                            transform_cols(nxt);
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -320,8 +356,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (UPS) {
             if (more) {
                 __syncthreads();           // every wave is done with the expanded patch of chunk ch
-                expand(stg_n);
-                fetchD(pat_n, 0);
+                expand(lds + so_n);
+                fetchD(L::HIP + bBase);
                 transform_rows();
                 transform_cols(0);
             }
@@ -329,13 +365,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
-    // Bias: A^T M A adds M[1][1] to all four outputs of the tile, so one extra k-step into accumulator 5 with A = the bias column and
-    // B = a row of ones adds the bias (one vector load per lane).
-    {
-        const float bv0 = p.bias[nb * BN + wn * 32 + l31];
-        const float ab = half ? 0.f : bv0, ones = half ? 0.f : 1.f;
-        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, ones, acc[5], 0, 0, 0);
-    }
     const int px = x0 + (wtx * C::GTW + txl) * 2, py = y0 + (wty * C::GTH + tyl) * 2;
 #ifdef SSM_WINO_ABLATE
     if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
@@ -383,6 +412,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const float sm = ((y00 + y10) + (y01 + y11)) * 0.25f;
                 if (ok1 && cok) st1(qp, qb, sm);
             }
+            __builtin_amdgcn_sched_barrier(0);      // one cout at a time: 16 accumulator reads live, not 256
         }
     };
     if (full) store_all(std::true_type{});
