@@ -10,10 +10,13 @@ runs once per pair, the 7 t values are batched through stage 2.  One "step" = `-
 = 56 frames.  N > 1: every rank processes its own pairs (weak scaling, no data-path collective); value = all ranks'
 frames / max-over-ranks time.
 
-The headline (`value`, `dtype`, `roofline`) is the exact-fp32 mode: every product on v_mfma_f32_32x32x2_f32, the
-arithmetic of the reference (north_star: "within 1e-3 ... in fp32"; SURVEY 8d roof = fp32 MFMA 157.3 TFLOP/s).  The
-faster split modes are reported beside it under `modes`, each with its own frame rate, roofline (against the 2.5
-PFLOP/s fp16 peak) and parity - they are options, not the configuration the metric is quoted on.
+The headline (`value`, `dtype`, `roofline`) is fp32 arithmetic throughout - every product, sum and transform in fp32 on
+v_mfma_f32_32x32x2_f32 / fp32 VALU (north_star: "within 1e-3 ... in fp32"; SURVEY 8d roof = fp32 MFMA 157.3 TFLOP/s) - in mode
+`f32w`: the 3x3 convolutions (71 % of the FLOPs) are evaluated as Winograd F(2x2,3x3), which needs 2.25x fewer multiplies than
+the direct form for the same result (what cuDNN - `cudnn.benchmark = True`, scripts/main.py:296 of the reference - and MIOpen
+choose for 3x3 fp32 layers too); the 7x7 / 5x5 / final convolutions run in the direct form.  Mode `f32` (EVERY convolution in
+the direct form, an fmaf chain per output) is reported beside it under `modes`, and so are the split-fp16 modes (narrower than
+fp32: options, not the configuration the metric is quoted on), each with its own frame rate, roofline and parity.
 
 Objects on the JSON line:
   roofline      dominant kernel family = the 48 convolution launches of a pair.  achieved = algorithmic conv FLOP of
@@ -22,9 +25,12 @@ Objects on the JSON line:
                 HIP-event durations of those launches in a single-stream region run right after the timed one (with
                 several pairs in flight the per-kernel spans overlap), plus the per-kernel table with --detail.
                 traffic = HBM bytes of those launches per pair from rocprofv3 --pmc passes (profiles/).
+                `achieved` / `frac` count ALGORITHMIC (direct-form) FLOP as SURVEY 8d defines them, so in mode f32w they can
+                exceed the matrix peak; `issued` = the multiply-adds the matrix cores actually execute (Winograd layers:
+                direct FLOP / 2.25) / the same time - the utilisation of the fp32 MFMA pipe, always <= 1.
   roofline_warp the HBM-bound gather kernels (compute_inputs + synthesis): algorithmic bytes (104 + 72 B/px per t)
                 / their event-timed duration; peak 8 TB/s.
-  modes         f16x3 / f16f8: frames/s, roofline, parity of the split fp16 (+fp8) modes on the same pairs.
+  modes         f32 (direct form everywhere) / f16x3 / f16f8 (split fp16 (+fp8), narrower than fp32): frames/s, roofline, parity on the same pairs.
   cpu_baseline  the CPU oracle (torch CPU fp32 ops, pinned to the reference by golden fixtures) on this host: warm,
                 best of a thread sweep; C1 (256x256, 1 t) and C2 (1 pair x 7 t) in the hoisted loop and in the
                 reference-style loop that recomputes stage 1 per t.  A reported baseline, not the target.
@@ -51,7 +57,7 @@ H_IN, W_IN, N_T = 720, 1280, 7
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA
 PEAK_HBM_GBS = 8000.0
-HEADLINE_PRECISION = "f32"
+HEADLINE_PRECISION = "f32w"
 DTYPE_NOTE = {"f32": "f32",
               "f32w": "f32",
               "f16": "f16 (f32 accumulate) - reduced precision",
@@ -59,7 +65,11 @@ DTYPE_NOTE = {"f32": "f32",
               "f16f8": "split f16+e4m3: 1x f16 MFMA + 2x block-scaled e4m3 MFMA for the compensation products (~15-bit products, "
                        "activations stored as f16 hi + e4m3 lo, f32 accumulate) - narrower than f32"}
 # rocprofv3 --pmc traffic summaries (tools/pmc_traffic.sh) per mode: (file under profiles/, conv kernel family keys)
-PMC_FILES = {"f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "final_conv_kernel")),
+ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (csrc/ssm_wino.hip), 7x7 / 5x5 / "
+                     "final convolutions in the direct form (csrc/ssm_conv.hip, ssm_elem.hip)",
+             "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output)"}
+PMC_FILES = {"f32w": ("r4_pmc_traffic_f32w_summary.json", ("wino_kernel", "conv_mfma_kernel", "final_conv_kernel")),
+             "f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "final_conv_kernel")),
              "f16x3": ("r1k_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel")),
              "f16f8": ("r1q_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel"))}
 
@@ -109,7 +119,9 @@ def setup_ranks(args):
     return rank, local_rank, world, torch.device("cuda", local_rank)
 
 
-def conv_flops_per_pair(h, w, n_t):
+def conv_flops_per_pair(h, w, n_t, issued_for=None):
+    """Algorithmic (direct-form) conv FLOP of a pair; issued_for = "f32w": the FLOP the matrix cores execute in that mode (3x3
+    layers with >= 32 output channels run as Winograd F(2x2,3x3): 16 instead of 36 multiply-adds per 2x2 outputs)."""
     from ssm_amd.weights import unet_layers
     scale = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8,
              "conv9": 4, "fuse_": 1, "final": 1}
@@ -119,7 +131,10 @@ def conv_flops_per_pair(h, w, n_t):
         for name, cin, cout, k in unet_layers(st, True):
             s = 2 if name.startswith("conv10") else 1 if name.startswith("conv11") else \
                 [v for p, v in scale.items() if name.startswith(p)][0]
-            tot += 2.0 * (h // s) * (w // s) * cin * cout * k * k
+            fl = 2.0 * (h // s) * (w // s) * cin * cout * k * k
+            if issued_for == "f32w" and k == 3 and name != "final_conv" and (w // s) % 2 == 0 and cin % 8 == 0:
+                fl *= 16.0 / 36.0
+            tot += fl
         return tot
     return stage(1) + n_t * stage(2)
 
@@ -454,6 +469,7 @@ def infer_bench(args):
     sd1d = {k: v.detach() for k, v in model.stage1_model.state_dict().items()}
     sd2d = {k: v.detach() for k, v in model.stage2_model.state_dict().items()}
     flops_pair = conv_flops_per_pair(Hp, Wp, N_T)
+    flops_issued_w = conv_flops_per_pair(Hp, Wp, N_T, "f32w")
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -474,7 +490,9 @@ def infer_bench(args):
         res = {"value": N_T * P * world * steps / elapsed, "ms_per_step": ms_step, "ms_per_pair": ms_step / P, "elapsed_s": elapsed}
         peak = PEAK_F32_MFMA_TFLOPS if precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
-        kname = {"f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
+        kname = {"f32w": "wino_kernel<*, ups 0|1> (3x3 layers) + conv_mfma_kernel<*> (7x7, 5x5) (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> "
+                         "(v_mfma_f32_4x4x1_16B_f32)",
+                 "f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "
                           "v_mfma_scale_f32_32x32x64_f8f6f4)"}.get(precision, "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)")
         pmc_file, pmc_keys = PMC_FILES.get(precision, (None, ()))
@@ -488,6 +506,12 @@ def infer_bench(args):
                            "flop_per_pair": flops_pair, "traffic": traffic or None,
                            "traffic_note": "HBM bytes per pair of the conv launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from "
                                            "separate rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/%s" % (pmc_file or "-")}
+        if precision == "f32w":
+            iss = flops_issued_w * P / (ms_step * 1e-3) / 1e12
+            res["roofline"]["issued"] = {"flop_per_pair": flops_issued_w, "achieved": round(iss, 2), "frac": round(iss / peak, 4),
+                                         "note": "multiply-adds the matrix cores execute (Winograd F(2x2,3x3) layers: direct-form FLOP x 16/36) "
+                                                 "/ the same wall time = utilisation of the fp32 MFMA pipe; `achieved` / `frac` above count "
+                                                 "direct-form FLOP (SURVEY 8d) and may exceed the matrix peak"}
         if clk is not None:
             ghz = read_clock_probe(clk)
             if ghz:
@@ -516,7 +540,7 @@ def infer_bench(args):
             conv = summ["conv"]
             conv_ms = conv["ms"] / n_solo
             kach = flops_pair / (conv_ms * 1e-3) / 1e12
-            mfma_per_prod = {"f16x3": 3, "f16f8": 1.5}.get(precision, 1)
+            mfma_per_prod = {"f16x3": 3, "f16f8": 1.5, "f32w": flops_issued_w / flops_pair}.get(precision, 1)
             res["roofline"]["detail"] = {"region": "%d single-stream pairs run right after the timed region, HIP-event brackets around every "
                                                    "launch on the launch stream" % n_solo,
                                          "launches_per_batch": conv["launches"] // nb_solo, "pairs_per_batch": PB, "ms_per_pair_in_kernel": round(conv_ms, 3),
@@ -553,7 +577,7 @@ def infer_bench(args):
         "value": round(main_res["value"], 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(main_res["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE_NOTE[headline], "data": "synthetic",
-        "config": {"precision": headline,
+        "config": {"precision": headline, "algorithm": ALGO_NOTE.get(headline, "see dtype"),
                    "workload": "superslomo_original.ini inference: synthetic %dx%d pairs (padded %dx%d) -> 7 intermediates t=i/8 each, "
                                "stage 1 once per pair, random-init (deterministic) weights" % (w_in, h_in, Wp, Hp),
                    "pairs_per_step": P, "pairs_per_batch": PB, "frames_per_step": N_T * P, "ms_per_pair": round(main_res["ms_per_pair"], 3),
@@ -573,6 +597,8 @@ def infer_bench(args):
         r = results[m] = run_mode(m, max(2, args.steps // 2), args.warmup, timers)
         out.setdefault("modes", {})[m] = {"value": round(r["value"], 3), "unit": "frames/s", "ms_per_pair": round(r["ms_per_pair"], 3),
                                           "dtype": DTYPE_NOTE[m], "roofline": r["roofline"]}
+        if m in ALGO_NOTE:
+            out["modes"][m]["algorithm"] = ALGO_NOTE[m]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.size == "720p":
         pair = torch.cat([xs[0][:, 0], xs[0][:, 1]], 1)
@@ -624,7 +650,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (no roofline.detail)")
     ap.add_argument("--precision", default=None, choices=["f32", "f32w", "f16x3", "f16", "f16f8"],
                     help="headline conv arithmetic (default f32 = the reference's arithmetic)")
-    ap.add_argument("--modes", default="f16x3,f16f8", help="comma list of further modes reported under `modes` (N=1, 720p only); '' = none")
+    ap.add_argument("--modes", default="f32,f16x3,f16f8", help="comma list of further modes reported under `modes` (N=1, 720p only); '' = none")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "recurrent"],
                     help="infer = the headline (BASELINE configs[1]); train = configs[2]: training step on 352x352 crops, "
                          "2 samples per GPU, gradient all-reduce over RCCL; recurrent = configs[3]: superslomo_recurrent.ini "

@@ -19,12 +19,14 @@ import torch.nn as nn
 from ssm_amd import hipbind as hb
 from ssm_amd.engine import PairEngine, WindowEngine
 
-# Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f32" (default) = the reference's arithmetic:
-# every product on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32).  Opt-in split modes, narrower than fp32: "f16x3"
-# evaluates a product as three fp16 MFMAs on hi/lo-split operands (~22-bit operands), "f16f8" as one fp16 MFMA on the hi
-# parts plus two block-scaled e4m3 MFMAs for the compensation terms (~15-bit products); both accumulate in fp32 and meet
-# the 1e-3 frame bar in the tests at 2.5x / 2.9x the frame rate.  "f16" is plain fp16 inputs (config 5).
-DEFAULT_PRECISION = "f32"
+# Arithmetic of the convolutions on the planned path (ssm_amd.engine.MODES).  "f32w" (default) and "f32" are fp32 throughout
+# (the reference's arithmetic: every product and sum in fp32 on v_mfma_f32_32x32x2_f32): "f32" evaluates every convolution in the
+# direct form (an fmaf chain per output), "f32w" evaluates the 3x3 layers as Winograd F(2x2,3x3) - 2.25x fewer multiplies, the same
+# result up to fp32 rounding (both sit 2e-4 from the CPU oracle at 736x1280; tests/emulate_winograd_precision.py).  Opt-in split
+# modes, narrower than fp32: "f16x3" evaluates a product as three fp16 MFMAs on hi/lo-split operands (~22-bit operands), "f16f8"
+# as one fp16 MFMA on the hi parts plus two block-scaled e4m3 MFMAs for the compensation terms (~15-bit products); both accumulate
+# in fp32 and meet the 1e-3 frame bar in the tests at 2.5x / 2.9x the frame rate.  "f16" is plain fp16 inputs (config 5).
+DEFAULT_PRECISION = "f32w"
 DEFAULT_TRAIN_PRECISION = "f32"
 
 from . import unetflow as unet
@@ -164,7 +166,7 @@ class FullModel(nn.Module):
     def _stamp(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    precision = None    # "f32" | "f16x3" | "f16"; None -> $SSM_PRECISION or the default below
+    precision = None    # "f32w" | "f32" | "f16x3" | "f16f8" | "f16"; None -> $SSM_PRECISION or the default above
 
     def engine_for(self, B1, B2, H, W, device):
         mode = self.precision or os.environ.get("SSM_PRECISION", DEFAULT_PRECISION)

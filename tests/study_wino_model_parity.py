@@ -1,3 +1,4 @@
+"""Study (GPU box, not collected by pytest): whole-model parity of modes f32 / f32w against the CPU oracle at 64x64 and 736x1280."""
 import sys, torch
 sys.path[:0] = ['/root/repo', '/root/repo/superslomo-videointerpolation-pytorch_amd', '/root/repo/superslomo-videointerpolation-pytorch_amd/scripts']
 from models.superslomo_r import FullModel
