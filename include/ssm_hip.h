@@ -133,9 +133,10 @@ int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_pa
  * Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A per 2x2 output tile: 16 instead of 36 multiplies per (cin, cout, 4 outputs),
  * i.e. 2.25x fewer matrix-core cycles; in fp32 the result differs from the direct form by rounding only (about as much as
  * a different summation order).  W must be even; Cin and the first cat source multiples of CK.
- * ssm_wino_plan: tile configuration for the problem (BN = cout block to pack for, CK = channel chunk).
+ * ssm_wino_plan: tile configuration for the problem (ups: the fused-upsample entry point; BN = cout block to pack for, CK =
+ * channel chunk); two kernel forms - one workgroup per CU with 16 frequency accumulators per wave, or two per CU with 8.
  * ssm_wino_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/BN][Cin][4][BN][4] (+ bias padded to BN).          */
-int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int *kind, int *BN, int *CK);
+int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK);
 int ssm_wino_force_kind(int kind);       /* tests / tuning only (-1 = automatic); returns the number of configurations */
 size_t ssm_wino_packed_weight_floats(int Cout, int Cin, int BN);
 int ssm_wino_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin,

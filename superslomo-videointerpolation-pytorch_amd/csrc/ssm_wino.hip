@@ -31,6 +31,10 @@
 #include <type_traits>
 #include <cstdlib>
 
+#ifndef WS_B64
+#define WS_B64 1        // B-operand rows as two aligned ds_read_b64 (patch stored one float in); 0: ds_read2_b32 on the aligned patch
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -61,19 +65,20 @@ struct WinoParams {
 };
 
 // WN cout blocks x (WTY x WTX) tile groups = 4 waves; a tile group = GTW x (32/GTW) Winograd tiles of 2x2 pixels
-template <int WN_, int WTY_, int WTX_, int GTW_, int CK_>
+// NBLK = 4: wino_kernel (a wave = one block, all 16 frequencies); NBLK = 2: wino2_kernel (a wave = one block, 8 frequencies)
+template <int WN_, int WTY_, int WTX_, int GTW_, int CK_, int NBLK_ = 4>
 struct WCfg {
-    static constexpr int WN = WN_, WTY = WTY_, WTX = WTX_, GTW = GTW_, GTH = 32 / GTW_, CK = CK_;
+    static constexpr int WN = WN_, WTY = WTY_, WTX = WTX_, GTW = GTW_, GTH = 32 / GTW_, CK = CK_, NBLK = NBLK_;
     static constexpr int BN = 32 * WN;
     static constexpr int TH = 2 * GTH * WTY, TW = 2 * GTW * WTX;      // output pixels per workgroup
-    static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;       // patch rows y0-1 .. y0+TH, columns x0-4 .. x0+TW+3
+    static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;       // patch rows y0-1 .. y0+TH, columns x0-4 .. x0+TW+3 (stored from patch column 1)
     static constexpr int USZ = CK * 16 * BN, PSZ = CK * PH * PW;
     static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;   // fused upsample: low-res raw patch
     static constexpr int RSZ = CK * LH * LW;
     static constexpr int NPOS = (TH / 2 + 1) * (TW / 2 + 1);
     static constexpr int CG = (2 * NPOS <= 256 && CK >= 2) ? ((4 * NPOS <= 256 && CK >= 4) ? ((8 * NPOS <= 256 && CK >= 8) ? 8 : 4) : 2) : 1;
     static constexpr int CPT = CK / CG;
-    static_assert(WN * WTY * WTX == 4, "4 waves per workgroup");
+    static_assert(WN * WTY * WTX == NBLK && (NBLK == 4 || NBLK == 2), "4 waves per workgroup: 4 blocks, or 2 blocks x 2 frequency halves");
     static_assert(GTW == 8 || GTW == 16 || GTW == 32, "tile group is 32x1, 16x2 or 8x4 tiles");
     static_assert(CK % 4 == 0 && USZ % 256 == 0, "even number of k-steps per chunk; filter stage = whole 1-KiB DMA groups");
     static_assert(NPOS <= 256, "fused-upsample expander: one position per thread");
@@ -87,12 +92,12 @@ struct WLds {
     static constexpr int NDQ = DSZ / 4;                         // 16-byte pieces of activation per chunk
     static constexpr int NGP = (NDQ + 63) / 64;
     static constexpr int NG = NGU + NGP;
-    static constexpr int STAGE = NG * 256;                      // floats per stage
+    static constexpr int STAGE = NG * 256 + 256;                // floats per stage (+ 1 KiB: the patch lands one float in)
     static constexpr int NIU = (NGU + 3) / 4, NIP = (NGP + 3) / 4, NI = NIU + NIP;   // DMA instructions per wave per chunk
     static constexpr int NST = 2;                               // stages (double buffer)
     static constexpr int HIP = NST * STAGE;                     // expanded patch (UPS)
     static constexpr int BYTES = (NST * STAGE + (UPS ? C::PSZ : 0)) * 4;
-    static_assert(BYTES <= 160 * 1024, "LDS budget (one workgroup per CU)");
+    static_assert(BYTES <= (C::NBLK == 4 ? 160 : 80) * 1024, "LDS budget (one or two workgroups per CU)");
 };
 
 #ifdef SSM_WINO_ABLATE
@@ -122,6 +127,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int b = id / p.tilesY;
     const int x0 = tx * C::TW, y0 = ty * C::TH;
 
+    // The DMA lands the patch ONE FLOAT into its LDS region (16-byte aligned global pieces, 4-byte aligned LDS destination): the 4x4
+    // patch of tile tx then starts at the EVEN patch column 2tx+4, so each of its rows is two aligned ds_read_b64 - conflict-free at
+    // 256 B/clk, where ds_read2_b32 at a lane stride of two dwords is a 2-way bank conflict on both dwords (8 LDS cycles, not 2).
     const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
     const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
     const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int g = 4 * kk + wid;
             if (g < L::NGP) {
                 const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
-                const unsigned m0v = lsb + (unsigned)(L::NGU + g) * 1024u;
+                const unsigned m0v = lsb + (unsigned)(L::NGU + g) * 1024u + ((UPS || !WS_B64) ? 0u : 4u);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
             }
         }
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // per-lane operand bases (floats) inside a stage: U of (cin = 2cp + half, cout = wn*32 + l31), patch of the lane's tile
     const int aBase = half * (4 * BN) + (wn * 32 + l31);          // in f32x4 units
-    const int bBase = half * (PH * PW) + ((wty * C::GTH + tyl) * 2) * PW + (wtx * C::GTW + txl) * 2 + 3;
+    const int bBase = (half * (PH * PW) + ((wty * C::GTH + tyl) * 2) * PW + (wtx * C::GTW + txl) * 2 + 3 + WS_B64) / 2;      // f32x2 units
 
     constexpr int S = CK / 2;                  // k-steps per chunk
     const int nchunks = p.Cin / CK;
@@ -193,10 +201,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // k-step use immediate offsets instead of one address computation per read).
     const f32x4 *lds4 = (const f32x4 *)lds;       // A operands: 16-byte units (ai counts f32x4)
     auto ldA = [&](int ai, int q, int buf) { a[buf][q] = lds4[ai + q * BN]; };
+    const f32x2 *lds2 = (const f32x2 *)lds;       // B operands: 8-byte units (bi counts f32x2)
     auto ldB = [&](int bi, int h) {
         const int i = h >> 1, j = (h & 1) * 2;
-        d[4 * i + j] = lds[bi + i * PW + j];
-        d[4 * i + j + 1] = lds[bi + i * PW + j + 1];
+#if WS_B64
+        const f32x2 t2 = lds2[bi + (i * PW + j) / 2];
+        float e0 = t2[0], e1 = t2[1];
+#else
+        float e0 = lds[2 * bi + 1 + i * PW + j], e1 = lds[2 * bi + 1 + i * PW + j + 1];
+#endif
+        asm volatile("" : "+v"(e0), "+v"(e1));        // two scalars from here on: no packed-fp32 arithmetic on the pair (DESIGN 3.3 fence)
+        d[4 * i + j] = e0;
+        d[4 * i + j + 1] = e1;
     };
     auto fetchA = [&](int ai, int buf) {
 #pragma unroll
@@ -245,20 +261,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int i = ly0 + pi, j = lx0 + pj;
                 const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
                 const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
-                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;
+                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;      // column 2j+1 = xa x[j0] + xb x[j0+1]
+                const float ca = j0 == j1 ? 1.f : 0.25f, cb = j0 == j1 ? 0.f : 0.75f;      // column 2j+2 = ca x[j0] + cb x[j0+1]
                 const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
                 const int Y = 2 * i + 1, X = 2 * j + 1;
                 const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
                 const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
-                const float *r0 = raw + (cg * CPT * LH + (i0 - ly0)) * LW + 3 - lx0;
-                const float *r1 = raw + (cg * CPT * LH + (i1 - ly0)) * LW + 3 - lx0;
-                float *dd = hip + (cg * CPT * PH + 2 * pi) * PW + 2 * pj + 3;
-#pragma unroll 1
+                // all 2 x CPT x 2 low-res values first (immediate offsets off four per-thread bases), then the arithmetic, then the
+                // stores: the phase is issue-bound instead of CPT read -> compute -> write latency chains.  The right neighbour is read
+                // at j0 + 1 even where the source index is clamped (j1 == j0): its weight xb is then exactly 0 and the value - the
+                // zero frame or a neighbouring pixel - is finite.
+                const float *r0 = raw + (cg * CPT * LH + (i0 - ly0)) * LW + 3 - lx0 + j0;
+                const float *r1 = raw + (cg * CPT * LH + (i1 - ly0)) * LW + 3 - lx0 + j0;
+                float *dd = hip + (cg * CPT * PH + 2 * pi) * PW + 2 * pj + 3 + WS_B64;       // hi-res pixel x0 + 2pj - 1 -> patch column 2pj + 4 (3 without the one-float shift)
+                float v00[CPT], v01[CPT], v10[CPT], v11[CPT];
+#pragma unroll
                 for (int cc = 0; cc < CPT; ++cc) {
-                    const float v00 = r0[cc * LH * LW + j0], v01 = r0[cc * LH * LW + j1];
-                    const float v10 = r1[cc * LH * LW + j0], v11 = r1[cc * LH * LW + j1];
-                    const float h00 = xa * v00 + xb * v01, h01 = xb * v00 + xa * v01;
-                    const float h10 = xa * v10 + xb * v11, h11 = xb * v10 + xa * v11;
+                    v00[cc] = r0[cc * LH * LW];
+                    v01[cc] = r0[cc * LH * LW + 1];
+                    v10[cc] = r1[cc * LH * LW];
+                    v11[cc] = r1[cc * LH * LW + 1];
+                }
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc) {
+                    const float h00 = xa * v00[cc] + xb * v01[cc], h01 = ca * v00[cc] + cb * v01[cc];
+                    const float h10 = xa * v10[cc] + xb * v11[cc], h11 = ca * v10[cc] + cb * v11[cc];
                     dd[cc * PH * PW] = m00 * (ya * h00 + yb * h10);
                     dd[cc * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
                     dd[cc * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     expand(lds);
     constexpr int PO = UPS ? L::HIP : C::USZ;          // patch offset: inside the stage, or the expanded patch
     fetchA(aBase, 0);
-    fetchD(PO + bBase);
+    fetchD(PO / 2 + bBase);
     transform_rows();
     transform_cols(0);
 
@@ -307,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int cur = s & 1, nxt = cur ^ 1;
             const bool last = s == S - 1;
             int ai = (last ? so_n : so + (s + 1) * (32 * BN)) / 4 + aBase;
-            int bi = (UPS ? L::HIP : (last ? so_n : so) + C::USZ) + (last ? 0 : (s + 1) * (2 * PH * PW)) + bBase;
+            int bi = ((UPS ? L::HIP : (last ? so_n : so) + C::USZ) + (last ? 0 : (s + 1) * (2 * PH * PW))) / 2 + bBase;
             asm volatile("" : "+v"(ai), "+v"(bi));
 #pragma unroll
             for (int f = 0; f < 16; ++f) {
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (more) {
                 __syncthreads();           // every wave is done with the expanded patch of chunk ch
                 expand(lds + so_n);
-                fetchD(L::HIP + bBase);
+                fetchD(L::HIP / 2 + bBase);
                 transform_rows();
                 transform_cols(0);
             }
@@ -419,6 +446,335 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else store_all(std::false_type{});
 }
 
+
+// =====================================================================================================================
+// Second form: TWO workgroups per CU.  A wave owns 8 of the 16 frequencies (rows 2h, 2h+1 of the 4x4 frequency grid, h = wave & 1)
+// of one 32-cout x 32-tile block: 8 accumulators = 128 registers, so two waves share a SIMD and the prologue (first DMA), the
+// barriers, the fused-upsample expansion and the epilogue of one workgroup hide behind the MFMAs of the other - what the first form,
+// alone on its CU, exposes (tools/r4_abl.sh: 9 us of overhead per workgroup on a 32-channel layer against 7 us of MFMA).  Per k-step a
+// wave fetches 2 (not 4) filter quads and 3 (not 4) patch rows and does half of the input transform; the two halves of the output
+// transform meet through LDS once per tile: Y rows = (M0 + M1 | M1) + (M2 | -M2 - M3).
+template <class C, bool UPS, int FH>
+__device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
+    using L = WLds<C, UPS>;
+    constexpr int BN = C::BN, PH = C::PH, PW = C::PW, CK = C::CK;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb = wid >> 1;                                          // block of this wave pair
+    const int wn = wb % C::WN, wty = (wb / C::WN) % C::WTY, wtx = wb / (C::WN * C::WTY);
+    const int tyl = l31 / C::GTW, txl = l31 % C::GTW;
+
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    // The DMA lands the patch ONE FLOAT into its LDS region (16-byte aligned global pieces, 4-byte aligned LDS destination): the 4x4
+    // patch of tile tx then starts at the EVEN patch column 2tx+4, so each of its rows is two aligned ds_read_b64 - conflict-free at
+    // 256 B/clk, where ds_read2_b32 at a lane stride of two dwords is a 2-way bank conflict on both dwords (8 LDS cycles, not 2).
+    const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
+    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
+    const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
+    const float *wbase = p.wpk + (long long)nb * p.Cin * (16 * BN);
+
+    int poff[L::NIP];
+#pragma unroll
+    for (int i = 0; i < L::NIP; ++i) {
+        const int qq = (i * 4 + wid) * 64 + lane;
+        if (qq < L::NDQ) {
+            const int c = qq / (L::DH * L::DW4);
+            const int rem = qq - c * (L::DH * L::DW4);
+            const int r = rem / L::DW4;
+            const int j = rem - r * L::DW4;
+            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+        } else {
+            poff[i] = 0;
+        }
+    }
+    const int uoff = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+    auto issue_k = [&](int ch, int stage, int k) {
+        const int c0 = ch * CK;
+        const unsigned lsb = lds0 + (unsigned)(stage * L::STAGE) * 4u;
+        if (k < L::NIU) {
+            const int g = 4 * k + wid;
+            if (g < L::NGU) {
+                const float *base = wbase + (long long)c0 * (16 * BN) + g * 256;
+                const unsigned m0v = lsb + (unsigned)g * 1024u;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
+            }
+        } else {
+            const int kk = k - L::NIU;
+            const int g = 4 * kk + wid;
+            if (g < L::NGP) {
+                const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
+                const unsigned m0v = lsb + (unsigned)(L::NGU + g) * 1024u + ((UPS || !WS_B64) ? 0u : 4u);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
+            }
+        }
+    };
+    auto issue = [&](int ch, int stage) {
+#pragma unroll
+        for (int k = 0; k < L::NI; ++k) issue_k(ch, stage, k);
+    };
+
+    f32x16 acc[8];          // local frequency fl <-> grid position (row 2*FH + fl/4, column fl%4)
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int aBase = half * (4 * BN) + (wn * 32 + l31) + FH * 2 * BN;           // f32x4 units; filter quads 2FH, 2FH+1
+    const int bBase = (half * (PH * PW) + ((wty * C::GTH + tyl) * 2 + FH) * PW + (wtx * C::GTW + txl) * 2 + 3 + WS_B64) / 2;   // f32x2 units; patch rows FH .. FH+2
+
+    constexpr int S = CK / 2;
+    const int nchunks = p.Cin / CK;
+    const f32x4 *lds4 = (const f32x4 *)lds;
+    f32x4 a[2][2];
+    float d[12], t[8], v[2][8];
+    auto ldA = [&](int ai, int q, int buf) { a[buf][q] = lds4[ai + q * BN]; };
+    const f32x2 *lds2 = (const f32x2 *)lds;       // B operands: 8-byte units (bi counts f32x2)
+    auto ldB = [&](int bi, int h) {
+        const int i = h >> 1, j = (h & 1) * 2;
+#if WS_B64
+        const f32x2 t2 = lds2[bi + (i * PW + j) / 2];
+        float e0 = t2[0], e1 = t2[1];
+#else
+        float e0 = lds[2 * bi + 1 + i * PW + j], e1 = lds[2 * bi + 1 + i * PW + j + 1];
+#endif
+        asm volatile("" : "+v"(e0), "+v"(e1));        // two scalars from here on: no packed-fp32 arithmetic on the pair (DESIGN 3.3 fence)
+        d[4 * i + j] = e0;
+        d[4 * i + j + 1] = e1;
+    };
+    // rows 2FH, 2FH+1 of B^T d from patch rows e0, e1, e2 = d rows FH, FH+1, FH+2
+    auto transform_rows = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (FH == 0) {
+                t[j] = d[j] - d[8 + j];          // d0 - d2
+                t[4 + j] = d[4 + j] + d[8 + j];  // d1 + d2
+            } else {
+                t[j] = d[4 + j] - d[j];          // d2 - d1
+                t[4 + j] = d[j] - d[8 + j];      // d1 - d3
+            }
+        }
+    };
+    auto transform_cols = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v[buf][4 * i] = t[4 * i] - t[4 * i + 2];
+            v[buf][4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+            v[buf][4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
+            v[buf][4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[buf][i]));
+    };
+
+    auto expand = [&](const float *stg) {
+        if constexpr (UPS) {
+            constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, CG = C::CG, CPT = C::CPT;
+            constexpr int LH = C::LH, LW = C::LW;
+            const float *raw = stg + C::USZ;
+            float *hip = lds + L::HIP;
+            const int cg = tid / NPOS, pos = tid - cg * NPOS;
+            if (cg < CG) {
+                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+                const int pi = pos / PRW, pj = pos - pi * PRW;
+                const int i = ly0 + pi, j = lx0 + pj;
+                const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
+                const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
+                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;      // column 2j+1 = xa x[j0] + xb x[j0+1]
+                const float ca = j0 == j1 ? 1.f : 0.25f, cb = j0 == j1 ? 0.f : 0.75f;      // column 2j+2 = ca x[j0] + cb x[j0+1]
+                const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
+                const int Y = 2 * i + 1, X = 2 * j + 1;
+                const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
+                const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
+                const float *r0 = raw + (cg * CPT * LH + (i0 - ly0)) * LW + 3 - lx0 + j0;
+                const float *r1 = raw + (cg * CPT * LH + (i1 - ly0)) * LW + 3 - lx0 + j0;
+                float *dd = hip + (cg * CPT * PH + 2 * pi) * PW + 2 * pj + 3 + WS_B64;       // hi-res pixel x0 + 2pj - 1 -> patch column 2pj + 4 (3 without the one-float shift)
+                float v00[CPT], v01[CPT], v10[CPT], v11[CPT];
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc) {
+                    v00[cc] = r0[cc * LH * LW];
+                    v01[cc] = r0[cc * LH * LW + 1];
+                    v10[cc] = r1[cc * LH * LW];
+                    v11[cc] = r1[cc * LH * LW + 1];
+                }
+#pragma unroll
+                for (int cc = 0; cc < CPT; ++cc) {
+                    const float h00 = xa * v00[cc] + xb * v01[cc], h01 = ca * v00[cc] + cb * v01[cc];
+                    const float h10 = xa * v10[cc] + xb * v11[cc], h11 = ca * v10[cc] + cb * v11[cc];
+                    dd[cc * PH * PW] = m00 * (ya * h00 + yb * h10);
+                    dd[cc * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
+                    dd[cc * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
+                    dd[cc * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    issue(0, 0);
+    if (nchunks > 1) issue(1, 1);
+    if constexpr (FH == 0) {        // bias: accumulator of frequency (1,1) = local 5 of the first half
+        const float bv0 = p.bias[nb * BN + wn * 32 + l31];
+        const float ab = half ? 0.f : bv0, ones = half ? 0.f : 1.f;
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, ones, acc[5], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    expand(lds);
+    constexpr int PO = UPS ? L::HIP : C::USZ;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ldA(aBase, q, 0);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) ldB(PO / 2 + bBase, h);
+    transform_rows();
+    transform_cols(0);
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int so = (ch & 1) * L::STAGE, so_n = ((ch + 1) & 1) * L::STAGE;
+        const bool dma = ch + 2 < nchunks;
+        const bool more = ch + 1 < nchunks;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            const bool last = s == S - 1;
+            int ai = (last ? so_n : so + (s + 1) * (32 * BN)) / 4 + aBase;
+            int bi = ((UPS ? L::HIP : (last ? so_n : so) + C::USZ) + (last ? 0 : (s + 1) * (2 * PH * PW))) / 2 + bBase;
+            asm volatile("" : "+v"(ai), "+v"(bi));
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][f >> 2][f & 3], v[cur][f], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!last) {
+                    if (f < 2) ldA(ai, f, nxt);
+                    else if (f < 5) {
+                        ldB(bi, 2 * (f - 2));
+                        ldB(bi, 2 * (f - 2) + 1);
+                    }
+                    if (f == 6) transform_rows();
+                    if (f == 7) transform_cols(nxt);
+                } else if (more) {
+                    if (f == 0) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __syncthreads();
+                    }
+                    if (f >= 1 && f < 3) ldA(ai, f - 1, nxt);
+                    else if (f >= 3 && f < 6) {
+                        if constexpr (!UPS) {
+                            ldB(bi, 2 * (f - 3));
+                            ldB(bi, 2 * (f - 3) + 1);
+                        }
+                    }
+                    if (f >= 1) {
+                        constexpr int PER = (L::NI + 6) / 7;
+#pragma unroll
+                        for (int j = 0; j < PER; ++j) {
+                            const int k = (f - 1) * PER + j;
+                            if (k < L::NI && dma) issue_k(ch + 2, ch & 1, k);
+                        }
+                    }
+                    if constexpr (!UPS) {
+                        if (f == 7) {
+                            transform_rows();
+                            transform_cols(nxt);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (UPS) {
+            if (more) {
+                __syncthreads();
+                expand(lds + so_n);
+#pragma unroll
+                for (int h = 0; h < 6; ++h) ldB(L::HIP / 2 + bBase, h);
+                transform_rows();
+                transform_cols(0);
+            }
+        }
+    }
+
+    // ---- epilogue: column half of A^T M A per wave, the two row halves meet through LDS ------------------------------------------
+    __syncthreads();                               // every LDS read of the last chunk is complete: the stages become the exchange buffer
+    f32x4 *xb4 = (f32x4 *)lds + (wb * 16) * 64 + lane;       // [block][r][lane] quads
+    if constexpr (FH == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // rows 2, 3 of M: c = (m0 + m1 + m2 | m1 - m2 - m3) per row;  contribution to Y rows: (c2 | -c2 - c3)
+            const float c20 = acc[0][r] + acc[1][r] + acc[2][r], c21 = acc[1][r] - acc[2][r] - acc[3][r];
+            const float c30 = acc[4][r] + acc[5][r] + acc[6][r], c31 = acc[5][r] - acc[6][r] - acc[7][r];
+            f32x4 q = {c20, c21, -c20 - c30, -c21 - c31};
+            xb4[r * 64] = q;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    if constexpr (FH == 0) {
+        const int px = x0 + (wtx * C::GTW + txl) * 2, py = y0 + (wty * C::GTH + tyl) * 2;
+        const float sl = p.lrelu ? p.slope : 1.f;
+        float *dstb = p.dst + (long long)b * p.dsb;
+        float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
+        const int cu0 = nb * BN + wn * 32;
+        const bool full = cu0 + 32 <= p.Cout;
+        const unsigned pb0 = 4u * ((unsigned)(4 * half) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
+        const unsigned pb1 = pb0 + 4u * (unsigned)p.dsh;
+        const unsigned qb = 4u * ((unsigned)(4 * half) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
+        const bool ok0 = py < p.H && px < p.W, ok1 = py + 1 < p.H && px < p.W;
+        auto st2 = [](const float *base, unsigned off_bytes, f32x2 val) {
+            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        auto st1 = [](const float *base, unsigned off_bytes, float val) {
+            asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        auto store_all = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cu = cu0 + (r & 3) + 8 * (r >> 2);
+                const bool cok = FULL || cu + 4 * half < p.Cout;
+                const f32x4 q = xb4[r * 64];
+                const float c00 = acc[0][r] + acc[1][r] + acc[2][r], c01 = acc[1][r] - acc[2][r] - acc[3][r];
+                const float c10 = acc[4][r] + acc[5][r] + acc[6][r], c11 = acc[5][r] - acc[6][r] - acc[7][r];
+                float y00 = (c00 + c10) + q[0], y01 = (c01 + c11) + q[1];
+                float y10 = c10 + q[2], y11 = c11 + q[3];
+                y00 = fmaxf(y00, y00 * sl);
+                y01 = fmaxf(y01, y01 * sl);
+                y10 = fmaxf(y10, y10 * sl);
+                y11 = fmaxf(y11, y11 * sl);
+                float *bp = dstb + (long long)cu * p.dsc;
+                f32x2 r0 = {y00, y01}, r1 = {y10, y11};
+                if (ok0 && cok) st2(bp, pb0, r0);
+                if (ok1 && cok) st2(bp, pb1, r1);
+                if (poolb) {
+                    float *qp = poolb + (long long)cu * p.psc;
+                    const float sm = ((y00 + y10) + (y01 + y11)) * 0.25f;
+                    if (ok1 && cok) st1(qp, qb, sm);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (full) store_all(std::true_type{});
+        else store_all(std::false_type{});
+    }
+}
+
+template <class C, bool UPS>
+__global__ __launch_bounds__(256, 2) void wino2_kernel(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // the frequency half is wave-uniform: both bodies contain the same sequence of barriers
+    if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) == 0) wino2_body<C, UPS, 0>(p, lds);
+    else wino2_body<C, UPS, 1>(p, lds);
+}
+
 // ---- tile configurations ------------------------------------------------------------------------------------------
 //                     WN WTY WTX GTW CK        BN   TH  TW (pixels)
 using W64A = WCfg<2, 2, 1, 32, 8>;        //    64    4  64
@@ -428,8 +784,16 @@ using W64G = WCfg<2, 2, 1, 8, 8>;         //    64   16  16
 using W128G = WCfg<4, 1, 1, 8, 4>;        //   128    8  16
 using W64H = WCfg<2, 2, 1, 16, 8>;        //    64    8  32
 using W128H = WCfg<4, 1, 1, 16, 4>;       //   128    4  32
+// two workgroups per CU (wino2_kernel): 2 blocks x 2 frequency halves
+using V32A = WCfg<1, 2, 1, 32, 8, 2>;     //    32    4  64
+using V32H = WCfg<1, 2, 1, 16, 8, 2>;     //    32    8  32
+using V32G = WCfg<1, 2, 1, 8, 8, 2>;      //    32   16  16
+using V64A = WCfg<2, 1, 1, 32, 4, 2>;     //    64    2  64
+using V64G = WCfg<2, 1, 1, 8, 4, 2>;      //    64    8  16
 
-#define SSM_WINO_KINDS(X) X(W64A_, W64A) X(W32A_, W32A) X(W128A_, W128A) X(W64G_, W64G) X(W128G_, W128G) X(W64H_, W64H) X(W128H_, W128H)
+#define SSM_WINO_KINDS(X)                                                                                          \
+    X(W64A_, W64A) X(W32A_, W32A) X(W128A_, W128A) X(W64G_, W64G) X(W128G_, W128G) X(W64H_, W64H) X(W128H_, W128H) \
+    X(V32A_, V32A) X(V32H_, V32H) X(V32G_, V32G) X(V64A_, V64A) X(V64G_, V64G)
 
 enum WinoKind {
 #define X(name, cfg) name,
@@ -439,12 +803,12 @@ enum WinoKind {
 };
 
 struct WKindInfo {
-    int bn, th, tw, ck;
+    int bn, th, tw, ck, nblk;
 };
 
 template <class C>
 constexpr WKindInfo winfo_of() {
-    return WKindInfo{C::BN, C::TH, C::TW, C::CK};
+    return WKindInfo{C::BN, C::TH, C::TW, C::CK, C::NBLK};
 }
 
 constexpr WKindInfo kWInfo[NWKIND] = {
@@ -455,16 +819,27 @@ constexpr WKindInfo kWInfo[NWKIND] = {
 
 std::atomic<int> g_force_wkind{-1};
 
-// Estimated matrix-pipe cycles of a launch: one workgroup per CU, every workgroup Cin/2 k-steps of 16 MFMAs (64 cycles each) plus a
-// fixed prologue/epilogue; rounds of 256 workgroups.
-double estimate_wino(const WKindInfo &ki, int Cin, int Cout, int B, int H, int W) {
+// Estimated duration (cycles) of a launch.  The matrix work of one CU-round is mf = Cin/2 k-steps x 16 MFMAs x 64 cycles: one
+// workgroup of the first form (all 16 frequencies per wave, 256 resident workgroups), or two co-resident workgroups of the second
+// form (8 frequencies per wave, 512 resident).  Around it: an efficiency factor (operand fetches and transforms share the issue
+// stream with the MFMAs), a fixed cost per round (prologue + epilogue: exposed in the first form, mostly hidden behind the
+// neighbour in the second), the fused-upsample expansion per chunk, and whole rounds only (all workgroups of a launch are equal).
+// Constants fitted to sweeps of every configuration over the layer shapes at batch 2 and 7 (tools/r4_sweep.sh; the picks are
+// within 0.4 % of the per-layer best in sum, 3 % at worst).
+double estimate_wino(const WKindInfo &ki, int Cin, int Cout, int B, int H, int W, int ups) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * ((Cout + ki.bn - 1) / ki.bn);
-    const double per = (double)(Cin / 2) * 16.0 * 64.0 + 12000.0;
-    return (double)((nwg + 255) / 256) * per;
+    const double mf = (double)(Cin / 2) * 16.0 * 64.0;
+    const double chunks = (double)Cin / ki.ck;
+    if (ki.nblk == 4) return (double)((nwg + 255) / 256) * (mf * 1.25 + 22000.0 + (ups ? 900.0 * chunks : 0.0));
+    const double per = mf * 1.3 + 6000.0 + (ups ? 500.0 * chunks : 0.0);
+    const long long full = nwg / 512, rem = nwg % 512;
+    double t = (double)full * per;
+    if (rem) t += rem > 256 ? per : mf * 0.5 * 1.25 + 16000.0 + (ups ? 500.0 * chunks : 0.0);     // a last round of lone workgroups
+    return t;
 }
 
-int pick_wkind(int Cin, int Cout, int B, int H, int W) {
+int pick_wkind(int Cin, int Cout, int B, int H, int W, int ups) {
     const int forced = g_force_wkind.load();
     if (forced >= 0 && forced < NWKIND) return forced;
     int best = -1;
@@ -473,7 +848,7 @@ int pick_wkind(int Cin, int Cout, int B, int H, int W) {
         const WKindInfo &ki = kWInfo[i];
         if (ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;      // over half of the cout block would be padding
         if (Cin % ki.ck) continue;
-        const double t = estimate_wino(ki, Cin, Cout, B, H, W);
+        const double t = estimate_wino(ki, Cin, Cout, B, H, W, ups);
         if (best < 0 || t < bt * 0.999) {
             best = i;
             bt = t;
@@ -493,7 +868,9 @@ int wlaunch(WinoParams &p, int B, hipStream_t st) {
         return SSM_E_ARG;
     }
     constexpr int lds_bytes = WLds<C, UPS>::BYTES;
-    auto kern = wino_kernel<C, UPS>;
+    void (*kern)(const WinoParams);
+    if constexpr (C::NBLK == 4) kern = wino_kernel<C, UPS>;
+    else kern = wino2_kernel<C, UPS>;
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
@@ -597,8 +974,8 @@ int wfill(WinoParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *
 
 }  // namespace
 
-extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int *kind, int *BN, int *CK) {
-    const int kd = (W % 2 == 0) ? pick_wkind(Cin, Cout, B, H, W) : -1;
+extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK) {
+    const int kd = (W % 2 == 0) ? pick_wkind(Cin, Cout, B, H, W, ups) : -1;
     if (kd < 0) {
         ssm::set_error("wino conv: no tile configuration for Cin=%d Cout=%d on a %dx%d map (needs even W, Cin a multiple of 8)", Cin, Cout, H, W);
         return SSM_E_UNSUPPORTED;
@@ -634,7 +1011,7 @@ extern "C" int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, con
                                    ssm_view pool, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
     int kind = 0, BN = 0, CK = 0;
     SSM_REQUIRE(B > 0, "wino conv: bad batch");
-    const int rc = ssm_wino_plan(C1 + C2, Cout, B, H, W, &kind, &BN, &CK);
+    const int rc = ssm_wino_plan(C1 + C2, Cout, B, H, W, 0, &kind, &BN, &CK);
     if (rc != SSM_OK) return rc;
     WinoParams p;
     const int rf = wfill(p, x1, C1, x2, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W);
@@ -654,7 +1031,7 @@ extern "C" int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, c
     int kind = 0, BN = 0, CK = 0;
     SSM_REQUIRE(B > 0, "wino conv_ups: bad batch");
     SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino conv_ups: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
-    const int rc = ssm_wino_plan(C1 + C2, Cout, B, H, W, &kind, &BN, &CK);
+    const int rc = ssm_wino_plan(C1 + C2, Cout, B, H, W, 1, &kind, &BN, &CK);
     if (rc != SSM_OK) return rc;
     WinoParams p;
     const int rf = wfill(p, a, C1, b, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W / 2);

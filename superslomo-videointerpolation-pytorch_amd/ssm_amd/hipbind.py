@@ -50,7 +50,7 @@ SIGNATURES = {
     "ssm_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int,
                                 _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
-    "ssm_wino_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
+    "ssm_wino_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino_force_kind": (_c_int, [_c_int]),
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
@@ -290,11 +290,11 @@ def conv2d_ups(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1):
 
 
 # ---- 3x3 convolution as Winograd F(2x2,3x3) in fp32 (csrc/ssm_wino.hip) ------------------------------------
-def wino_plan(cin, cout, B, H, W):
-    """(kind, BN, CK) of the Winograd tile configuration for the problem."""
+def wino_plan(cin, cout, B, H, W, ups=False):
+    """(kind, BN, CK) of the Winograd tile configuration for the problem (ups: the fused-upsample entry point)."""
     lib = load()
     kind, bn, ck = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    check(lib.ssm_wino_plan(cin, cout, B, H, W, ctypes.byref(kind), ctypes.byref(bn), ctypes.byref(ck)))
+    check(lib.ssm_wino_plan(cin, cout, B, H, W, 1 if ups else 0, ctypes.byref(kind), ctypes.byref(bn), ctypes.byref(ck)))
     return kind.value, bn.value, ck.value
 
 
@@ -315,7 +315,7 @@ class PackedWino:
         self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
         assert self.k == 3 and weight.shape[3] == 3, "the Winograd form is for 3x3 filters"
         self.ups = bool(ups)
-        _, self.bn, self.ck = wino_plan(self.cin, self.cout, B, H, W)
+        _, self.bn, self.ck = wino_plan(self.cin, self.cout, B, H, W, self.ups)
         assert self.cin % self.ck == 0, "Cin must be a multiple of %d" % self.ck
         self.cin_p = self.cin
         lib = load()
@@ -331,7 +331,7 @@ class PackedWino:
 def conv2d_wino(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1):
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
-    assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W)[1:], "filter was packed for another tile configuration"
+    assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W, False)[1:], "filter was packed for another tile configuration"
     check(lib.ssm_wino_conv2d_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                   pool if pool is not None else NULL_VIEW, B, H, W, pk.cout, slope,
                                   SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
@@ -341,7 +341,7 @@ def conv2d_ups_wino(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1):
     """conv3x3(upsample2x(cat[a, b])) in the Winograd form: a, b LOW-res padded-plane views, H, W the OUTPUT size."""
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
-    assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W)[1:], "filter was packed for another tile configuration"
+    assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W, True)[1:], "filter was packed for another tile configuration"
     check(lib.ssm_wino_conv2d_ups_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y, B, H, W,
                                       pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 

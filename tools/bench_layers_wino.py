@@ -61,7 +61,11 @@ def main():
         pk = hb.PackedConv(wt, bs, B, h, w, ups=ups)
         if w % 2:
             continue
-        pw = hb.PackedWino(wt, bs, B, h, w, ups=ups)
+        try:
+            pw = hb.PackedWino(wt, bs, B, h, w, ups=ups)
+        except (RuntimeError, AssertionError) as e:
+            print("%-10s skipped: %s" % (name, str(e)[:80]), flush=True)
+            continue
         bv = xb.view() if xb is not None else None
         if ups:
             f0 = lambda: hb.conv2d_ups(xa.view(), c1, bv, c2, pk, y0.view(), B, h, w)  # noqa: E731
@@ -69,14 +73,19 @@ def main():
         else:
             f0 = lambda: hb.conv2d(xa.view(), c1, bv, c2, pk, y0.view(), None, B, h, w)  # noqa: E731
             f1 = lambda: hb.conv2d_wino(xa.view(), c1, bv, c2, pw, y1.view(), None, B, h, w)  # noqa: E731
-        t0, t1 = timed(f0), timed(f1)
-        diff = float((y0.interior - y1.interior).abs().max())
+        t0 = timed(f0) if not os.environ.get("NO_DIRECT") else float("nan")
+        try:
+            t1 = timed(f1)
+        except (RuntimeError, AssertionError) as e:        # forced configuration not applicable to this layer
+            print("%-10s skipped: %s" % (name, str(e)[:80]), flush=True)
+            continue
+        diff = float((y0.interior - y1.interior).abs().max()) if not os.environ.get("NO_DIRECT") else float("nan")
         gf = 2.0 * B * h * w * cout * cin * 9 / 1e9
         tot[0] += gf
         tot[1] += t0
         tot[2] += t1
         print("%-10s %5d %5d %4dx%-4d %4d %9.2f | %8.3f %7.1f | %8.3f %7.1f %5d | %6.2f %9.2e" % (
-            name, cin, cout, h, w, ups, gf, t0, gf / t0, t1, gf / t1, hb.wino_plan(cin, cout, B, h, w)[0], t0 / t1, diff), flush=True)
+            name, cin, cout, h, w, ups, gf, t0, gf / t0, t1, gf / t1, hb.wino_plan(cin, cout, B, h, w, ups)[0], t0 / t1, diff), flush=True)
         del xa, xb, y0, y1, pk, pw
     print("TOTAL 3x3 layers: %.1f GFLOP; direct %.2f ms = %.1f TFLOP/s; winograd %.2f ms = %.1f TFLOP/s algorithmic (fp32 MFMA peak 157.3)" % (
         tot[0], tot[1], tot[0] / tot[1], tot[2], tot[0] / tot[2]))
