@@ -640,7 +640,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int so = (ch & 1) * L::STAGE, so_n = ((ch + 1) & 1) * L::STAGE;
-        const bool dma = ch + 2 < nchunks;
+        const bool dma = ch + 2 < nchunks && !WABL(1);
         const bool more = ch + 1 < nchunks;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -662,7 +662,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                     if (f == 6) transform_rows();
                     if (f == 7) transform_cols(nxt);
                 } else if (more) {
-                    if (f == 0) {
+                    if (f == 0 && !WABL(16)) {
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __syncthreads();
                     }
@@ -704,6 +704,9 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     }
 
     // ---- epilogue: column half of A^T M A per wave, the two row halves meet through LDS ------------------------------------------
+#ifdef SSM_WINO_ABLATE
+    if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
+#endif
     __syncthreads();                               // every LDS read of the last chunk is complete: the stages become the exchange buffer
     f32x4 *xb4 = (f32x4 *)lds + (wb * 16) * 64 + lane;       // [block][r][lane] quads
     if constexpr (FH == 1) {
@@ -770,6 +773,8 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
 template <class C, bool UPS>
 __global__ __launch_bounds__(256, 2) void wino2_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (A first-round stagger of the two workgroups that share a CU - half a workgroup's matrix time of s_sleep for workgroups 256..511 -
+    // was measured on the same box and changed nothing: 195.2 vs 196.4 TFLOP/s over the 3x3 layers.)
     // the frequency half is wave-uniform: both bodies contain the same sequence of barriers
     if ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) == 0) wino2_body<C, UPS, 0>(p, lds);
     else wino2_body<C, UPS, 1>(p, lds);
