@@ -142,7 +142,7 @@ def conv_flops_per_pair(h, w, n_t, issued_for=None):
 TRAIN_DTYPE_NOTE = {
     "f16f8": "f32 parameters/activations/gradients; products via 1x f16 + 2x block-scaled e4m3 MFMA (forward, data gradients) and 3x bf16 "
              "MFMA on hi/lo-split operands (weight gradients), f32 accumulate - narrower than f32",
-    "f32": "f32 (fp32 MFMA)"}
+    "f32": "f32 (fp32 MFMA)", "f32w": "f32 (fp32 MFMA; forward and data-gradient 3x3 convolutions as Winograd F(2x2,3x3))"}
 
 
 def train_bench(args):
@@ -169,7 +169,7 @@ def train_bench(args):
         model.loss.load_vgg16(synthetic_vgg_state_dict())
     model = model.to(dev).train()
     train_mode = args.precision or os.environ.get("SSM_TRAIN_PRECISION", "f32")
-    assert train_mode in ("f32", "f16f8"), "--mode train: --precision f32 (default, exact) or f16f8"
+    assert train_mode in ("f32", "f32w", "f16f8"), "--mode train: --precision f32 (default, direct form), f32w (3x3 layers as Winograd) or f16f8"
     model.train_precision = train_mode
     trainer = Trainer(model, cfg)
     B, S = 2, 352

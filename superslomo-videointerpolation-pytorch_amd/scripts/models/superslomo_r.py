@@ -248,7 +248,7 @@ class FullModel(nn.Module):
 
     # ---- training step ------------------------------------------------------------------------------------------
     grad_sync = None            # a ssm_amd.dist.GradientAllReduce (set by the Trainer), or None
-    train_precision = None      # "f32" (default; $SSM_TRAIN_PRECISION) | "f16f8" (opt-in: split forward / data gradients, bf16x3 weight gradients)
+    train_precision = None      # "f32" (default; $SSM_TRAIN_PRECISION) | "f32w" (opt-in: fp32 throughout, forward + data-gradient 3x3 convolutions as Winograd F(2x2,3x3)) | "f16f8" (opt-in: split forward / data gradients, bf16x3 weight gradients)
 
     def _train_engine(self, B, H, W, device):
         """The training plan + its PairGrad.  f16f8: the inference plan (fused upsample, fp16 + fp8 matrix path) writing fp32
@@ -256,15 +256,15 @@ class FullModel(nn.Module):
         materialised upsample tensors."""
         from ssm_amd.backward import PairGrad
         mode = self.train_precision or os.environ.get("SSM_TRAIN_PRECISION", DEFAULT_TRAIN_PRECISION)
-        assert mode in ("f16f8", "f32"), "training precision must be f16f8 or f32"
-        self.loss.__dict__["train_precision"] = mode        # the VGG16 term runs in the same arithmetic
+        assert mode in ("f16f8", "f32", "f32w"), "training precision must be f32, f32w or f16f8"
+        self.loss.__dict__["train_precision"] = "f32" if mode == "f32w" else mode        # the VGG16 term runs in the same arithmetic (direct form)
         key = (B, H, W, str(device), mode)
         if getattr(self, "_train", None) is None or self._train[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}
             sd2 = {k: v.detach() for k, v in self.stage2_model.state_dict().items()}
             self._train = None
-            if mode == "f32":
-                eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, "f32", fuse_upsample=False)
+            if mode in ("f32", "f32w"):        # f32w: forward and data-gradient 3x3 convolutions in the Winograd form
+                eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, mode, fuse_upsample=False)
             else:
                 eng = PairEngine(sd1, sd2, B, B, H, W, device, self.cross_skip, "f16f8", fuse_upsample=True, twins=True)
             self._train = (key, eng, PairGrad(eng))

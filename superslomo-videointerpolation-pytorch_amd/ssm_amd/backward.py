@@ -227,8 +227,11 @@ class UNetGrad:
                 self.pk_t[name] = hb.PackedConv16(transposed_filter(w), torch.zeros(ci, device=self.dev), self.plan.W // s, q8=True,
                                                   scale=self.plan.scales[name])
             else:
-                self.pk_t[name] = hb.PackedConv(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B,
-                                                self.plan.H // s, self.plan.W // s)
+                # the data gradient of a 3x3 convolution is a 3x3 convolution with the transposed + flipped filter: on an f32w plan it
+                # runs in the Winograd form like the forward (its "input channels" are the layer's output channels)
+                use_w = getattr(self.plan, "wino", False) and hb.wino_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
+                cls = hb.PackedWino if use_w else hb.PackedConv
+                self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
 
     def _layer(self, name, dy, dpool, dx, need_wgrad, act=True):
         """One convolution: dZ, parameter gradients, data gradient into `dx` (None: not needed)."""
@@ -282,7 +285,8 @@ class UNetGrad:
             if self.hl8:
                 hb.conv2d_hl8(self.dzq[name].view(), cpad, None, 0, pk, None, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             else:
-                hb.conv2d(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
+                fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
+                fn(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             if tm is not None:
                 e1.record()
 

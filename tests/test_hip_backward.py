@@ -188,11 +188,11 @@ def _oracle_training_loss(p1, p2, img6, t, target, lr, lw, vgg=None, lp=0.0):
 # forward activations carry ~3e-5 of fp8-compensation noise, which flips the LeakyReLU branch of the few elements that sit within
 # that distance of zero - the gradient is exact for the perturbed network, so single tensors (the 2x2-pixel bottleneck at 64x64)
 # can differ by several per cent in max-abs while the direction stays put.
-GRAD_BARS = {"f32": (0.99999, 1e-4), "f16f8": (0.999, 1e-1)}
+GRAD_BARS = {"f32": (0.99999, 1e-4), "f32w": (0.99999, 1e-4), "f16f8": (0.999, 1e-1)}
 # measured at 64x64: f32 2.0e-6, f16f8 1.9e-2 (7.1e-2 with the VGG term on: 2x2-pixel bottleneck maps); with the VGG term the exact
 # plan sits at 6.6e-4 (bar below); at 352x352 (config 3's shape): f32 6.8e-4 - reassociation noise amplified by the net -, f16f8 3.0e-3
 GRAD_BARS_VGG = {"f32": (0.99999, 2e-3), "f16f8": (0.999, 1e-1)}
-GRAD_BARS_352 = {"f32": (0.99999, 2e-3), "f16f8": (0.9995, 1.5e-2)}
+GRAD_BARS_352 = {"f32": (0.99999, 2e-3), "f32w": (0.99999, 2e-3), "f16f8": (0.9995, 1.5e-2)}
 
 
 def _train_model_p(dev, precision):
@@ -230,7 +230,7 @@ def oracle_352():
     return xin, tgt, t, float(L.detach()), pred.detach(), grads
 
 
-@pytest.mark.parametrize("train_precision", ["f32", "f16f8"])
+@pytest.mark.parametrize("train_precision", ["f32", "f32w", "f16f8"])
 def test_training_step_at_config3_size_vs_oracle(dev, oracle_352, train_precision):
     """BASELINE config 3 at its workload size: one training step on 2 x 352x352 (the per-GPU share of batch 16), both training
     precisions: loss and frame against the oracle's forward, all 96 parameter gradients against CPU autograd of the oracle."""
@@ -238,7 +238,7 @@ def test_training_step_at_config3_size_vs_oracle(dev, oracle_352, train_precisio
     m, _, _ = _train_model_p(dev, train_precision)
     img, losses = m(xin.to(dev), t.to(dev), tgt.to(dev), None, False)
     losses.mean(dim=0)[0].backward()
-    assert float((img.cpu() - pred).abs().max()) < (3e-4 if train_precision == "f32" else 6e-4)
+    assert float((img.cpu() - pred).abs().max()) < (6e-4 if train_precision == "f16f8" else 3e-4)
     assert abs(float(losses.detach().mean(0)[0]) - L) < 1e-4 * abs(L)
     worst = []
     for stage, mod in (("s1", m.stage1_model), ("s2", m.stage2_model)):
@@ -278,7 +278,7 @@ def test_f16f8_gradients_survive_small_loss_gradients(dev, oracle_352):
     assert float((c == 0).float().mean()) <= float((ref == 0).float().mean()) + 1e-6, "gradients flushed to zero"
 
 
-@pytest.mark.parametrize("train_precision", ["f16f8", "f32"])
+@pytest.mark.parametrize("train_precision", ["f16f8", "f32", "f32w"])
 def test_training_step_gradients_vs_oracle_autograd(dev, train_precision):
     """FullModel (FREEZE=FALSE) forward + `losses.mean(0)[0].backward()` on the HIP path: every one of the 96 parameter
     gradients against CPU autograd of the oracle on the same 64x64 batch of 2."""
