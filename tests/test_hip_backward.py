@@ -188,7 +188,7 @@ def _oracle_training_loss(p1, p2, img6, t, target, lr, lw, vgg=None, lp=0.0):
 # forward activations carry ~3e-5 of fp8-compensation noise, which flips the LeakyReLU branch of the few elements that sit within
 # that distance of zero - the gradient is exact for the perturbed network, so single tensors (the 2x2-pixel bottleneck at 64x64)
 # can differ by several per cent in max-abs while the direction stays put.
-GRAD_BARS = {"f32": (0.99999, 1e-4), "f32w": (0.99999, 1e-4), "f16f8": (0.999, 1e-1)}
+GRAD_BARS = {"f32": (0.99999, 1e-4), "f32w": (0.99999, 3e-4), "f16f8": (0.999, 1e-1)}      # f32w measured 5.9e-5 (Winograd rounding in forward + data gradients)
 # measured at 64x64: f32 2.0e-6, f16f8 1.9e-2 (7.1e-2 with the VGG term on: 2x2-pixel bottleneck maps); with the VGG term the exact
 # plan sits at 6.6e-4 (bar below); at 352x352 (config 3's shape): f32 6.8e-4 - reassociation noise amplified by the net -, f16f8 3.0e-3
 GRAD_BARS_VGG = {"f32": (0.99999, 2e-3), "f16f8": (0.999, 1e-1)}
