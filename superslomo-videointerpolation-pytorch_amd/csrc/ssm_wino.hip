@@ -24,6 +24,9 @@
 // barrier per chunk sits inside the LAST k-step of the chunk: by then all LDS reads of the chunk are complete (the last k-step's
 // operands are in registers), so its stage is handed to the DMA of chunk c+2 at once, chunk c+1 (issued a chunk ago) becomes visible,
 // and the operands of its first k-step are fetched and transformed behind the remaining MFMAs - the matrix pipe never waits for LDS.
+//
+// Two kernel forms share this file: wino_kernel (this description: 16 frequencies per wave, one workgroup per CU) and wino2_kernel
+// (further down: 8 frequencies per wave, two workgroups per CU - what the plan picks for most layers; DESIGN.md 3.2d says why).
 #include "ssm_common.h"
 
 #include <atomic>
@@ -210,8 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
         float e0 = lds[2 * bi + 1 + i * PW + j], e1 = lds[2 * bi + 1 + i * PW + j + 1];
 #endif
-        asm volatile("" : "+v"(e0), "+v"(e1));        // two scalars from here on: no packed-fp32 arithmetic on the pair (DESIGN 3.3 fence)
-        d[4 * i + j] = e0;
+        d[4 * i + j] = e0;            // (pinned as scalars where they are consumed: transform_rows)
         d[4 * i + j + 1] = e1;
     };
     auto fetchA = [&](int ai, int buf) {
@@ -225,6 +227,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], in two halves of 16 add/sub that go into separate MFMA gaps
     float t[16];
     auto transform_rows = [&]() {
+        // the patch values arrive as 8-byte pairs: pin each as a scalar HERE (where the wait for the loads belongs anyway), so that no
+        // packed-fp32 arithmetic is formed on the pairs (DESIGN 3.3 fence).  Pinning at the load would put an s_waitcnt lgkmcnt(0)
+        // behind every ds_read_b64 - the full LDS latency, eight times per k-step.
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(d[i]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t[j] = d[j] - d[8 + j];
@@ -547,12 +554,13 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
 #else
         float e0 = lds[2 * bi + 1 + i * PW + j], e1 = lds[2 * bi + 1 + i * PW + j + 1];
 #endif
-        asm volatile("" : "+v"(e0), "+v"(e1));        // two scalars from here on: no packed-fp32 arithmetic on the pair (DESIGN 3.3 fence)
-        d[4 * i + j] = e0;
+        d[4 * i + j] = e0;            // (pinned as scalars where they are consumed: transform_rows)
         d[4 * i + j + 1] = e1;
     };
     // rows 2FH, 2FH+1 of B^T d from patch rows e0, e1, e2 = d rows FH, FH+1, FH+2
     auto transform_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(d[i]));      // scalars from here on (see wino_kernel)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (FH == 0) {
@@ -653,11 +661,21 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
             for (int f = 0; f < 8; ++f) {
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][f >> 2][f & 3], v[cur][f], acc[f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef WS_BFIRST
+#define WS_BFIRST 1        // patch rows first (gaps 0-2), filter quads after them: the transform in gaps 6-7 finds its operands landed
+#endif
                 if (!last) {
-                    if (f < 2) ldA(ai, f, nxt);
-                    else if (f < 5) {
-                        ldB(bi, 2 * (f - 2));
-                        ldB(bi, 2 * (f - 2) + 1);
+                    if (WS_BFIRST) {
+                        if (f < 3) {
+                            ldB(bi, 2 * f);
+                            ldB(bi, 2 * f + 1);
+                        } else if (f < 5) ldA(ai, f - 3, nxt);
+                    } else {
+                        if (f < 2) ldA(ai, f, nxt);
+                        else if (f < 5) {
+                            ldB(bi, 2 * (f - 2));
+                            ldB(bi, 2 * (f - 2) + 1);
+                        }
                     }
                     if (f == 6) transform_rows();
                     if (f == 7) transform_cols(nxt);
@@ -666,11 +684,20 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __syncthreads();
                     }
-                    if (f >= 1 && f < 3) ldA(ai, f - 1, nxt);
-                    else if (f >= 3 && f < 6) {
-                        if constexpr (!UPS) {
-                            ldB(bi, 2 * (f - 3));
-                            ldB(bi, 2 * (f - 3) + 1);
+                    if (WS_BFIRST) {
+                        if (f >= 1 && f < 4) {
+                            if constexpr (!UPS) {
+                                ldB(bi, 2 * (f - 1));
+                                ldB(bi, 2 * (f - 1) + 1);
+                            }
+                        } else if (f >= 4 && f < 6) ldA(ai, f - 4, nxt);
+                    } else {
+                        if (f >= 1 && f < 3) ldA(ai, f - 1, nxt);
+                        else if (f >= 3 && f < 6) {
+                            if constexpr (!UPS) {
+                                ldB(bi, 2 * (f - 3));
+                                ldB(bi, 2 * (f - 3) + 1);
+                            }
                         }
                     }
                     if (f >= 1) {
