@@ -120,23 +120,30 @@ def setup_ranks(args):
 
 
 def conv_flops_per_pair(h, w, n_t, issued_for=None):
-    """Algorithmic (direct-form) conv FLOP of a pair; issued_for = "f32w": the FLOP the matrix cores execute in that mode (3x3
-    layers with >= 32 output channels run as Winograd F(2x2,3x3): 16 instead of 36 multiply-adds per 2x2 outputs)."""
+    """Algorithmic (direct-form) conv FLOP of a pair as SURVEY 8d counts them (stage 1 once, stage 2 per t).  issued_for = "f32" /
+    "f32w": the multiply-adds the matrix cores actually execute in that mode: the t-independent input channels of stage 2's conv1a
+    (6 of 16) and conv7a (512 of 1024) are convolved once per pair (ssm_amd.engine.UNetPlan.hoist); "f32w": 3x3 layers with >= 32
+    output channels run as Winograd F(2x2,3x3), 16 instead of 36 multiply-adds per 2x2 outputs."""
     from ssm_amd.weights import unet_layers
     scale = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8,
              "conv9": 4, "fuse_": 1, "final": 1}
 
-    def stage(st):
+    def stage(st, reps):
         tot = 0.0
         for name, cin, cout, k in unet_layers(st, True):
             s = 2 if name.startswith("conv10") else 1 if name.startswith("conv11") else \
                 [v for p, v in scale.items() if name.startswith(p)][0]
-            fl = 2.0 * (h // s) * (w // s) * cin * cout * k * k
+            fl = 2.0 * (h // s) * (w // s) * cin * cout * k * k * reps
+            if issued_for in ("f32", "f32w") and st == 2 and reps > 1:
+                if name == "conv1a":
+                    fl *= (10.0 * reps + 6.0) / (16.0 * reps)
+                elif name == "conv7a":
+                    fl *= (reps + 1.0) / (2.0 * reps)
             if issued_for == "f32w" and k == 3 and name != "final_conv" and (w // s) % 2 == 0 and cin % 8 == 0:
                 fl *= 16.0 / 36.0
             tot += fl
         return tot
-    return stage(1) + n_t * stage(2)
+    return stage(1, 1) + stage(2, n_t)
 
 
 TRAIN_DTYPE_NOTE = {
@@ -469,7 +476,7 @@ def infer_bench(args):
     sd1d = {k: v.detach() for k, v in model.stage1_model.state_dict().items()}
     sd2d = {k: v.detach() for k, v in model.stage2_model.state_dict().items()}
     flops_pair = conv_flops_per_pair(Hp, Wp, N_T)
-    flops_issued_w = conv_flops_per_pair(Hp, Wp, N_T, "f32w")
+    flops_issued = {m: conv_flops_per_pair(Hp, Wp, N_T, m) for m in ("f32", "f32w")}
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -506,12 +513,16 @@ def infer_bench(args):
                            "flop_per_pair": flops_pair, "traffic": traffic or None,
                            "traffic_note": "HBM bytes per pair of the conv launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from "
                                            "separate rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/%s" % (pmc_file or "-")}
-        if precision == "f32w":
-            iss = flops_issued_w * P / (ms_step * 1e-3) / 1e12
-            res["roofline"]["issued"] = {"flop_per_pair": flops_issued_w, "achieved": round(iss, 2), "frac": round(iss / peak, 4),
-                                         "note": "multiply-adds the matrix cores execute (Winograd F(2x2,3x3) layers: direct-form FLOP x 16/36) "
-                                                 "/ the same wall time = utilisation of the fp32 MFMA pipe; `achieved` / `frac` above count "
-                                                 "direct-form FLOP (SURVEY 8d) and may exceed the matrix peak"}
+        if precision in flops_issued:
+            fi = flops_issued[precision]
+            iss = fi * P / (ms_step * 1e-3) / 1e12
+            res["roofline"]["issued"] = {"flop_per_pair": fi, "achieved": round(iss, 2), "frac": round(iss / peak, 4),
+                                         "note": "multiply-adds the matrix cores execute / the same wall time = utilisation of the fp32 MFMA "
+                                                 "pipe: the t-independent input channels of stage 2's conv1a (6 of 16) and conv7a (512 of "
+                                                 "1024) are convolved once per pair instead of once per t" +
+                                                 ("; Winograd F(2x2,3x3) layers: direct-form FLOP x 16/36" if precision == "f32w" else "") +
+                                                 ".  `achieved` / `frac` above count direct-form FLOP as SURVEY 8d does (stage 2 in full "
+                                                 "per t) and may exceed the matrix peak"}
         if clk is not None:
             ghz = read_clock_probe(clk)
             if ghz:
@@ -540,7 +551,7 @@ def infer_bench(args):
             conv = summ["conv"]
             conv_ms = conv["ms"] / n_solo
             kach = flops_pair / (conv_ms * 1e-3) / 1e12
-            mfma_per_prod = {"f16x3": 3, "f16f8": 1.5, "f32w": flops_issued_w / flops_pair}.get(precision, 1)
+            mfma_per_prod = {"f16x3": 3, "f16f8": 1.5, "f32w": flops_issued["f32w"] / flops_pair, "f32": flops_issued["f32"] / flops_pair}.get(precision, 1)
             res["roofline"]["detail"] = {"region": "%d single-stream pairs run right after the timed region, HIP-event brackets around every "
                                                    "launch on the launch stream" % n_solo,
                                          "launches_per_batch": conv["launches"] // nb_solo, "pairs_per_batch": PB, "ms_per_pair_in_kernel": round(conv_ms, 3),

@@ -127,6 +127,18 @@ int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_pack
 int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
                        ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 
+/* The two convolutions above with a pre-activation addend: y = act(conv(x) + bias + add[b / add_div]), add = a view
+ * [B / add_div, Cout, H, W].  For the parts of a convolution's input that do not depend on the batch index - the reference
+ * evaluates stage 2 once per interpolation time t (evaluate_interpolation_results.py:234-242), but the image channels of its
+ * first convolution's 16-channel input (flow_interpolation.py:364-367: channels 0:3 and 13:16) and the stage-1 half of the
+ * cross-skip concat in front of conv7a (flow_interpolation.py:98-101,224-231) are the same for every t of a pair: their
+ * partial sums are computed once per pair by a plain call and enter the per-t launches here.  add.ptr NULL = the plain form. */
+int ssm_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                       ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, int k, float slope, int flags,
+                       void *stream);
+int ssm_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                           ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+
 /* ---- the same 3x3 convolution as Winograd F(2x2,3x3), all arithmetic fp32 (v_mfma_f32_32x32x2_f32) ---------------
  * Same operator and operand layout as ssm_conv2d_fwd / ssm_conv2d_ups_fwd for k = 3 (layers.conv,
  * scripts/models/layers.py:21-33; decoder step scripts/models/flow_computation.py:244-247), evaluated as
@@ -145,6 +157,12 @@ int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w
                         ssm_view y, ssm_view pool, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
                             ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+/* ... with the pre-activation addend of ssm_conv2d_add_fwd (8-byte aligned view). */
+int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                            ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags,
+                            void *stream);
+int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 
 /* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------
  * Same operator as ssm_conv2d_fwd.  Default mode evaluates a*b as a_hi*b_hi + a_hi*b_lo +

@@ -64,6 +64,11 @@ struct ConvParams {
     float slope;
     int lrelu;
     int abl;             // diagnostics build only (make ablate): 1 = no LDS-DMA after the second chunk, 2 = no stores
+    // optional pre-activation addend [B / adiv][Cout][H][W] (batch entry b reads entry b / adiv): the part of the sum that does
+    // not depend on the batch index - e.g. the image channels of stage 2's first convolution, equal for the 7 t of a pair
+    const float *add;
+    long long asb, asc;
+    int ash, adiv;
 };
 
 template <int KS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int CK_, int GW_ = 32>
@@ -209,7 +214,28 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
-
+    if (p.add) {
+        // The accumulators start from the addend (register r of lane (l31, half) = cout (r&3) + 8*(r>>2) + 4*half, pixel l31 of the
+        // group): the loads fly while the first chunk's DMA is in flight.  Addressing as in the store loop - a wave-uniform base
+        // per cout (SGPRs) + ONE 32-bit per-lane byte offset per pixel group - so the 16 x NT x MT loads need no registers beyond
+        // the accumulators (per-load 64-bit addresses cost 30-40 VGPRs = one resident workgroup per CU).  No predicates: Cout is a
+        // multiple of 32 (checked on the host), pixels beyond the map read the addend's frame / slack and are never stored.
+        const float *ab = p.add + (long long)(b / p.adiv) * p.asb;
+        const int ax = x0 + wx * (C::MTX * GW) + gx, ay = y0 + wy * (C::MTY * GH) + gy;
+        unsigned aoff[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            aoff[m] = 4u * ((unsigned)(4 * half) * (unsigned)p.asc + (unsigned)(ay + (m / C::MTX) * GH) * (unsigned)p.ash + (unsigned)(ax + (m % C::MTX) * GW));
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cu = nb * BN + (wn * NT + n) * 32 + (r & 3) + 8 * (r >> 2);          // uniform
+                const char *bp = (const char *)(ab + (long long)cu * p.asc);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[n][m][r] = *(const float *)(bp + aoff[m]);
+            }
+    }
     // per-lane operand bases (floats): filter inside a stage, activation inside the patch
     const int aBase = half * (KS2 * BN) + wn * (NT * 32) + l31;
     const int bBase = half * (PH * PW) + (wy * C::MTY * GH + gy) * PW + wx * (C::MTX * GW) + gx + (4 - C::PAD);
@@ -649,6 +675,10 @@ int fill_common(ConvParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const f
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
     p.abl = 0;
+    p.add = nullptr;
+    p.asb = p.asc = 0;
+    p.ash = 0;
+    p.adiv = 1;
 #ifdef SSM_CONV_ABLATE
     if (const char *e = getenv("SSM_CONV_ABL")) p.abl = atoi(e);
 #endif
@@ -698,9 +728,24 @@ extern "C" int ssm_pack_weights(const float *w, const float *bias, float *wp, fl
     return ssm::check_launch("ssm_pack_weights");
 }
 
-extern "C" int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed,
-                              const float *bias_packed, ssm_view y, ssm_view pool, int B, int H, int W, int Cout,
-                              int k, float slope, int flags, void *stream) {
+namespace {
+int set_add(ConvParams &p, ssm_view add, int add_div, int B) {
+    if (!add.ptr) return SSM_OK;
+    SSM_REQUIRE(add_div >= 1 && B % add_div == 0, "conv: the addend serves %d batch entries each, batch %d is no multiple", add_div, B);
+    SSM_REQUIRE(p.Cout % 32 == 0, "conv: the addend form needs Cout to be a multiple of 32 (got %d)", p.Cout);
+    SSM_REQUIRE(4LL * (4 * add.sc + (long long)(p.H + 64) * add.sh) < 0x7fffffffLL, "conv: addend plane too large for 32-bit offsets");
+    p.add = add.ptr;
+    p.asb = add.sb;
+    p.asc = add.sc;
+    p.ash = add.sh;
+    p.adiv = add_div;
+    return SSM_OK;
+}
+}  // namespace
+
+extern "C" int ssm_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                  ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, int k, float slope, int flags,
+                                  void *stream) {
     int kind = 0, BN = 0, CK = 0;
     SSM_REQUIRE(B > 0, "conv: bad batch");
     const int rc = ssm_conv_plan(k, C1 + C2, Cout, B, H, W, pool.ptr ? 1 : 0, 0, &kind, &BN, &CK);
@@ -708,6 +753,8 @@ extern "C" int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const fl
     ConvParams p;
     const int rf = fill_common(p, x1, C1, x2, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W);
     if (rf != SSM_OK) return rf;
+    const int ra = set_add(p, add, add_div, B);
+    if (ra != SSM_OK) return ra;
     if (pool.ptr) {
         SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv: fused pool needs even H, W");
         p.pool = pool.ptr;
@@ -718,8 +765,15 @@ extern "C" int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const fl
     return dispatch<false>(kind, p, B, (hipStream_t)stream);
 }
 
-extern "C" int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
-                                  ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+extern "C" int ssm_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed,
+                              const float *bias_packed, ssm_view y, ssm_view pool, int B, int H, int W, int Cout,
+                              int k, float slope, int flags, void *stream) {
+    const ssm_view none = {nullptr, 0, 0, 0};
+    return ssm_conv2d_add_fwd(x1, C1, x2, C2, w_packed, bias_packed, y, pool, none, 1, B, H, W, Cout, k, slope, flags, stream);
+}
+
+extern "C" int ssm_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                      ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
     int kind = 0, BN = 0, CK = 0;
     SSM_REQUIRE(B > 0, "conv_ups: bad batch");
     SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_ups: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
@@ -728,5 +782,13 @@ extern "C" int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const 
     ConvParams p;
     const int rf = fill_common(p, a, C1, b, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W / 2);
     if (rf != SSM_OK) return rf;
+    const int ra = set_add(p, add, add_div, B);
+    if (ra != SSM_OK) return ra;
     return dispatch<true>(kind, p, B, (hipStream_t)stream);
+}
+
+extern "C" int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
+                                  ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    const ssm_view none = {nullptr, 0, 0, 0};
+    return ssm_conv2d_ups_add_fwd(a, C1, b, C2, w_packed, bias_packed, y, none, 1, B, H, W, Cout, slope, flags, stream);
 }

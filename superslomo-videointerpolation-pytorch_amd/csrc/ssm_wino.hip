@@ -65,6 +65,11 @@ struct WinoParams {
     float slope;
     int lrelu;
     int abl;             // diagnostics build only (make wabl): 1 no LDS-DMA in the loop, 2 no stores, 4 no B fetch/transform, 8 no A fetch, 16 no barrier
+    // optional pre-activation addend [B / adiv][Cout][H][W] (batch entry b reads entry b / adiv): the batch-independent part of the
+    // sum, e.g. the stage-1 half of stage 2's conv7a (cross skip), equal for the 7 t of a pair; added after the output transform
+    const float *add;
+    long long asb, asc;
+    int ash, adiv;
 };
 
 // WN cout blocks x (WTY x WTX) tile groups = 4 waves; a tile group = GTW x (32/GTW) Winograd tiles of 2x2 pixels
@@ -418,12 +423,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto st1 = [](const float *base, unsigned off_bytes, float val) {
         asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
     };
+    const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * half) * p.asc + (long long)py * p.ash + px : nullptr;
     auto store_all = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cu = cu0 + (r & 3) + 8 * (r >> 2);      // uniform; this lane's cout = cu + 4*half
             const bool cok = FULL || cu + 4 * half < p.Cout;
+            f32x2 ad0 = {0.f, 0.f}, ad1 = {0.f, 0.f};
+            if (addb) {
+                if (ok0 && cok) ad0 = *(const f32x2 *)(addb + (long long)cu * p.asc);
+                if (ok1 && cok) ad1 = *(const f32x2 *)(addb + (long long)cu * p.asc + p.ash);
+            }
             // Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]
             float s0[4], s1[4];
 #pragma unroll
@@ -431,8 +442,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 s0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
                 s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
             }
-            float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-            float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            float y00 = s0[0] + s0[1] + s0[2] + ad0[0], y01 = s0[1] - s0[2] - s0[3] + ad0[1];
+            float y10 = s1[0] + s1[1] + s1[2] + ad1[0], y11 = s1[1] - s1[2] - s1[3] + ad1[1];
             y00 = fmaxf(y00, y00 * sl);
             y01 = fmaxf(y01, y01 * sl);
             y10 = fmaxf(y10, y10 * sl);
@@ -765,17 +776,23 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
         auto st1 = [](const float *base, unsigned off_bytes, float val) {
             asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
         };
+        const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * half) * p.asc + (long long)py * p.ash + px : nullptr;
         auto store_all = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cu = cu0 + (r & 3) + 8 * (r >> 2);
                 const bool cok = FULL || cu + 4 * half < p.Cout;
+                f32x2 ad0 = {0.f, 0.f}, ad1 = {0.f, 0.f};
+                if (addb) {
+                    if (ok0 && cok) ad0 = *(const f32x2 *)(addb + (long long)cu * p.asc);
+                    if (ok1 && cok) ad1 = *(const f32x2 *)(addb + (long long)cu * p.asc + p.ash);
+                }
                 const f32x4 q = xb4[r * 64];
                 const float c00 = acc[0][r] + acc[1][r] + acc[2][r], c01 = acc[1][r] - acc[2][r] - acc[3][r];
                 const float c10 = acc[4][r] + acc[5][r] + acc[6][r], c11 = acc[5][r] - acc[6][r] - acc[7][r];
-                float y00 = (c00 + c10) + q[0], y01 = (c01 + c11) + q[1];
-                float y10 = c10 + q[2], y11 = c11 + q[3];
+                float y00 = (c00 + c10) + q[0] + ad0[0], y01 = (c01 + c11) + q[1] + ad0[1];
+                float y10 = c10 + q[2] + ad1[0], y11 = c11 + q[3] + ad1[1];
                 y00 = fmaxf(y00, y00 * sl);
                 y01 = fmaxf(y01, y01 * sl);
                 y10 = fmaxf(y10, y10 * sl);
@@ -998,9 +1015,26 @@ int wfill(WinoParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
     p.abl = 0;
+    p.add = nullptr;
+    p.asb = p.asc = 0;
+    p.ash = 0;
+    p.adiv = 1;
 #ifdef SSM_WINO_ABLATE
     if (const char *e = getenv("SSM_WINO_ABL")) p.abl = atoi(e);
 #endif
+    return SSM_OK;
+}
+
+int wset_add(WinoParams &p, ssm_view add, int add_div, int B) {
+    if (!add.ptr) return SSM_OK;
+    SSM_REQUIRE(add_div >= 1 && B % add_div == 0, "wino conv: the addend serves %d batch entries each, batch %d is no multiple", add_div, B);
+    SSM_REQUIRE((reinterpret_cast<size_t>(add.ptr) & 7) == 0 && add.sh % 2 == 0 && add.sc % 2 == 0 && add.sb % 2 == 0,
+                "wino conv: the addend view must be 8-byte aligned (read as row pairs)");
+    p.add = add.ptr;
+    p.asb = add.sb;
+    p.asc = add.sc;
+    p.ash = add.sh;
+    p.adiv = add_div;
     return SSM_OK;
 }
 
@@ -1039,8 +1073,9 @@ extern "C" int ssm_wino_pack_weights(const float *w, const float *bias, float *w
     return ssm::check_launch("ssm_wino_pack_weights");
 }
 
-extern "C" int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
-                                   ssm_view pool, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+extern "C" int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                       ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags,
+                                       void *stream) {
     int kind = 0, BN = 0, CK = 0;
     SSM_REQUIRE(B > 0, "wino conv: bad batch");
     const int rc = ssm_wino_plan(C1 + C2, Cout, B, H, W, 0, &kind, &BN, &CK);
@@ -1048,6 +1083,8 @@ extern "C" int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, con
     WinoParams p;
     const int rf = wfill(p, x1, C1, x2, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W);
     if (rf != SSM_OK) return rf;
+    const int ra = wset_add(p, add, add_div, B);
+    if (ra != SSM_OK) return ra;
     if (pool.ptr) {
         SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino conv: fused pool needs even H, W");
         p.pool = pool.ptr;
@@ -1058,8 +1095,14 @@ extern "C" int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, con
     return wdispatch<false>(kind, p, B, (hipStream_t)stream);
 }
 
-extern "C" int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
-                                       int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+extern "C" int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                   ssm_view pool, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    const ssm_view none = {nullptr, 0, 0, 0};
+    return ssm_wino_conv2d_add_fwd(x1, C1, x2, C2, w_packed, bias_packed, y, pool, none, 1, B, H, W, Cout, slope, flags, stream);
+}
+
+extern "C" int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                           ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
     int kind = 0, BN = 0, CK = 0;
     SSM_REQUIRE(B > 0, "wino conv_ups: bad batch");
     SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino conv_ups: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
@@ -1068,5 +1111,13 @@ extern "C" int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, c
     WinoParams p;
     const int rf = wfill(p, a, C1, b, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W / 2);
     if (rf != SSM_OK) return rf;
+    const int ra = wset_add(p, add, add_div, B);
+    if (ra != SSM_OK) return ra;
     return wdispatch<true>(kind, p, B, (hipStream_t)stream);
+}
+
+extern "C" int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                       int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    const ssm_view none = {nullptr, 0, 0, 0};
+    return ssm_wino_conv2d_ups_add_fwd(a, C1, b, C2, w_packed, bias_packed, y, none, 1, B, H, W, Cout, slope, flags, stream);
 }

@@ -67,6 +67,10 @@ def base_mode(mode):
     return "f32" if mode == "f32w" else mode
 
 
+# fp32 inference plans with several interpolation times per pair: convolve the t-independent input channels of stage 2's conv1a /
+# conv7a once per pair (UNetPlan.hoist); $SSM_HOIST=0 evaluates them per t like the reference
+HOIST_PAIR_PARTS = os.environ.get("SSM_HOIST", "1") != "0"
+
 # layers of an f32w plan that stay on the direct kernel ($SSM_WINO_SKIP=conv11b,...; "all" = none in Winograd form)
 WINO_SKIP = frozenset(n for n in os.environ.get("SSM_WINO_SKIP", "").split(",") if n)
 
@@ -97,7 +101,7 @@ class UNetPlan:
                 "t10a", "c10", "t11a", "c11", "tf")
 
     def __init__(self, stage, state_dict, B, H, W, device, cross_skip=True, mode="f32", fuse_upsample=True,
-                 bottleneck="CONV", seq_len=1, dec=None, twins=False, final4=None):
+                 bottleneck="CONV", seq_len=1, dec=None, twins=False, final4=None, hoist=None):
         """B = encoder batch.  With a recurrent bottleneck the batch holds `seq_len` windows of B/seq_len
         sequences in time-major order (index = window * S + sequence).  dec = (b0, Bd): the decoder runs on
         encoder batch entries [b0, b0+Bd) only (inference returns the middle window); None = all."""
@@ -117,6 +121,15 @@ class UNetPlan:
         self._Bcur = B
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.fuse_up = bool(fuse_upsample)      # concat+upsample fused into the consumer conv's loader (every mode)
+        # hoist = (B1, G): stage-2 inference plan whose batch holds G interpolation times for each of B1 pairs (entry p*G + i).  The
+        # parts of two convolutions' inputs that do not depend on t - the image channels 0:3 / 13:16 of conv1a's 16-channel input
+        # (flow_interpolation.py:364-367) and the stage-1 half of the cross-skip concat in front of conv7a (:98-101,224-231) - are
+        # convolved ONCE per pair (run_pair_parts) and enter the per-t launches as a pre-activation addend: the same sums in another
+        # order, 6/16 of conv1a's and 1/2 of conv7a's multiply-adds done once instead of G times (like stage 1 itself)
+        self.hoist = None
+        if hoist is not None and stage == 2 and mode == "f32" and self.fuse_up and not twins and hoist[1] > 1 and bottleneck == "CONV":
+            assert B == hoist[0] * hoist[1] and dec is None
+            self.hoist = (int(hoist[0]), int(hoist[1]))
         # final_conv (32 -> 4 / 5 channels) on the 4x4x1-MFMA kernel instead of a 32-cout tile (mode f32, inference plans);
         # stage 2 can then run the synthesis in its epilogue (run_decoder(synth=...))
         self.final4 = (mode == "f32" and self.fuse_up) if final4 is None else (bool(final4) and mode == "f32")
@@ -162,6 +175,10 @@ class UNetPlan:
         t["t11a"], t["c11"] = D(32, 1), D(32, 1)
         t["tf"] = D(32, 1)
         t["out"] = hb.Planes(Bd, cfin, H, W, device)     # final_conv always leaves fp32 planes (flows / logits)
+        if self.hoist:
+            t["pair1a"] = hb.Planes(self.hoist[0], 32, H, W, device)                  # conv1a's image-channel partial sums, per pair
+            if self.cross:
+                t["pair7a"] = hb.Planes(self.hoist[0], 512, H // 16, W // 16, device)  # conv7a's stage-1 half, per pair
         # (outer decoder levels run in the sub-pixel form on inference plans: _subpixel / ssm_amd.subpixel)
         self.f32 = {}
         if self.twins:
@@ -175,6 +192,7 @@ class UNetPlan:
         layers with ONE launch once the filters exist (hb.PackBatch over the parameters' storage); the first call, and any call
         with tensors at other addresses, goes layer by layer (it also chooses the power-of-two pre-scales on the host)."""
         self.sp, self._sd_for_sp = {}, state_dict        # sub-pixel decoder levels are rebuilt from the new weights on first use
+        self.pk_pair = {}
         tensors = []
         for name in self.layers:
             tensors += [state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")]]
@@ -208,7 +226,18 @@ class UNetPlan:
                 use_w = (self.wino and name != "final_conv" and name not in WINO_SKIP and "all" not in WINO_SKIP
                          and hb.wino_supported(ci, co, self.H // s, self.W // s, k))
                 cls = hb.PackedWino if use_w else hb.PackedConv
-                self.pk[name] = cls(w, b, nb, self.H // s, self.W // s, pool=name in POOLED, ups=ups)
+                if self.hoist and name == "conv1a":
+                    # per-t part: channels 3:13 (warped frames + estimated flows); per-pair part: the frames themselves in stage 1's
+                    # input order (I0 = channels 13:16, I1 = channels 0:3), no bias, no activation
+                    zb = torch.zeros_like(b)
+                    self.pk[name] = cls(w[:, 3:13].contiguous(), b, nb, self.H // s, self.W // s)
+                    self.pk_pair[name] = cls(torch.cat([w[:, 13:16], w[:, 0:3]], 1).contiguous(), zb, self.hoist[0], self.H // s, self.W // s)
+                elif self.hoist and name == "conv7a" and self.cross:
+                    zb = torch.zeros_like(b)
+                    self.pk[name] = cls(w[:, :512].contiguous(), b, nb, self.H // s, self.W // s, ups=ups)
+                    self.pk_pair[name] = cls(w[:, 512:].contiguous(), zb, self.hoist[0], self.H // s, self.W // s, ups=ups)
+                else:
+                    self.pk[name] = cls(w, b, nb, self.H // s, self.W // s, pool=name in POOLED, ups=ups)
         self._pack = None
         if batchable:
             entries = [(self.pk[name], state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")], False)
@@ -239,6 +268,9 @@ class UNetPlan:
             hb.conv2d_hl8(v(src), s.G * 8, v(src2) if src2 else None, c2, pk, None if final else v(dst),
                           y32, v(pool) if pool else None, self._Bcur, s.H, s.W,
                           lrelu=lrelu, fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
+        elif self.hoist and name == "conv1a":
+            fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
+            fn(v(src, c0=3), 10, None, 0, pk, v(dst), None, self._Bcur, s.H, s.W, lrelu=lrelu, add=self.t["pair1a"].view(), add_div=self.hoist[1])
         else:
             fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
             fn(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst), v(pool) if pool else None, self._Bcur, s.H, s.W, lrelu=lrelu)
@@ -295,6 +327,9 @@ class UNetPlan:
             hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
                               d.view(), self.f32[dst].view() if self.twins else None, self._Bcur, d.H, d.W, lrelu=True,
                               fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
+        elif self.hoist and name == "conv7a" and self.cross:
+            fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
+            fn(self._v(a), A.C, None, 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True, add=self.t["pair7a"].view(), add_div=self.hoist[1])
         else:
             fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
             fn(self._v(a), A.C, bview, Bp.C if Bp else 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True)
@@ -320,6 +355,31 @@ class UNetPlan:
                                                 hb.stream_ptr()))
         if tm is not None:
             e1.record()
+
+    def run_pair_parts(self, pair_planes, c6_planes):
+        """Hoisted plan: the per-pair partial sums of conv1a (over the frame pair, stage 1's 6-channel input planes) and of conv7a
+        (over the upsampled stage-1 bottleneck output), B1 entries each - launched once per pass, before the per-t stage-2 batch."""
+        B1 = self.hoist[0]
+        tm = self.timer
+        pk = self.pk_pair["conv1a"]
+        P = self.t["pair1a"]
+        if tm is not None:
+            e0, e1 = tm.span("conv", "s2.conv1a(pair)", 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * pk.k * pk.k)
+            e0.record()
+        fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
+        fn(pair_planes.view(), 6, None, 0, pk, P.view(), None, B1, P.H, P.W, lrelu=False)
+        if tm is not None:
+            e1.record()
+        if self.cross:
+            pk = self.pk_pair["conv7a"]
+            P = self.t["pair7a"]
+            if tm is not None:
+                e0, e1 = tm.span("conv", "s2.conv7a(pair)", 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * 9)
+                e0.record()
+            fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
+            fn(c6_planes.view(), 512, None, 0, pk, P.view(), B1, P.H, P.W, lrelu=False)
+            if tm is not None:
+                e1.record()
 
     def run(self, cross_planes=None, cross_broadcast=False, cross_b0=0, synth=None):
         """Input must already be in self.t['in'].  Returns the Planes of final_conv's output (decoder batch).
@@ -391,7 +451,7 @@ class UNetPlan:
 
     def _decode(self, c, uc, cross_planes, cross_broadcast, cross_b0, synth=None):
         if self.cross:
-            if cross_planes is None:
+            if cross_planes is None and not self.hoist:
                 raise RuntimeError("stage 2 was built with CROSS_SKIP but no stage-1 encoding was given")
             uc("conv7a", "c6", None, "u7", "t7a", b_planes=cross_planes, b_broadcast=cross_broadcast, b_b0=cross_b0)
         else:
@@ -540,7 +600,8 @@ class PairEngine:
         self.bcast = (B1 == 1 and B2 > 1)
         self.grouped = B1 > 1 and self.G > 1
         self.s1 = UNetPlan(1, sd1, B1, H, W, device, cross_skip, full_mode, fuse_upsample, twins=twins, final4=fuse_final)
-        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, full_mode, fuse_upsample, twins=twins, final4=fuse_final)
+        self.s2 = UNetPlan(2, sd2, B2, H, W, device, cross_skip, full_mode, fuse_upsample, twins=twins, final4=fuse_final,
+                           hoist=(B1, B2 // B1) if HOIST_PAIR_PARTS else None)
         self.fuse_final = self.s2.final4          # stage 2: final_conv + synthesis in one kernel (no 5-channel map)
         self.t_dev = torch.empty(B2, dtype=torch.float32, device=device)
         self.img = torch.empty(B2, 3, H, W, dtype=torch.float32, device=device)
@@ -548,7 +609,7 @@ class PairEngine:
         self.img6 = None        # the caller's [B1,6,H,W] pairs, read in place by the gather kernels
         self.est = torch.empty(B2, 4, H, W, dtype=torch.float32, device=device) if self.hl8 else None   # Ft1^ | Ft0^
         self.c6x = None
-        if self.grouped and self.cross:     # stage-1 bottleneck output repeated G times per pair: conv7a's second source
+        if self.grouped and self.cross and not self.s2.hoist:     # stage-1 bottleneck output repeated G times per pair: conv7a's second source
             c6 = self.s1.t["c6"]
             self.c6x = (hb.HPlanes(B2, c6.C, c6.H, c6.W, device, q8=self.q8) if self.hl8 else hb.Planes(B2, c6.C, c6.H, c6.W, device))
 
@@ -577,7 +638,7 @@ class PairEngine:
 
     def _cross_planes(self):
         """(planes, broadcast) of conv7a's cross-skip source for the stage-2 batch."""
-        if not self.cross:
+        if not self.cross or self.s2.hoist:
             return None, False
         if not self.grouped:
             return self.s1.t["c6"], self.bcast
@@ -621,6 +682,8 @@ class PairEngine:
         if tm is not None:
             e1.record()
         cross, cbc = self._cross_planes()
+        if self.s2.hoist:
+            self.s2.run_pair_parts(self.s1.t["in"], self.s1.t["c6"])
 
         def in16_view(b0):     # the synthesis reads channels 6..9 of its `in16` argument: in the split modes they alias the 4 est-flow planes
             if self.hl8:

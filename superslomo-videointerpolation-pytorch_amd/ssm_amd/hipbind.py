@@ -50,6 +50,14 @@ SIGNATURES = {
     "ssm_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int,
                                 _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_conv2d_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int,
+                                    _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_conv2d_ups_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int,
+                                        _c_int, _c_float, _c_int, _vp]),
+    "ssm_wino_conv2d_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int,
+                                         _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_wino_conv2d_ups_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int,
+                                             _c_int, _c_float, _c_int, _vp]),
     "ssm_wino_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino_force_kind": (_c_int, [_c_int]),
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
@@ -269,24 +277,26 @@ class PackedConv:
                                    self.cin, self.cin_p, self.k, self.bn, stream_ptr()))
 
 
-def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1):
+def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+    """add: optional pre-activation addend view [B / add_div, Cout, H, W] (batch entry b reads entry b // add_div)."""
     lib = load()
     assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
     assert (pk.bn, pk.ck) == conv_plan(pk.k, c1 + c2, pk.cout, B, H, W, pool is not None)[1:], \
         "filter was packed for another tile configuration (batch/size/pool changed)"
-    check(lib.ssm_conv2d_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
-                             pool if pool is not None else NULL_VIEW, B, H, W, pk.cout, pk.k, slope,
-                             SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+    check(lib.ssm_conv2d_add_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
+                                 pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, H, W,
+                                 pk.cout, pk.k, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
-def conv2d_ups(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1):
+def conv2d_ups(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
     """conv3x3(upsample2x(cat[a, b])) in exact fp32: a, b LOW-res padded-plane views, H, W the OUTPUT size."""
     lib = load()
     assert pk.k == 3 and pk.cin_p == c1 + c2, "packed 3x3 filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
     assert (pk.bn, pk.ck) == conv_plan(3, c1 + c2, pk.cout, B, H, W, False, True)[1:], \
         "filter was packed for another tile configuration (batch/size changed, or not packed with ups=True)"
-    check(lib.ssm_conv2d_ups_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y, B, H, W,
-                                 pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+    check(lib.ssm_conv2d_ups_add_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
+                                     add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
+                                     SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
 # ---- 3x3 convolution as Winograd F(2x2,3x3) in fp32 (csrc/ssm_wino.hip) ------------------------------------
@@ -328,22 +338,23 @@ class PackedWino:
                                         self.bn, stream_ptr()))
 
 
-def conv2d_wino(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1):
+def conv2d_wino(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
     assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W, False)[1:], "filter was packed for another tile configuration"
-    check(lib.ssm_wino_conv2d_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
-                                  pool if pool is not None else NULL_VIEW, B, H, W, pk.cout, slope,
-                                  SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+    check(lib.ssm_wino_conv2d_add_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
+                                      pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, H, W,
+                                      pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
-def conv2d_ups_wino(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1):
+def conv2d_ups_wino(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
     """conv3x3(upsample2x(cat[a, b])) in the Winograd form: a, b LOW-res padded-plane views, H, W the OUTPUT size."""
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
     assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W, True)[1:], "filter was packed for another tile configuration"
-    check(lib.ssm_wino_conv2d_ups_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y, B, H, W,
-                                      pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+    check(lib.ssm_wino_conv2d_ups_add_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
+                                          add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
+                                          SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
 # ---- HL8 (fp16 hi/lo) tensors and the fp16-MFMA convolution ------------------------------------

@@ -176,3 +176,34 @@ def test_final_conv_fused_synthesis_vs_oracle(dev):
     assert torch.equal(y3b, y3)
     v0 = 1 - torch.sigmoid(out5[:, 0:1])
     assert _err(aux[:, 4:5].cpu(), v0) < 1e-5 and _err(aux[:, 0:2].cpu(), in16[:, 6:8] + out5[:, 1:3]) < 5e-5
+
+
+@pytest.mark.parametrize("kind,k", [("K7", 7), ("K7G", 7), ("K3N64", 3), ("K3N128G", 3), ("K5", 5)])
+def test_direct_conv_pre_activation_addend(dev, kind, k):
+    """y = act(conv(x) + bias + add[b // add_div]) (ssm_conv2d_add_fwd / ssm_conv2d_ups_add_fwd): the accumulators start from the addend.
+    Stage 2 uses it for the image channels of conv1a (7x7, 10 of 16 input channels per t, the other 6 once per pair)."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(500 + KINDS.index(kind))
+    _force(kind)
+    B, div, cin, cout = 4, 2, 10, 64
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    cases = [(False, (22, 44))] + ([(True, (11, 23))] if k == 3 else [])
+    for ups, (h, wd) in cases:
+        H, W = (2 * h, 2 * wd) if ups else (h, wd)
+        x = torch.randn(B, 16, h, wd, generator=g)                    # the convolution reads channels 3:13 of a 16-channel tensor
+        add = torch.randn(B // div, cout, H, W, generator=g)
+        xs = x[:, 3:13]
+        xin = O.upsample2x_bilinear(xs) if ups else xs
+        z = O.conv2d(xin, w, bias) + add.repeat_interleave(div, 0)
+        want = torch.where(z >= 0, z, z * 0.1)
+        px = hb.Planes(B, 16, h, wd, dev).load(x.to(dev))
+        pa = hb.Planes(B // div, cout, H, W, dev).load(add.to(dev))
+        y = hb.Planes(B, cout, H, W, dev)
+        pk = hb.PackedConv(w.to(dev), bias.to(dev), B, H, W, ups=ups)
+        if ups:
+            hb.conv2d_ups(px.view(c0=3), cin, None, 0, pk, y.view(), B, H, W, add=pa.view(), add_div=div)
+        else:
+            hb.conv2d(px.view(c0=3), cin, None, 0, pk, y.view(), None, B, H, W, add=pa.view(), add_div=div)
+        assert _err(y.to_nchw().cpu(), want) < 5e-5, "%s ups=%d: %.3e" % (kind, ups, _err(y.to_nchw().cpu(), want))

@@ -111,3 +111,32 @@ def test_wino_deep_channels_and_scale_invariance(dev):
         pk = hb.PackedWino((w * sw).to(dev), (bias * sx * sw).to(dev), B, H, W)
         hb.conv2d_wino(px.view(), cin, None, 0, pk, y.view(), None, B, H, W)
         assert _err(y.to_nchw().cpu(), want) < 5e-5 * sx * sw, "scale %g x %g: %.3e" % (sx, sw, _err(y.to_nchw().cpu(), want))
+
+
+@pytest.mark.parametrize("kind", ["W64A", "V32H", "V64G"])
+def test_wino_pre_activation_addend(dev, kind):
+    """y = act(conv(x) + bias + add[b // add_div]) (ssm_wino_conv2d_add_fwd / ssm_wino_conv2d_ups_add_fwd): the form stage 2 uses for the
+    t-independent half of conv7a's input (one addend entry per pair serves the G interpolation times of that pair)."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(300 + KINDS.index(kind))
+    _force(kind)
+    B, div, cin, cout = 6, 3, 16, 64
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    for ups, (h, wd) in ((False, (22, 44)), (True, (11, 23))):
+        H, W = (2 * h, 2 * wd) if ups else (h, wd)
+        x = torch.randn(B, cin, h, wd, generator=g)
+        add = torch.randn(B // div, cout, H, W, generator=g)
+        xin = O.upsample2x_bilinear(x) if ups else x
+        z = O.conv2d(xin, w, bias) + add.repeat_interleave(div, 0)
+        want = torch.where(z >= 0, z, z * 0.1)
+        px = hb.Planes(B, cin, h, wd, dev).load(x.to(dev))
+        pa = hb.Planes(B // div, cout, H, W, dev).load(add.to(dev))
+        y = hb.Planes(B, cout, H, W, dev)
+        pk = hb.PackedWino(w.to(dev), bias.to(dev), B, H, W, ups=ups)
+        if ups:
+            hb.conv2d_ups_wino(px.view(), cin, None, 0, pk, y.view(), B, H, W, add=pa.view(), add_div=div)
+        else:
+            hb.conv2d_wino(px.view(), cin, None, 0, pk, y.view(), None, B, H, W, add=pa.view(), add_div=div)
+        assert _err(y.to_nchw().cpu(), want) < 5e-5, "%s ups=%d: %.3e" % (kind, ups, _err(y.to_nchw().cpu(), want))
