@@ -186,15 +186,16 @@ def test_direct_conv_pre_activation_addend(dev, kind, k):
     from ssm_amd import hipbind as hb
     g = torch.Generator().manual_seed(500 + KINDS.index(kind))
     _force(kind)
-    B, div, cin, cout = 4, 2, 10, 64
+    B, div, cout = 4, 2, 64
+    cin = 12 if k == 3 else 10          # whole channel chunks of the tile configuration (3x3: 4, 5x5 / 7x7: 2)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
     bias = torch.randn(cout, generator=g) * 0.1
     cases = [(False, (22, 44))] + ([(True, (11, 23))] if k == 3 else [])
     for ups, (h, wd) in cases:
         H, W = (2 * h, 2 * wd) if ups else (h, wd)
-        x = torch.randn(B, 16, h, wd, generator=g)                    # the convolution reads channels 3:13 of a 16-channel tensor
+        x = torch.randn(B, 16, h, wd, generator=g)                    # the convolution reads channels 3:3+cin of a 16-channel tensor
         add = torch.randn(B // div, cout, H, W, generator=g)
-        xs = x[:, 3:13]
+        xs = x[:, 3:3 + cin]
         xin = O.upsample2x_bilinear(xs) if ups else xs
         z = O.conv2d(xin, w, bias) + add.repeat_interleave(div, 0)
         want = torch.where(z >= 0, z, z * 0.1)
