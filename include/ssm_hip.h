@@ -132,7 +132,9 @@ int ssm_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_pa
  * evaluates stage 2 once per interpolation time t (evaluate_interpolation_results.py:234-242), but the image channels of its
  * first convolution's 16-channel input (flow_interpolation.py:364-367: channels 0:3 and 13:16) and the stage-1 half of the
  * cross-skip concat in front of conv7a (flow_interpolation.py:98-101,224-231) are the same for every t of a pair: their
- * partial sums are computed once per pair by a plain call and enter the per-t launches here.  add.ptr NULL = the plain form. */
+ * partial sums are computed once per pair by a plain call and enter the per-t launches here.  add.ptr NULL = the plain form.
+ * The direct kernels read the addend unpredicated: Cout must be a multiple of the plan's BN and add a padded-plane view
+ * (readable frame / tail slack for the tile overshoot); the Winograd kernels predicate their reads.                       */
 int ssm_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
                        ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, int k, float slope, int flags,
                        void *stream);

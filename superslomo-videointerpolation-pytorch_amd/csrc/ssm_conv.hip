@@ -729,10 +729,11 @@ extern "C" int ssm_pack_weights(const float *w, const float *bias, float *wp, fl
 }
 
 namespace {
-int set_add(ConvParams &p, ssm_view add, int add_div, int B) {
+int set_add(ConvParams &p, ssm_view add, int add_div, int B, int BN) {
     if (!add.ptr) return SSM_OK;
     SSM_REQUIRE(add_div >= 1 && B % add_div == 0, "conv: the addend serves %d batch entries each, batch %d is no multiple", add_div, B);
-    SSM_REQUIRE(p.Cout % 32 == 0, "conv: the addend form needs Cout to be a multiple of 32 (got %d)", p.Cout);
+    // the kernel loads the addend for every cout of its block without predicates: no padded couts allowed
+    SSM_REQUIRE(p.Cout % BN == 0, "conv: the addend form needs Cout (%d) to be a multiple of the cout block (%d) of the tile configuration", p.Cout, BN);
     SSM_REQUIRE(4LL * (4 * add.sc + (long long)(p.H + 64) * add.sh) < 0x7fffffffLL, "conv: addend plane too large for 32-bit offsets");
     p.add = add.ptr;
     p.asb = add.sb;
@@ -753,7 +754,7 @@ extern "C" int ssm_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, cons
     ConvParams p;
     const int rf = fill_common(p, x1, C1, x2, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W);
     if (rf != SSM_OK) return rf;
-    const int ra = set_add(p, add, add_div, B);
+    const int ra = set_add(p, add, add_div, B, BN);
     if (ra != SSM_OK) return ra;
     if (pool.ptr) {
         SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv: fused pool needs even H, W");
@@ -782,7 +783,7 @@ extern "C" int ssm_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, co
     ConvParams p;
     const int rf = fill_common(p, a, C1, b, C2, w_packed, bias_packed, y, H, W, Cout, slope, flags, CK, W / 2);
     if (rf != SSM_OK) return rf;
-    const int ra = set_add(p, add, add_div, B);
+    const int ra = set_add(p, add, add_div, B, BN);
     if (ra != SSM_OK) return ra;
     return dispatch<true>(kind, p, B, (hipStream_t)stream);
 }

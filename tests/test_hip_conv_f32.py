@@ -186,7 +186,7 @@ def test_direct_conv_pre_activation_addend(dev, kind, k):
     from ssm_amd import hipbind as hb
     g = torch.Generator().manual_seed(500 + KINDS.index(kind))
     _force(kind)
-    B, div, cout = 4, 2, 64
+    B, div, cout = 4, 2, 128         # a whole number of cout blocks for every tile configuration (the addend is loaded unpredicated)
     cin = 12 if k == 3 else 10          # whole channel chunks of the tile configuration (3x3: 4, 5x5 / 7x7: 2)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
     bias = torch.randn(cout, generator=g) * 0.1
