@@ -39,7 +39,7 @@ def test_every_wino_configuration_plain_cat_pool(dev, kind):
     from ssm_amd import hipbind as hb
     g = torch.Generator().manual_seed(KINDS.index(kind))
     _force(kind)
-    for B, H, W, c1, c2, cout in ((2, 22, 44, 16, 8, 40), (1, 23, 40, 32, 0, 64), (3, 6, 2, 8, 8, 32), (1, 46, 80, 24, 8, 136)):
+    for B, H, W, c1, c2, cout in ((2, 22, 44, 16, 8, 40), (1, 23, 40, 32, 0, 64), (3, 6, 2, 8, 8, 32), (1, 46, 80, 24, 8, 136), (1, 12, 20, 8, 0, 32)):     # the last: ONE chunk
         a = torch.randn(B, c1, H, W, generator=g)
         b = torch.randn(B, max(c2, 1), H, W, generator=g)
         w = torch.randn(cout, c1 + c2, 3, 3, generator=g) / ((c1 + c2) * 9) ** 0.5
