@@ -14,8 +14,10 @@ The headline (`value`, `dtype`, `roofline`) is fp32 arithmetic throughout - ever
 v_mfma_f32_32x32x2_f32 / fp32 VALU (north_star: "within 1e-3 ... in fp32"; SURVEY 8d roof = fp32 MFMA 157.3 TFLOP/s) - in mode
 `f32w`: the 3x3 convolutions (71 % of the FLOPs) are evaluated as Winograd F(2x2,3x3), which needs 2.25x fewer multiplies than
 the direct form for the same result (what cuDNN - `cudnn.benchmark = True`, scripts/main.py:296 of the reference - and MIOpen
-choose for 3x3 fp32 layers too); the 7x7 / 5x5 / final convolutions run in the direct form.  Mode `f32` (EVERY convolution in
-the direct form, an fmaf chain per output) is reported beside it under `modes`, and so are the split-fp16 modes (narrower than
+choose for 3x3 fp32 layers too); the 7x7 / 5x5 / final convolutions run in the direct form.  In both fp32 modes the partial sums
+of stage 2's conv1a / conv7a over their t-independent input channels (the frames; the stage-1 half of the cross-skip concat) are
+computed once per pair instead of once per t - the second step of the stage-1 hoisting SURVEY Appendix B proposes ($SSM_HOIST=0
+turns it off).  Mode `f32` (EVERY convolution in the direct form, an fmaf chain per output) is reported beside it under `modes`, and so are the split-fp16 modes (narrower than
 fp32: options, not the configuration the metric is quoted on), each with its own frame rate, roofline and parity.
 
 Objects on the JSON line:
@@ -27,7 +29,7 @@ Objects on the JSON line:
                 traffic = HBM bytes of those launches per pair from rocprofv3 --pmc passes (profiles/).
                 `achieved` / `frac` count ALGORITHMIC (direct-form) FLOP as SURVEY 8d defines them, so in mode f32w they can
                 exceed the matrix peak; `issued` = the multiply-adds the matrix cores actually execute (Winograd layers:
-                direct FLOP / 2.25) / the same time - the utilisation of the fp32 MFMA pipe, always <= 1.
+                direct FLOP / 2.25; hoisted channels once per pair) / the same time - the utilisation of the fp32 MFMA pipe, <= 1.
   roofline_warp the HBM-bound gather kernels (compute_inputs + synthesis): algorithmic bytes (104 + 72 B/px per t)
                 / their event-timed duration; peak 8 TB/s.
   modes         f32 (direct form everywhere) / f16x3 / f16f8 (split fp16 (+fp8), narrower than fp32): frames/s, roofline, parity on the same pairs.
