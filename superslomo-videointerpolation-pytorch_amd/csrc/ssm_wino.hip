@@ -746,20 +746,27 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
 #endif
     __syncthreads();                               // every LDS read of the last chunk is complete: the stages become the exchange buffer
+    // Each wave turns its two frequency rows into its share of the two output rows of every cout: 4 values per accumulator register r,
+    //   half 0 (rows 0, 1 of M): (c0 + c1 | c1),   half 1 (rows 2, 3): (c2 | -c2 - c3),   c_i = (m_i0 + m_i1 + m_i2 | m_i1 - m_i2 - m_i3),
+    // and the two shares add up to Y.  The work after the exchange (sum, addend, activation, stores) is split between the two waves of a
+    // pair: half 0 finishes registers 0..7, half 1 registers 8..15 - each wave sends the shares of the OTHER wave's registers through
+    // LDS.  (One wave finishing all 16 while its partner idles made the epilogue twice as long; on the 32-channel full-resolution
+    // layers the epilogue is a quarter of the workgroup's time.)
+    auto share = [&](int r) -> f32x4 {
+        const float ca0 = acc[0][r] + acc[1][r] + acc[2][r], ca1 = acc[1][r] - acc[2][r] - acc[3][r];
+        const float cb0 = acc[4][r] + acc[5][r] + acc[6][r], cb1 = acc[5][r] - acc[6][r] - acc[7][r];
+        if constexpr (FH == 0) return f32x4{ca0 + cb0, ca1 + cb1, cb0, cb1};
+        else return f32x4{ca0, ca1, -ca0 - cb0, -ca1 - cb1};
+    };
+    constexpr int RO = FH == 0 ? 0 : 8;             // registers this wave finishes; it sends the other eight
     f32x4 *xb4 = (f32x4 *)lds + (wb * 16) * 64 + lane;       // [block][r][lane] quads
-    if constexpr (FH == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // rows 2, 3 of M: c = (m0 + m1 + m2 | m1 - m2 - m3) per row;  contribution to Y rows: (c2 | -c2 - c3)
-            const float c20 = acc[0][r] + acc[1][r] + acc[2][r], c21 = acc[1][r] - acc[2][r] - acc[3][r];
-            const float c30 = acc[4][r] + acc[5][r] + acc[6][r], c31 = acc[5][r] - acc[6][r] - acc[7][r];
-            f32x4 q = {c20, c21, -c20 - c30, -c21 - c31};
-            xb4[r * 64] = q;
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int r = 8 - RO; r < 16 - RO; ++r) {
+        xb4[r * 64] = share(r);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    if constexpr (FH == 0) {
+    {
         const int px = x0 + (wtx * C::GTW + txl) * 2, py = y0 + (wty * C::GTH + tyl) * 2;
         const float sl = p.lrelu ? p.slope : 1.f;
         float *dstb = p.dst + (long long)b * p.dsb;
@@ -780,7 +787,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
         auto store_all = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = RO; r < RO + 8; ++r) {
                 const int cu = cu0 + (r & 3) + 8 * (r >> 2);
                 const bool cok = FULL || cu + 4 * half < p.Cout;
                 f32x2 ad0 = {0.f, 0.f}, ad1 = {0.f, 0.f};
@@ -789,10 +796,9 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                     if (ok1 && cok) ad1 = *(const f32x2 *)(addb + (long long)cu * p.asc + p.ash);
                 }
                 const f32x4 q = xb4[r * 64];
-                const float c00 = acc[0][r] + acc[1][r] + acc[2][r], c01 = acc[1][r] - acc[2][r] - acc[3][r];
-                const float c10 = acc[4][r] + acc[5][r] + acc[6][r], c11 = acc[5][r] - acc[6][r] - acc[7][r];
-                float y00 = (c00 + c10) + q[0] + ad0[0], y01 = (c01 + c11) + q[1] + ad0[1];
-                float y10 = c10 + q[2] + ad1[0], y11 = c11 + q[3] + ad1[1];
+                const f32x4 m = share(r);
+                float y00 = m[0] + q[0] + ad0[0], y01 = m[1] + q[1] + ad0[1];
+                float y10 = m[2] + q[2] + ad1[0], y11 = m[3] + q[3] + ad1[1];
                 y00 = fmaxf(y00, y00 * sl);
                 y01 = fmaxf(y01, y01 * sl);
                 y10 = fmaxf(y10, y10 * sl);
@@ -881,7 +887,8 @@ double estimate_wino(const WKindInfo &ki, int Cin, int Cout, int B, int H, int W
     const double mf = (double)(Cin / 2) * 16.0 * 64.0;
     const double chunks = (double)Cin / ki.ck;
     if (ki.nblk == 4) return (double)((nwg + 255) / 256) * (mf * 1.25 + 22000.0 + (ups ? 900.0 * chunks : 0.0));
-    const double per = mf * 1.3 + 6000.0 + (ups ? 500.0 * chunks : 0.0);
+    // (the 8x32-pixel tile measures ~1 % ahead of the 4x64 one where both divide the map: shorter patch rows per DMA piece)
+    const double per = (mf * 1.3 + 6000.0 + (ups ? 500.0 * chunks : 0.0)) * ((ki.th == 8 && ki.tw == 32) ? 0.995 : 1.0);
     const long long full = nwg / 512, rem = nwg % 512;
     double t = (double)full * per;
     if (rem) t += rem > 256 ? per : mf * 0.5 * 1.25 + 16000.0 + (ups ? 500.0 * chunks : 0.0);     // a last round of lone workgroups
