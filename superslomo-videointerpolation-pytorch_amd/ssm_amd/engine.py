@@ -145,7 +145,7 @@ class UNetPlan:
         self.refresh_weights(state_dict, check_shapes=True)
         self.rnn = None
         if bottleneck != "CONV":
-            self.rnn = RecurrentBottleneck(bottleneck, state_dict, B // seq_len, seq_len, H // 32, W // 32, device, mode)   # gate convs: direct form
+            self.rnn = RecurrentBottleneck(bottleneck, state_dict, B // seq_len, seq_len, H // 32, W // 32, device, self.mode_name)
         Bd = self.Bd
         if self.hl8:
             P = lambda c, s: hb.HPlanes(B, c, H // s, W // s, device, q8=self.q8)  # noqa: E731
@@ -485,6 +485,7 @@ class RecurrentBottleneck:
     def __init__(self, kind, state_dict, S, T, h, w, device, mode="f32", prefix="conv6."):
         assert kind in ("CLSTM", "CGRU")
         self.kind, self.S, self.T, self.h, self.w, self.device = kind, S, T, h, w, device
+        self.wino = mode == "f32w"          # gate convolutions (3x3, 512 / 256 -> 1024 / 512 channels) in the Winograd form
         mode = base_mode(mode)
         self.mode, self.hl8, self.prefix = mode, mode != "f32", prefix
         self.q8 = mode == "f16f8"
@@ -506,7 +507,8 @@ class RecurrentBottleneck:
     def _pack(self, w, b, batch):
         if self.hl8:
             return hb.PackedConv16(w.contiguous(), b, self.w, q8=self.q8)
-        return hb.PackedConv(w.contiguous(), b, batch, self.h, self.w)
+        cls = hb.PackedWino if (self.wino and hb.wino_supported(w.shape[1], w.shape[0], self.h, self.w, 3)) else hb.PackedConv
+        return cls(w.contiguous(), b, batch, self.h, self.w)
 
     def refresh_weights(self, state_dict):
         dev = self.device
@@ -529,7 +531,8 @@ class RecurrentBottleneck:
             hb.conv2d_hl8(src_view, cin, None, 0, pk, None, dst_view, None, batch, self.h, self.w, lrelu=False,
                           fast=self.mode == "f16")
         else:
-            hb.conv2d(src_view, cin, None, 0, pk, dst_view, None, batch, self.h, self.w, lrelu=False)
+            fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
+            fn(src_view, cin, None, 0, pk, dst_view, None, batch, self.h, self.w, lrelu=False)
 
     def _hview(self, planes, ch, slot):
         """View of `hid` channels starting at channel ch of slot `slot` in the layout the convolutions read."""

@@ -77,7 +77,7 @@ def test_cell_kernels_vs_formulas(dev):
 
 
 @pytest.mark.parametrize("kind", ["CLSTM", "CGRU"])
-@pytest.mark.parametrize("mode", ["f32", "f16x3", "f16f8"])
+@pytest.mark.parametrize("mode", ["f32", "f32w", "f16x3", "f16f8"])
 def test_bottleneck_engine_vs_oracle(dev, kind, mode):
     from ssm_amd import hipbind as hb
     from ssm_amd.engine import RecurrentBottleneck
@@ -88,7 +88,7 @@ def test_bottleneck_engine_vs_oracle(dev, kind, mode):
     xs = [torch.randn(S, 512, h, w) * 0.3 for _ in range(T)]
     want = O.unet_bottleneck_recurrent(sd, kind, xs)
     rb = RecurrentBottleneck(kind, sd, S, T, h, w, dev, mode)
-    P = (lambda *a: hb.HPlanes(*a, q8=mode == "f16f8")) if mode != "f32" else hb.Planes
+    P = (lambda *a: hb.HPlanes(*a, q8=mode == "f16f8")) if mode not in ("f32", "f32w") else hb.Planes
     x, out = P(T * S, 512, h, w, dev), P(T * S, 512, h, w, dev)
     x.load(torch.cat(xs, 0).to(dev))
     rb.run(x, out)
@@ -147,7 +147,7 @@ def test_stage_models_windows(dev, kind):
 
 
 @pytest.mark.parametrize("kind", ["CLSTM", "CGRU"])
-@pytest.mark.parametrize("precision", ["f16f8", "f16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16f8", "f16x3", "f32", "f32w"])
 def test_full_model_recurrent_vs_oracle(dev, kind, precision):
     from ssm_amd.weights import synthetic_frames, synthetic_state_dict
     m = _model(kind, dev, precision)
@@ -239,7 +239,7 @@ def test_recurrent_full_model_trains(dev):
     assert hist[-1] < hist[0], hist
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16f8"])
+@pytest.mark.parametrize("precision", ["f32", "f32w", "f16f8"])
 def test_recurrent_config4_at_720p(dev, precision):
     """BASELINE config 4 at its workload size: superslomo_recurrent.ini (N_FRAMES = 4, ConvBLSTM bottleneck) on a
     1280x720 clip (padded 736x1280): (a) deterministic, (b) the hoisted 7-t evaluation (stage 1 + its BLSTM once per clip,
@@ -263,4 +263,4 @@ def test_recurrent_config4_at_720p(dev, precision):
         want, _ = O.full_model_infer_windows(p1, p2, x, torch.full((1, 3, 1, 1, 1), 0.5), True, "CLSTM")
     err = float((a[3:4].cpu() - want).abs().max())
     print("recurrent 720p [%s]: max|HIP - oracle| at t=0.5 = %.3e" % (precision, err))
-    assert err < (5e-4 if precision == "f32" else 6e-4), err
+    assert err < (6e-4 if precision == "f16f8" else 5e-4), err
