@@ -678,9 +678,13 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                 if (!last) {
                     if (WS_BFIRST) {
                         if (f < 3) {
-                            ldB(bi, 2 * f);
-                            ldB(bi, 2 * f + 1);
-                        } else if (f < 5) ldA(ai, f - 3, nxt);
+                            if (!WABL(4)) {
+                                ldB(bi, 2 * f);
+                                ldB(bi, 2 * f + 1);
+                            }
+                        } else if (f < 5) {
+                            if (!WABL(8)) ldA(ai, f - 3, nxt);
+                        }
                     } else {
                         if (f < 2) ldA(ai, f, nxt);
                         else if (f < 5) {
@@ -688,8 +692,10 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                             ldB(bi, 2 * (f - 2) + 1);
                         }
                     }
-                    if (f == 6) transform_rows();
-                    if (f == 7) transform_cols(nxt);
+                    if (!WABL(4)) {
+                        if (f == 6) transform_rows();
+                        if (f == 7) transform_cols(nxt);
+                    }
                 } else if (more) {
                     if (f == 0 && !WABL(16)) {
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -698,10 +704,14 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                     if (WS_BFIRST) {
                         if (f >= 1 && f < 4) {
                             if constexpr (!UPS) {
-                                ldB(bi, 2 * (f - 1));
-                                ldB(bi, 2 * (f - 1) + 1);
+                                if (!WABL(4)) {
+                                    ldB(bi, 2 * (f - 1));
+                                    ldB(bi, 2 * (f - 1) + 1);
+                                }
                             }
-                        } else if (f >= 4 && f < 6) ldA(ai, f - 4, nxt);
+                        } else if (f >= 4 && f < 6) {
+                            if (!WABL(8)) ldA(ai, f - 4, nxt);
+                        }
                     } else {
                         if (f >= 1 && f < 3) ldA(ai, f - 1, nxt);
                         else if (f >= 3 && f < 6) {
@@ -720,7 +730,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                         }
                     }
                     if constexpr (!UPS) {
-                        if (f == 7) {
+                        if (f == 7 && !WABL(4)) {
                             transform_rows();
                             transform_cols(nxt);
                         }
