@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: shader clock while one conv layer runs back to back (is the matrix pipe clock- or issue-limited?).
-usage: python tools/clock_under_load.py [--f32] [--b N] [layer ...]   (default: a few stage-2 layers at B=7, 736x1280;
---f32: the fp32-MFMA kernel of ssm_conv.hip instead of the fp16 split kernels)"""
+usage: python tools/clock_under_load.py [--f32 | --wino] [--b N] [layer ...]   (default: a few stage-2 layers at B=7, 736x1280;
+--f32: the fp32-MFMA kernel of ssm_conv.hip instead of the fp16 split kernels; --wino: the Winograd F(2x2,3x3) fp32 kernels of
+ssm_wino.hip on the 3x3 layers)"""
 import ctypes
 import os
 import sys
@@ -44,7 +45,8 @@ def measure(fn, ms=30.0):
 def main():
     argv = sys.argv[1:]
     f32 = "--f32" in argv
-    argv = [a for a in argv if a != "--f32"]
+    wino = "--wino" in argv
+    argv = [a for a in argv if a not in ("--f32", "--wino")]
     B = 7
     if "--b" in argv:
         i = argv.index("--b")
@@ -60,6 +62,20 @@ def main():
             continue
         s = layer_scale(name)
         h, w = H // s, W // s
+        if wino:
+            if k != 3 or cout < 32:
+                continue
+            pk = hb.PackedWino(torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5, torch.zeros(cout, device=dev), B, h, w)
+            x = hb.Planes(B, cin, h, w, dev)
+            x.interior.normal_()
+            y = hb.Planes(B, cout, h, w, dev)
+            fn = lambda: hb.conv2d_wino(x.view(), cin, None, 0, pk, y.view(), None, B, h, w)  # noqa: E731
+            ghz, ms = measure(fn)
+            gf = 2.0 * B * h * w * cout * cin * 9 / 1e9
+            iss = gf / ms * 16.0 / 36.0
+            print("%-8s wino   %.3f ms  %6.1f TF algorithmic  %6.1f TF issued  clock %.3f GHz  -> MFMA busy %.0f %% of the pipe at that clock"
+                  % (name, ms, gf / ms, iss, ghz, 100 * iss / (157.3 * ghz / 2.4)))
+            continue
         if f32:
             pk = hb.PackedConv(torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5, torch.zeros(cout, device=dev), B, h, w)
             x = hb.Planes(B, cin, h, w, dev)
