@@ -152,6 +152,7 @@ int ssm_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *
  * ssm_wino_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/BN][Cin][4][BN][4] (+ bias padded to BN).          */
 int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK);
 int ssm_wino_force_kind(int kind);       /* tests / tuning only (-1 = automatic); returns the number of configurations */
+int ssm_wino_deep_ring(int on);          /* process-wide: let the 4-stage DMA-ring configurations take part in ssm_wino_plan; returns the old setting */
 size_t ssm_wino_packed_weight_floats(int Cout, int Cin, int BN);
 int ssm_wino_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin,
                           int BN, void *stream);

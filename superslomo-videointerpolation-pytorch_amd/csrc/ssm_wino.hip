@@ -74,9 +74,10 @@ struct WinoParams {
 
 // WN cout blocks x (WTY x WTX) tile groups = 4 waves; a tile group = GTW x (32/GTW) Winograd tiles of 2x2 pixels
 // NBLK = 4: wino_kernel (a wave = one block, all 16 frequencies); NBLK = 2: wino2_kernel (a wave = one block, 8 frequencies)
-template <int WN_, int WTY_, int WTX_, int GTW_, int CK_, int NBLK_ = 4>
+template <int WN_, int WTY_, int WTX_, int GTW_, int CK_, int NBLK_ = 4, int NST_ = 2>
 struct WCfg {
     static constexpr int WN = WN_, WTY = WTY_, WTX = WTX_, GTW = GTW_, GTH = 32 / GTW_, CK = CK_, NBLK = NBLK_;
+    static constexpr int NST = NST_;           // LDS stages of the DMA ring (form 2; form 1 is double-buffered)
     static constexpr int BN = 32 * WN;
     static constexpr int TH = 2 * GTH * WTY, TW = 2 * GTW * WTX;      // output pixels per workgroup
     static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;       // patch rows y0-1 .. y0+TH, columns x0-4 .. x0+TW+3 (stored from patch column 1)
@@ -102,7 +103,8 @@ struct WLds {
     static constexpr int NG = NGU + NGP;
     static constexpr int STAGE = NG * 256 + 256;                // floats per stage (+ 1 KiB: the patch lands one float in)
     static constexpr int NIU = (NGU + 3) / 4, NIP = (NGP + 3) / 4, NI = NIU + NIP;   // DMA instructions per wave per chunk
-    static constexpr int NST = 2;                               // stages (double buffer)
+    static constexpr int NMIN = NGU / 4 + NGP / 4;              // ... of the wave that issues fewest (counted vmcnt waits)
+    static constexpr int NST = C::NST;                          // stages of the DMA ring
     static constexpr int HIP = NST * STAGE;                     // expanded patch (UPS)
     static constexpr int BYTES = (NST * STAGE + (UPS ? C::PSZ : 0)) * 4;
     static_assert(BYTES <= (C::NBLK == 4 ? 160 : 80) * 1024, "LDS budget (one or two workgroups per CU)");
@@ -639,14 +641,26 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
         }
     };
 
-    issue(0, 0);
-    if (nchunks > 1) issue(1, 1);
+    // DMA ring of NST stages: chunk c lives in stage c % NST; the first NST chunks are issued here, chunk c + NST at the barrier inside
+    // chunk c.  Waits are COUNTED: `s_waitcnt vmcnt(k * NMIN)` leaves the k newest chunks' DMAs in flight (every wave issues at least
+    // NMIN instructions per chunk, vmcnt retires in order), so with NST > 2 a chunk has NST - 1 chunk times to land instead of one -
+    // on boxes / layers where the L2 / MALL answers slowly the double buffer loses 10 %.
+    auto wait_newer = [&](int k) {        // wait until at most the k newest chunks of this wave's DMAs are outstanding (k uniform)
+        if (k <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NMIN) : "memory");
+        else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L::NMIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L::NMIN) : "memory");
+    };
+    static_assert(L::NST >= 2 && L::NST <= 5 && 3 * L::NMIN <= 63, "ring depth / vmcnt range");
+#pragma unroll
+    for (int c = 0; c < L::NST; ++c)
+        if (c < nchunks) issue(c, c);
     if constexpr (FH == 0) {        // bias: accumulator of frequency (1,1) = local 5 of the first half
         const float bv0 = p.bias[nb * BN + wn * 32 + l31];
         const float ab = half ? 0.f : bv0, ones = half ? 0.f : 1.f;
         acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, ones, acc[5], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_newer(min(nchunks, (int)L::NST) - 1 > 3 ? 3 : min(nchunks, (int)L::NST) - 1);      // chunk 0 has landed
     __syncthreads();
     expand(lds);
     constexpr int PO = UPS ? L::HIP : C::USZ;
@@ -658,9 +672,12 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     transform_cols(0);
 
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int so = (ch & 1) * L::STAGE, so_n = ((ch + 1) & 1) * L::STAGE;
-        const bool dma = ch + 2 < nchunks && !WABL(1);
+        const int st = ch % L::NST;
+        const int so = st * L::STAGE, so_n = (st + 1 == L::NST ? 0 : st + 1) * L::STAGE;
+        const bool dma = ch + L::NST < nchunks && !WABL(1);
         const bool more = ch + 1 < nchunks;
+        // chunks newer than ch+1 whose DMAs may stay in flight across this chunk's barrier
+        const int newer = min((int)L::NST - 2, nchunks - 2 - ch);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
@@ -698,7 +715,8 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                     }
                 } else if (more) {
                     if (f == 0 && !WABL(16)) {
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        wait_newer(newer > 3 ? 3 : newer);                  // chunk ch+1 has landed (this wave's share of it)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __syncthreads();
                     }
                     if (WS_BFIRST) {
@@ -726,7 +744,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
 #pragma unroll
                         for (int j = 0; j < PER; ++j) {
                             const int k = (f - 1) * PER + j;
-                            if (k < L::NI && dma) issue_k(ch + 2, ch & 1, k);
+                            if (k < L::NI && dma) issue_k(ch + L::NST, st, k);
                         }
                     }
                     if constexpr (!UPS) {
@@ -855,10 +873,14 @@ using V32H = WCfg<1, 2, 1, 16, 8, 2>;     //    32    8  32
 using V32G = WCfg<1, 2, 1, 8, 8, 2>;      //    32   16  16
 using V64A = WCfg<2, 1, 1, 32, 4, 2>;     //    64    2  64
 using V64G = WCfg<2, 1, 1, 8, 4, 2>;      //    64    8  16
+// ... with 4-channel chunks in a ring of four stages (DMA lookahead of three chunks = six k-steps instead of three)
+using V32A4 = WCfg<1, 2, 1, 32, 4, 2, 4>;
+using V32H4 = WCfg<1, 2, 1, 16, 4, 2, 4>;
+using V32G4 = WCfg<1, 2, 1, 8, 4, 2, 4>;
 
 #define SSM_WINO_KINDS(X)                                                                                          \
     X(W64A_, W64A) X(W32A_, W32A) X(W128A_, W128A) X(W64G_, W64G) X(W128G_, W128G) X(W64H_, W64H) X(W128H_, W128H) \
-    X(V32A_, V32A) X(V32H_, V32H) X(V32G_, V32G) X(V64A_, V64A) X(V64G_, V64G)
+    X(V32A_, V32A) X(V32H_, V32H) X(V32G_, V32G) X(V64A_, V64A) X(V64G_, V64G) X(V32A4_, V32A4) X(V32H4_, V32H4) X(V32G4_, V32G4)
 
 enum WinoKind {
 #define X(name, cfg) name,
@@ -868,12 +890,12 @@ enum WinoKind {
 };
 
 struct WKindInfo {
-    int bn, th, tw, ck, nblk;
+    int bn, th, tw, ck, nblk, nst;
 };
 
 template <class C>
 constexpr WKindInfo winfo_of() {
-    return WKindInfo{C::BN, C::TH, C::TW, C::CK, C::NBLK};
+    return WKindInfo{C::BN, C::TH, C::TW, C::CK, C::NBLK, C::NST};
 }
 
 constexpr WKindInfo kWInfo[NWKIND] = {
@@ -883,6 +905,7 @@ constexpr WKindInfo kWInfo[NWKIND] = {
 };
 
 std::atomic<int> g_force_wkind{-1};
+std::atomic<int> g_deep_ring{0};       // the 4-stage kinds take part in the automatic choice (ssm_wino_deep_ring; $SSM_WINO_RING=4)
 
 // Estimated duration (cycles) of a launch.  The matrix work of one CU-round is mf = Cin/2 k-steps x 16 MFMAs x 64 cycles: one
 // workgroup of the first form (all 16 frequencies per wave, 256 resident workgroups), or two co-resident workgroups of the second
@@ -914,7 +937,8 @@ int pick_wkind(int Cin, int Cout, int B, int H, int W, int ups) {
         const WKindInfo &ki = kWInfo[i];
         if (ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;      // over half of the cout block would be padding
         if (Cin % ki.ck) continue;
-        const double t = estimate_wino(ki, Cin, Cout, B, H, W, ups);
+        if (ki.nst > 2 && !g_deep_ring.load()) continue;
+        const double t = estimate_wino(ki, Cin, Cout, B, H, W, ups) * (ki.nst > 2 ? 0.99 : 1.0);
         if (best < 0 || t < bt * 0.999) {
             best = i;
             bt = t;
@@ -1067,6 +1091,11 @@ extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, in
     if (BN) *BN = kWInfo[kd].bn;
     if (CK) *CK = kWInfo[kd].ck;
     return SSM_OK;
+}
+
+extern "C" int ssm_wino_deep_ring(int on) {
+    const int was = g_deep_ring.exchange(on ? 1 : 0);
+    return was;
 }
 
 extern "C" int ssm_wino_force_kind(int kind) {
