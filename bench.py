@@ -68,8 +68,10 @@ DTYPE_NOTE = {"f32": "f32",
                        "activations stored as f16 hi + e4m3 lo, f32 accumulate) - narrower than f32"}
 # rocprofv3 --pmc traffic summaries (tools/pmc_traffic.sh) per mode: (file under profiles/, conv kernel family keys)
 ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (csrc/ssm_wino.hip), 7x7 / 5x5 / "
-                     "final convolutions in the direct form (csrc/ssm_conv.hip, ssm_elem.hip)",
-             "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output)"}
+                     "final convolutions in the direct form (csrc/ssm_conv.hip, ssm_elem.hip); the t-independent input channels of stage 2's "
+                     "conv1a / conv7a convolved once per pair",
+             "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output; the t-independent input channels of "
+                    "stage 2's conv1a / conv7a summed once per pair and added - SSM_HOIST=0 keeps one chain)"}
 PMC_FILES = {"f32w": ("r4_pmc_traffic_f32w_summary.json", ("wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel")),
              "f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "final_conv_kernel")),
              "f16x3": ("r1k_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel")),
