@@ -358,6 +358,25 @@ def perceptual_loss(p, pred, target):
 # --------------------------------------------------------------------------
 # frame formats either side of the path (uint8 <-> normalised padded tensors)
 # --------------------------------------------------------------------------
+def training_loss(p1, p2, img6, t, target, lambda_r, lambda_w, vgg=None, lambda_p=0.0):
+    """FullModel.forward(inference_mode=False) for one window with FREEZE=FALSE on both stages, written in differentiable torch
+    ops: the reference's [B,4] loss tensor `[total, lambda_r*L1(I_t^, I_t), lambda_w*sum of the four L1 warp terms, lambda_p*
+    perceptual]` (scripts/models/losses.py:103-170,196-249; superslomo_r.py:204-243) and the predicted frame.  img6 [B,6,H,W],
+    t [B,1,1,1], target [B,3,H,W].  `losses.mean(0)[0].backward()` is what the reference Trainer does (scripts/main.py:138-141)."""
+    c6, flow4 = stage1(p1, img6)
+    in16 = flow_interp_inputs(img6, flow4, t)
+    out5 = stage2(p2, in16, c6)
+    pred = synthesize(img6, in16, out5, t)
+    i0, i1 = img6[:, 0:3], img6[:, 3:6]
+    m = lambda z: z.flatten(1).mean(1)        # noqa: E731
+    ft1, ft0 = in16[:, 6:8] + out5[:, 1:3], in16[:, 8:10] + out5[:, 3:5]
+    wrp = ((warp(i1, flow4[:, 0:2]) - i0).abs() + (warp(i0, flow4[:, 2:4]) - i1).abs()
+           + (warp(i0, ft0) - target).abs() + (warp(i1, ft1) - target).abs())
+    rec, wrp = lambda_r * m((pred - target).abs()), lambda_w * m(wrp)
+    per = lambda_p * perceptual_loss(vgg, pred, target) if vgg is not None else torch.zeros_like(rec)
+    return torch.stack([rec + wrp + per, rec, wrp, per], 1), pred
+
+
 def frames_from_u8(frames_u8, mean, std, pad_before_norm=False, multiple=32):
     """[N,H,W,3] uint8 -> [N,3,Hp,Wp] fp32.  pad_before_norm=False: ToTensor + Normalize + EvalPad
     (scripts/utils/dataloaders/augmentations.py:141-200, zero pad in normalised space);

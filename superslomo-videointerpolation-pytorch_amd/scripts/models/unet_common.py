@@ -26,6 +26,7 @@ log = logging.getLogger(__name__)
 
 class StageUNet(nn.Module):
     STAGE = 0
+    precision = None        # plan arithmetic of a stage model called on its own: "f32" (default) | "f32w" | "f16x3" | "f16f8"
 
     def __init__(self, in_channels, out_channels, cross_skip, verbose=False, cfg=None):
         super().__init__()
@@ -113,13 +114,14 @@ class StageUNet(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def plan_for(self, B, H, W, device, seq_len=1):
-        key = (B, H, W, str(device), seq_len)
+        mode = self.precision or "f32"
+        key = (B, H, W, str(device), seq_len, mode)
         stamp = self._stamp()
         hit = self._plans.get(key)
         if hit is None or hit[0] != stamp:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             hit = (stamp, UNetPlan(self.STAGE, sd, B, H, W, device, self.cross_skip_connect,
-                                   bottleneck=self.bottleneck_type, seq_len=seq_len))
+                                   mode=mode, bottleneck=self.bottleneck_type, seq_len=seq_len))
             self._plans = {key: hit}          # one live plan per module: activations are large
         return hit[1]
 

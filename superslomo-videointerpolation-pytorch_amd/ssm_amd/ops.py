@@ -15,6 +15,7 @@ the reference's scripts/models surface that is a tensor function is registered w
 CUDA (= HIP) only: there is no CPU kernel, a CPU tensor raises.  The planned whole-path engine (ssm_amd.engine) calls the
 same C ABI directly on pre-allocated plans; these operators are the drop-in, composable form.
 """
+import weakref
 from collections import OrderedDict
 from typing import Optional
 
@@ -24,27 +25,43 @@ from torch.library import custom_op
 
 from . import hipbind as hb
 
-_PACKS = OrderedDict()      # (weight/bias identity + version, problem) -> PackedConv; small LRU
+_PACKS = OrderedDict()      # (weight/bias identity + version, problem) -> (weakrefs of the source tensors, PackedConv); small LRU
 _PACKS_MAX = 256
+
+
+def _cached_pack(key, sources, build):
+    """LRU lookup that ties an entry to the LIFETIME of the tensors it was packed from: an address + version key alone can be
+    re-issued by the caching allocator to the parameters of a later model (same shapes, same construction sequence), and the entry
+    holds only the packed copy.  A hit therefore needs every source tensor object of the entry to be the one passed in now."""
+    ent = _PACKS.get(key)
+    if ent is not None and all(r() is t for r, t in zip(ent[0], sources)):
+        _PACKS.move_to_end(key)
+        return ent[1]
+    pk = build()
+    _PACKS[key] = (tuple(weakref.ref(t) for t in sources), pk)
+    _PACKS.move_to_end(key)
+    if len(_PACKS) > _PACKS_MAX:
+        _PACKS.popitem(last=False)
+    return pk
 
 
 def packed_filter(weight, bias, B, H, W):
     """Repacked filter for this problem, refreshed when the parameters are replaced or written in place."""
-    key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, tuple(weight.shape), B, H, W)
-    pk = _PACKS.get(key)
-    if pk is None:
-        pk = hb.PackedConv(weight.detach(), bias.detach(), B, H, W, False)
-        _PACKS[key] = pk
-        if len(_PACKS) > _PACKS_MAX:
-            _PACKS.popitem(last=False)
-    else:
-        _PACKS.move_to_end(key)
-    return pk
+    key = ("fwd", weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, tuple(weight.shape), B, H, W)
+    return _cached_pack(key, (weight, bias), lambda: hb.PackedConv(weight.detach(), bias.detach(), B, H, W, False))
 
 
-def _padded_input(x, pk):
+def packed_filter_transposed(weight, B, H, W):
+    """The data-gradient filter W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx] (zero bias), cached like the forward one."""
+    from .backward import transposed_filter
+    key = ("bwd", weight.data_ptr(), weight._version, tuple(weight.shape), B, H, W)
+    return _cached_pack(key, (weight,), lambda: hb.PackedConv(transposed_filter(weight.detach()),
+                                                             torch.zeros(weight.shape[1], device=weight.device), B, H, W))
+
+
+def _padded_input(x, cin_p):
     B, C, H, W = x.shape
-    src = hb.Planes(B, pk.cin_p, H, W, x.device)       # zero frame + channels padded to the chunk size
+    src = hb.Planes(B, cin_p, H, W, x.device)       # zero frame + channels padded to the chunk size
     xs = x if x.stride(3) == 1 else x.contiguous()
     hb.check(hb.load().ssm_copy_view(hb.view_of(xs), src.view(), B, C, H, W, hb.stream_ptr()))
     return src
@@ -57,7 +74,7 @@ def conv2d(x: Tensor, weight: Tensor, bias: Tensor, lrelu: bool, slope: float) -
     B, C, H, W = x.shape
     pk = packed_filter(weight, bias, B, H, W)
     assert C == pk.cin, "conv expects %d input channels, got %d" % (pk.cin, C)
-    src = _padded_input(x, pk)
+    src = _padded_input(x, pk.cin_p)
     y = torch.empty(B, pk.cout, H, W, dtype=torch.float32, device=x.device)
     hb.conv2d(src.view(), pk.cin_p, None, 0, pk, hb.view_of(y), None, B, H, W, lrelu=lrelu, slope=slope)
     return y
@@ -72,18 +89,18 @@ def _conv_setup(ctx, inputs, output):
     x, weight, bias, lrelu, slope = inputs
     ctx.save_for_backward(x, weight, output)
     ctx.lrelu, ctx.slope = lrelu, slope
+    ctx.cin_p = packed_filter(weight, bias, x.shape[0], x.shape[2], x.shape[3]).cin_p      # a cache hit: the forward just packed it
 
 
 def _conv_backward(ctx, dy):
     """Data gradient = the forward kernel on the transposed, flipped filter, weight gradient = ssm_conv2d_wgrad, bias
     gradient = ssm_bias_grad (what torch's autograd does for the reference's nn.Conv2d / LeakyReLU pair)."""
-    from .backward import transposed_filter
     x, weight, y = ctx.saved_tensors
     lib, st = hb.load(), hb.stream_ptr()
     B, co, H, W = y.shape
     ci, k = weight.shape[1], weight.shape[2]
     dy = dy.contiguous()
-    pk_t = hb.PackedConv(transposed_filter(weight.detach()), torch.zeros(ci, device=y.device), B, H, W)
+    pk_t = packed_filter_transposed(weight, B, H, W)
     dz = hb.Planes(B, pk_t.cin_p, H, W, y.device)
     hb.check(lib.ssm_lrelu_bwd(hb.view_of(dy), hb.NULL_VIEW, hb.view_of(y), dz.view(), B, co, H, W, ctx.slope,
                                1 if ctx.lrelu else 0, st))
@@ -92,7 +109,7 @@ def _conv_backward(ctx, dy):
         dx = torch.empty(B, ci, H, W, dtype=torch.float32, device=y.device)
         hb.conv2d(dz.view(), pk_t.cin_p, None, 0, pk_t, hb.view_of(dx), None, B, H, W, lrelu=False)
     if ctx.needs_input_grad[1]:
-        src = _padded_input(x.detach(), packed_filter(weight, torch.zeros(co, device=y.device), B, H, W))
+        src = _padded_input(x.detach(), ctx.cin_p)
         dw = torch.empty_like(weight)
         hb.check(lib.ssm_conv2d_wgrad(src.view(), dz.view(), dw.data_ptr(), B, ci, co, H, W, k, ci, 0, 1, st))
     if ctx.needs_input_grad[2]:

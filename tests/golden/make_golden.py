@@ -65,10 +65,51 @@ def npy(t):
     return t.detach().cpu().numpy().astype(np.float32)
 
 
+GRAD_KEYS = ("conv1a.0.weight", "conv6.1.0.weight", "conv11b.0.bias", "final_conv.weight", "final_conv.bias")
+
+
+def make_grads(ssm):
+    """Training-mode forward + BACKWARD of the imported reference at 64x64: `losses.mean(0)[0].backward()` as
+    Trainer does (main.py:138-141 of the reference), gradients of a few parameters of both stages -> train_grads_64.npz.  Same
+    inputs as train_forward_64.npz; per-sample t differ so the t-dependent terms of the adjoint are exercised.  LAMBDA_P = 0:
+    the perceptual term needs the pretrained VGG16 the environment cannot fetch, so the fixture pins the
+    reconstruction + four warp terms (lambda_r = 60, lambda_w = 10 of the shipped ini)."""
+    cfgT = make_cfg(True)
+    cfgT.set("TRAIN", "LAMBDA_P", "0")
+    cfgT.set("STAGE1", "FREEZE", "FALSE")
+    cfgT.set("STAGE2", "FREEZE", "FALSE")
+    with torch.enable_grad():
+        fmT = ssm.FullModel(cfgT)
+        fmT.stage1_model.load_state_dict(synthetic_state_dict(1, True))
+        fmT.stage2_model.load_state_dict(synthetic_state_dict(2, True))
+        fmT.train()
+        u8t = torch.stack([synthetic_frames_u8(3, 64, 64, seed=60), synthetic_frames_u8(3, 64, 64, seed=61)])
+        clip = torch.cat([normalize_and_pad(u8t[0]), normalize_and_pad(u8t[1])], 0)
+        xin, tgt = clip[:, [0, 2]], clip[:, 1:2]
+        tt = torch.tensor([0.375, 0.625]).view(2, 1, 1, 1, 1)
+        img, losses = fmT(xin, tt, tgt, None, False)
+        losses.mean(0)[0].backward()
+    out = {"u8": u8t.numpy(), "t": npy(tt), "img": npy(img), "losses": npy(losses)}
+    for st, mod in ((1, fmT.stage1_model), (2, fmT.stage2_model)):
+        params = dict(mod.named_parameters())
+        for k in GRAD_KEYS:
+            g = params[k].grad
+            out["s%d.%s" % (st, k)] = npy(g[::8, ::8] if k == "conv6.1.0.weight" else g)      # 512x512x3x3: every 8th (cout, cin)
+        # every parameter's gradient, condensed: sum and abs-sum (96 tensors x 2 numbers)
+        out["s%d.names" % st] = np.array(sorted(params))
+        out["s%d.sum" % st] = np.array([params[k].grad.double().sum().item() for k in sorted(params)])
+        out["s%d.abssum" % st] = np.array([params[k].grad.double().abs().sum().item() for k in sorted(params)])
+    np.savez_compressed(os.path.join(HERE, "train_grads_64.npz"), **out)
+    print("training-mode losses [B,4]:", losses.detach())
+    print("train_grads_64.npz %.1f KB" % (os.path.getsize(os.path.join(HERE, "train_grads_64.npz")) / 1024))
+
+
 def main():
     torch.set_grad_enabled(False)
     torch.manual_seed(1234)
     layers, unetflow, ssm = import_reference()
+    if "--grads-only" in sys.argv:
+        return make_grads(ssm)
     rng = np.random.RandomState(7)
 
     # ---------------- per-op fixtures -------------------------------------
@@ -204,6 +245,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "train_forward_64.npz"), u8=u8t.numpy(), t=npy(tt), img=npy(img),
                         losses=npy(losses))
     print("training-mode losses [B,4]:", losses)
+    make_grads(ssm)
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -169,19 +169,8 @@ def _oracle_training_loss(p1, p2, img6, t, target, lr, lw, vgg=None, lp=0.0):
     """The reference's total loss (losses.py:196-249 with FREEZE=FALSE; perceptual term on when `vgg` weights are
     given), batch mean of column 0."""
     from oracle import ssm_oracle as O
-    c6, flow4 = O.stage1(p1, img6)
-    in16 = O.flow_interp_inputs(img6, flow4, t)
-    out5 = O.stage2(p2, in16, c6)
-    pred = O.synthesize(img6, in16, out5, t)
-    i0, i1 = img6[:, 0:3], img6[:, 3:6]
-    m = lambda z: z.flatten(1).mean(1)        # noqa: E731
-    ft1, ft0 = in16[:, 6:8] + out5[:, 1:3], in16[:, 8:10] + out5[:, 3:5]
-    warp = ((O.warp(i1, flow4[:, 0:2]) - i0).abs() + (O.warp(i0, flow4[:, 2:4]) - i1).abs()
-            + (O.warp(i0, ft0) - target).abs() + (O.warp(i1, ft1) - target).abs())
-    total = lr * m((pred - target).abs()) + lw * m(warp)
-    if vgg is not None:
-        total = total + lp * O.perceptual_loss(vgg, pred, target)
-    return total.mean(), pred
+    losses, pred = O.training_loss(p1, p2, img6, t, target, lr, lw, vgg, lp)
+    return losses.mean(0)[0], pred
 
 
 # Gradient bars per training precision.  f32: exact-fp32 products, gradients agree to fp32 reassociation.  f16f8 (default): the
@@ -321,6 +310,37 @@ def test_training_step_gradients_vs_oracle_autograd(dev, train_precision):
     cos_bar, rel_bar = GRAD_BARS[train_precision]
     assert all(c > cos_bar for _, c, _ in worst), worst[:4]
     assert worst[0][0] < rel_bar, worst[:4]
+
+
+@pytest.mark.parametrize("train_precision", ["f32", "f32w"])
+def test_training_backward_vs_reference_gradient_fixture(dev, golden, train_precision):
+    """The HIP training step against gradients of the REFERENCE itself (tests/golden/train_grads_64.npz: the imported reference's
+    FullModel(inference_mode=False) + `losses.mean(0)[0].backward()` at 64x64, LAMBDA_P = 0; reference losses.py:196-249,
+    superslomo_r.py:240-243): [B,4] losses, five parameter gradients per stage in full, sum / abs-sum of all 96."""
+    from ssm_amd.weights import normalize_and_pad
+    g = golden("train_grads_64")
+    u8 = torch.from_numpy(g["u8"])
+    clip = torch.cat([normalize_and_pad(u8[0]), normalize_and_pad(u8[1])], 0).to(dev)
+    xin, tgt = clip[:, [0, 2]].contiguous(), clip[:, 1:2].contiguous()
+    m, _, _ = _train_model_p(dev, train_precision)          # no VGG weights loaded: the perceptual term is 0, as in the fixture
+    img, losses = m(xin, torch.from_numpy(g["t"]).to(dev), tgt, None, False)
+    losses.mean(dim=0)[0].backward()
+    assert float((img.cpu() - torch.from_numpy(g["img"])).abs().max()) < 2e-4
+    want = torch.from_numpy(g["losses"])
+    assert float(((losses.detach().cpu() - want).abs() / want.abs().clamp_min(1.0)).max()) < 1e-4
+    bar = GRAD_BARS[train_precision][1]
+    for st, mod in ((1, m.stage1_model), (2, m.stage2_model)):
+        params = dict(mod.named_parameters())
+        for k in ("conv1a.0.weight", "conv6.1.0.weight", "conv11b.0.bias", "final_conv.weight", "final_conv.bias"):
+            got = params[k].grad.cpu()
+            got = got[::8, ::8] if k == "conv6.1.0.weight" else got
+            w = torch.from_numpy(g["s%d.%s" % (st, k)])
+            assert rel_err(got, w) < bar, (st, k, rel_err(got, w))
+        names = [str(n) for n in g["s%d.names" % st]]
+        assert names == sorted(params)
+        for n, s_want, a_want in zip(names, g["s%d.sum" % st], g["s%d.abssum" % st]):
+            gr = params[n].grad.double()
+            assert abs(gr.abs().sum().item() - a_want) < 2e-3 * a_want, (st, n)
 
 
 def test_training_step_with_adam_reduces_loss(dev):

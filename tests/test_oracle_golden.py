@@ -94,3 +94,33 @@ def test_config1_256(golden):
     assert maxdiff(img[:, :, 96:160, 96:160], g["img_center64"]) < 2e-4
     assert abs(img.double().abs().sum().item() - float(g["img_abssum"])) < 1e-5 * float(g["img_abssum"])
     assert maxdiff(inter[0][:, :, ::4, ::4], g["F01_sub4"]) < 2e-4
+
+
+def test_training_backward_gradients(golden):
+    """The oracle's autograd (oracle.training_loss, `losses.mean(0)[0].backward()`) against gradients produced by the imported
+    reference's own FullModel(..., inference_mode=False) + backward at 64x64 (tests/golden/make_golden.py::make_grads; reference
+    scripts/models/losses.py:196-249, superslomo_r.py:240-243): the [B,4] losses, five parameter gradients of each stage in full
+    (conv6.1.0.weight every 8th channel pair) and the sum / abs-sum of every one of the 96 gradients."""
+    g = golden("train_grads_64")
+    u8 = T(g["u8"])
+    clip = torch.cat([normalize_and_pad(u8[0]), normalize_and_pad(u8[1])], 0)
+    xin, tgt = clip[:, [0, 2]], clip[:, 1]
+    img6 = torch.cat([xin[:, 0], xin[:, 1]], 1)
+    p1 = {k: v.clone().requires_grad_() for k, v in synthetic_state_dict(1, True).items()}
+    p2 = {k: v.clone().requires_grad_() for k, v in synthetic_state_dict(2, True).items()}
+    losses, pred = O.training_loss(p1, p2, img6, T(g["t"]).view(2, 1, 1, 1), tgt, 60.0, 10.0)
+    losses.mean(0)[0].backward()
+    assert maxdiff(pred.detach(), g["img"]) < 1e-4
+    want = T(g["losses"])
+    assert float(((losses.detach() - want).abs() / want.abs().clamp_min(1.0)).max()) < 1e-5
+    for st, p in ((1, p1), (2, p2)):
+        for k in ("conv1a.0.weight", "conv6.1.0.weight", "conv11b.0.bias", "final_conv.weight", "final_conv.bias"):
+            got = p[k].grad[::8, ::8] if k == "conv6.1.0.weight" else p[k].grad
+            w = T(g["s%d.%s" % (st, k)])
+            assert float((got - w).abs().max() / w.abs().max()) < 1e-4, (st, k)
+        names = [str(n) for n in g["s%d.names" % st]]
+        assert names == sorted(p)
+        for n, s_want, a_want in zip(names, g["s%d.sum" % st], g["s%d.abssum" % st]):
+            gr = p[n].grad.double()
+            assert abs(gr.abs().sum().item() - a_want) < 1e-4 * a_want, (st, n)
+            assert abs(gr.sum().item() - s_want) < 1e-4 * a_want, (st, n)
