@@ -127,7 +127,8 @@ def conv_flops_per_pair(h, w, n_t, issued_for=None):
     """Algorithmic (direct-form) conv FLOP of a pair as SURVEY 8d counts them (stage 1 once, stage 2 per t).  issued_for = "f32" /
     "f32w": the multiply-adds the matrix cores actually execute in that mode: the t-independent input channels of stage 2's conv1a
     (6 of 16) and conv7a (512 of 1024) are convolved once per pair (ssm_amd.engine.UNetPlan.hoist); "f32w": 3x3 layers with >= 32
-    output channels run as Winograd F(2x2,3x3), 16 instead of 36 multiply-adds per 2x2 outputs."""
+    output channels run as Winograd F(2x2,3x3), 16 instead of 36 multiply-adds per 2x2 outputs; 7x7 / 5x5 layers in the 1-D
+    Winograd forms along x where the plan uses them (issued_factor)."""
     from ssm_amd.weights import unet_layers
     scale = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8,
              "conv9": 4, "fuse_": 1, "final": 1}
@@ -143,11 +144,78 @@ def conv_flops_per_pair(h, w, n_t, issued_for=None):
                     fl *= (10.0 * reps + 6.0) / (16.0 * reps)
                 elif name == "conv7a":
                     fl *= (reps + 1.0) / (2.0 * reps)
-            if issued_for == "f32w" and k == 3 and name != "final_conv" and (w // s) % 2 == 0 and cin % 8 == 0:
-                fl *= 16.0 / 36.0
+            if issued_for:
+                fl *= issued_factor(name, issued_for)
             tot += fl
         return tot
     return stage(1, 1) + stage(2, n_t)
+
+
+def layer_kernel_size(lname):
+    """7 / 5 / 3 for a layer name of SURVEY Appendix A ("conv1a", "conv10b", "fuse_conv", "conv6(CLSTM)", "conv1a(pair)")."""
+    if lname.startswith("conv1") and not lname.startswith(("conv10", "conv11")):
+        return 7
+    return 5 if lname.startswith("conv2") else 3
+
+
+WINO1D = {7: 8.0 / 14.0, 5: 8.0 / 20.0}       # F(2,7) / F(4,5) along x: 8 frequencies per 2 / 4 outputs instead of 7 / 5 taps each
+
+
+def issued_factor(lname, precision):
+    """Multiply-adds the matrix cores issue per direct-form multiply-add of this layer in this precision mode."""
+    if precision != "f32w" or lname.startswith("final"):
+        return 1.0
+    k = layer_kernel_size(lname)
+    if k == 3:
+        return 16.0 / 36.0
+    from ssm_amd import engine
+    return WINO1D[k] if getattr(engine, "wino1d_enabled", lambda k: False)(k) else 1.0
+
+
+def family_rooflines(by_name, n_pairs, precision, peak):
+    """Per kernel family of the fp32 modes (3x3 / 7x7 / 5x5 / final): in-kernel time per pair, FLOP issued on the matrix cores,
+    fraction of the fp32-MFMA peak - from the HIP-event brackets of the single-stream region."""
+    fams = {}
+    for n, (ms, fl, cnt) in by_name.items():
+        lname = n.split(".", 1)[1]
+        key = "final_conv (4x4x1 MFMA)" if lname.startswith("final") else "%dx%d layers" % ((layer_kernel_size(lname),) * 2)
+        d = fams.setdefault(key, {"ms": 0.0, "alg": 0.0, "iss": 0.0})
+        d["ms"] += ms
+        d["alg"] += fl
+        d["iss"] += fl * issued_factor(lname, precision)
+    return {k: {"ms_per_pair_in_kernel": round(d["ms"] / n_pairs, 3), "flop_issued_per_pair": d["iss"] / n_pairs,
+                "achieved_in_kernel": round(d["iss"] / d["ms"] / 1e9, 2), "frac_in_kernel": round(d["iss"] / d["ms"] / 1e9 / peak, 4),
+                "algorithmic_achieved_in_kernel": round(d["alg"] / d["ms"] / 1e9, 2)} for k, d in fams.items()}
+
+
+def family_clocks(eng, dev, peak, fams):
+    """Shader clock under each conv family of the headline mode (one resident wave on a side stream comparing s_memtime with the
+    100 MHz s_memrealtime, tools/clock_probe.hip, while stage 2's layers of that family run back to back on resident inputs):
+    the power management holds different clocks under the Winograd and the direct kernels, so each family's roof at the clock it
+    was delivered is peak x ghz / 2.4."""
+    out = {}
+    for k in (3, 7, 5):
+        key = "%dx%d layers" % (k, k)
+        if key not in fams:
+            continue
+        eng.s2.run_family(k)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        eng.s2.run_family(k)
+        torch.cuda.synchronize(dev)
+        reps = max(2, int(0.7 / max(time.perf_counter() - t0, 1e-4)))
+        probe = start_clock_probe(dev, 0.4)
+        if probe is None:
+            return None
+        for _ in range(reps):
+            eng.s2.run_family(k)
+        ghz = read_clock_probe(probe)
+        torch.cuda.synchronize(dev)
+        if ghz:
+            out[key] = {"ghz": round(ghz, 3), "peak_at_clock": round(peak * ghz / 2.4, 1),
+                        "frac_in_kernel_at_clock": round(fams[key]["achieved_in_kernel"] / (peak * ghz / 2.4), 4)}
+    out["note"] = "stage-2 layers of one family back to back for 0.7 s, clock averaged over 0.4 s of it"
+    return out
 
 
 TRAIN_DTYPE_NOTE = {
@@ -182,6 +250,8 @@ def train_bench(args):
     train_mode = args.precision or os.environ.get("SSM_TRAIN_PRECISION", "f32")
     assert train_mode in ("f32", "f32w", "f16f8"), "--mode train: --precision f32 (default, direct form), f32w (3x3 layers as Winograd) or f16f8"
     model.train_precision = train_mode
+    if args.force_allreduce:            # one-rank process group: still hand every gradient bucket to RCCL (ssm_amd.dist.GradientAllReduce.attach)
+        os.environ["SSM_FORCE_ALLREDUCE"] = "1"
     trainer = Trainer(model, cfg)
     B, S = 2, 352
     clips = torch.cat([synthetic_frames(3, S, S, seed=100 + 2 * rank + i) for i in range(B)], 0).to(dev)   # [B,3,3,S,S]
@@ -220,12 +290,36 @@ def train_bench(args):
                                   "losses: L1 reconstruction + 4 L1 warp terms + %s" % (B, world, "VGG16 conv4_3 perceptual term OFF" if args.no_perceptual else
                                                                                   "VGG16 conv4_3 perceptual term (synthetic VGG weights)"),
                       "global_batch": B * world},
-           "allreduce": {"bytes": trainer.allreduce.bytes, "ms_per_step": round(ar_ms, 3)},
+           "allreduce": {"bytes": trainer.allreduce.bytes, "ms_per_step": round(ar_ms, 3), "buckets_per_step": trainer.allreduce.last_buckets,
+                         "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                         "note": "ms_per_step = exposed wait of the bucketed exchange (overlapped with the backward)"},
            "host_enqueue_ms_per_step": round(1e3 * sdist.timed_steps.last_enqueue_s / args.steps, 3)}
     if rank == 0:
         summ = timer.summary()
         out["time_split_ms_per_step"] = {fam: round(d["ms"] / 3, 3) for fam, d in summ.items()}
         out["tflops"] = {fam: round(d["flops"] / d["ms"] / 1e9, 1) for fam, d in summ.items() if d["flops"] > 0}
+        # roofline of the step (forward 93.9 GMAC per sample, backward = data + weight gradients of the same
+        # convolutions, + the VGG16 conv4_3 passes): every MFMA-bound family against the MFMA peak.  `achieved` = the
+        # direct-form conv FLOP of one step (all families, as counted by the per-launch brackets) / the step's wall time in the
+        # timed region; families.* = the same FLOP / the summed HIP-event durations of that family's launches (in-kernel rate).
+        peak = PEAK_F16_MFMA_TFLOPS if train_mode == "f16f8" else PEAK_F32_MFMA_TFLOPS
+        fl_step = sum(d["flops"] for d in summ.values()) / 3.0
+        ach = fl_step / (1e-3 * out["ms_per_step"]) / 1e12
+        out["roofline"] = {
+            "bound": "mfma",
+            "kernel": ("conv16 / wgrad_bf16x3 kernels" if train_mode == "f16f8" else
+                       "conv_mfma_kernel / wino2_kernel (forward, data gradients), wgrad kernels (weight gradients), VGG16 conv kernels: "
+                       "all MFMA families of a step"),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flop_per_step": fl_step,
+            "region": "the timed region: direct-form conv FLOP of %d steps / its wall time (launch gaps, elementwise kernels, Adam "
+                      "and the exchange count against it)" % args.steps,
+            "families": {fam: {"flop_per_step": d["flops"] / 3.0, "ms_per_step_in_kernel": round(d["ms"] / 3, 3),
+                               "achieved_in_kernel": round(d["flops"] / d["ms"] / 1e9, 2),
+                               "frac_in_kernel": round(d["flops"] / d["ms"] / 1e9 / peak, 4)}
+                         for fam, d in summ.items() if d["flops"] > 0},
+            "traffic": None,
+            "note": ("3x3 forward / data-gradient layers run as Winograd F(2x2,3x3): their matrix cores issue 16/36 of the direct-form "
+                     "FLOP counted here" if train_mode == "f32w" else "every product issued in the direct form: FLOP counted = FLOP issued")}
         if args.detail:
             det = {fam: {n: {"ms_per_step": v[0] / 3, "tflops": (v[1] / v[0] / 1e9 if v[0] > 0 else 0.0)}
                          for n, v in d["by_name"].items()} for fam, d in summ.items()}
@@ -288,6 +382,23 @@ def recurrent_bench(args):
         out["time_split_ms_per_step"] = {"conv": round(conv["ms"] / 3, 3),
                                          "conv6_recurrent": round(sum(v[0] for n, v in conv["by_name"].items() if "conv6(" in n) / 3, 3)}
         out["tflops"] = round(conv["flops"] / conv["ms"] / 1e9, 1)
+        # roofline (SURVEY 8d, C4 = C2's layers at batch 3 windows (x 7 t in stage 2) + the ConvBLSTM gate convolutions): direct-form
+        # conv FLOP of a clip from the per-launch brackets; issued = the multiply-saving layers' share scaled (mode f32w)
+        peak = PEAK_F32_MFMA_TFLOPS if model.precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
+        fl_clip = conv["flops"] / 3.0
+        issued = sum(v[1] / 3.0 * issued_factor(n.split(".", 1)[1], model.precision) for n, v in conv["by_name"].items())
+        ms_clip = out["ms_per_step"]
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "wino2_kernel / wino_kernel (3x3 layers and gate convolutions), conv kernels of the 7x7 / 5x5 layers, final_conv_kernel",
+            "achieved": round(issued / (1e-3 * ms_clip) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(issued / (1e-3 * ms_clip) / 1e12 / peak, 4), "flop_per_clip": issued,
+            "region": "the timed region: multiply-adds the matrix cores issue for %d clips / its wall time" % args.steps,
+            "algorithmic": {"flop_per_clip": fl_clip, "achieved": round(fl_clip / (1e-3 * ms_clip) / 1e12, 2),
+                            "x_peak": round(fl_clip / (1e-3 * ms_clip) / 1e12 / peak, 4),
+                            "note": "direct-form FLOP (SURVEY 8d); exceeds the issued figure where layers run in a Winograd form"},
+            "in_kernel": {"ms_per_clip": round(conv["ms"] / 3, 3), "issued_achieved": round(issued / (1e-3 * conv["ms"] / 3) / 1e12, 2),
+                          "issued_frac": round(issued / (1e-3 * conv["ms"] / 3) / 1e12 / peak, 4)},
+            "traffic": None}
         if not args.no_cpu_baseline:
             from oracle import ssm_oracle as O
             xs = clips[k[0] % 2].cpu()
@@ -510,28 +621,33 @@ def infer_bench(args):
         pmc = os.path.join(ROOT, "profiles", pmc_file) if pmc_file else ""
         pj = json.load(open(pmc)) if pmc and os.path.exists(pmc) else None
         traffic = sum(pj.get(k, {}).get("hbm_bytes_per_step", 0.0) for k in pmc_keys) if pj else None
-        res["roofline"] = {"bound": "mfma", "kernel": kname + ", the conv launches of a pair", "achieved": round(ach, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "region": "the timed region: algorithmic conv FLOP of %d pairs / its wall time (%d batch(es) of %d pair(s) in "
-                                     "flight; non-conv kernels and gaps count against it)" % (P * steps, args.streams, PB),
-                           "flop_per_pair": flops_pair, "traffic": traffic or None,
+        fi = flops_issued.get(precision, flops_pair)
+        iss = fi * P / (ms_step * 1e-3) / 1e12
+        if precision in flops_issued:
+            issued_note = ("the multiply-adds the matrix cores execute: the t-independent input channels of stage 2's conv1a (6 of 16) and "
+                           "conv7a (512 of 1024) are convolved once per pair instead of once per t" +
+                           ("; Winograd layers: direct-form FLOP x 16/36 (F(2x2,3x3)), x 8/14 (7x7 as F(2,7) along x), x 8/20 (5x5 as "
+                            "F(4,5) along x) where those forms run" if precision == "f32w" else ""))
+        else:
+            issued_note = "direct-form FLOP (each product costs %s narrow MFMA operations in this mode)" % \
+                          {"f16x3": "3 fp16", "f16f8": "1 fp16 + 2 fp8"}.get(precision, "1")
+        res["roofline"] = {"bound": "mfma", "kernel": kname + ", the conv launches of a pair", "achieved": round(iss, 2), "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(iss / peak, 4),
+                           "region": "the timed region: FLOP issued on the matrix cores for %d pairs / its wall time (%d batch(es) of %d "
+                                     "pair(s) in flight; non-conv kernels and gaps count against it)" % (P * steps, args.streams, PB),
+                           "flop_per_pair": fi, "flop_note": issued_note,
+                           "algorithmic": {"flop_per_pair": flops_pair, "achieved": round(ach, 2), "x_peak": round(ach / peak, 4),
+                                           "note": "direct-form FLOP as SURVEY 8d counts them (5.855 TFLOP per pair: stage 1 once, stage 2 "
+                                                   "in full per t) / the same wall time: the rate a direct-form kernel would need for this "
+                                                   "frame rate; above the matrix peak where the multiply-saving forms are used"},
+                           "traffic": traffic or None,
                            "traffic_note": "HBM bytes per pair of the conv launches: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE from "
                                            "separate rocprofv3 --pmc passes (tools/pmc_traffic.sh): profiles/%s" % (pmc_file or "-")}
-        if precision in flops_issued:
-            fi = flops_issued[precision]
-            iss = fi * P / (ms_step * 1e-3) / 1e12
-            res["roofline"]["issued"] = {"flop_per_pair": fi, "achieved": round(iss, 2), "frac": round(iss / peak, 4),
-                                         "note": "multiply-adds the matrix cores execute / the same wall time = utilisation of the fp32 MFMA "
-                                                 "pipe: the t-independent input channels of stage 2's conv1a (6 of 16) and conv7a (512 of "
-                                                 "1024) are convolved once per pair instead of once per t" +
-                                                 ("; Winograd F(2x2,3x3) layers: direct-form FLOP x 16/36" if precision == "f32w" else "") +
-                                                 ".  `achieved` / `frac` above count direct-form FLOP as SURVEY 8d does (stage 2 in full "
-                                                 "per t) and may exceed the matrix peak"}
         if clk is not None:
             ghz = read_clock_probe(clk)
             if ghz:
                 res["roofline"]["shader_clock"] = {
-                    "ghz": round(ghz, 3), "peak_at_clock": round(peak * ghz / 2.4, 1), "frac_at_clock": round(ach / (peak * ghz / 2.4), 4),
+                    "ghz": round(ghz, 3), "peak_at_clock": round(peak * ghz / 2.4, 1), "frac_at_clock": round(iss / (peak * ghz / 2.4), 4),
                     "note": "average shader clock over the first 2 s of the timed region (one resident wave comparing s_memtime with the "
                             "100 MHz s_memrealtime, tools/clock_probe.hip); peak_at_clock = peak x ghz / 2.4 (single 7x7 / 5x5 layers run "
                             "back to back are power-managed down to 2.2 GHz, the mix of a whole pair holds the clock)"}
@@ -559,9 +675,15 @@ def infer_bench(args):
             res["roofline"]["detail"] = {"region": "%d single-stream pairs run right after the timed region, HIP-event brackets around every "
                                                    "launch on the launch stream" % n_solo,
                                          "launches_per_batch": conv["launches"] // nb_solo, "pairs_per_batch": PB, "ms_per_pair_in_kernel": round(conv_ms, 3),
-                                         "achieved_in_kernel": round(kach, 2), "frac_in_kernel": round(kach / peak, 4),
+                                         "achieved_in_kernel": round(fi / (conv_ms * 1e-3) / 1e12, 2),
+                                         "frac_in_kernel": round(fi / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                                         "algorithmic_achieved_in_kernel": round(kach, 2),
                                          "mfma_issue_frac_in_kernel": round(mfma_per_prod * kach / peak, 4),
                                          "wall_ms_per_pair_single_stream": round(solo_ms, 3)}
+            if precision in flops_issued:
+                res["roofline"]["families"] = family_rooflines(conv["by_name"], n_solo, precision, peak)
+                if precision == headline:
+                    res["roofline"]["family_clocks"] = family_clocks(solo, dev, peak, res["roofline"]["families"])
             wk = summ["warp"]
             wms = wk["ms"] / n_solo
             wach = wk["bytes"] / n_solo / (wms * 1e-3) / 1e9
@@ -603,6 +725,8 @@ def infer_bench(args):
     for k in ("roofline", "roofline_warp", "time_split_ms_per_pair"):
         if k in main_res:
             out[k] = main_res[k]
+    if torch.distributed.is_initialized():          # rendezvous, timing barrier and max-over-ranks reduction ran on this backend
+        out["dist"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size()}
 
     results = {headline: main_res}
     side = [m for m in args.modes.split(",") if m and m != headline] if (world == 1 and args.size == "720p") else []
@@ -674,6 +798,8 @@ def main():
                     help="720p = BASELINE configs[1] (the headline); 4k = configs[4] shape (3840x2160, use --precision f16)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams (= engine passes in flight) per GPU")
     ap.add_argument("--no-perceptual", action="store_true", help="--mode train: leave the VGG16 perceptual loss term out")
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="--mode train in a process group of one rank: run the bucketed gradient all-reduce on RCCL anyway")
     ap.add_argument("--graphs", type=int, default=0, help="1: replay each pair's launch sequence from a captured HIP graph")
     ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo stand-in for the per-pair work (launcher test; no GPU)")

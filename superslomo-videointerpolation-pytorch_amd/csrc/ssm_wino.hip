@@ -651,7 +651,12 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
         else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L::NMIN) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L::NMIN) : "memory");
     };
+    // The counted waits rely on the chunk loop issuing NO other VMEM instruction (global load / store) than these DMAs: any such
+    // instruction would shift the vmcnt positions.  Stores happen only in the epilogue, after the last wait.
     static_assert(L::NST >= 2 && L::NST <= 5 && 3 * L::NMIN <= 63, "ring depth / vmcnt range");
+    // the epilogue reuses the DMA stages (from lds[0]) as the exchange buffer of the wave pairs: [2 blocks][16 registers][64 lanes]
+    // quads = 32 KiB; with UPS the expanded patch starts right behind the stages (L::HIP) and must not be overrun
+    static_assert(C::NBLK == 4 || L::NST * L::STAGE * 4 >= 2 * 16 * 64 * 16, "exchange buffer does not fit in the DMA stages");
 #pragma unroll
     for (int c = 0; c < L::NST; ++c)
         if (c < nchunks) issue(c, c);

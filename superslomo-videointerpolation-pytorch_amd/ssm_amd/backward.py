@@ -86,6 +86,7 @@ class UNetGrad:
     def __init__(self, plan):
         self.plan = plan
         self.hl8 = plan.hl8
+        assert plan.hoist is None, "a hoisted inference plan (per-pair partial sums) cannot serve the backward"
         if self.hl8:
             assert plan.q8 and plan.twins, "the backward over an HL8 plan needs mode f16f8 with fp32 twins"
         else:

@@ -122,7 +122,10 @@ class GradientAllReduce:
         travel over xGMI while the encoder's and the other U-Net's backward still computes.  Few, large buckets (4 per
         U-Net, ~20 MB): xGMI is point-to-point, ring steps are per-link bound, small messages waste it."""
         world = dist.get_world_size() if dist.is_initialized() else 1
-        pair_grad.sync = self if world > 1 else None
+        # $SSM_FORCE_ALLREDUCE=1: run the bucketed exchange also in a process group of ONE rank (the collective is then an identity
+        # on RCCL) - the only way to exercise the RCCL path of the training step on a one-GPU box
+        forced = dist.is_initialized() and os.environ.get("SSM_FORCE_ALLREDUCE", "0") != "0"
+        pair_grad.sync = self if (world > 1 or forced) else None
         pair_grad.sync_scale = 1.0 / world
 
     def reduce(self, view):
@@ -168,7 +171,7 @@ class GradientAllReduce:
         """Average the gradients over the ranks (no-op when not distributed).  Returns seconds spent (host clock
         around an explicitly synchronised region when on a GPU).  Gradients that already sit in a few flat buffers are
         reduced in place (no gather / scatter copies: 2 x 96 launches per step); otherwise through one staging buffer."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not self._works):
             return 0.0
         if self._works:          # the backward handed its buckets over as they completed (attach): only wait
             return self._finish_buckets()

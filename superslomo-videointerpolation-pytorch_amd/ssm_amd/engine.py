@@ -127,6 +127,7 @@ class UNetPlan:
         # convolved ONCE per pair (run_pair_parts) and enter the per-t launches as a pre-activation addend: the same sums in another
         # order, 6/16 of conv1a's and 1/2 of conv7a's multiply-adds done once instead of G times (like stage 1 itself)
         self.hoist = None
+        self._pair_parts_ready = False     # hoisted plans: set by run_pair_parts(), asserted by the per-t conv1a / conv7a launches
         if hoist is not None and stage == 2 and mode == "f32" and self.fuse_up and not twins and hoist[1] > 1 and bottleneck == "CONV":
             assert B == hoist[0] * hoist[1] and dec is None
             self.hoist = (int(hoist[0]), int(hoist[1]))
@@ -269,6 +270,7 @@ class UNetPlan:
                           y32, v(pool) if pool else None, self._Bcur, s.H, s.W,
                           lrelu=lrelu, fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         elif self.hoist and name == "conv1a":
+            assert self._pair_parts_ready, "hoisted stage-2 plan: run_pair_parts() must run before the per-t launches of a pass"
             fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
             fn(v(src, c0=3), 10, None, 0, pk, v(dst), None, self._Bcur, s.H, s.W, lrelu=lrelu, add=self.t["pair1a"].view(), add_div=self.hoist[1])
         else:
@@ -328,6 +330,7 @@ class UNetPlan:
                               d.view(), self.f32[dst].view() if self.twins else None, self._Bcur, d.H, d.W, lrelu=True,
                               fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         elif self.hoist and name == "conv7a" and self.cross:
+            assert self._pair_parts_ready, "hoisted stage-2 plan: run_pair_parts() must run before the per-t launches of a pass"
             fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
             fn(self._v(a), A.C, None, 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True, add=self.t["pair7a"].view(), add_div=self.hoist[1])
         else:
@@ -360,6 +363,7 @@ class UNetPlan:
         """Hoisted plan: the per-pair partial sums of conv1a (over the frame pair, stage 1's 6-channel input planes) and of conv7a
         (over the upsampled stage-1 bottleneck output), B1 entries each - launched once per pass, before the per-t stage-2 batch."""
         B1 = self.hoist[0]
+        self._pair_parts_ready = True      # consumed by conv1a / conv7a of this pass, cleared when the decoder has run
         tm = self.timer
         pk = self.pk_pair["conv1a"]
         P = self.t["pair1a"]
@@ -403,6 +407,26 @@ class UNetPlan:
         c("conv5a", "p5", "t5a")
         c("conv5b", "t5a", "c5", pool="p6")
 
+    def run_family(self, k):
+        """Diagnostics (bench.py: shader clock per kernel family): launch this plan's convolutions of kernel size k once more on
+        the tensors a previous run() left resident - k = 7: conv1a, conv1b; 5: conv2a, conv2b; 3: every 3x3 layer but final_conv."""
+        c = self._conv
+        self._b0, self._Bcur = 0, self.B
+        self._pair_parts_ready = self.hoist is not None      # the previous pass's partial sums are still resident
+        if k == 7:
+            c("conv1a", "in", "t1a")
+            c("conv1b", "t1a", "c1", pool="p2")
+        elif k == 5:
+            c("conv2a", "p2", "t2a")
+            c("conv2b", "t2a", "c2", pool="p3")
+        else:
+            assert self.rnn is None and (self.hoist or not self.cross) and self.dec_b0 == 0 and self.Bd == self.B
+            for a, src, dst, pool in (("conv3a", "p3", "t3a", None), ("conv3b", "t3a", "c3", "p4"), ("conv4a", "p4", "t4a", None),
+                                      ("conv4b", "t4a", "c4", "p5"), ("conv5a", "p5", "t5a", None), ("conv5b", "t5a", "c5", "p6")):
+                c(a, src, dst, pool=pool)
+            self.run_bottleneck()
+            self._decode(c, self._up_conv, None, False, 0, final=False)
+
     def run_bottleneck(self):
         self._b0, self._Bcur = 0, self.B
         if self.rnn is not None:
@@ -426,6 +450,7 @@ class UNetPlan:
             return self._decode(c, uc, cross_planes, cross_broadcast, cross_b0, synth)
         finally:
             self._b0, self._Bcur = 0, self.B
+            self._pair_parts_ready = False
 
     def _final(self, synth):
         """final_conv: flow_computation.py:145-153 / flow_interpolation.py:149-157."""
@@ -449,7 +474,7 @@ class UNetPlan:
             e1.record()
         return None if synth is not None else out
 
-    def _decode(self, c, uc, cross_planes, cross_broadcast, cross_b0, synth=None):
+    def _decode(self, c, uc, cross_planes, cross_broadcast, cross_b0, synth=None, final=True):
         if self.cross:
             if cross_planes is None and not self.hoist:
                 raise RuntimeError("stage 2 was built with CROSS_SKIP but no stage-1 encoding was given")
@@ -466,7 +491,7 @@ class UNetPlan:
         uc("conv11a", "c10", "c2", "u11", "t11a")
         c("conv11b", "t11a", "c11")
         c("fuse_conv", "c11", "tf", src2="c1")
-        return self._final(synth)
+        return self._final(synth) if final else None
 
 
 class RecurrentBottleneck:
