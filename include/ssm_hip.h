@@ -167,6 +167,26 @@ int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const floa
 int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
                                 ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 
+/* ---- the 7x7 / 5x5 convolutions as one-dimensional Winograd along x, all arithmetic fp32 (v_mfma_f32_32x32x2_f32) ----------
+ * Same operator and operand layout as ssm_conv2d_add_fwd for k = 7 / 5 (layers.conv, scripts/models/layers.py:21-33; the layers
+ * conv1a/conv1b (k = 7) and conv2a/conv2b (k = 5) of both U-Nets, scripts/models/flow_computation.py:36-45 and
+ * flow_interpolation.py:36-45; fused 2x2 mean, layers.py:60-63), evaluated as F(2,7) / F(4,5) along x - eight frequencies over the
+ * points {0, +-1, +-2, +-1/2, inf} - and in the direct form along y: 8 multiplies per 2 (k = 7) / 4 (k = 5) outputs and filter
+ * row instead of 14 / 20, i.e. 1.75x / 2.5x fewer matrix-core cycles; in fp32 the result differs from the direct form by
+ * rounding only (a single layer: 5-8e-6 at unit output scale, tests/emulate_winograd_1d_precision.py).
+ * One input source (these layers have no concat); Cin a multiple of CK (= 2; pad the view), Cout a multiple of BN.
+ * ssm_wino1d_plan: tile configuration (BN = cout block to pack for, CK = channel chunk).
+ * ssm_wino1d_pack_weights: OIHW fp32 filter -> U[ky] = G g[ky] as [Cout/BN][CinP][k][2][BN][4] (+ bias padded to BN).
+ * Outputs, addend and pooled outputs move as aligned 8- / 16-byte pieces when the views allow (W a multiple of 2 / 4 and
+ * aligned strides: padded planes always do), element by element otherwise.                                                    */
+int ssm_wino1d_plan(int k, int Cin, int Cout, int B, int H, int W, int *kind, int *BN, int *CK);
+int ssm_wino1d_force_kind(int kind);     /* tests / tuning only (-1 = automatic); returns the number of configurations */
+size_t ssm_wino1d_packed_weight_floats(int Cout, int CinP, int k, int BN);
+int ssm_wino1d_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin,
+                            int CinP, int k, int BN, void *stream);
+int ssm_wino1d_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const float *bias_packed, ssm_view y, ssm_view pool,
+                              ssm_view add, int add_div, int B, int H, int W, int Cout, int k, float slope, int flags, void *stream);
+
 /* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------
  * Same operator as ssm_conv2d_fwd.  Default mode evaluates a*b as a_hi*b_hi + a_hi*b_lo +
  * a_lo*b_hi with fp32 accumulation (fp32-grade products at 16/3 x the fp32-MFMA rate);

@@ -125,6 +125,13 @@ class StageUNet(nn.Module):
             self._plans = {key: hit}          # one live plan per module: activations are large
         return hit[1]
 
+    @staticmethod
+    def _cross_planes(plan, B, H, W, device):
+        """Buffer for the stage-1 bottleneck output in the layout the plan's conv7a reads (fp32 planes, or HL8 / Q8 in the split modes)."""
+        if plan.hl8:
+            return hb.HPlanes(B, 512, H // 32, W // 32, device, q8=plan.q8)
+        return hb.Planes(B, 512, H // 32, W // 32, device)
+
     def _run_planned_windows(self, unet_in, cross_list=None):
         """unet_in [B,T,C,H,W] -> (list of T conv6 outputs, list of T final outputs), windows coupled by the
         recurrent bottleneck: all T windows go through one plan as a time-major batch."""
@@ -136,7 +143,7 @@ class StageUNet(nn.Module):
         plan.t["in"].load(unet_in.transpose(0, 1).reshape(T * B, C, H, W))
         cross_planes = None
         if plan.cross:
-            cross_planes = hb.Planes(T * B, 512, H // 32, W // 32, unet_in.device).load(torch.cat(list(cross_list), dim=0))
+            cross_planes = self._cross_planes(plan, T * B, H, W, unet_in.device).load(torch.cat(list(cross_list), dim=0))
         out = plan.run(cross_planes=cross_planes).to_nchw()
         c6 = plan.t["c6"].to_nchw()
         return list(c6.reshape(T, B, *c6.shape[1:]).unbind(0)), list(out.reshape(T, B, *out.shape[1:]).unbind(0))
@@ -153,6 +160,6 @@ class StageUNet(nn.Module):
         plan.t["in"].load(x)
         cross_planes = None
         if plan.cross:
-            cross_planes = hb.Planes(B, 512, H // 32, W // 32, x.device).load(cross)
+            cross_planes = self._cross_planes(plan, B, H, W, x.device).load(cross)
         out = plan.run(cross_planes=cross_planes)
         return plan.t["c6"].to_nchw(), out.to_nchw()

@@ -232,6 +232,9 @@ class UNetGrad:
                 # runs in the Winograd form like the forward (its "input channels" are the layer's output channels)
                 use_w = getattr(self.plan, "wino", False) and hb.wino_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
                 cls = hb.PackedWino if use_w else hb.PackedConv
+                from .engine import wino1d_enabled
+                if getattr(self.plan, "wino", False) and wino1d_enabled(k) and hb.wino1d_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
+                    cls = hb.PackedWino1d          # data gradient of a 7x7 / 5x5 layer: the same convolution on the transposed filter
                 self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
 
     def _layer(self, name, dy, dpool, dx, need_wgrad, act=True):
@@ -286,8 +289,8 @@ class UNetGrad:
             if self.hl8:
                 hb.conv2d_hl8(self.dzq[name].view(), cpad, None, 0, pk, None, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             else:
-                fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
-                fn(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
+                from .engine import conv_fn
+                conv_fn(pk)(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             if tm is not None:
                 e1.record()
 

@@ -74,6 +74,24 @@ HOIST_PAIR_PARTS = os.environ.get("SSM_HOIST", "1") != "0"
 # layers of an f32w plan that stay on the direct kernel ($SSM_WINO_SKIP=conv11b,...; "all" = none in Winograd form)
 WINO_SKIP = frozenset(n for n in os.environ.get("SSM_WINO_SKIP", "").split(",") if n)
 
+# kernel sizes of an f32w plan that run as 1-D Winograd along x (F(2,7) / F(4,5), csrc/ssm_wino1d.hip); $SSM_WINO1D=7 / 5 / 0 narrows it
+WINO1D = os.environ.get("SSM_WINO1D", "57")
+
+
+def wino1d_enabled(k):
+    """Does mode f32w evaluate the k x k layers in the 1-D Winograd form?  (bench.py: FLOP issued on the matrix cores)"""
+    return k in (5, 7) and str(k) in WINO1D
+
+
+def conv_fn(pk, ups=False):
+    """The launcher that goes with a packed filter's algorithm."""
+    if pk.algo == "wino1d":
+        return hb.conv2d_wino1d
+    if pk.algo == "wino":
+        return hb.conv2d_ups_wino if ups else hb.conv2d_wino
+    return hb.conv2d_ups if ups else hb.conv2d
+
+
 POOLED = ("conv1b", "conv2b", "conv3b", "conv4b", "conv5b")      # 2x2 mean fused into these convs
 _SCALE = (("conv10", 2), ("conv11", 1), ("conv1", 1), ("conv2", 2), ("conv3", 4), ("conv4", 8), ("conv5", 16),
           ("conv6", 32), ("conv7", 16), ("conv8", 8), ("conv9", 4), ("fuse_conv", 1), ("final_conv", 1))
@@ -227,6 +245,9 @@ class UNetPlan:
                 use_w = (self.wino and name != "final_conv" and name not in WINO_SKIP and "all" not in WINO_SKIP
                          and hb.wino_supported(ci, co, self.H // s, self.W // s, k))
                 cls = hb.PackedWino if use_w else hb.PackedConv
+                if (self.wino and wino1d_enabled(k) and name not in WINO_SKIP and "all" not in WINO_SKIP
+                        and hb.wino1d_supported(ci, co, self.H // s, self.W // s, k)):
+                    cls = hb.PackedWino1d
                 if self.hoist and name == "conv1a":
                     # per-t part: channels 3:13 (warped frames + estimated flows); per-pair part: the frames themselves in stage 1's
                     # input order (I0 = channels 13:16, I1 = channels 0:3), no bias, no activation
@@ -271,11 +292,9 @@ class UNetPlan:
                           lrelu=lrelu, fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         elif self.hoist and name == "conv1a":
             assert self._pair_parts_ready, "hoisted stage-2 plan: run_pair_parts() must run before the per-t launches of a pass"
-            fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
-            fn(v(src, c0=3), 10, None, 0, pk, v(dst), None, self._Bcur, s.H, s.W, lrelu=lrelu, add=self.t["pair1a"].view(), add_div=self.hoist[1])
+            conv_fn(pk)(v(src, c0=3), 10, None, 0, pk, v(dst), None, self._Bcur, s.H, s.W, lrelu=lrelu, add=self.t["pair1a"].view(), add_div=self.hoist[1])
         else:
-            fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
-            fn(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst), v(pool) if pool else None, self._Bcur, s.H, s.W, lrelu=lrelu)
+            conv_fn(pk)(v(src), s.C, v(src2) if src2 else None, c2, pk, v(dst), v(pool) if pool else None, self._Bcur, s.H, s.W, lrelu=lrelu)
         if tm is not None:
             e1.record()
 
@@ -370,8 +389,7 @@ class UNetPlan:
         if tm is not None:
             e0, e1 = tm.span("conv", "s2.conv1a(pair)", 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * pk.k * pk.k)
             e0.record()
-        fn = hb.conv2d_wino if pk.algo == "wino" else hb.conv2d
-        fn(pair_planes.view(), 6, None, 0, pk, P.view(), None, B1, P.H, P.W, lrelu=False)
+        conv_fn(pk)(pair_planes.view(), 6, None, 0, pk, P.view(), None, B1, P.H, P.W, lrelu=False)
         if tm is not None:
             e1.record()
         if self.cross:

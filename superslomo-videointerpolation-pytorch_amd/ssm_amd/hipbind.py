@@ -63,6 +63,12 @@ SIGNATURES = {
     "ssm_wino_deep_ring": (_c_int, [_c_int]),
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
+    "ssm_wino1d_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
+    "ssm_wino1d_force_kind": (_c_int, [_c_int]),
+    "ssm_wino1d_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "ssm_wino1d_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_wino1d_conv2d_add_fwd": (_c_int, [SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                           _c_int, _c_float, _c_int, _vp]),
     "ssm_wino_conv2d_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int,
                                      _c_float, _c_int, _vp]),
     "ssm_wino_conv2d_ups_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int,
@@ -358,6 +364,56 @@ def conv2d_ups_wino(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=Non
     check(lib.ssm_wino_conv2d_ups_add_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                           add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
                                           SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
+# ---- 7x7 / 5x5 convolutions as 1-D Winograd along x, F(2,7) / F(4,5), in fp32 (csrc/ssm_wino1d.hip) -----------------
+def wino1d_plan(k, cin, cout, B, H, W):
+    """(kind, BN, CK) of the 1-D Winograd tile configuration for the problem."""
+    lib = load()
+    kind, bn, ck = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.ssm_wino1d_plan(k, cin, cout, B, H, W, ctypes.byref(kind), ctypes.byref(bn), ctypes.byref(ck)))
+    return kind.value, bn.value, ck.value
+
+
+def wino1d_supported(cin, cout, H, W, k):
+    """Can this layer run in the 1-D Winograd form?  (7x7 with 32-channel output blocks, 5x5 with 32 / 64)"""
+    return k in (5, 7) and cout % 32 == 0
+
+
+class PackedWino1d:
+    """7x7 / 5x5 filter with its rows pre-transformed (U[ky] = G g[ky]) and packed for the 1-D Winograd kernel's tile
+    configuration; an explicit handle owned by the Python side like PackedConv."""
+
+    algo = "wino1d"
+
+    def __init__(self, weight, bias, B, H, W, pool=False, ups=False):
+        require_device(weight, "conv weight")
+        require_device(bias, "conv bias")
+        assert not ups, "the 7x7 / 5x5 layers have no fused-upsample form"
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        assert self.k in (5, 7) and weight.shape[3] == self.k, "the 1-D Winograd form is for 7x7 and 5x5 filters"
+        self.ups = False
+        _, self.bn, self.ck = wino1d_plan(self.k, self.cin, self.cout, B, H, W)
+        self.cin_p = (self.cin + self.ck - 1) // self.ck * self.ck
+        lib = load()
+        nw = lib.ssm_wino1d_packed_weight_floats(self.cout, self.cin_p, self.k, self.bn)
+        nb = lib.ssm_packed_bias_floats(self.cout, self.bn)
+        self.w = torch.empty(nw, dtype=torch.float32, device=weight.device)
+        self.b = torch.empty(nb, dtype=torch.float32, device=weight.device)
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        check(lib.ssm_wino1d_pack_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout, self.cin,
+                                          self.cin_p, self.k, self.bn, stream_ptr()))
+
+
+def conv2d_wino1d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+    """Same call shape as conv2d / conv2d_wino; these layers take one source (x2 must be None)."""
+    lib = load()
+    assert x2 is None and c2 == 0, "the 1-D Winograd layers have no concatenated source"
+    assert pk.cin_p == c1, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1)
+    assert (pk.bn, pk.ck) == wino1d_plan(pk.k, c1, pk.cout, B, H, W)[1:], "filter was packed for another tile configuration"
+    check(lib.ssm_wino1d_conv2d_add_fwd(x1, c1, pk.w.data_ptr(), pk.b.data_ptr(), y, pool if pool is not None else NULL_VIEW,
+                                        add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, pk.k, slope,
+                                        SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
 # ---- HL8 (fp16 hi/lo) tensors and the fp16-MFMA convolution ------------------------------------

@@ -31,7 +31,8 @@ def test_issued_flop_follows_from_hoisting_and_winograd():
     c7a = 2.0 * (px / 256) * 1024 * 512 * 9        # stage-2 conv7a per t (1/16 resolution)
     saved = 6 * (6 / 16) * c1a + 6 * 0.5 * c7a     # six of seven evaluations of the t-independent channels
     assert abs((alg - f32) - saved) / saved < 1e-9
-    # mode f32w: every 3x3 layer except the final convs at 16/36 of its (hoisted) count
+    # mode f32w: every 3x3 layer except the final convs at 16/36 of its (hoisted) count; the 7x7 layers as F(2,7) along x (8 frequencies
+    # per 2 outputs and filter row instead of 14 products), the 5x5 layers as F(4,5) (8 per 4 outputs instead of 20)
     scale = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8, "conv9": 4, "fuse_": 1, "final": 1}
     want = 0.0
     for st, reps in ((1, 1), (2, 7)):
@@ -44,6 +45,10 @@ def test_issued_flop_follows_from_hoisting_and_winograd():
                 fl *= 8 / 14
             if k == 3 and name != "final_conv":
                 fl *= 16 / 36
+            elif k == 7:
+                fl *= 8 / 14
+            elif k == 5:
+                fl *= 8 / 20
             want += fl
     assert abs(f32w - want) / want < 1e-9
     assert f32w < f32 < alg
