@@ -422,13 +422,15 @@ std::atomic<int> g_force_w1kind{-1};
 
 // Estimated duration (cycles) of a launch: two co-resident workgroups per CU share the matrix pipe; a CU-round of two workgroups
 // costs their matrix work (Cin/2 x KS x 8 MFMAs of 64 cycles each, per wave) plus what the neighbour cannot hide (per chunk: two
-// barriers + the transform, weighted by the patch rows per output row; per workgroup: prologue + epilogue); whole rounds only.
+// barriers + the transform, by its (cin, row, tile) units; per workgroup: prologue + epilogue); whole rounds only.  Measured at batch 14
+// (tools/bench_layers_wino1d.py): conv1b 6.05 ms with the 8x32 tile vs 6.32 with 4x64, conv2b 2.28 (4x64) vs 2.42 (2x128).
 double estimate_w1(const W1KindInfo &ki, int Cin, int Cout, int B, int H, int W) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * (Cout / ki.bn);
     const double mf = (double)(Cin / 2) * ki.ks * 8.0 * 64.0;
     const double chunks = (double)Cin / ki.ck;
-    const double per = 2.0 * mf * 1.1 + chunks * (300.0 + 60.0 * ki.ph) + 6000.0;
+    const double nu = (double)ki.ck * ki.ph * (ki.tw / ki.m);          // transform units per chunk: the taller tiles share more of the halo rows
+    const double per = 2.0 * mf * 1.1 + chunks * (300.0 + 3.0 * nu) + 6000.0;
     const long long full = nwg / 512, rem = nwg % 512;
     double t = (double)full * per;
     if (rem) t += rem > 256 ? per : mf * 1.2 + chunks * 800.0 + 12000.0;

@@ -233,7 +233,7 @@ class UNetGrad:
                 use_w = getattr(self.plan, "wino", False) and hb.wino_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
                 cls = hb.PackedWino if use_w else hb.PackedConv
                 from .engine import wino1d_enabled
-                if getattr(self.plan, "wino", False) and wino1d_enabled(k) and hb.wino1d_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
+                if getattr(self.plan, "wino1d", False) and wino1d_enabled(k) and hb.wino1d_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
                     cls = hb.PackedWino1d          # data gradient of a 7x7 / 5x5 layer: the same convolution on the transposed filter
                 self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
 

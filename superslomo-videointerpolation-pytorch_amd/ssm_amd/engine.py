@@ -139,6 +139,10 @@ class UNetPlan:
         self._Bcur = B
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.fuse_up = bool(fuse_upsample)      # concat+upsample fused into the consumer conv's loader (every mode)
+        # 7x7 / 5x5 layers in the 1-D Winograd form: inference plans only.  The training plans (materialised upsample tensors) keep them
+        # direct: the 8-point transforms round ~5x coarser than an fmaf chain, which moves more pre-activations across the LeakyReLU /
+        # |.| kinks of the loss - the parameter gradients at 64x64 then sit 4e-4 from CPU autograd instead of 6e-5 (bar 3e-4)
+        self.wino1d = self.wino and self.fuse_up and not twins
         # hoist = (B1, G): stage-2 inference plan whose batch holds G interpolation times for each of B1 pairs (entry p*G + i).  The
         # parts of two convolutions' inputs that do not depend on t - the image channels 0:3 / 13:16 of conv1a's 16-channel input
         # (flow_interpolation.py:364-367) and the stage-1 half of the cross-skip concat in front of conv7a (:98-101,224-231) - are
@@ -245,7 +249,7 @@ class UNetPlan:
                 use_w = (self.wino and name != "final_conv" and name not in WINO_SKIP and "all" not in WINO_SKIP
                          and hb.wino_supported(ci, co, self.H // s, self.W // s, k))
                 cls = hb.PackedWino if use_w else hb.PackedConv
-                if (self.wino and wino1d_enabled(k) and name not in WINO_SKIP and "all" not in WINO_SKIP
+                if (self.wino1d and wino1d_enabled(k) and name not in WINO_SKIP and "all" not in WINO_SKIP
                         and hb.wino1d_supported(ci, co, self.H // s, self.W // s, k)):
                     cls = hb.PackedWino1d
                 if self.hoist and name == "conv1a":

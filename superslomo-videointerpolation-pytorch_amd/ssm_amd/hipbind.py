@@ -168,7 +168,14 @@ def check(rc):
         raise RuntimeError("libssm_hip: %s (code %d)" % (msg.decode() if msg else "error", rc))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """torch's current HIP stream of the current device as the C ABI's `void *stream`.  The raw accessor skips the Stream object
+    torch.cuda.current_stream() builds (9 us per call - with ~400 launches per training step that was 3.5 ms of host time per step)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
