@@ -167,6 +167,24 @@ int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const floa
 int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
                                 ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 
+/* ---- the 3x3 convolution as Winograd F(4x4,3x3), all arithmetic fp32 (v_mfma_f32_16x16x4_f32) ------------------------------
+ * Same operator and operand layout as ssm_wino_conv2d_add_fwd / ssm_wino_conv2d_ups_add_fwd (layers.conv, scripts/models/layers.py:21-33;
+ * decoder step scripts/models/flow_computation.py:244-247), evaluated per 4x4 output tile from its 6x6 input patch over the points
+ * {0, +-1, +-2, inf}: 36 instead of 144 multiplies per (cin, cout, 16 outputs) - 1.78x fewer matrix-core cycles than F(2x2,3x3); in
+ * fp32 a single layer sits ~1e-5 from a float64 evaluation at unit output scale (per-layer bar 5e-5), the pair -> frame path at
+ * 736x1280 is unchanged within its fp32 noise (tests/emulate_winograd_f44_precision.py).
+ * Cin and the first cat source multiples of 4, Cout a multiple of 32; any H, W (fused upsample: even).
+ * ssm_wino4_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/32][Cin][9][32][4] (+ bias).                              */
+int ssm_wino4_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK);
+int ssm_wino4_force_kind(int kind);      /* tests / tuning only (-1 = automatic); returns the number of configurations */
+size_t ssm_wino4_packed_weight_floats(int Cout, int Cin);
+int ssm_wino4_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin, void *stream);
+int ssm_wino4_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                             ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags,
+                             void *stream);
+int ssm_wino4_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                 ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+
 /* ---- the 7x7 / 5x5 convolutions as one-dimensional Winograd along x, all arithmetic fp32 (v_mfma_f32_32x32x2_f32) ----------
  * Same operator and operand layout as ssm_conv2d_add_fwd for k = 7 / 5 (layers.conv, scripts/models/layers.py:21-33; the layers
  * conv1a/conv1b (k = 7) and conv2a/conv2b (k = 5) of both U-Nets, scripts/models/flow_computation.py:36-45 and

@@ -1,0 +1,701 @@
+// 3x3 convolution as Winograd F(4x4,3x3) on the CDNA4 fp32 matrix cores (v_mfma_f32_16x16x4_f32), all arithmetic fp32.
+//
+// Same operator as ssm_wino.hip / ssm_conv.hip for k = 3 (layers.conv of the reference, scripts/models/layers.py:21-33: stride-1
+// 'same' cross-correlation, zero padding, bias, LeakyReLU; fused 2x2 mean, scripts/models/layers.py:60-63; two-source input =
+// torch.cat on C; fused F.upsample(torch.cat([a, b], 1), bilinear x2), scripts/models/flow_computation.py:244-247), evaluated as
+//
+//      Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A          per 4x4 output tile (d = its 6x6 input patch, g = the 3x3 filter)
+//
+// over the points {0, 1, -1, 2, -2, inf}: 36 multiplies per (cin, cout, 16 outputs) instead of 144 - 4x fewer matrix-core cycles than
+// the direct form, 1.78x fewer than F(2x2,3x3).  In fp32 a single layer sits ~1e-5 from a float64 evaluation at unit output scale
+// (direct form 2e-6, F(2x2) 1e-6; per-layer bar 5e-5); the whole pair -> frame path at 736x1280 is unchanged within its fp32 noise
+// (2.32e-4 from float64 in every form: tests/emulate_winograd_f44_precision.py).
+//
+// Structure (as csrc/ssm_wino1d.hip): the 36 frequencies of a tile cost 144 vector operations per (cin, tile) - too many to sit in
+// the MFMA loop of every wave as in ssm_wino.hip - so the workgroup transforms the chunk's patch ONCE into V [cin][f/4][tile][4] in
+// LDS (two threads per (cin, tile): three frequency rows each), and the matrix loop only reads operands: per 4 frequencies one
+// ds_read_b128 of U and one of V feed 4 MFMAs.  GEMM view per frequency: M_f[cout][tile] = sum_cin U_f[cout][cin] V_f[cin][tile] with
+// v_mfma_f32_16x16x4_f32 (A = 16 couts x 4 cin, B = 4 cin x 16 tiles): a wave owns 16 couts x 16 tiles for ALL 36 frequencies = 36
+// accumulators of 4 registers, so the output transform A^T M A is lane-local, a lane finishes whole 4x4 pixel tiles (16-byte stores,
+// the 2x2 mean is lane-local too), and two workgroups share a CU (<= 256 registers per wave).  The bias rides on frequency (1,1):
+// A^T[a][1] = 1 for every output row / column a.
+//
+// Data movement as in ssm_conv.hip / ssm_wino.hip: padded planes, per chunk of 4 input channels the [4][9][32][4] filter values (double-
+// buffered) and the [4][TH+2][TW+8] patch (or, fused upsample, the low-res [4][TH/2+2][TW/2+8] patch, expanded in LDS by the same
+// expander) arrive by LDS-DMA.  The patch is single-buffered: the DMA of chunk c+1 is issued inside the matrix loop of chunk c, when
+// the transform of chunk c - the patch's only reader - is complete.
+#include "ssm_common.h"
+
+#include <atomic>
+#include <mutex>
+#include <type_traits>
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct W4Params {
+    const float *src1;
+    const float *src2;
+    long long sb1, sb2;  // batch strides
+    long long sc;        // channel stride (both sources)
+    int sh;              // row stride (both sources)
+    int C1, Cin;         // channels of source 1, total
+    const float *wpk;    // U, [Cout/32][Cin][9][32][4]
+    const float *bias;
+    float *dst;
+    long long dsb, dsc;
+    int dsh;
+    float *pool;
+    long long psb, psc;
+    int psh;
+    int H, W, Cout;      // OUTPUT map
+    int hs, ws;          // UPS: source map (H/2, W/2)
+    int tilesX, tilesY, NB;
+    float slope;
+    int lrelu;
+    int vec;             // 1: outputs / addend / pooled outputs may be moved as aligned 16- / 8-byte pieces (checked on the host)
+    int abl;             // diagnostics build only: 1 no LDS-DMA in the loop, 2 no stores, 4 no transform
+    const float *add;    // optional pre-activation addend [B / adiv][Cout][H][W] (ssm_conv2d_add_fwd)
+    long long asb, asc;
+    int ash, adiv;
+};
+
+// 2 cout halves x 2 tile groups = 4 waves; a tile group = GTX x GTY tiles of 4x4 pixels (16 tiles); the groups sit WTY x WTX
+template <int GTX_, int WTY_, int WTX_>
+struct W4Cfg {
+    static constexpr int GTX = GTX_, GTY = 16 / GTX_, WTY = WTY_, WTX = WTX_;
+    static constexpr int CK = 4, BN = 32, NT = 32;                             // chunk = one MFMA k-step of 4 input channels
+    static constexpr int NTX = GTX * WTX, NTY = GTY * WTY;                     // tiles per workgroup, by axis
+    static constexpr int TH = 4 * NTY, TW = 4 * NTX;                           // output pixels per workgroup
+    static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;               // patch rows y0-1 .., columns x0-4 .. x0+TW+3
+    static constexpr int SHIFT = 1;                                            // floats: a tile's window starts at patch column 4 Tx + 3 + SHIFT
+    static constexpr int USZ = CK * 9 * BN * 4;                                // filter floats per chunk
+    static constexpr int PSZ = CK * PH * PW;                                   // patch floats per chunk
+    static constexpr int VSZ = CK * 9 * NT * 4;                                // transformed patch
+    static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;       // fused upsample: low-res raw patch
+    static constexpr int RSZ = CK * LH * LW;
+    static constexpr int NPOS = (TH / 2 + 1) * (TW / 2 + 1);                   // 2x2 hi-res block positions of the expander
+    static_assert(WTY * WTX == 2 && (GTX == 4 || GTX == 8 || GTX == 16), "two tile groups of 16 tiles");
+    static_assert(USZ % 256 == 0 && NPOS <= 256, "filter stage = whole 1-KiB DMA groups; expander: one position per thread");
+};
+
+template <class C, bool UPS>
+struct W4Lds {
+    static constexpr int DSZ = UPS ? C::RSZ : C::PSZ;
+    static constexpr int DH = UPS ? C::LH : C::PH, DW4 = UPS ? C::LW4 : C::PW4;
+    static constexpr int NGU = C::USZ / 256;                    // 1-KiB groups of filter per chunk
+    static constexpr int NDQ = DSZ / 4;                         // 16-byte pieces of (raw) patch per chunk
+    static constexpr int NGP = (NDQ + 63) / 64;
+    static constexpr int NIU = (NGU + 3) / 4, NIP = (NGP + 3) / 4, NI = NIU + NIP;   // DMA instructions per wave per chunk
+    static constexpr int UOFF = 0;                              // two filter stages
+    static constexpr int DOFF = 2 * C::USZ;                     // the DMA'd patch (plain: lands SHIFT floats in; UPS: the low-res raw patch)
+    static constexpr int DCAP = NGP * 256 + 256;
+    static constexpr int HOFF = DOFF + DCAP;                    // UPS: the expanded hi-res patch
+    static constexpr int POFF = UPS ? HOFF : DOFF;              // the patch the transform reads (its floats start at + SHIFT in the plain form)
+    static constexpr int VOFF = HOFF + (UPS ? C::PSZ + 4 : 0);  // transformed patch
+    static constexpr int BYTES = (VOFF + C::VSZ) * 4;
+    static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0, "16-byte aligned regions");
+    static_assert(BYTES <= 80 * 1024, "LDS budget (two workgroups per CU)");
+};
+
+#ifdef SSM_WINO_ABLATE
+#define W4ABL(bit) (p.abl & (bit))
+#else
+#define W4ABL(bit) 0
+#endif
+
+template <class C, bool UPS>
+__global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using L = W4Lds<C, UPS>;
+    constexpr int BN = C::BN, PH = C::PH, PW = C::PW, CK = C::CK, NT = C::NT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wid & 1, tg = wid >> 1;          // cout half, tile group of this wave
+
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
+    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
+    const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
+    const float *wbase = p.wpk + (long long)nb * p.Cin * (9 * BN * 4);
+
+    // per-lane source offsets (bytes) of the patch pieces this wave brings per chunk; the filter pieces are linear
+    int poff[L::NIP];
+#pragma unroll
+    for (int i = 0; i < L::NIP; ++i) {
+        const int qq = (i * 4 + wid) * 64 + lane;
+        if (qq < L::NDQ) {
+            const int c = qq / (L::DH * L::DW4);
+            const int rem = qq - c * (L::DH * L::DW4);
+            const int r = rem / L::DW4;
+            const int j = rem - r * L::DW4;
+            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+        } else {
+            poff[i] = 0;          // tail of the last 1-KiB piece: lands in the region's padding
+        }
+    }
+    const int uoff = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+
+    // k-th DMA instruction of this wave for chunk `ch`: k < NIU filter group 4k + wave into filter stage `stage`, else the patch
+    auto issue_k = [&](int ch, int stage, int k) {
+        const int c0 = ch * CK;
+        if (k < L::NIU) {
+            const int g = 4 * k + wid;
+            if (g < L::NGU) {
+                const float *base = wbase + (long long)c0 * (9 * BN * 4) + g * 256;
+                const unsigned m0v = lds0 + (unsigned)(L::UOFF + stage * C::USZ) * 4u + (unsigned)g * 1024u;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
+            }
+        } else {
+            const int kk = k - L::NIU;
+            const int g = 4 * kk + wid;
+            if (g < L::NGP) {
+                const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
+                const unsigned m0v = lds0 + (unsigned)L::DOFF * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
+            }
+        }
+    };
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.Cin / CK;
+#pragma unroll
+    for (int k = 0; k < L::NI; ++k) issue_k(0, 0, k);
+    // Bias: A^T[a][1] = 1 for every output row and column a (the point p = 1), so the accumulator of frequency (1,1) = 7 starts from
+    // the bias: one MFMA k-step with A = the bias column (k = 0) and B = a row of ones.
+    {
+        const float bv0 = p.bias[nb * BN + cb * 16 + l15];
+        const float ab = q ? 0.f : bv0, ones = q ? 0.f : 1.f;
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab, ones, acc[7], 0, 0, 0);
+    }
+
+    // ---- per-thread constants of the transform phase: unit = (cin, tile), two threads per unit (frequency rows 0..2 | 3..5) -------
+    const int thh = wid >> 1;                        // wave-uniform: which three frequency rows this thread computes
+    const int tu = tid & 127;                        // unit: cin = tu / 32, tile = tu % 32
+    const int tcin = tu >> 5, ttile = tu & 31;
+    // tile index -> position inside the workgroup's tile: group g2 = tile / 16, (gy, gx) inside the group
+    const int tgx = (ttile & 15) % C::GTX, tgy = (ttile & 15) / C::GTX, tg2 = ttile >> 4;
+    const int tTx = (tg2 % C::WTX) * C::GTX + tgx, tTy = (tg2 / C::WTX) * C::GTY + tgy;
+    const int t_src = L::POFF + (UPS ? 0 : C::SHIFT) + (tcin * PH + 4 * tTy) * PW + 4 * tTx + 3 + (UPS ? C::SHIFT : 0);   // floats; 16-byte aligned
+    const int t_dst = L::VOFF / 4 + (tcin * 9) * NT + ttile;                                                              // f32x4 units
+
+    // ---- the matrix loop's operand bases (f32x4 units): U of (cin = 4cp + q, fq, cout = cb*16 + l15), V of (cin, fq, tile) ---------
+    const f32x4 *lds4 = (const f32x4 *)lds;
+    const int aBase = L::UOFF / 4 + q * (9 * BN) + cb * 16 + l15;
+    const int bBase = L::VOFF / 4 + q * (9 * NT) + tg * 16 + l15;
+
+    // fused upsample: low-res raw chunk -> hi-res patch; one thread = one 2x2 hi-res block position, walking the chunk's channels
+    auto expand = [&]() {
+        if constexpr (UPS) {
+            constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, LH = C::LH, LW = C::LW;
+            const float *raw = lds + L::DOFF;
+            float *hip = lds + L::HOFF;
+            if (tid < NPOS) {
+                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+                const int pi = tid / PRW, pj = tid - pi * PRW;
+                const int i = ly0 + pi, j = lx0 + pj;
+                const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
+                const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
+                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;      // column 2j+1 = xa x[j0] + xb x[j0+1]
+                const float ca = j0 == j1 ? 1.f : 0.25f, cbw = j0 == j1 ? 0.f : 0.75f;     // column 2j+2 = ca x[j0] + cbw x[j0+1]
+                const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
+                const int Y = 2 * i + 1, X = 2 * j + 1;
+                const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
+                const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
+                // (the right neighbour is read at j0 + 1 even where the source index is clamped: its weight is then exactly 0 and the
+                // value - the zero frame or a neighbouring pixel - is finite)
+                const float *r0 = raw + (i0 - ly0) * LW + 3 - lx0 + j0;
+                const float *r1 = raw + (i1 - ly0) * LW + 3 - lx0 + j0;
+                float *dd = hip + (2 * pi) * PW + 2 * pj + 3 + C::SHIFT;       // hi-res pixel x0 + 2pj - 1 -> patch column 2pj + 3 (+ SHIFT)
+                float v00[CK], v01[CK], v10[CK], v11[CK];
+#pragma unroll
+                for (int cc = 0; cc < CK; ++cc) {
+                    v00[cc] = r0[cc * LH * LW];
+                    v01[cc] = r0[cc * LH * LW + 1];
+                    v10[cc] = r1[cc * LH * LW];
+                    v11[cc] = r1[cc * LH * LW + 1];
+                }
+#pragma unroll
+                for (int cc = 0; cc < CK; ++cc) {
+                    const float h00 = xa * v00[cc] + xb * v01[cc], h01 = ca * v00[cc] + cbw * v01[cc];
+                    const float h10 = xa * v10[cc] + xb * v11[cc], h11 = ca * v10[cc] + cbw * v11[cc];
+                    dd[cc * PH * PW] = m00 * (ya * h00 + yb * h10);
+                    dd[cc * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
+                    dd[cc * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
+                    dd[cc * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    // V = B^T d B of one (cin, tile): this thread's three frequency rows.  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0;
+    // 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] (the points 0, 1, -1, 2, -2, inf).
+    auto transform = [&]() {
+        const float *rp = lds + t_src;
+        float d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4 a4 = *(const f32x4 *)(rp + i * PW);
+            const f32x2 a2 = *(const f32x2 *)(rp + i * PW + 4);
+            d[i][0] = a4[0];
+            d[i][1] = a4[1];
+            d[i][2] = a4[2];
+            d[i][3] = a4[3];
+            d[i][4] = a2[0];
+            d[i][5] = a2[1];
+        }
+        // the values arrive as 16- / 8-byte pieces: pin each as a scalar so that no packed-fp32 arithmetic is formed (DESIGN 3.3 fence)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(d[i][j]));
+        float w[3][6];          // three rows of B^T d
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (thh == 0) {
+                const float t1 = d[4][j] - 4.f * d[2][j], t2 = d[3][j] - 4.f * d[1][j];
+                w[0][j] = (4.f * d[0][j] - 5.f * d[2][j]) + d[4][j];
+                w[1][j] = t1 + t2;
+                w[2][j] = t1 - t2;
+            } else {
+                const float t3 = d[4][j] - d[2][j], t4 = d[3][j] - d[1][j];
+                w[0][j] = t3 + 2.f * t4;
+                w[1][j] = t3 - 2.f * t4;
+                w[2][j] = (4.f * d[1][j] - 5.f * d[3][j]) + d[5][j];
+            }
+        }
+        float v[18];            // (rows) x B: frequency 18 thh + 6 i + j
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float t1 = w[i][4] - 4.f * w[i][2], t2 = w[i][3] - 4.f * w[i][1];
+            const float t3 = w[i][4] - w[i][2], t4 = w[i][3] - w[i][1];
+            v[6 * i] = (4.f * w[i][0] - 5.f * w[i][2]) + w[i][4];
+            v[6 * i + 1] = t1 + t2;
+            v[6 * i + 2] = t1 - t2;
+            v[6 * i + 3] = t3 + 2.f * t4;
+            v[6 * i + 4] = t3 - 2.f * t4;
+            v[6 * i + 5] = (4.f * w[i][1] - 5.f * w[i][3]) + w[i][5];
+        }
+        f32x4 *vo = (f32x4 *)lds + t_dst;
+        if (thh == 0) {          // frequencies 0..17: quads 0..3 whole, the low half of quad 4
+#pragma unroll
+            for (int g = 0; g < 4; ++g) vo[g * NT] = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            *(f32x2 *)(vo + 4 * NT) = f32x2{v[16], v[17]};
+        } else {                 // frequencies 18..35: the high half of quad 4, quads 5..8 whole
+            *((f32x2 *)(vo + 4 * NT) + 1) = f32x2{v[0], v[1]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) vo[(5 + g) * NT] = f32x4{v[2 + 4 * g], v[3 + 4 * g], v[4 + 4 * g], v[5 + 4 * g]};
+        }
+    };
+
+    f32x4 a[2], bq[2];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int stage = ch & 1;
+        // chunk ch has landed for every wave; every wave is done with the MFMAs of chunk ch-1 (V and the other filter stage are free)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool dma_next = ch + 1 < nchunks && !(W4ABL(1) && ch >= 1);
+        expand();
+        if (!W4ABL(4) || ch == 0) transform();
+        __syncthreads();
+
+        // ---- matrix phase: 9 groups of 4 frequencies = 36 MFMAs; the operands of group g+1 are fetched behind the first MFMA of
+        // group g, the DMA of chunk ch+1 (filter into the other stage, patch into the buffer the transform just finished with) is
+        // issued one instruction per group -----------------------------------------------------------------------------------------
+        const int ai = aBase + stage * (C::USZ / 4), bi = bBase;
+        a[0] = lds4[ai];
+        bq[0] = lds4[bi];
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            const int cur = g & 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[4 * g + e], 0, 0, 0);
+                if (e == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 1 < 9) {
+                        a[cur ^ 1] = lds4[ai + (g + 1) * BN];
+                        bq[cur ^ 1] = lds4[bi + (g + 1) * NT];
+                    }
+                    if (g < L::NI && dma_next) issue_k(ch + 1, stage ^ 1, g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (L::NI > 9) {
+            if (dma_next) {
+#pragma unroll
+                for (int k = 9; k < L::NI; ++k) issue_k(ch + 1, stage ^ 1, k);
+            }
+        }
+    }
+
+    // ---- epilogue: Y = A^T M A per accumulator register (4 couts per lane), addend, LeakyReLU, stores, fused 2x2 mean -------------
+    // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+#ifdef SSM_WINO_ABLATE
+    if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
+#endif
+    {
+        const int gx = l15 % C::GTX, gy = l15 / C::GTX;
+        const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
+        const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
+        const float sl = p.lrelu ? p.slope : 1.f;
+        float *dstb = p.dst + (long long)b * p.dsb;
+        float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
+        const int cu0 = nb * BN + cb * 16;          // Cout is a multiple of 32 (checked on the host)
+        const unsigned pb = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
+        const unsigned qb = 4u * ((unsigned)(4 * q) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
+        const bool vok = py + 4 <= p.H && px + 4 <= p.W && p.vec;          // whole tile inside the map, rows as aligned 16-byte pieces
+        auto st4 = [](const float *base, unsigned off_bytes, f32x4 val) {
+            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        auto st2 = [](const float *base, unsigned off_bytes, f32x2 val) {
+            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        auto st1 = [](const float *base, unsigned off_bytes, float val) {
+            asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * q) * p.asc + (long long)py * p.ash + px : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cu = cu0 + r;          // uniform; this lane's cout = cu + 4 * q
+            float t[4][6];                   // A^T M: over the frequency rows i, for every frequency column j
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r], m5 = acc[30 + j][r];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                t[0][j] = (m0 + s1) + s2;
+                t[1][j] = d1 + 2.f * d2;
+                t[2][j] = s1 + 4.f * s2;
+                t[3][j] = (d1 + m5) + 8.f * d2;
+            }
+            float y[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s1 = t[i][1] + t[i][2], d1 = t[i][1] - t[i][2], s2 = t[i][3] + t[i][4], d2 = t[i][3] - t[i][4];
+                y[i][0] = (t[i][0] + s1) + s2;
+                y[i][1] = d1 + 2.f * d2;
+                y[i][2] = s1 + 4.f * s2;
+                y[i][3] = (d1 + t[i][5]) + 8.f * d2;
+            }
+            if (addb) {
+                const float *ap = addb + (long long)cu * p.asc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (vok) {
+                        const f32x4 z = *(const f32x4 *)(ap + (long long)i * p.ash);
+                        y[i][0] += z[0];
+                        y[i][1] += z[1];
+                        y[i][2] += z[2];
+                        y[i][3] += z[3];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (py + i < p.H && px + e < p.W) y[i][e] += ap[(long long)i * p.ash + e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[i][e] = fmaxf(y[i][e], y[i][e] * sl);
+            float *bp = dstb + (long long)cu * p.dsc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (vok) {
+                    st4(bp + (long long)i * p.dsh, pb, f32x4{y[i][0], y[i][1], y[i][2], y[i][3]});
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (py + i < p.H && px + e < p.W) st1(bp + (long long)i * p.dsh + e, pb, y[i][e]);
+                }
+            }
+            if (poolb) {
+                // 2x2 mean, vertical pairs first then the horizontal pair (the association of the direct kernel); H, W even (host check)
+                float *qp = poolb + (long long)cu * p.psc;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float o0 = ((y[2 * i][0] + y[2 * i + 1][0]) + (y[2 * i][1] + y[2 * i + 1][1])) * 0.25f;
+                    const float o1 = ((y[2 * i][2] + y[2 * i + 1][2]) + (y[2 * i][3] + y[2 * i + 1][3])) * 0.25f;
+                    const bool rok = py + 2 * i < p.H;
+                    if (rok && px + 4 <= p.W && p.vec) st2(qp + (long long)i * p.psh, qb, f32x2{o0, o1});
+                    else if (rok) {
+                        if (px + 2 <= p.W) st1(qp + (long long)i * p.psh, qb, o0);
+                        if (px + 4 <= p.W) st1(qp + (long long)i * p.psh + 1, qb, o1);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- tile configurations ---------------------------------------------------------------------------------------------------------
+//                     GTX WTY WTX          tiles of 4x4 px     TH   TW
+using X4A = W4Cfg<8, 2, 1>;      //          8 x 4                16   32
+using X4B = W4Cfg<16, 2, 1>;     //         16 x 2                 8   64
+using X4C = W4Cfg<4, 1, 2>;      //          8 x 4 (4x4 groups)   16   32
+// (row tiles stay <= 16: a tile that overshoots the map reads TH - 2 rows past the plane's frame, which the 64 Ki floats of slack behind
+// every tensor cover up to 4K-wide planes)
+
+#define SSM_W4_KINDS(X) X(X4A_, X4A) X(X4B_, X4B) X(X4C_, X4C)
+
+enum W4Kind {
+#define X(name, cfg) name,
+    SSM_W4_KINDS(X)
+#undef X
+        NW4KIND
+};
+
+struct W4KindInfo {
+    int th, tw;
+};
+
+template <class C>
+constexpr W4KindInfo w4info_of() {
+    return W4KindInfo{C::TH, C::TW};
+}
+
+constexpr W4KindInfo kW4Info[NW4KIND] = {
+#define X(name, cfg) w4info_of<cfg>(),
+    SSM_W4_KINDS(X)
+#undef X
+};
+
+std::atomic<int> g_force_w4kind{-1};
+
+// Estimated duration (cycles) of a launch: two co-resident workgroups per CU share the matrix pipe; per chunk a workgroup needs 36
+// MFMAs of 32 cycles per wave and, around them, two barriers + the transform (+ the expansion); whole rounds of 512 workgroups.
+double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W, int ups) {
+    const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
+    const long long nwg = tiles * (Cout / 32);
+    const double chunks = (double)Cin / 4.0;
+    const double mf = chunks * 36.0 * 32.0;
+    const double per = 2.0 * mf * 1.15 + chunks * (ups ? 500.0 : 250.0) + 7000.0;
+    const long long full = nwg / 512, rem = nwg % 512;
+    double t = (double)full * per;
+    if (rem) t += rem > 256 ? per : mf * 1.3 + chunks * (ups ? 1100.0 : 700.0) + 9000.0;
+    return t;
+}
+
+int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
+    const int forced = g_force_w4kind.load();
+    if (forced >= 0 && forced < NW4KIND) return forced;
+    int best = -1;
+    double bt = 0.0;
+    for (int i = 0; i < NW4KIND; ++i) {
+        const double t = estimate_w4(kW4Info[i], Cin, Cout, B, H, W, ups);
+        if (best < 0 || t < bt * 0.999) {
+            best = i;
+            bt = t;
+        }
+    }
+    return best;
+}
+
+template <class C, bool UPS>
+int w4launch(W4Params &p, int B, hipStream_t st) {
+    p.tilesX = (p.W + C::TW - 1) / C::TW;
+    p.tilesY = (p.H + C::TH - 1) / C::TH;
+    p.NB = p.Cout / C::BN;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) {
+        ssm::set_error("wino4 conv: grid of %lld workgroups out of range", blocks);
+        return SSM_E_ARG;
+    }
+    constexpr int lds_bytes = W4Lds<C, UPS>::BYTES;
+    auto kern = wino4_kernel<C, UPS>;
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    if (attr_rc != hipSuccess) {
+        ssm::set_error("wino4 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
+        return SSM_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+    return ssm::check_launch(UPS ? "ssm_wino4_conv2d_ups_fwd" : "ssm_wino4_conv2d_fwd");
+}
+
+template <bool UPS>
+int w4dispatch(int kind, W4Params &p, int B, hipStream_t st) {
+    switch (kind) {
+#define X(name, cfg) \
+    case name: return w4launch<cfg, UPS>(p, B, st);
+        SSM_W4_KINDS(X)
+#undef X
+    }
+    return SSM_E_UNSUPPORTED;
+}
+
+// U = G g G^T,  G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], evaluated in float64 and rounded
+// once; packed index -> (nb, cin, fq, n, e), frequency f = 4 fq + e = 6 i + j
+__global__ void wino4_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ wp,
+                                  float *__restrict__ bp, int Cout, int Cin, long long total, int nbias) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        long long r = idx;
+        const int e = (int)(r % 4);
+        r /= 4;
+        const int n = (int)(r % 32);
+        r /= 32;
+        const int fq = (int)(r % 9);
+        r /= 9;
+        const int cin = (int)(r % Cin);
+        const int nb = (int)(r / Cin);
+        const int co = nb * 32 + n, f = 4 * fq + e, i = f / 6, j = f % 6;
+        double val = 0.0;
+        if (co < Cout) {
+            const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+            const float *g = w + ((long long)co * Cin + cin) * 9;
+            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 3; ++c) val += G[i][a] * (double)g[3 * a + c] * G[j][c];
+        }
+        wp[idx] = (float)val;
+    }
+    if (idx < nbias) bp[idx] = (idx < Cout) ? bias[idx] : 0.f;
+}
+
+int w4fill(W4Params &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y, ssm_view pool,
+           ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, int srcW) {
+    SSM_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && C1 > 0 && C2 >= 0, "wino4 conv: bad sizes");
+    SSM_REQUIRE(Cout % 32 == 0, "wino4 conv: Cout (%d) must be a multiple of 32", Cout);
+    SSM_REQUIRE(x1.ptr && y.ptr && w_packed && bias_packed, "wino4 conv: null pointer");
+    SSM_REQUIRE(C1 % 4 == 0 && C2 % 4 == 0, "wino4 conv: channel counts (%d,%d) must be multiples of 4", C1, C2);
+    SSM_REQUIRE(ssm::aligned16(x1.ptr) && x1.sh % 4 == 0 && x1.sc % 4 == 0 && x1.sb % 4 == 0,
+                "wino4 conv: input 1 is not a padded-plane view (16-byte alignment)");
+    SSM_REQUIRE(x1.sh >= srcW + 2 * SSM_PADX, "wino4 conv: input 1 row stride %d leaves no zero frame for W=%d", x1.sh, srcW);
+    SSM_REQUIRE(ssm::aligned16(w_packed), "wino4 conv: packed filter must be 16-byte aligned");
+    if (C2 > 0) {
+        SSM_REQUIRE(x2.ptr && ssm::aligned16(x2.ptr) && x2.sb % 4 == 0, "wino4 conv: input 2 is not a padded-plane view");
+        SSM_REQUIRE(x2.sh == x1.sh && x2.sc == x1.sc, "wino4 conv: cat sources must share row/channel strides");
+    }
+    SSM_REQUIRE(4LL * x1.sc * 4 < 0x7fffffffLL, "wino4 conv: channel stride too large");
+    p.src1 = x1.ptr;
+    p.src2 = C2 > 0 ? x2.ptr : x1.ptr;
+    p.sb1 = x1.sb;
+    p.sb2 = C2 > 0 ? x2.sb : 0;
+    p.sc = x1.sc;
+    p.sh = x1.sh;
+    p.C1 = C1;
+    p.Cin = C1 + C2;
+    p.wpk = w_packed;
+    p.bias = bias_packed;
+    p.dst = y.ptr;
+    p.dsb = y.sb;
+    p.dsc = y.sc;
+    p.dsh = y.sh;
+    p.pool = nullptr;
+    p.psb = p.psc = 0;
+    p.psh = 0;
+    p.H = H;
+    p.W = W;
+    p.hs = H / 2;
+    p.ws = W / 2;
+    p.Cout = Cout;
+    p.slope = slope;
+    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.abl = 0;
+    p.add = nullptr;
+    p.asb = p.asc = 0;
+    p.ash = 0;
+    p.adiv = 1;
+#ifdef SSM_WINO_ABLATE
+    if (const char *e = getenv("SSM_WINO4_ABL")) p.abl = atoi(e);
+#endif
+    bool vec = W % 4 == 0 && ssm::aligned16(y.ptr) && y.sh % 4 == 0 && y.sc % 4 == 0 && y.sb % 4 == 0;
+    if (add.ptr) {
+        SSM_REQUIRE(add_div >= 1 && B % add_div == 0, "wino4 conv: the addend serves %d batch entries each, batch %d is no multiple", add_div, B);
+        p.add = add.ptr;
+        p.asb = add.sb;
+        p.asc = add.sc;
+        p.ash = add.sh;
+        p.adiv = add_div;
+        vec = vec && ssm::aligned16(add.ptr) && add.sh % 4 == 0 && add.sc % 4 == 0 && add.sb % 4 == 0;
+    }
+    if (pool.ptr) {
+        SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino4 conv: fused pool needs even H, W");
+        p.pool = pool.ptr;
+        p.psb = pool.sb;
+        p.psc = pool.sc;
+        p.psh = pool.sh;
+        vec = vec && (reinterpret_cast<size_t>(pool.ptr) & 7) == 0 && pool.sh % 2 == 0 && pool.sc % 2 == 0 && pool.sb % 2 == 0;
+    }
+    p.vec = vec ? 1 : 0;
+    return SSM_OK;
+}
+
+}  // namespace
+
+extern "C" int ssm_wino4_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK) {
+    if (Cin % 4 || Cout % 32 || Cin <= 0 || Cout <= 0) {
+        ssm::set_error("wino4 conv: no tile configuration for Cin=%d Cout=%d (Cin a multiple of 4, Cout a multiple of 32)", Cin, Cout);
+        return SSM_E_UNSUPPORTED;
+    }
+    if (kind) *kind = pick_w4kind(Cin, Cout, B, H, W, ups);
+    if (BN) *BN = 32;
+    if (CK) *CK = 4;
+    return SSM_OK;
+}
+
+extern "C" int ssm_wino4_force_kind(int kind) {
+    g_force_w4kind.store(kind >= 0 && kind < NW4KIND ? kind : -1);
+    return NW4KIND;
+}
+
+extern "C" size_t ssm_wino4_packed_weight_floats(int Cout, int Cin) { return (size_t)(Cout / 32) * (size_t)Cin * 9 * 32 * 4; }
+
+extern "C" int ssm_wino4_pack_weights(const float *w, const float *bias, float *wp, float *bp, int Cout, int Cin, void *stream) {
+    SSM_REQUIRE(w && bias && wp && bp, "wino4 pack_weights: null pointer");
+    SSM_REQUIRE(Cout > 0 && Cin > 0 && Cout % 32 == 0, "wino4 pack_weights: bad sizes (Cout a multiple of 32)");
+    const long long total = (long long)ssm_wino4_packed_weight_floats(Cout, Cin);
+    const int nbias = Cout;
+    const long long n = total > nbias ? total : nbias;
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
+                       total, nbias);
+    return ssm::check_launch("ssm_wino4_pack_weights");
+}
+
+extern "C" int ssm_wino4_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                        ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags,
+                                        void *stream) {
+    int kind = 0;
+    const int rc = ssm_wino4_plan(C1 + C2, Cout, B, H, W, 0, &kind, nullptr, nullptr);
+    if (rc != SSM_OK) return rc;
+    W4Params p;
+    const int rf = w4fill(p, x1, C1, x2, C2, w_packed, bias_packed, y, pool, add, add_div, B, H, W, Cout, slope, flags, W);
+    if (rf != SSM_OK) return rf;
+    return w4dispatch<false>(kind, p, B, (hipStream_t)stream);
+}
+
+extern "C" int ssm_wino4_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                            ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    int kind = 0;
+    SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino4 conv_ups: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
+    const int rc = ssm_wino4_plan(C1 + C2, Cout, B, H, W, 1, &kind, nullptr, nullptr);
+    if (rc != SSM_OK) return rc;
+    W4Params p;
+    const ssm_view none = {nullptr, 0, 0, 0};
+    const int rf = w4fill(p, a, C1, b, C2, w_packed, bias_packed, y, none, add, add_div, B, H, W, Cout, slope, flags, W / 2);
+    if (rf != SSM_OK) return rf;
+    return w4dispatch<true>(kind, p, B, (hipStream_t)stream);
+}

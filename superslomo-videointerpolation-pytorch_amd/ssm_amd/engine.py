@@ -78,6 +78,14 @@ WINO_SKIP = frozenset(n for n in os.environ.get("SSM_WINO_SKIP", "").split(",") 
 WINO1D = os.environ.get("SSM_WINO1D", "57")
 
 
+# 3x3 layers of an f32w plan as F(4x4,3x3) (csrc/ssm_wino4.hip) instead of F(2x2,3x3): $SSM_WINO4=0 keeps F(2x2); a comma list names layers
+WINO4 = os.environ.get("SSM_WINO4", "1")
+
+
+def wino4_enabled(name):
+    return WINO4 not in ("0", "") and (WINO4 == "1" or name in WINO4.split(","))
+
+
 def wino1d_enabled(k):
     """Does mode f32w evaluate the k x k layers in the 1-D Winograd form?  (bench.py: FLOP issued on the matrix cores)"""
     return k in (5, 7) and str(k) in WINO1D
@@ -87,6 +95,8 @@ def conv_fn(pk, ups=False):
     """The launcher that goes with a packed filter's algorithm."""
     if pk.algo == "wino1d":
         return hb.conv2d_wino1d
+    if pk.algo == "wino4":
+        return hb.conv2d_ups_wino4 if ups else hb.conv2d_wino4
     if pk.algo == "wino":
         return hb.conv2d_ups_wino if ups else hb.conv2d_wino
     return hb.conv2d_ups if ups else hb.conv2d
@@ -249,6 +259,8 @@ class UNetPlan:
                 use_w = (self.wino and name != "final_conv" and name not in WINO_SKIP and "all" not in WINO_SKIP
                          and hb.wino_supported(ci, co, self.H // s, self.W // s, k))
                 cls = hb.PackedWino if use_w else hb.PackedConv
+                if use_w and self.wino1d and wino4_enabled(name) and hb.wino4_supported(ci, co, self.H // s, self.W // s, k):
+                    cls = hb.PackedWino4          # inference plans: F(4x4,3x3)
                 if (self.wino1d and wino1d_enabled(k) and name not in WINO_SKIP and "all" not in WINO_SKIP
                         and hb.wino1d_supported(ci, co, self.H // s, self.W // s, k)):
                     cls = hb.PackedWino1d
@@ -354,11 +366,9 @@ class UNetPlan:
                               fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
         elif self.hoist and name == "conv7a" and self.cross:
             assert self._pair_parts_ready, "hoisted stage-2 plan: run_pair_parts() must run before the per-t launches of a pass"
-            fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
-            fn(self._v(a), A.C, None, 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True, add=self.t["pair7a"].view(), add_div=self.hoist[1])
+            conv_fn(pk, True)(self._v(a), A.C, None, 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True, add=self.t["pair7a"].view(), add_div=self.hoist[1])
         else:
-            fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
-            fn(self._v(a), A.C, bview, Bp.C if Bp else 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True)
+            conv_fn(pk, True)(self._v(a), A.C, bview, Bp.C if Bp else 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True)
         if tm is not None:
             e1.record()
 
@@ -402,8 +412,7 @@ class UNetPlan:
             if tm is not None:
                 e0, e1 = tm.span("conv", "s2.conv7a(pair)", 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * 9)
                 e0.record()
-            fn = hb.conv2d_ups_wino if pk.algo == "wino" else hb.conv2d_ups
-            fn(c6_planes.view(), 512, None, 0, pk, P.view(), B1, P.H, P.W, lrelu=False)
+            conv_fn(pk, True)(c6_planes.view(), 512, None, 0, pk, P.view(), B1, P.H, P.W, lrelu=False)
             if tm is not None:
                 e1.record()
 

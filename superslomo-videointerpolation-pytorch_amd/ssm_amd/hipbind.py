@@ -63,6 +63,14 @@ SIGNATURES = {
     "ssm_wino_deep_ring": (_c_int, [_c_int]),
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
+    "ssm_wino4_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
+    "ssm_wino4_force_kind": (_c_int, [_c_int]),
+    "ssm_wino4_packed_weight_floats": (_sz, [_c_int, _c_int]),
+    "ssm_wino4_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _vp]),
+    "ssm_wino4_conv2d_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int,
+                                          _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_wino4_conv2d_ups_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int,
+                                              _c_int, _c_float, _c_int, _vp]),
     "ssm_wino1d_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino1d_force_kind": (_c_int, [_c_int]),
     "ssm_wino1d_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int, _c_int]),
@@ -371,6 +379,57 @@ def conv2d_ups_wino(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=Non
     check(lib.ssm_wino_conv2d_ups_add_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                           add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
                                           SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
+# ---- 3x3 convolution as Winograd F(4x4,3x3) in fp32 (csrc/ssm_wino4.hip) -------------------------------------------------
+def wino4_plan(cin, cout, B, H, W, ups=False):
+    lib = load()
+    kind, bn, ck = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.ssm_wino4_plan(cin, cout, B, H, W, 1 if ups else 0, ctypes.byref(kind), ctypes.byref(bn), ctypes.byref(ck)))
+    return kind.value, bn.value, ck.value
+
+
+def wino4_supported(cin, cout, H, W, k=3):
+    """Can this layer run as F(4x4,3x3)?  (3x3, whole 4-channel chunks, 32-channel output blocks)"""
+    return k == 3 and cin % 4 == 0 and cout % 32 == 0
+
+
+class PackedWino4:
+    """3x3 filter pre-transformed for F(4x4,3x3) (U = G g G^T, 36 frequencies) and packed [Cout/32][Cin][9][32][4]; an explicit
+    handle owned by the Python side like PackedConv."""
+
+    algo = "wino4"
+
+    def __init__(self, weight, bias, B, H, W, pool=False, ups=False):
+        require_device(weight, "conv weight")
+        require_device(bias, "conv bias")
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        assert self.k == 3 and weight.shape[3] == 3, "F(4x4,3x3) is for 3x3 filters"
+        self.ups = bool(ups)
+        _, self.bn, self.ck = wino4_plan(self.cin, self.cout, B, H, W, self.ups)
+        self.cin_p = self.cin
+        lib = load()
+        self.w = torch.empty(lib.ssm_wino4_packed_weight_floats(self.cout, self.cin), dtype=torch.float32, device=weight.device)
+        self.b = torch.empty(self.cout, dtype=torch.float32, device=weight.device)
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        check(lib.ssm_wino4_pack_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout, self.cin, stream_ptr()))
+
+
+def conv2d_wino4(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+    lib = load()
+    assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
+    check(lib.ssm_wino4_conv2d_add_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
+                                       pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, H, W,
+                                       pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
+def conv2d_ups_wino4(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+    """conv3x3(upsample2x(cat[a, b])) as F(4x4,3x3): a, b LOW-res padded-plane views, H, W the OUTPUT size."""
+    lib = load()
+    assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
+    check(lib.ssm_wino4_conv2d_ups_add_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
+                                           add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
+                                           SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
 # ---- 7x7 / 5x5 convolutions as 1-D Winograd along x, F(2,7) / F(4,5), in fp32 (csrc/ssm_wino1d.hip) -----------------

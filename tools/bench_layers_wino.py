@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-layer A/B of the 3x3 layers at the 736x1280 shapes of SURVEY Appendix A: direct fp32-MFMA kernel (csrc/ssm_conv.hip) vs the
 Winograd F(2x2,3x3) fp32 kernel (csrc/ssm_wino.hip), plain and fused-upsample forms.  TFLOP/s are ALGORITHMIC (direct-form FLOPs).
-usage: python tools/bench_layers_wino.py [B] [H] [W] [wino_kind|-1]"""
+usage: python tools/bench_layers_wino.py [B] [H] [W] [wino_kind|-1]      (W4=1: the Winograd column is F(4x4,3x3), csrc/ssm_wino4.hip;
+W4KIND forces its tile configuration)"""
 import os
 import sys
 
@@ -37,6 +38,9 @@ def main():
     force = int(sys.argv[4]) if len(sys.argv) > 4 else -1
     dev = torch.device("cuda:0")
     hb.load().ssm_wino_force_kind(force)
+    w4 = os.environ.get("W4", "0") != "0"
+    if w4:
+        hb.load().ssm_wino4_force_kind(int(os.environ.get("W4KIND", "-1")))
     tot = [0.0, 0.0, 0.0]
     print("%-10s %5s %5s %9s %4s %9s | %8s %7s | %8s %7s %5s | %6s %9s" % ("layer", "cin", "cout", "hxw", "ups", "GFLOP", "direct ms", "TF/s",
                                                                        "wino ms", "TF/s", "kind", "ratio", "max|diff|"))
@@ -62,17 +66,17 @@ def main():
         if w % 2:
             continue
         try:
-            pw = hb.PackedWino(wt, bs, B, h, w, ups=ups)
+            pw = (hb.PackedWino4 if w4 else hb.PackedWino)(wt, bs, B, h, w, ups=ups)
         except (RuntimeError, AssertionError) as e:
             print("%-10s skipped: %s" % (name, str(e)[:80]), flush=True)
             continue
         bv = xb.view() if xb is not None else None
         if ups:
             f0 = lambda: hb.conv2d_ups(xa.view(), c1, bv, c2, pk, y0.view(), B, h, w)  # noqa: E731
-            f1 = lambda: hb.conv2d_ups_wino(xa.view(), c1, bv, c2, pw, y1.view(), B, h, w)  # noqa: E731
+            f1 = lambda: (hb.conv2d_ups_wino4 if w4 else hb.conv2d_ups_wino)(xa.view(), c1, bv, c2, pw, y1.view(), B, h, w)  # noqa: E731
         else:
             f0 = lambda: hb.conv2d(xa.view(), c1, bv, c2, pk, y0.view(), None, B, h, w)  # noqa: E731
-            f1 = lambda: hb.conv2d_wino(xa.view(), c1, bv, c2, pw, y1.view(), None, B, h, w)  # noqa: E731
+            f1 = lambda: (hb.conv2d_wino4 if w4 else hb.conv2d_wino)(xa.view(), c1, bv, c2, pw, y1.view(), None, B, h, w)  # noqa: E731
         t0 = timed(f0) if not os.environ.get("NO_DIRECT") else float("nan")
         try:
             t1 = timed(f1)
@@ -85,7 +89,7 @@ def main():
         tot[1] += t0
         tot[2] += t1
         print("%-10s %5d %5d %4dx%-4d %4d %9.2f | %8.3f %7.1f | %8.3f %7.1f %5d | %6.2f %9.2e" % (
-            name, cin, cout, h, w, ups, gf, t0, gf / t0, t1, gf / t1, hb.wino_plan(cin, cout, B, h, w, ups)[0], t0 / t1, diff), flush=True)
+            name, cin, cout, h, w, ups, gf, t0, gf / t0, t1, gf / t1, (hb.wino4_plan if w4 else hb.wino_plan)(cin, cout, B, h, w, ups)[0], t0 / t1, diff), flush=True)
         del xa, xb, y0, y1, pk, pw
     print("TOTAL 3x3 layers: %.1f GFLOP; direct %.2f ms = %.1f TFLOP/s; winograd %.2f ms = %.1f TFLOP/s algorithmic (fp32 MFMA peak 157.3)" % (
         tot[0], tot[1], tot[0] / tot[1], tot[2], tot[0] / tot[2]))
