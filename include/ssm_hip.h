@@ -176,6 +176,8 @@ int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const fl
  * Cin and the first cat source multiples of 4, Cout a multiple of 32; any H, W (fused upsample: even).
  * ssm_wino4_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/32][Cin][9][32][4] (+ bias).                              */
 int ssm_wino4_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK);
+int ssm_wino4_preferred(int Cin, int Cout, int B, int H, int W, int ups);   /* 1: modelled faster than F(2x2,3x3) for this problem */
+double ssm_wino_estimate(int Cin, int Cout, int B, int H, int W, int ups);     /* modelled cycles of ssm_wino_conv2d_*_fwd (-1: unsupported) */
 int ssm_wino4_force_kind(int kind);      /* tests / tuning only (-1 = automatic); returns the number of configurations */
 size_t ssm_wino4_packed_weight_floats(int Cout, int Cin);
 int ssm_wino4_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin, void *stream);

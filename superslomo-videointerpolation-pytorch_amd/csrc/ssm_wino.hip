@@ -1098,6 +1098,11 @@ extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, in
     return SSM_OK;
 }
 
+extern "C" double ssm_wino_estimate(int Cin, int Cout, int B, int H, int W, int ups) {
+    const int kd = (W % 2 == 0 && Cin % 8 == 0) ? pick_wkind(Cin, Cout, B, H, W, ups) : -1;
+    return kd < 0 ? -1.0 : estimate_wino(kWInfo[kd], Cin, Cout, B, H, W, ups);
+}
+
 extern "C" int ssm_wino_deep_ring(int on) {
     const int was = g_deep_ring.exchange(on ? 1 : 0);
     return was;

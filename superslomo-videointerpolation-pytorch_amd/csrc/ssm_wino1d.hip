@@ -210,6 +210,10 @@ __global__ __launch_bounds__(256, 2) void wino1d_kernel(const W1Params p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const bool dma_next = ch + 1 < nchunks && !(W1ABL(1) && ch >= 1);
+#ifndef W1_DMA_EARLY
+#define W1_DMA_EARLY 0      // 1: the whole DMA of chunk ch+1 as a burst right behind the barrier (its stage was released by chunk ch-1)
+#endif                      // - measured 2-3 % slower than one instruction per macro-step (conv1b 6.22 vs 6.01 ms at batch 14)
+        if (W1_DMA_EARLY && dma_next) issue(ch + 1, stage ^ 1);
 
         // ---- input transform: raw rows -> V.  One unit = (cin, row, tile): 8 floats in, 8 frequencies out -------------------------
         if (!W1ABL(4) || ch == 0) {
@@ -271,13 +275,13 @@ __global__ __launch_bounds__(256, 2) void wino1d_kernel(const W1Params p) {
                 if (f == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (s + 1 < S) fetch(stage, s + 1, buf ^ 1);
-                    if (s < L::NI && dma_next) issue_k(ch + 1, stage ^ 1, s);
+                    if (!W1_DMA_EARLY && s < L::NI && dma_next) issue_k(ch + 1, stage ^ 1, s);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (L::NI > S) {
+        if constexpr (L::NI > S && !W1_DMA_EARLY) {
             if (dma_next) {
 #pragma unroll
                 for (int k = S; k < L::NI; ++k) issue_k(ch + 1, stage ^ 1, k);

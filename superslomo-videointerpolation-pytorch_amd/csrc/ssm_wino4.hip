@@ -6,10 +6,12 @@
 //
 //      Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A          per 4x4 output tile (d = its 6x6 input patch, g = the 3x3 filter)
 //
-// over the points {0, 1, -1, 2, -2, inf}: 36 multiplies per (cin, cout, 16 outputs) instead of 144 - 4x fewer matrix-core cycles than
-// the direct form, 1.78x fewer than F(2x2,3x3).  In fp32 a single layer sits ~1e-5 from a float64 evaluation at unit output scale
-// (direct form 2e-6, F(2x2) 1e-6; per-layer bar 5e-5); the whole pair -> frame path at 736x1280 is unchanged within its fp32 noise
-// (2.32e-4 from float64 in every form: tests/emulate_winograd_f44_precision.py).
+// over the points {0, +-a, +-b, inf}, a = 5/8, b = 8/5: 36 multiplies per (cin, cout, 16 outputs) instead of 144 - 4x fewer matrix-core
+// cycles than the direct form, 1.78x fewer than F(2x2,3x3).  The usual points {0, +-1, +-2} make all transform constants dyadic, but
+// in fp32 they cost accuracy: with 512 input channels a layer sits 3.2e-6 rms / 4.6e-5 max from a float64 evaluation at unit output
+// scale; the reciprocal pair (5/8, 8/5) - same operation count, the constants become fused multiply-add operands - brings that to
+// 1.4e-6 rms / 1.1e-5 max (direct form: 4e-7 rms; per-layer bar 5e-5).  The whole pair -> frame path at 736x1280 is unchanged within
+// its fp32 noise (tests/emulate_winograd_f44_precision.py).
 //
 // Structure (as csrc/ssm_wino1d.hip): the 36 frequencies of a tile cost 144 vector operations per (cin, tile) - too many to sit in
 // the MFMA loop of every wave as in ssm_wino.hip - so the workgroup transforms the chunk's patch ONCE into V [cin][f/4][tile][4] in
@@ -17,13 +19,15 @@
 // ds_read_b128 of U and one of V feed 4 MFMAs.  GEMM view per frequency: M_f[cout][tile] = sum_cin U_f[cout][cin] V_f[cin][tile] with
 // v_mfma_f32_16x16x4_f32 (A = 16 couts x 4 cin, B = 4 cin x 16 tiles): a wave owns 16 couts x 16 tiles for ALL 36 frequencies = 36
 // accumulators of 4 registers, so the output transform A^T M A is lane-local, a lane finishes whole 4x4 pixel tiles (16-byte stores,
-// the 2x2 mean is lane-local too), and two workgroups share a CU (<= 256 registers per wave).  The bias rides on frequency (1,1):
-// A^T[a][1] = 1 for every output row / column a.
+// the 2x2 mean is lane-local too), and two workgroups share a CU (<= 256 registers per wave).  The bias is added after the output
+// transform (sum of products, then + bias: the reference's order).
 //
 // Data movement as in ssm_conv.hip / ssm_wino.hip: padded planes, per chunk of 4 input channels the [4][9][32][4] filter values (double-
 // buffered) and the [4][TH+2][TW+8] patch (or, fused upsample, the low-res [4][TH/2+2][TW/2+8] patch, expanded in LDS by the same
-// expander) arrive by LDS-DMA.  The patch is single-buffered: the DMA of chunk c+1 is issued inside the matrix loop of chunk c, when
-// the transform of chunk c - the patch's only reader - is complete.
+// expander) arrive by LDS-DMA.  The filter DMA of chunk c+1 is issued right behind the barrier that opens chunk c (its stage was freed
+// by the matrix loop of chunk c-1), so it has the transform and the matrix loop of chunk c to land; the patch is single-buffered: its DMA
+// for chunk c+1 is issued as one burst at the start of the matrix loop of chunk c, when the transform of chunk c - the patch's only
+// reader - is complete.
 #include "ssm_common.h"
 
 #include <atomic>
@@ -58,6 +62,8 @@ struct W4Params {
     int lrelu;
     int vec;             // 1: outputs / addend / pooled outputs may be moved as aligned 16- / 8-byte pieces (checked on the host)
     int abl;             // diagnostics build only: 1 no LDS-DMA in the loop, 2 no stores, 4 no transform
+    unsigned long long *dbg;   // diagnostics build only ($SSM_WINO4_ABL & 32): per-phase shader-cycle sums of wave 0 of every workgroup
+    int stagger;         // s_sleep units (64 cycles) by which the second workgroup of every CU starts late (first round; $SSM_WINO4_STAGGER)
     const float *add;    // optional pre-activation addend [B / adiv][Cout][H][W] (ssm_conv2d_add_fwd)
     long long asb, asc;
     int ash, adiv;
@@ -100,6 +106,15 @@ struct W4Lds {
     static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0, "16-byte aligned regions");
     static_assert(BYTES <= 80 * 1024, "LDS budget (two workgroups per CU)");
 };
+
+// interpolation points 0, +-PA, +-PB, inf (PA * PB = 1); the transform matrices in the monic form:
+//   B^T rows: [a2b2 0 -(a2+b2) 0 1 0], [0 -+a b2  -b2  +-a 1 0], [0 -+b a2  -a2  +-b 1 0], [0 a2b2 0 -(a2+b2) 0 1]
+//   A^T[k][f] = p_f^k (k = 0..3; the point at infinity contributes to k = 3 only);  G[f] = [1 p p^2] / prod_{q != p}(p - q), G[inf] = [0 0 1]
+#define W4_PA 0.625
+#define W4_PB 1.6
+constexpr float kA = (float)W4_PA, kB = (float)W4_PB, kA2 = (float)(W4_PA * W4_PA), kB2 = (float)(W4_PB * W4_PB);
+constexpr float kA3 = (float)(W4_PA * W4_PA * W4_PA), kB3 = (float)(W4_PB * W4_PB * W4_PB);
+constexpr float kP0 = (float)(W4_PA * W4_PA * W4_PB * W4_PB), kS2 = (float)(W4_PA * W4_PA + W4_PB * W4_PB);
 
 #ifdef SSM_WINO_ABLATE
 #define W4ABL(bit) (p.abl & (bit))
@@ -176,15 +191,18 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = p.Cin / CK;
+    // Two workgroups share a CU and run the same program: started together they reach their barriers, transform phases and epilogues
+    // together, and nothing overlaps.  The second workgroup of every CU (dispatch order: workgroup i + 256) starts late; all
+    // workgroups of a launch take equally long, so the offset persists through the launch.
+    if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
 #pragma unroll
     for (int k = 0; k < L::NI; ++k) issue_k(0, 0, k);
-    // Bias: A^T[a][1] = 1 for every output row and column a (the point p = 1), so the accumulator of frequency (1,1) = 7 starts from
-    // the bias: one MFMA k-step with A = the bias column (k = 0) and B = a row of ones.
-    {
-        const float bv0 = p.bias[nb * BN + cb * 16 + l15];
-        const float ab = q ? 0.f : bv0, ones = q ? 0.f : 1.f;
-        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab, ones, acc[7], 0, 0, 0);
-    }
+    // bias of this lane's four couts (cb*16 + 4q + r): added after the output transform
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * BN + cb * 16 + 4 * q + r];
 
     // ---- per-thread constants of the transform phase: unit = (cin, tile), two threads per unit (frequency rows 0..2 | 3..5) -------
     const int thh = wid >> 1;                        // wave-uniform: which three frequency rows this thread computes
@@ -246,8 +264,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         }
     };
 
-    // V = B^T d B of one (cin, tile): this thread's three frequency rows.  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0;
-    // 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] (the points 0, 1, -1, 2, -2, inf).
+    // V = B^T d B of one (cin, tile): this thread's three frequency rows (frequency order: points 0, +a, -a, +b, -b, inf)
     auto transform = [&]() {
         const float *rp = lds + t_src;
         float d[6][6];
@@ -270,29 +287,29 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         float w[3][6];          // three rows of B^T d
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            if (thh == 0) {
-                const float t1 = d[4][j] - 4.f * d[2][j], t2 = d[3][j] - 4.f * d[1][j];
-                w[0][j] = (4.f * d[0][j] - 5.f * d[2][j]) + d[4][j];
-                w[1][j] = t1 + t2;
-                w[2][j] = t1 - t2;
-            } else {
-                const float t3 = d[4][j] - d[2][j], t4 = d[3][j] - d[1][j];
-                w[0][j] = t3 + 2.f * t4;
-                w[1][j] = t3 - 2.f * t4;
-                w[2][j] = (4.f * d[1][j] - 5.f * d[3][j]) + d[5][j];
+            if (thh == 0) {          // points 0, +a, -a
+                const float te = d[4][j] - kB2 * d[2][j], to = d[3][j] - kB2 * d[1][j];
+                w[0][j] = (kP0 * d[0][j] - kS2 * d[2][j]) + d[4][j];
+                w[1][j] = te + kA * to;
+                w[2][j] = te - kA * to;
+            } else {                 // points +b, -b, inf
+                const float te = d[4][j] - kA2 * d[2][j], to = d[3][j] - kA2 * d[1][j];
+                w[0][j] = te + kB * to;
+                w[1][j] = te - kB * to;
+                w[2][j] = (kP0 * d[1][j] - kS2 * d[3][j]) + d[5][j];
             }
         }
         float v[18];            // (rows) x B: frequency 18 thh + 6 i + j
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float t1 = w[i][4] - 4.f * w[i][2], t2 = w[i][3] - 4.f * w[i][1];
-            const float t3 = w[i][4] - w[i][2], t4 = w[i][3] - w[i][1];
-            v[6 * i] = (4.f * w[i][0] - 5.f * w[i][2]) + w[i][4];
-            v[6 * i + 1] = t1 + t2;
-            v[6 * i + 2] = t1 - t2;
-            v[6 * i + 3] = t3 + 2.f * t4;
-            v[6 * i + 4] = t3 - 2.f * t4;
-            v[6 * i + 5] = (4.f * w[i][1] - 5.f * w[i][3]) + w[i][5];
+            const float te = w[i][4] - kB2 * w[i][2], to = w[i][3] - kB2 * w[i][1];
+            const float ue = w[i][4] - kA2 * w[i][2], uo = w[i][3] - kA2 * w[i][1];
+            v[6 * i] = (kP0 * w[i][0] - kS2 * w[i][2]) + w[i][4];
+            v[6 * i + 1] = te + kA * to;
+            v[6 * i + 2] = te - kA * to;
+            v[6 * i + 3] = ue + kB * uo;
+            v[6 * i + 4] = ue - kB * uo;
+            v[6 * i + 5] = (kP0 * w[i][1] - kS2 * w[i][3]) + w[i][5];
         }
         f32x4 *vo = (f32x4 *)lds + t_dst;
         if (thh == 0) {          // frequencies 0..17: quads 0..3 whole, the low half of quad 4
@@ -306,51 +323,71 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         }
     };
 
-    f32x4 a[2], bq[2];
+#ifdef SSM_WINO_ABLATE
+    unsigned long long tph[5] = {0, 0, 0, 0, 0};       // wait + top barrier | expand + transform | mid barrier | matrix loop | epilogue
+    const bool stamp = (p.abl & 32) && p.dbg;
+    unsigned long long tk = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long tstart = tk;
+#define W4STAMP(i)                                              \
+    if (stamp) {                                                \
+        const unsigned long long tn = __builtin_amdgcn_s_memtime(); \
+        tph[i] += tn - tk;                                      \
+        tk = tn;                                                \
+    }
+#else
+#define W4STAMP(i)
+#endif
+    f32x4 a[3], bq[3];
     for (int ch = 0; ch < nchunks; ++ch) {
         const int stage = ch & 1;
         // chunk ch has landed for every wave; every wave is done with the MFMAs of chunk ch-1 (V and the other filter stage are free)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        W4STAMP(0)
         const bool dma_next = ch + 1 < nchunks && !(W4ABL(1) && ch >= 1);
+        if (dma_next) {          // filter of chunk ch+1 into the stage the matrix loop of chunk ch-1 has just released
+#pragma unroll
+            for (int k = 0; k < L::NIU; ++k) issue_k(ch + 1, stage ^ 1, k);
+        }
         expand();
         if (!W4ABL(4) || ch == 0) transform();
+        W4STAMP(1)
         __syncthreads();
+        W4STAMP(2)
+        if (dma_next) {          // patch of chunk ch+1 into the buffer the transform has just finished with
+#pragma unroll
+            for (int k = L::NIU; k < L::NI; ++k) issue_k(ch + 1, stage ^ 1, k);
+        }
 
-        // ---- matrix phase: 9 groups of 4 frequencies = 36 MFMAs; the operands of group g+1 are fetched behind the first MFMA of
-        // group g, the DMA of chunk ch+1 (filter into the other stage, patch into the buffer the transform just finished with) is
-        // issued one instruction per group -----------------------------------------------------------------------------------------
+        // ---- matrix phase: 9 groups of 4 frequencies = 36 MFMAs of 32 cycles; the operands of group g+2 are fetched behind the first
+        // MFMA of group g (a ring of three register sets: a group of four MFMAs alone is shorter than the LDS latency) ---------------
         const int ai = aBase + stage * (C::USZ / 4), bi = bBase;
         a[0] = lds4[ai];
         bq[0] = lds4[bi];
+        a[1] = lds4[ai + BN];
+        bq[1] = lds4[bi + NT];
 #pragma unroll
         for (int g = 0; g < 9; ++g) {
-            const int cur = g & 1;
+            const int cur = g % 3, nxt = (g + 2) % 3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[4 * g + e], 0, 0, 0);
                 if (e == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (g + 1 < 9) {
-                        a[cur ^ 1] = lds4[ai + (g + 1) * BN];
-                        bq[cur ^ 1] = lds4[bi + (g + 1) * NT];
+                    if (g + 2 < 9) {
+                        a[nxt] = lds4[ai + (g + 2) * BN];
+                        bq[nxt] = lds4[bi + (g + 2) * NT];
                     }
-                    if (g < L::NI && dma_next) issue_k(ch + 1, stage ^ 1, g);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (L::NI > 9) {
-            if (dma_next) {
-#pragma unroll
-                for (int k = 9; k < L::NI; ++k) issue_k(ch + 1, stage ^ 1, k);
-            }
-        }
+        W4STAMP(3)
     }
 
     // ---- epilogue: Y = A^T M A per accumulator register (4 couts per lane), addend, LeakyReLU, stores, fused 2x2 mean -------------
-    // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+    // A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]
 #ifdef SSM_WINO_ABLATE
     if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
 #endif
@@ -384,18 +421,18 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
                 const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r], m5 = acc[30 + j][r];
                 const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                 t[0][j] = (m0 + s1) + s2;
-                t[1][j] = d1 + 2.f * d2;
-                t[2][j] = s1 + 4.f * s2;
-                t[3][j] = (d1 + m5) + 8.f * d2;
+                t[1][j] = kA * d1 + kB * d2;
+                t[2][j] = kA2 * s1 + kB2 * s2;
+                t[3][j] = (kA3 * d1 + m5) + kB3 * d2;
             }
             float y[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float s1 = t[i][1] + t[i][2], d1 = t[i][1] - t[i][2], s2 = t[i][3] + t[i][4], d2 = t[i][3] - t[i][4];
-                y[i][0] = (t[i][0] + s1) + s2;
-                y[i][1] = d1 + 2.f * d2;
-                y[i][2] = s1 + 4.f * s2;
-                y[i][3] = (d1 + t[i][5]) + 8.f * d2;
+                y[i][0] = ((t[i][0] + s1) + s2) + bv[r];
+                y[i][1] = (kA * d1 + kB * d2) + bv[r];
+                y[i][2] = (kA2 * s1 + kB2 * s2) + bv[r];
+                y[i][3] = ((kA3 * d1 + t[i][5]) + kB3 * d2) + bv[r];
             }
             if (addb) {
                 const float *ap = addb + (long long)cu * p.asc;
@@ -447,6 +484,17 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#ifdef SSM_WINO_ABLATE
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4STAMP(4)
+        if (tid == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(p.dbg + i, tph[i]);
+            atomicAdd(p.dbg + 5, tk - tstart);
+            atomicAdd(p.dbg + 6, 1ULL);
+        }
+    }
+#endif
 }
 
 // ---- tile configurations ---------------------------------------------------------------------------------------------------------
@@ -482,18 +530,20 @@ constexpr W4KindInfo kW4Info[NW4KIND] = {
 };
 
 std::atomic<int> g_force_w4kind{-1};
+std::atomic<unsigned long long *> g_w4dbg{nullptr};      // diagnostics (ssm_wino4_debug_buffer)
 
-// Estimated duration (cycles) of a launch: two co-resident workgroups per CU share the matrix pipe; per chunk a workgroup needs 36
-// MFMAs of 32 cycles per wave and, around them, two barriers + the transform (+ the expansion); whole rounds of 512 workgroups.
+// Estimated duration (cycles) of a launch, fitted to tools/bench_layers_wino.py at batch 7 and the in-kernel phase timers
+// (tools/wino4_phase_probe.py): a CU-round of two co-resident workgroups costs ~5300 cycles per chunk of 4 input channels - 2 x 36 MFMAs
+// of 32 cycles are 2304 of them; the rest is the issue cost of the chunk's 32 LDS-DMA instructions, the transform and two barriers,
+// which the two waves of a SIMD cannot hide from each other - plus prologue + epilogue; whole rounds of 512 workgroups.
 double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W, int ups) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * (Cout / 32);
     const double chunks = (double)Cin / 4.0;
-    const double mf = chunks * 36.0 * 32.0;
-    const double per = 2.0 * mf * 1.15 + chunks * (ups ? 500.0 : 250.0) + 7000.0;
+    const double per = chunks * (5300.0 + (ups ? 300.0 : 0.0)) + 14000.0;
     const long long full = nwg / 512, rem = nwg % 512;
     double t = (double)full * per;
-    if (rem) t += rem > 256 ? per : mf * 1.3 + chunks * (ups ? 1100.0 : 700.0) + 9000.0;
+    if (rem) t += rem > 256 ? per : chunks * (3200.0 + (ups ? 300.0 : 0.0)) + 12000.0;     // a last round of lone workgroups
     return t;
 }
 
@@ -546,8 +596,8 @@ int w4dispatch(int kind, W4Params &p, int B, hipStream_t st) {
     return SSM_E_UNSUPPORTED;
 }
 
-// U = G g G^T,  G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], evaluated in float64 and rounded
-// once; packed index -> (nb, cin, fq, n, e), frequency f = 4 fq + e = 6 i + j
+// U = G g G^T with G[f] = [1 p p^2] / prod_{q != p} (p - q) over the finite points p = 0, +a, -a, +b, -b and G[inf] = [0 0 1], evaluated in
+// float64 and rounded once; packed index -> (nb, cin, fq, n, e), frequency f = 4 fq + e = 6 i + j
 __global__ void wino4_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ wp,
                                   float *__restrict__ bp, int Cout, int Cin, long long total, int nbias) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -564,8 +614,18 @@ __global__ void wino4_pack_kernel(const float *__restrict__ w, const float *__re
         const int co = nb * 32 + n, f = 4 * fq + e, i = f / 6, j = f % 6;
         double val = 0.0;
         if (co < Cout) {
-            const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+            const double pt[5] = {0.0, W4_PA, -W4_PA, W4_PB, -W4_PB};
+            double G[6][3];
+            for (int f5 = 0; f5 < 5; ++f5) {
+                double nrm = 1.0;
+                for (int o = 0; o < 5; ++o)
+                    if (o != f5) nrm *= pt[f5] - pt[o];
+                G[f5][0] = 1.0 / nrm;
+                G[f5][1] = pt[f5] / nrm;
+                G[f5][2] = pt[f5] * pt[f5] / nrm;
+            }
+            G[5][0] = G[5][1] = 0.0;
+            G[5][2] = 1.0;
             const float *g = w + ((long long)co * Cin + cin) * 9;
             for (int a = 0; a < 3; ++a)
                 for (int c = 0; c < 3; ++c) val += G[i][a] * (double)g[3 * a + c] * G[j][c];
@@ -622,6 +682,12 @@ int w4fill(W4Params &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w
 #ifdef SSM_WINO_ABLATE
     if (const char *e = getenv("SSM_WINO4_ABL")) p.abl = atoi(e);
 #endif
+    p.dbg = g_w4dbg.load();
+    static const int stagger = [] {
+        const char *e = getenv("SSM_WINO4_STAGGER");
+        return e ? atoi(e) : 0;
+    }();
+    p.stagger = stagger;
     bool vec = W % 4 == 0 && ssm::aligned16(y.ptr) && y.sh % 4 == 0 && y.sc % 4 == 0 && y.sb % 4 == 0;
     if (add.ptr) {
         SSM_REQUIRE(add_div >= 1 && B % add_div == 0, "wino4 conv: the addend serves %d batch entries each, batch %d is no multiple", add_div, B);
@@ -655,6 +721,24 @@ extern "C" int ssm_wino4_plan(int Cin, int Cout, int B, int H, int W, int ups, i
     if (BN) *BN = 32;
     if (CK) *CK = 4;
     return SSM_OK;
+}
+
+// diagnostics only (not in include/ssm_hip.h): 7 device counters that the ablation build fills when $SSM_WINO4_ABL has bit 32 set
+extern "C" int ssm_wino4_debug_buffer(unsigned long long *dev_counters) {
+    g_w4dbg.store(dev_counters);
+    return SSM_OK;
+}
+
+// 1 when the plan should run this 3x3 layer as F(4x4,3x3) rather than F(2x2,3x3).  Measured per layer at 736x1280, batch 7
+// (tools/bench_layers_wino.py, W4=1 against the default): F(4x4) is 5-25 % faster everywhere except on the 23x40 maps (32 tiles of 16
+// pixels per workgroup: half of every tile row is overshoot; 0.24 vs 0.15 ms) and on the fused-upsample layers with 512+ input channels
+// (conv7a / conv8a / conv9a: 128-256 chunks of expander + transform; 2-5 % slower).  The two cost models are not calibrated against each
+// other, so the rule is stated directly.
+extern "C" int ssm_wino4_preferred(int Cin, int Cout, int B, int H, int W, int ups) {
+    if (Cin % 4 || Cout % 32 || Cin <= 0 || Cout <= 0) return 0;
+    if ((long long)H * W < 2048) return 0;
+    if (ups && Cin >= 512) return 0;
+    return 1;
 }
 
 extern "C" int ssm_wino4_force_kind(int kind) {

@@ -259,7 +259,8 @@ class UNetPlan:
                 use_w = (self.wino and name != "final_conv" and name not in WINO_SKIP and "all" not in WINO_SKIP
                          and hb.wino_supported(ci, co, self.H // s, self.W // s, k))
                 cls = hb.PackedWino if use_w else hb.PackedConv
-                if use_w and self.wino1d and wino4_enabled(name) and hb.wino4_supported(ci, co, self.H // s, self.W // s, k):
+                if (use_w and self.wino1d and wino4_enabled(name) and hb.wino4_supported(ci, co, self.H // s, self.W // s, k)
+                        and (WINO4 != "1" or hb.wino4_preferred(ci, co, nb, self.H // s, self.W // s, ups))):
                     cls = hb.PackedWino4          # inference plans: F(4x4,3x3)
                 if (self.wino1d and wino1d_enabled(k) and name not in WINO_SKIP and "all" not in WINO_SKIP
                         and hb.wino1d_supported(ci, co, self.H // s, self.W // s, k)):

@@ -65,6 +65,8 @@ SIGNATURES = {
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "ssm_wino4_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino4_force_kind": (_c_int, [_c_int]),
+    "ssm_wino4_preferred": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ssm_wino_estimate": (ctypes.c_double, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ssm_wino4_packed_weight_floats": (_sz, [_c_int, _c_int]),
     "ssm_wino4_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _vp]),
     "ssm_wino4_conv2d_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int,
@@ -392,6 +394,11 @@ def wino4_plan(cin, cout, B, H, W, ups=False):
 def wino4_supported(cin, cout, H, W, k=3):
     """Can this layer run as F(4x4,3x3)?  (3x3, whole 4-channel chunks, 32-channel output blocks)"""
     return k == 3 and cin % 4 == 0 and cout % 32 == 0
+
+
+def wino4_preferred(cin, cout, B, H, W, ups=False):
+    """Does the library's cost model put F(4x4,3x3) ahead of F(2x2,3x3) for this problem?"""
+    return bool(load().ssm_wino4_preferred(cin, cout, B, H, W, 1 if ups else 0))
 
 
 class PackedWino4:

@@ -2,7 +2,7 @@
 multiplies per 16 outputs of F(2x2,3x3) - in fp32 on the oracle's whole pair -> frame path, against float64 and the direct form.
 W1D=1 also evaluates the 7x7 / 5x5 layers in the 1-D forms of csrc/ssm_wino1d.hip (F(2,7), F(4,5) along x).
 
-    python tests/emulate_winograd_f44_precision.py [H] [W] [my] [mx] [t]          (PTS=half: points 0, +-1, +-1/2 instead of 0, +-1, +-2)
+    python tests/emulate_winograd_f44_precision.py [H] [W] [my] [mx] [t]          (PTS=half: points 0, +-1, +-1/2 instead of 0, +-1, +-2; PTS=rec: 0, +-5/8, +-8/5 - the kernel's)
 """
 import os
 import sys
@@ -44,7 +44,7 @@ def cook_toom(m, r, pts):
     return tuple(torch.tensor(M, dtype=torch.float64) for M in (AT, G, BT))
 
 
-PTS4 = [0.0, 1.0, -1.0, 0.5, -0.5] if os.environ.get("PTS") == "half" else [0.0, 1.0, -1.0, 2.0, -2.0]
+PTS4 = {"half": [0.0, 1.0, -1.0, 0.5, -0.5], "rec": [0.0, 0.625, -0.625, 1.6, -1.6]}.get(os.environ.get("PTS", ""), [0.0, 1.0, -1.0, 2.0, -2.0])
 MATS = {2: cook_toom(2, 3, [0.0, 1.0, -1.0]), 4: cook_toom(4, 3, PTS4)}
 MATS1D = {7: (2,) + cook_toom(2, 7, [0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5]), 5: (4,) + cook_toom(4, 5, [0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5])}
 
