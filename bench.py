@@ -123,7 +123,7 @@ def setup_ranks(args):
     return rank, local_rank, world, torch.device("cuda", local_rank)
 
 
-def conv_flops_per_pair(h, w, n_t, issued_for=None):
+def conv_flops_per_pair(h, w, n_t, issued_for=None, batch=2):
     """Algorithmic (direct-form) conv FLOP of a pair as SURVEY 8d counts them (stage 1 once, stage 2 per t).  issued_for = "f32" /
     "f32w": the multiply-adds the matrix cores actually execute in that mode: the t-independent input channels of stage 2's conv1a
     (6 of 16) and conv7a (512 of 1024) are convolved once per pair (ssm_amd.engine.UNetPlan.hoist); "f32w": 3x3 layers with >= 32
@@ -145,7 +145,7 @@ def conv_flops_per_pair(h, w, n_t, issued_for=None):
                 elif name == "conv7a":
                     fl *= (reps + 1.0) / (2.0 * reps)
             if issued_for:
-                fl *= issued_factor(name, issued_for)
+                fl *= issued_factor(name, issued_for, batch * reps, h, w)
             tot += fl
         return tot
     return stage(1, 1) + stage(2, n_t)
@@ -158,21 +158,24 @@ def layer_kernel_size(lname):
     return 5 if lname.startswith("conv2") else 3
 
 
-WINO1D = {7: 8.0 / 14.0, 5: 8.0 / 20.0}       # F(2,7) / F(4,5) along x: 8 frequencies per 2 / 4 outputs instead of 7 / 5 taps each
-
-
-def issued_factor(lname, precision):
-    """Multiply-adds the matrix cores issue per direct-form multiply-add of this layer in this precision mode."""
+def issued_factor(lname, precision, B=14, H=736, W=1280):
+    """Multiply-adds the matrix cores issue per direct-form multiply-add of this layer in this precision mode: the plan's algorithm
+    for the layer (ssm_amd.engine.choose_algo: F(4x4,3x3) x 1/4, F(2x2,3x3) x 16/36, F(2,7) x 8/14, F(4,5) x 8/20, direct x 1).
+    B, H, W: batch and full-resolution size of the plan the layer belongs to."""
     if precision != "f32w" or lname.startswith("final"):
         return 1.0
-    k = layer_kernel_size(lname)
-    if k == 3:
-        return 16.0 / 36.0
     from ssm_amd import engine
-    return WINO1D[k] if getattr(engine, "wino1d_enabled", lambda k: False)(k) else 1.0
+    from ssm_amd.weights import unet_layers
+    base = lname.split("(")[0]
+    if base == "conv6":            # recurrent bottleneck: gate convolutions in the F(2x2,3x3) form
+        return 16.0 / 36.0
+    ci, co, k = {n: (a, b, c) for n, a, b, c in unet_layers(2, True)}[base]
+    s = engine.layer_scale(base)
+    algo = engine.choose_algo(base, ci, co, k, B, H // s, W // s, base in engine.UNetPlan.UPS, True, True)
+    return engine.ISSUED_FACTOR[algo](k)
 
 
-def family_rooflines(by_name, n_pairs, precision, peak):
+def family_rooflines(by_name, n_pairs, precision, peak, batch=14, H=736, W=1280):
     """Per kernel family of the fp32 modes (3x3 / 7x7 / 5x5 / final): in-kernel time per pair, FLOP issued on the matrix cores,
     fraction of the fp32-MFMA peak - from the HIP-event brackets of the single-stream region."""
     fams = {}
@@ -182,7 +185,7 @@ def family_rooflines(by_name, n_pairs, precision, peak):
         d = fams.setdefault(key, {"ms": 0.0, "alg": 0.0, "iss": 0.0})
         d["ms"] += ms
         d["alg"] += fl
-        d["iss"] += fl * issued_factor(lname, precision)
+        d["iss"] += fl * issued_factor(lname, precision, batch, H, W)
     return {k: {"ms_per_pair_in_kernel": round(d["ms"] / n_pairs, 3), "flop_issued_per_pair": d["iss"] / n_pairs,
                 "achieved_in_kernel": round(d["iss"] / d["ms"] / 1e9, 2), "frac_in_kernel": round(d["iss"] / d["ms"] / 1e9 / peak, 4),
                 "algorithmic_achieved_in_kernel": round(d["alg"] / d["ms"] / 1e9, 2)} for k, d in fams.items()}
@@ -386,7 +389,7 @@ def recurrent_bench(args):
         # conv FLOP of a clip from the per-launch brackets; issued = the multiply-saving layers' share scaled (mode f32w)
         peak = PEAK_F32_MFMA_TFLOPS if model.precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         fl_clip = conv["flops"] / 3.0
-        issued = sum(v[1] / 3.0 * issued_factor(n.split(".", 1)[1], model.precision) for n, v in conv["by_name"].items())
+        issued = sum(v[1] / 3.0 * issued_factor(n.split(".", 1)[1], model.precision, N_T, 736, 1280) for n, v in conv["by_name"].items())
         ms_clip = out["ms_per_step"]
         out["roofline"] = {
             "bound": "mfma", "kernel": "wino2_kernel / wino_kernel (3x3 layers and gate convolutions), conv kernels of the 7x7 / 5x5 layers, final_conv_kernel",
@@ -591,7 +594,7 @@ def infer_bench(args):
     sd1d = {k: v.detach() for k, v in model.stage1_model.state_dict().items()}
     sd2d = {k: v.detach() for k, v in model.stage2_model.state_dict().items()}
     flops_pair = conv_flops_per_pair(Hp, Wp, N_T)
-    flops_issued = {m: conv_flops_per_pair(Hp, Wp, N_T, m) for m in ("f32", "f32w")}
+    flops_issued = {m: conv_flops_per_pair(Hp, Wp, N_T, m, PB) for m in ("f32", "f32w")}
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -626,8 +629,8 @@ def infer_bench(args):
         if precision in flops_issued:
             issued_note = ("the multiply-adds the matrix cores execute: the t-independent input channels of stage 2's conv1a (6 of 16) and "
                            "conv7a (512 of 1024) are convolved once per pair instead of once per t" +
-                           ("; Winograd layers: direct-form FLOP x 16/36 (F(2x2,3x3)), x 8/14 (7x7 as F(2,7) along x), x 8/20 (5x5 as "
-                            "F(4,5) along x) where those forms run" if precision == "f32w" else ""))
+                           ("; Winograd layers: direct-form FLOP x 1/4 (F(4x4,3x3)) or x 16/36 (F(2x2,3x3)), x 8/14 (7x7 as F(2,7) along x), "
+                            "x 8/20 (5x5 as F(4,5) along x), per layer as the plan picks the form" if precision == "f32w" else ""))
         else:
             issued_note = "direct-form FLOP (each product costs %s narrow MFMA operations in this mode)" % \
                           {"f16x3": "3 fp16", "f16f8": "1 fp16 + 2 fp8"}.get(precision, "1")
@@ -681,7 +684,7 @@ def infer_bench(args):
                                          "mfma_issue_frac_in_kernel": round(mfma_per_prod * kach / peak, 4),
                                          "wall_ms_per_pair_single_stream": round(solo_ms, 3)}
             if precision in flops_issued:
-                res["roofline"]["families"] = family_rooflines(conv["by_name"], n_solo, precision, peak)
+                res["roofline"]["families"] = family_rooflines(conv["by_name"], n_solo, precision, peak, PB * N_T, Hp, Wp)
                 if precision == headline:
                     res["roofline"]["family_clocks"] = family_clocks(solo, dev, peak, res["roofline"]["families"])
             wk = summ["warp"]

@@ -91,6 +91,28 @@ def wino1d_enabled(k):
     return k in (5, 7) and str(k) in WINO1D
 
 
+def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d):
+    """Algorithm of one convolution of an fp32 plan: "direct" (csrc/ssm_conv.hip), "wino" = F(2x2,3x3) (ssm_wino.hip), "wino4" =
+    F(4x4,3x3) (ssm_wino4.hip), "wino1d" = F(2,7) / F(4,5) along x (ssm_wino1d.hip).  wino: the plan is mode f32w; wino1d: it is an
+    inference plan (the 8-frequency forms stay out of the training plans).  Pure function of the problem: bench.py uses it to count the
+    multiply-adds the matrix cores issue."""
+    skip = name in WINO_SKIP or "all" in WINO_SKIP or name == "final_conv"
+    if wino1d and not skip and wino1d_enabled(k) and hb.wino1d_supported(ci, co, h, w, k):
+        return "wino1d"
+    if wino and not skip and hb.wino_supported(ci, co, h, w, k):
+        if (wino1d and wino4_enabled(name) and hb.wino4_supported(ci, co, h, w, k)
+                and (WINO4 != "1" or hb.wino4_preferred(ci, co, nb, h, w, ups))):
+            return "wino4"
+        return "wino"
+    return "direct"
+
+
+_ALGO_CLASS = {"direct": lambda: hb.PackedConv, "wino": lambda: hb.PackedWino, "wino4": lambda: hb.PackedWino4, "wino1d": lambda: hb.PackedWino1d}
+# multiply-adds issued on the matrix cores per direct-form multiply-add, by algorithm and kernel size
+ISSUED_FACTOR = {"direct": lambda k: 1.0, "wino": lambda k: 16.0 / 36.0, "wino4": lambda k: 36.0 / 144.0,
+                 "wino1d": lambda k: 8.0 / 14.0 if k == 7 else 8.0 / 20.0}
+
+
 def conv_fn(pk, ups=False):
     """The launcher that goes with a packed filter's algorithm."""
     if pk.algo == "wino1d":
@@ -256,15 +278,7 @@ class UNetPlan:
             else:
                 nb = self.Bd if name in self.DECODER else self.B
                 ups = self.fuse_up and name in self.UPS
-                use_w = (self.wino and name != "final_conv" and name not in WINO_SKIP and "all" not in WINO_SKIP
-                         and hb.wino_supported(ci, co, self.H // s, self.W // s, k))
-                cls = hb.PackedWino if use_w else hb.PackedConv
-                if (use_w and self.wino1d and wino4_enabled(name) and hb.wino4_supported(ci, co, self.H // s, self.W // s, k)
-                        and (WINO4 != "1" or hb.wino4_preferred(ci, co, nb, self.H // s, self.W // s, ups))):
-                    cls = hb.PackedWino4          # inference plans: F(4x4,3x3)
-                if (self.wino1d and wino1d_enabled(k) and name not in WINO_SKIP and "all" not in WINO_SKIP
-                        and hb.wino1d_supported(ci, co, self.H // s, self.W // s, k)):
-                    cls = hb.PackedWino1d
+                cls = _ALGO_CLASS[choose_algo(name, ci, co, k, nb, self.H // s, self.W // s, ups, self.wino, self.wino1d)]()
                 if self.hoist and name == "conv1a":
                     # per-t part: channels 3:13 (warped frames + estimated flows); per-pair part: the frames themselves in stage 1's
                     # input order (I0 = channels 13:16, I1 = channels 0:3), no bias, no activation
