@@ -207,6 +207,22 @@ int ssm_wino1d_pack_weights(const float *w_oihw, const float *bias, float *w_pac
 int ssm_wino1d_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const float *bias_packed, ssm_view y, ssm_view pool,
                               ssm_view add, int add_div, int B, int H, int W, int Cout, int k, float slope, int flags, void *stream);
 
+/* ---- every fp32 filter of a U-Net repacked by one launch (training: the parameters change each optimizer step) ------------
+ * A job = one convolution's OIHW parameter -> its packed form (algo: the per-layer pack entry point it replaces, same arithmetic,
+ * same layout).  transposed: pack the DATA-GRADIENT filter of the forward parameter, W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx]
+ * (the adjoint of layers.conv, scripts/models/layers.py:21-33, is the same convolution on it), read straight from the forward
+ * tensor; Cout / Cin are then the data-gradient convolution's (Cout = the forward layer's input channels), bias NULL = zeros.
+ * first = sum of max(total, nbias) over the preceding jobs.                                                                   */
+enum { SSM_PACK_DIRECT = 0, SSM_PACK_WINO = 1, SSM_PACK_WINO1D = 2, SSM_PACK_WINO4 = 3 };
+typedef struct {
+    const float *w;      /* OIHW parameter */
+    const float *bias;   /* or NULL */
+    float *wp, *bp;      /* packed filter, packed bias */
+    int Cout, Cin, CinP, k, BN, algo, transposed, nbias;
+    long long first, total;
+} ssm_pack32_job;
+int ssm_pack32_weights_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_elements, void *stream);
+
 /* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------
  * Same operator as ssm_conv2d_fwd.  Default mode evaluates a*b as a_hi*b_hi + a_hi*b_lo +
  * a_lo*b_hi with fp32 accumulation (fp32-grade products at 16/3 x the fp32-MFMA rate);

@@ -1,0 +1,153 @@
+// Every fp32 filter of a U-Net repacked by ONE launch from a device job table (training: the parameters change each optimizer
+// step; the per-layer pack entry points cost ~100 launches per U-Net and step, and the data-gradient filters another ~190 torch
+// launches for flip / permute / contiguous).  A job names the OIHW parameter, the packed destination and the form:
+//   direct  (ssm_pack_weights,        csrc/ssm_conv.hip)    [Cout/BN][CinP][k*k][BN]
+//   wino    (ssm_wino_pack_weights,   csrc/ssm_wino.hip)    [Cout/BN][Cin][4][BN][4]        U = G g G^T, F(2x2,3x3)
+//   wino1d  (ssm_wino1d_pack_weights, csrc/ssm_wino1d.hip)  [Cout/BN][CinP][k][2][BN][4]    U[ky] = G g[ky], F(2,7) / F(4,5)
+//   wino4   (ssm_wino4_pack_weights,  csrc/ssm_wino4.hip)   [Cout/32][Cin][9][32][4]        U = G g G^T, F(4x4,3x3)
+// `transposed` packs the DATA-GRADIENT filter of the forward parameter, W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx] (what
+// ssm_amd.backward.transposed_filter materialises), read straight from the OIHW tensor; such jobs have no bias (zeros).  Every
+// element is computed by the same arithmetic as the per-layer kernels (tests/test_hip_pack_batch.py holds them bit-identical).
+#include "ssm_common.h"
+
+namespace {
+
+struct Src {          // logical filter W'(co, ci, ky, kx) of a job
+    const float *w;
+    int O, I, k, transposed;       // the parameter is [O][I][k][k]
+    __device__ float at(int co, int ci, int ky, int kx) const {
+        if (!transposed) return w[(((long long)co * I + ci) * k + ky) * k + kx];
+        return w[(((long long)ci * I + co) * k + (k - 1 - ky)) * k + (k - 1 - kx)];
+    }
+};
+
+__device__ float pack_direct(const Src &s, const ssm_pack32_job &j, long long i) {
+    long long r = i;
+    const int n = (int)(r % j.BN);
+    r /= j.BN;
+    const int KS2 = j.k * j.k;
+    const int tap = (int)(r % KS2);
+    r /= KS2;
+    const int cin = (int)(r % j.CinP);
+    const int nb = (int)(r / j.CinP);
+    const int co = nb * j.BN + n;
+    return (co < j.Cout && cin < j.Cin) ? s.at(co, cin, tap / j.k, tap % j.k) : 0.f;
+}
+
+__device__ float pack_wino(const Src &s, const ssm_pack32_job &j, long long i) {      // as wino_pack_kernel
+    long long r = i;
+    const int e = (int)(r % 4);
+    r /= 4;
+    const int n = (int)(r % j.BN);
+    r /= j.BN;
+    const int q = (int)(r % 4);
+    r /= 4;
+    const int cin = (int)(r % j.Cin);
+    const int nb = (int)(r / j.Cin);
+    const int co = nb * j.BN + n;
+    if (co >= j.Cout) return 0.f;
+    float row[3];      // row q of G g
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g0 = s.at(co, cin, 0, c), g1 = s.at(co, cin, 1, c), g2 = s.at(co, cin, 2, c);
+        row[c] = q == 0 ? g0 : (q == 1 ? 0.5f * (g0 + g1 + g2) : (q == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    }
+    return e == 0 ? row[0] : (e == 1 ? 0.5f * (row[0] + row[1] + row[2]) : (e == 2 ? 0.5f * (row[0] - row[1] + row[2]) : row[2]));
+}
+
+__device__ float pack_wino1d(const Src &s, const ssm_pack32_job &j, long long i) {    // as wino1d_pack_kernel
+    long long r = i;
+    const int e = (int)(r % 4);
+    r /= 4;
+    const int n = (int)(r % j.BN);
+    r /= j.BN;
+    const int fq = (int)(r % 2);
+    r /= 2;
+    const int ky = (int)(r % j.k);
+    r /= j.k;
+    const int cin = (int)(r % j.CinP);
+    const int nb = (int)(r / j.CinP);
+    const int co = nb * j.BN + n, f = 4 * fq + e;
+    double val = 0.0;
+    if (co < j.Cout && cin < j.Cin) {
+        if (f == 7) {
+            val = (double)s.at(co, cin, ky, j.k - 1);
+        } else {
+            const double pt[7] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5};
+            const double cf[7] = {1.0, -2.0 / 9.0, -2.0 / 9.0, 1.0 / 90.0, 1.0 / 90.0, 32.0 / 45.0, 32.0 / 45.0};
+            double pw = 1.0;
+            for (int kx = 0; kx < j.k; ++kx) {
+                val += pw * (double)s.at(co, cin, ky, kx);
+                pw *= pt[f];
+            }
+            val *= cf[f];
+        }
+    }
+    return (float)val;
+}
+
+__device__ float pack_wino4(const Src &s, const ssm_pack32_job &j, long long idx) {   // as wino4_pack_kernel (points 0, +-5/8, +-8/5, inf)
+    long long r = idx;
+    const int e = (int)(r % 4);
+    r /= 4;
+    const int n = (int)(r % 32);
+    r /= 32;
+    const int fq = (int)(r % 9);
+    r /= 9;
+    const int cin = (int)(r % j.Cin);
+    const int nb = (int)(r / j.Cin);
+    const int co = nb * 32 + n, f = 4 * fq + e, fi = f / 6, fj = f % 6;
+    double val = 0.0;
+    if (co < j.Cout) {
+        const double pt[5] = {0.0, 0.625, -0.625, 1.6, -1.6};
+        double G[6][3];
+        for (int f5 = 0; f5 < 5; ++f5) {
+            double nrm = 1.0;
+            for (int o = 0; o < 5; ++o)
+                if (o != f5) nrm *= pt[f5] - pt[o];
+            G[f5][0] = 1.0 / nrm;
+            G[f5][1] = pt[f5] / nrm;
+            G[f5][2] = pt[f5] * pt[f5] / nrm;
+        }
+        G[5][0] = G[5][1] = 0.0;
+        G[5][2] = 1.0;
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) val += G[fi][a] * (double)s.at(co, cin, a, c) * G[fj][c];
+    }
+    return (float)val;
+}
+
+__global__ void pack32_batch_kernel(const ssm_pack32_job *__restrict__ jobs, int njobs, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = njobs - 1;          // the job whose [first, first + count) holds i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first <= i) lo = mid;
+        else hi = mid - 1;
+    }
+    const ssm_pack32_job j = jobs[lo];
+    const long long e = i - j.first;
+    const Src s{j.w, j.transposed ? j.Cin : j.Cout, j.transposed ? j.Cout : j.Cin, j.k, j.transposed};
+    if (e < j.total) {
+        float v;
+        switch (j.algo) {
+            case SSM_PACK_WINO: v = pack_wino(s, j, e); break;
+            case SSM_PACK_WINO1D: v = pack_wino1d(s, j, e); break;
+            case SSM_PACK_WINO4: v = pack_wino4(s, j, e); break;
+            default: v = pack_direct(s, j, e); break;
+        }
+        j.wp[e] = v;
+    }
+    if (e < j.nbias) j.bp[e] = (j.bias && e < j.Cout) ? j.bias[e] : 0.f;
+}
+
+}  // namespace
+
+extern "C" int ssm_pack32_weights_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_elements, void *stream) {
+    SSM_REQUIRE(jobs_device && n_jobs > 0 && total_elements > 0, "pack32 batch: empty job table");
+    const long long blocks = (total_elements + 255) / 256;
+    SSM_REQUIRE(blocks <= 0x7fffffffLL, "pack32 batch: %lld elements out of range", total_elements);
+    hipLaunchKernelGGL(pack32_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs, total_elements);
+    return ssm::check_launch("ssm_pack32_weights_batch");
+}

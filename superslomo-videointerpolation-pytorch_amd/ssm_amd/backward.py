@@ -220,6 +220,14 @@ class UNetGrad:
                     self._pack = (key, hb.PackBatch(entries, self.dev))
                 self._pack[1].run()
                 return
+        ws = [state_dict[param_key(n, "weight")] for n in names]
+        batch32 = (not self.hl8 and os.environ.get("SSM_PACK_BATCH", "1") != "0"
+                   and all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() for w in ws))
+        key32 = (tuple(names), hb.PackBatch.key(ws)) if batch32 else None
+        if batch32 and getattr(self, "_pack32", None) is not None and self._pack32[0] == key32:
+            self._pack32[1].run()          # every data-gradient filter straight from the forward parameters, one launch
+            return
+        self._pack32 = None
         for name in names:
             ci, co, k = self.plan.layers[name]
             s = layer_scale(name)
@@ -236,6 +244,8 @@ class UNetGrad:
                 if getattr(self.plan, "wino1d", False) and wino1d_enabled(k) and hb.wino1d_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
                     cls = hb.PackedWino1d          # data gradient of a 7x7 / 5x5 layer: the same convolution on the transposed filter
                 self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
+        if batch32:
+            self._pack32 = (key32, hb.PackBatch32([(self.pk_t[n], w, None, True) for n, w in zip(names, ws)], self.dev))
 
     def _layer(self, name, dy, dpool, dx, need_wgrad, act=True):
         """One convolution: dZ, parameter gradients, data gradient into `dx` (None: not needed)."""

@@ -263,6 +263,16 @@ class UNetPlan:
             if getattr(self, "rnn", None) is not None:
                 self.rnn.refresh_weights(state_dict)
             return
+        # fp32 plans (training repacks every step): one launch for all filters once they exist; hoisted inference plans pack slices
+        batch32 = (not self.hl8 and not self.hoist and os.environ.get("SSM_PACK_BATCH", "1") != "0"
+                   and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors))
+        if batch32 and getattr(self, "_pack32", None) is not None and self._pack32[0] == hb.PackBatch.key(tensors):
+            self._pack32[1].run()
+            if "final_conv" in self.layers:
+                self.final_wb = (state_dict[param_key("final_conv", "weight")].detach(), state_dict[param_key("final_conv", "bias")].detach())
+            if getattr(self, "rnn", None) is not None:
+                self.rnn.refresh_weights(state_dict)
+            return
         for name, (ci, co, k) in self.layers.items():
             w = state_dict[param_key(name, "weight")].to(device=self.device, dtype=torch.float32)
             b = state_dict[param_key(name, "bias")].to(device=self.device, dtype=torch.float32)
@@ -291,6 +301,11 @@ class UNetPlan:
                     self.pk_pair[name] = cls(w[:, 512:].contiguous(), zb, self.hoist[0], self.H // s, self.W // s, ups=ups)
                 else:
                     self.pk[name] = cls(w, b, nb, self.H // s, self.W // s, pool=name in POOLED, ups=ups)
+        self._pack32 = None
+        if batch32:
+            entries = [(self.pk[name], state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")], False)
+                       for name in self.layers]
+            self._pack32 = (hb.PackBatch.key(tensors), hb.PackBatch32(entries, self.device))
         self._pack = None
         if batchable:
             entries = [(self.pk[name], state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")], False)

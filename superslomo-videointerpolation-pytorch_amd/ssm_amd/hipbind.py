@@ -63,6 +63,7 @@ SIGNATURES = {
     "ssm_wino_deep_ring": (_c_int, [_c_int]),
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
+    "ssm_pack32_weights_batch": (_c_int, [_vp, _c_int, ctypes.c_longlong, _vp]),
     "ssm_wino4_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino4_force_kind": (_c_int, [_c_int]),
     "ssm_wino4_preferred": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
@@ -616,6 +617,43 @@ class PackBatch:
 
     def run(self):
         check(load().ssm_pack16q_weights_batch(self.table.data_ptr(), self.n, self.total, stream_ptr()))
+
+
+class SsmPack32Job(ctypes.Structure):
+    """ssm_pack32_job (include/ssm_hip.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("bp", ctypes.c_void_p),
+                ("Cout", ctypes.c_int), ("Cin", ctypes.c_int), ("CinP", ctypes.c_int), ("k", ctypes.c_int), ("BN", ctypes.c_int),
+                ("algo", ctypes.c_int), ("transposed", ctypes.c_int), ("nbias", ctypes.c_int), ("first", ctypes.c_longlong),
+                ("total", ctypes.c_longlong)]
+
+
+class PackBatch32:
+    """Every fp32 filter of a U-Net repacked by one launch (ssm_pack32_weights_batch).  entries: (PackedConv / PackedWino /
+    PackedWino1d / PackedWino4 whose buffers are refilled, fp32 OIHW parameter on the device, bias tensor or None, transposed) -
+    transposed packs the data-gradient filter of the forward parameter (no torch flip / permute / copy).  The job table holds raw
+    pointers: rebuild it when `PackBatch.key()` of the parameters changes."""
+
+    ALGO = {"direct": 0, "wino": 1, "wino1d": 2, "wino4": 3}
+
+    def __init__(self, entries, device):
+        jobs = (SsmPack32Job * len(entries))()
+        off = 0
+        self.keep = []
+        for j, (pk, w, b, transposed) in zip(jobs, entries):
+            assert w.is_contiguous() and w.dtype == torch.float32 and w.device == pk.w.device
+            assert tuple(w.shape) == ((pk.cin, pk.cout, pk.k, pk.k) if transposed else (pk.cout, pk.cin, pk.k, pk.k)), \
+                "parameter %s does not match the packed filter (%d -> %d, k %d)" % (tuple(w.shape), pk.cin, pk.cout, pk.k)
+            j.w, j.bias, j.wp, j.bp = w.data_ptr(), (b.data_ptr() if b is not None else None), pk.w.data_ptr(), pk.b.data_ptr()
+            j.Cout, j.Cin, j.CinP, j.k, j.BN = pk.cout, pk.cin, pk.cin_p, pk.k, pk.bn
+            j.algo, j.transposed, j.nbias = self.ALGO[pk.algo], 1 if transposed else 0, pk.b.numel()
+            j.first, j.total = off, pk.w.numel()
+            off += max(pk.w.numel(), pk.b.numel())
+            self.keep.append((pk, w, b))
+        self.n, self.total = len(entries), off
+        self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
+
+    def run(self):
+        check(load().ssm_pack32_weights_batch(self.table.data_ptr(), self.n, self.total, stream_ptr()))
 
 
 def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slope=0.1, fast=False):
