@@ -96,7 +96,7 @@ __device__ float pack_wino4(const Src &s, const ssm_pack32_job &j, long long idx
     r /= 9;
     const int cin = (int)(r % j.Cin);
     const int nb = (int)(r / j.Cin);
-    const int co = nb * 32 + n, f = 4 * fq + e, fi = f / 6, fj = f % 6;
+    const int co = nb * 32 + n, f = 4 * fq + e, fi = (f % 18) / 3, fj = 3 * (f / 18) + f % 3;          // f = w4_freq(fi, fj) of csrc/ssm_wino4.hip
     double val = 0.0;
     if (co < j.Cout) {
         const double pt[5] = {0.0, 0.625, -0.625, 1.6, -1.6};

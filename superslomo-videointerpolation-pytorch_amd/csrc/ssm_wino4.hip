@@ -116,11 +116,151 @@ constexpr float kA = (float)W4_PA, kB = (float)W4_PB, kA2 = (float)(W4_PA * W4_P
 constexpr float kA3 = (float)(W4_PA * W4_PA * W4_PA), kB3 = (float)(W4_PB * W4_PB * W4_PB);
 constexpr float kP0 = (float)(W4_PA * W4_PA * W4_PB * W4_PB), kS2 = (float)(W4_PA * W4_PA + W4_PB * W4_PB);
 
+// Frequency index of (row-frequency i, column-frequency j), i, j = 0..5 over the points 0, +a, -a, +b, -b, inf: the column halves
+// j in {0,1,2} / {3,4,5} own 18 consecutive indices each - the two threads that share a (cin, tile) transform write whole quads.
+__host__ __device__ constexpr int w4_freq(int i, int j) { return 18 * (j / 3) + 3 * i + (j % 3); }
+
+// row pass: one patch row d[0..5] -> the three column-frequencies of half hh (hh = 0: points 0, +a, -a; hh = 1: +b, -b, inf)
+__device__ __forceinline__ void w4_row_pass(int hh, const float *d, float *x) {
+    if (hh == 0) {
+        const float te = d[4] - kB2 * d[2], to = d[3] - kB2 * d[1];
+        x[0] = (kP0 * d[0] - kS2 * d[2]) + d[4];
+        x[1] = te + kA * to;
+        x[2] = te - kA * to;
+    } else {
+        const float ue = d[4] - kA2 * d[2], uo = d[3] - kA2 * d[1];
+        x[0] = ue + kB * uo;
+        x[1] = ue - kB * uo;
+        x[2] = (kP0 * d[1] - kS2 * d[3]) + d[5];
+    }
+}
+
+// column pass: six values along y -> the six row-frequencies
+__device__ __forceinline__ void w4_col_pass(float x0, float x1, float x2, float x3, float x4, float x5, float *v, int stride) {
+    const float te = x4 - kB2 * x2, to = x3 - kB2 * x1;
+    const float ue = x4 - kA2 * x2, uo = x3 - kA2 * x1;
+    v[0] = (kP0 * x0 - kS2 * x2) + x4;
+    v[stride] = te + kA * to;
+    v[2 * stride] = te - kA * to;
+    v[3 * stride] = ue + kB * uo;
+    v[4 * stride] = ue - kB * uo;
+    v[5 * stride] = (kP0 * x1 - kS2 * x3) + x5;
+}
+
+// a thread's 18 frequencies v[3 i + jj] of half hh -> V [fq][NT tiles][4] at vo (f32x4 units, this tile's column): quads 0..3 whole
+// and the low half of quad 4 (hh = 0), or the high half of quad 4 and quads 5..8 (hh = 1)
+template <int NT>
+__device__ __forceinline__ void w4_store_v(int hh, const float *v, f32x4 *vo) {
+    if (hh == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vo[g * NT] = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        *(f32x2 *)(vo + 4 * NT) = f32x2{v[16], v[17]};
+    } else {
+        *((f32x2 *)(vo + 4 * NT) + 1) = f32x2{v[0], v[1]};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vo[(5 + g) * NT] = f32x4{v[2 + 4 * g], v[3 + 4 * g], v[4 + 4 * g], v[5 + 4 * g]};
+    }
+}
+
 #ifdef SSM_WINO_ABLATE
 #define W4ABL(bit) (p.abl & (bit))
 #else
 #define W4ABL(bit) 0
 #endif
+
+// ---- epilogue of both kernel forms: Y = A^T M A per accumulator register (4 couts per lane), + bias, addend, LeakyReLU, stores, fused
+// 2x2 mean.  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1].  cu0: first cout of the wave's 16-cout
+// block (this lane holds couts cu0 + 4 q + r), (px, py): the lane's 4x4 output tile.
+__device__ __forceinline__ void w4_epilogue(const W4Params &p, const f32x4 (&acc)[36], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
+        const float sl = p.lrelu ? p.slope : 1.f;
+        float *dstb = p.dst + (long long)b * p.dsb;
+        float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
+                const unsigned pb = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
+        const unsigned qb = 4u * ((unsigned)(4 * q) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
+        const bool vok = py + 4 <= p.H && px + 4 <= p.W && p.vec;          // whole tile inside the map, rows as aligned 16-byte pieces
+        auto st4 = [](const float *base, unsigned off_bytes, f32x4 val) {
+            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        auto st2 = [](const float *base, unsigned off_bytes, f32x2 val) {
+            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        auto st1 = [](const float *base, unsigned off_bytes, float val) {
+            asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+        };
+        const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * q) * p.asc + (long long)py * p.ash + px : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cu = cu0 + r;          // uniform; this lane's cout = cu + 4 * q
+            float t[4][6];                   // A^T M: over the frequency rows i, for every frequency column j
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float m0 = acc[w4_freq(0, j)][r], m1 = acc[w4_freq(1, j)][r], m2 = acc[w4_freq(2, j)][r], m3 = acc[w4_freq(3, j)][r],
+                            m4 = acc[w4_freq(4, j)][r], m5 = acc[w4_freq(5, j)][r];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                t[0][j] = (m0 + s1) + s2;
+                t[1][j] = kA * d1 + kB * d2;
+                t[2][j] = kA2 * s1 + kB2 * s2;
+                t[3][j] = (kA3 * d1 + m5) + kB3 * d2;
+            }
+            float y[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s1 = t[i][1] + t[i][2], d1 = t[i][1] - t[i][2], s2 = t[i][3] + t[i][4], d2 = t[i][3] - t[i][4];
+                y[i][0] = ((t[i][0] + s1) + s2) + bv[r];
+                y[i][1] = (kA * d1 + kB * d2) + bv[r];
+                y[i][2] = (kA2 * s1 + kB2 * s2) + bv[r];
+                y[i][3] = ((kA3 * d1 + t[i][5]) + kB3 * d2) + bv[r];
+            }
+            if (addb) {
+                const float *ap = addb + (long long)cu * p.asc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (vok) {
+                        const f32x4 z = *(const f32x4 *)(ap + (long long)i * p.ash);
+                        y[i][0] += z[0];
+                        y[i][1] += z[1];
+                        y[i][2] += z[2];
+                        y[i][3] += z[3];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (py + i < p.H && px + e < p.W) y[i][e] += ap[(long long)i * p.ash + e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[i][e] = fmaxf(y[i][e], y[i][e] * sl);
+            float *bp = dstb + (long long)cu * p.dsc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (vok) {
+                    st4(bp + (long long)i * p.dsh, pb, f32x4{y[i][0], y[i][1], y[i][2], y[i][3]});
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (py + i < p.H && px + e < p.W) st1(bp + (long long)i * p.dsh + e, pb, y[i][e]);
+                }
+            }
+            if (poolb) {
+                // 2x2 mean, vertical pairs first then the horizontal pair (the association of the direct kernel); H, W even (host check)
+                float *qp = poolb + (long long)cu * p.psc;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float o0 = ((y[2 * i][0] + y[2 * i + 1][0]) + (y[2 * i][1] + y[2 * i + 1][1])) * 0.25f;
+                    const float o1 = ((y[2 * i][2] + y[2 * i + 1][2]) + (y[2 * i][3] + y[2 * i + 1][3])) * 0.25f;
+                    const bool rok = py + 2 * i < p.H;
+                    if (rok && px + 4 <= p.W && p.vec) st2(qp + (long long)i * p.psh, qb, f32x2{o0, o1});
+                    else if (rok) {
+                        if (px + 2 <= p.W) st1(qp + (long long)i * p.psh, qb, o0);
+                        if (px + 4 <= p.W) st1(qp + (long long)i * p.psh + 1, qb, o1);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
 
 template <class C, bool UPS>
 __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
@@ -264,63 +404,24 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         }
     };
 
-    // V = B^T d B of one (cin, tile): this thread's three frequency rows (frequency order: points 0, +a, -a, +b, -b, inf)
+    // V = B^T d B of one (cin, tile): this thread's three column-frequencies (row pass first, then the six row-frequencies of each)
     auto transform = [&]() {
         const float *rp = lds + t_src;
-        float d[6][6];
+        float X[6][3];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const f32x4 a4 = *(const f32x4 *)(rp + i * PW);
             const f32x2 a2 = *(const f32x2 *)(rp + i * PW + 4);
-            d[i][0] = a4[0];
-            d[i][1] = a4[1];
-            d[i][2] = a4[2];
-            d[i][3] = a4[3];
-            d[i][4] = a2[0];
-            d[i][5] = a2[1];
+            float d[6] = {a4[0], a4[1], a4[2], a4[3], a2[0], a2[1]};
+            // the values arrive as 16- / 8-byte pieces: pin each as a scalar so that no packed-fp32 arithmetic is formed (DESIGN 3.3 fence)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(d[j]));
+            w4_row_pass(thh, d, X[i]);
         }
-        // the values arrive as 16- / 8-byte pieces: pin each as a scalar so that no packed-fp32 arithmetic is formed (DESIGN 3.3 fence)
+        float v[18];            // frequency w4_freq(i, 3 thh + jj) - 18 thh = 3 i + jj
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(d[i][j]));
-        float w[3][6];          // three rows of B^T d
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            if (thh == 0) {          // points 0, +a, -a
-                const float te = d[4][j] - kB2 * d[2][j], to = d[3][j] - kB2 * d[1][j];
-                w[0][j] = (kP0 * d[0][j] - kS2 * d[2][j]) + d[4][j];
-                w[1][j] = te + kA * to;
-                w[2][j] = te - kA * to;
-            } else {                 // points +b, -b, inf
-                const float te = d[4][j] - kA2 * d[2][j], to = d[3][j] - kA2 * d[1][j];
-                w[0][j] = te + kB * to;
-                w[1][j] = te - kB * to;
-                w[2][j] = (kP0 * d[1][j] - kS2 * d[3][j]) + d[5][j];
-            }
-        }
-        float v[18];            // (rows) x B: frequency 18 thh + 6 i + j
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float te = w[i][4] - kB2 * w[i][2], to = w[i][3] - kB2 * w[i][1];
-            const float ue = w[i][4] - kA2 * w[i][2], uo = w[i][3] - kA2 * w[i][1];
-            v[6 * i] = (kP0 * w[i][0] - kS2 * w[i][2]) + w[i][4];
-            v[6 * i + 1] = te + kA * to;
-            v[6 * i + 2] = te - kA * to;
-            v[6 * i + 3] = ue + kB * uo;
-            v[6 * i + 4] = ue - kB * uo;
-            v[6 * i + 5] = (kP0 * w[i][1] - kS2 * w[i][3]) + w[i][5];
-        }
-        f32x4 *vo = (f32x4 *)lds + t_dst;
-        if (thh == 0) {          // frequencies 0..17: quads 0..3 whole, the low half of quad 4
-#pragma unroll
-            for (int g = 0; g < 4; ++g) vo[g * NT] = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-            *(f32x2 *)(vo + 4 * NT) = f32x2{v[16], v[17]};
-        } else {                 // frequencies 18..35: the high half of quad 4, quads 5..8 whole
-            *((f32x2 *)(vo + 4 * NT) + 1) = f32x2{v[0], v[1]};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) vo[(5 + g) * NT] = f32x4{v[2 + 4 * g], v[3 + 4 * g], v[4 + 4 * g], v[5 + 4 * g]};
-        }
+        for (int jj = 0; jj < 3; ++jj) w4_col_pass(X[0][jj], X[1][jj], X[2][jj], X[3][jj], X[4][jj], X[5][jj], v + jj, 3);
+        w4_store_v<NT>(thh, v, (f32x4 *)lds + t_dst);
     };
 
 #ifdef SSM_WINO_ABLATE
@@ -394,95 +495,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     {
         const int gx = l15 % C::GTX, gy = l15 / C::GTX;
         const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
-        const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
-        const float sl = p.lrelu ? p.slope : 1.f;
-        float *dstb = p.dst + (long long)b * p.dsb;
-        float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
-        const int cu0 = nb * BN + cb * 16;          // Cout is a multiple of 32 (checked on the host)
-        const unsigned pb = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
-        const unsigned qb = 4u * ((unsigned)(4 * q) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
-        const bool vok = py + 4 <= p.H && px + 4 <= p.W && p.vec;          // whole tile inside the map, rows as aligned 16-byte pieces
-        auto st4 = [](const float *base, unsigned off_bytes, f32x4 val) {
-            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
-        };
-        auto st2 = [](const float *base, unsigned off_bytes, f32x2 val) {
-            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
-        };
-        auto st1 = [](const float *base, unsigned off_bytes, float val) {
-            asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
-        };
-        const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * q) * p.asc + (long long)py * p.ash + px : nullptr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cu = cu0 + r;          // uniform; this lane's cout = cu + 4 * q
-            float t[4][6];                   // A^T M: over the frequency rows i, for every frequency column j
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float m0 = acc[j][r], m1 = acc[6 + j][r], m2 = acc[12 + j][r], m3 = acc[18 + j][r], m4 = acc[24 + j][r], m5 = acc[30 + j][r];
-                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                t[0][j] = (m0 + s1) + s2;
-                t[1][j] = kA * d1 + kB * d2;
-                t[2][j] = kA2 * s1 + kB2 * s2;
-                t[3][j] = (kA3 * d1 + m5) + kB3 * d2;
-            }
-            float y[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float s1 = t[i][1] + t[i][2], d1 = t[i][1] - t[i][2], s2 = t[i][3] + t[i][4], d2 = t[i][3] - t[i][4];
-                y[i][0] = ((t[i][0] + s1) + s2) + bv[r];
-                y[i][1] = (kA * d1 + kB * d2) + bv[r];
-                y[i][2] = (kA2 * s1 + kB2 * s2) + bv[r];
-                y[i][3] = ((kA3 * d1 + t[i][5]) + kB3 * d2) + bv[r];
-            }
-            if (addb) {
-                const float *ap = addb + (long long)cu * p.asc;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (vok) {
-                        const f32x4 z = *(const f32x4 *)(ap + (long long)i * p.ash);
-                        y[i][0] += z[0];
-                        y[i][1] += z[1];
-                        y[i][2] += z[2];
-                        y[i][3] += z[3];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (py + i < p.H && px + e < p.W) y[i][e] += ap[(long long)i * p.ash + e];
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[i][e] = fmaxf(y[i][e], y[i][e] * sl);
-            float *bp = dstb + (long long)cu * p.dsc;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (vok) {
-                    st4(bp + (long long)i * p.dsh, pb, f32x4{y[i][0], y[i][1], y[i][2], y[i][3]});
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (py + i < p.H && px + e < p.W) st1(bp + (long long)i * p.dsh + e, pb, y[i][e]);
-                }
-            }
-            if (poolb) {
-                // 2x2 mean, vertical pairs first then the horizontal pair (the association of the direct kernel); H, W even (host check)
-                float *qp = poolb + (long long)cu * p.psc;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float o0 = ((y[2 * i][0] + y[2 * i + 1][0]) + (y[2 * i][1] + y[2 * i + 1][1])) * 0.25f;
-                    const float o1 = ((y[2 * i][2] + y[2 * i + 1][2]) + (y[2 * i][3] + y[2 * i + 1][3])) * 0.25f;
-                    const bool rok = py + 2 * i < p.H;
-                    if (rok && px + 4 <= p.W && p.vec) st2(qp + (long long)i * p.psh, qb, f32x2{o0, o1});
-                    else if (rok) {
-                        if (px + 2 <= p.W) st1(qp + (long long)i * p.psh, qb, o0);
-                        if (px + 4 <= p.W) st1(qp + (long long)i * p.psh + 1, qb, o1);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        w4_epilogue(p, acc, bv, b, nb * BN + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
     }
 #ifdef SSM_WINO_ABLATE
     if (stamp) {
@@ -497,6 +510,308 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
 #endif
 }
 
+// =====================================================================================================================================
+// Second form: ONE 512-thread workgroup per CU, software-pipelined.  The in-kernel phase timers of the first form (tools/
+// wino4_phase_probe.py) show where a 32-cout x 32-tile workgroup loses: per chunk of 4 input channels a wave issues 8 LDS-DMA
+// instructions (~150 cycles of issue each) and spends ~1100 cycles in the transform phase, against 1152 cycles of MFMAs - and the two
+// waves of a SIMD cannot hide that from each other.  Here a workgroup owns 32 couts x 64 tiles (8 waves: the filter DMA per MFMA
+// halves), everything is double-buffered in the 160 KiB of LDS (filter 2 x 18 KiB, patch 2 x 22 KiB, V 2 x 36 KiB), and the transform
+// of chunk c+1 - row loads, row pass, column passes, V stores - is spread over the 36 MFMA slots of chunk c, one or two LDS / six
+// vector instructions per slot, next to the operand fetches and the DMA issue: one barrier per chunk, and no phase in which the
+// matrix pipe has nothing queued.  (Fused upsample: the expansion of chunk c+1 keeps its own phase in front of the matrix loop - two
+// barriers per chunk - with the low-res raw patch double-buffered and one hi-res patch.)
+template <int GTX_, int WTY_, int WTX_>
+struct W8Cfg {
+    static constexpr int GTX = GTX_, GTY = 16 / GTX_, WTY = WTY_, WTX = WTX_;
+    static constexpr int CK = 4, BN = 32, NT = 64;
+    static constexpr int NTX = GTX * WTX, NTY = GTY * WTY;
+    static constexpr int TH = 4 * NTY, TW = 4 * NTX;
+    static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;
+    static constexpr int SHIFT = 1;
+    static constexpr int USZ = CK * 9 * BN * 4, PSZ = CK * PH * PW, VSZ = CK * 9 * NT * 4;
+    static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;
+    static constexpr int RSZ = CK * LH * LW;
+    static constexpr int NPOS = (TH / 2 + 1) * (TW / 2 + 1);
+    static_assert(WTY * WTX == 4 && (GTX == 4 || GTX == 8 || GTX == 16), "four tile groups of 16 tiles");
+    static_assert(USZ % 256 == 0 && NPOS <= 512 && TH <= 16, "filter stage = whole 1-KiB DMA groups; expander: one position per thread");
+};
+
+template <class C, bool UPS>
+struct W8Lds {
+    static constexpr int DSZ = UPS ? C::RSZ : C::PSZ;
+    static constexpr int DH = UPS ? C::LH : C::PH, DW4 = UPS ? C::LW4 : C::PW4;
+    static constexpr int NGU = C::USZ / 256, NDQ = DSZ / 4, NGP = (NDQ + 63) / 64;
+    static constexpr int NIU = (NGU + 7) / 8, NIP = (NGP + 7) / 8, NI = NIU + NIP;      // DMA instructions per wave per chunk
+    static constexpr int DCAP = NGP * 256 + 256;                // one DMA'd (raw) patch buffer
+    static constexpr int UOFF = 0, DOFF = 2 * C::USZ;           // two filter stages, two DMA'd patch buffers
+    static constexpr int HOFF = DOFF + 2 * DCAP;                // UPS: the one expanded hi-res patch
+    static constexpr int VOFF = HOFF + (UPS ? C::PSZ + 4 : 0);  // two transformed patches
+    static constexpr int BYTES = (VOFF + 2 * C::VSZ) * 4;
+    static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0 && DCAP % 4 == 0, "16-byte aligned regions");
+    static_assert(BYTES <= 160 * 1024 && NI <= 6, "LDS budget (one workgroup per CU); DMA issue slots of the matrix loop");
+};
+
+template <class C, bool UPS>
+__global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using L = W8Lds<C, UPS>;
+    constexpr int BN = C::BN, PH = C::PH, PW = C::PW, CK = C::CK, NT = C::NT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wid & 1, tg = wid >> 1;          // cout half, tile group (0..3) of this wave
+
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
+    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
+    const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
+    const float *wbase = p.wpk + (long long)nb * p.Cin * (9 * BN * 4);
+
+    int poff[L::NIP];
+#pragma unroll
+    for (int i = 0; i < L::NIP; ++i) {
+        const int qq = (i * 8 + wid) * 64 + lane;
+        if (qq < L::NDQ) {
+            const int c = qq / (L::DH * L::DW4);
+            const int rem = qq - c * (L::DH * L::DW4);
+            const int r = rem / L::DW4;
+            const int j = rem - r * L::DW4;
+            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+        } else {
+            poff[i] = 0;
+        }
+    }
+    const int uoff = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+
+    // k-th DMA instruction of this wave: k < NIU filter group 8k + wave of chunk `chu` into filter stage chu & 1; else patch group of
+    // chunk `chp` into patch buffer chp & 1 (the two are issued for different chunks: the patch runs one chunk further ahead)
+    auto issue_u = [&](int chu, int k) {
+        const int g = 8 * k + wid;
+        if (g < L::NGU) {
+            const float *base = wbase + (long long)(chu * CK) * (9 * BN * 4) + g * 256;
+            const unsigned m0v = lds0 + (unsigned)(L::UOFF + (chu & 1) * C::USZ) * 4u + (unsigned)g * 1024u;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
+        }
+    };
+    auto issue_p = [&](int chp, int kk) {
+        const int g = 8 * kk + wid;
+        if (g < L::NGP) {
+            const int c0 = chp * CK;
+            const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
+            const unsigned m0v = lds0 + (unsigned)(L::DOFF + (chp & 1) * L::DCAP) * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
+        }
+    };
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.Cin / CK;
+    // prologue: filter of chunk 0, patches of chunks 0 and 1
+#pragma unroll
+    for (int k = 0; k < L::NIU; ++k) issue_u(0, k);
+#pragma unroll
+    for (int k = 0; k < L::NIP; ++k) issue_p(0, k);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int k = 0; k < L::NIP; ++k) issue_p(1, k);
+    }
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * BN + cb * 16 + 4 * q + r];
+
+    // transform unit of this thread: (cin, tile), column-frequency half thh (wave-uniform)
+    const int thh = wid >> 2;
+    const int tu = tid & 255;
+    const int tcin = tu >> 6, ttile = tu & 63;
+    const int tgx = (ttile & 15) % C::GTX, tgy = (ttile & 15) / C::GTX, tg2 = ttile >> 4;
+    const int tTx = (tg2 % C::WTX) * C::GTX + tgx, tTy = (tg2 / C::WTX) * C::GTY + tgy;
+    const int t_rel = C::SHIFT + (tcin * PH + 4 * tTy) * PW + 4 * tTx + 3;      // floats from the start of a patch buffer (plain: DOFF + buf * DCAP; UPS: HOFF)
+    const int t_dst = (tcin * 9) * NT + ttile;                                  // f32x4 units from the start of a V buffer
+
+    const f32x4 *lds4 = (const f32x4 *)lds;
+    const int aBase = L::UOFF / 4 + q * (9 * BN) + cb * 16 + l15;
+    const int bBase = L::VOFF / 4 + q * (9 * NT) + tg * 16 + l15;
+
+    // fused upsample: low-res raw patch buffer `buf` -> the hi-res patch; one thread = one 2x2 hi-res block position
+    auto expand = [&](int buf) {
+        if constexpr (UPS) {
+            constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, LH = C::LH, LW = C::LW;
+            const float *raw = lds + L::DOFF + buf * L::DCAP;
+            float *hip = lds + L::HOFF;
+            // (the geometry is recomputed per chunk: hoisted out of the loop it would hold ~15 registers across the matrix phase, and
+            // the pipelined loop has none to spare)
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            if (tl < NPOS) {
+                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+                const int pi = tl / PRW, pj = tl - pi * PRW;
+                const int i = ly0 + pi, j = lx0 + pj;
+                const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
+                const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
+                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;
+                const float ca = j0 == j1 ? 1.f : 0.25f, cbw = j0 == j1 ? 0.f : 0.75f;
+                const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
+                const int Y = 2 * i + 1, X = 2 * j + 1;
+                const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
+                const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
+                const float *r0 = raw + (i0 - ly0) * LW + 3 - lx0 + j0;
+                const float *r1 = raw + (i1 - ly0) * LW + 3 - lx0 + j0;
+                float *dd = hip + (2 * pi) * PW + 2 * pj + 3 + C::SHIFT;
+                // two channels at a time: the pipelined loop leaves ~40 registers for this phase
+#pragma unroll 1
+                for (int c2 = 0; c2 < CK; c2 += 2) {
+                    float v00[2], v01[2], v10[2], v11[2];
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        v00[cc] = r0[(c2 + cc) * LH * LW];
+                        v01[cc] = r0[(c2 + cc) * LH * LW + 1];
+                        v10[cc] = r1[(c2 + cc) * LH * LW];
+                        v11[cc] = r1[(c2 + cc) * LH * LW + 1];
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const float h00 = xa * v00[cc] + xb * v01[cc], h01 = ca * v00[cc] + cbw * v01[cc];
+                        const float h10 = xa * v10[cc] + xb * v11[cc], h11 = ca * v10[cc] + cbw * v11[cc];
+                        dd[(c2 + cc) * PH * PW] = m00 * (ya * h00 + yb * h10);
+                        dd[(c2 + cc) * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
+                        dd[(c2 + cc) * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
+                        dd[(c2 + cc) * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    // The transform of one (cin, tile, half) as 36 micro-steps, so that the matrix loop can place one behind every MFMA:
+    //   steps 0..5   load patch row i (one ds_read_b128 + one ds_read_b64)
+    //   steps 2..7   row pass of row i - 2 (its load is two MFMAs + their slots old; three rows in flight = 18 registers)
+    //   steps 8..25  the three column passes, six steps each
+    //   steps 26..30 the five V stores
+    float trow[6][6], tX[6][3], tv[18];
+    auto tstep = [&](int m, const float *src, f32x4 *dst) {
+        if (m < 6) {
+            const f32x4 a4 = *(const f32x4 *)(src + m * PW);
+            const f32x2 a2 = *(const f32x2 *)(src + m * PW + 4);
+            trow[m][0] = a4[0];
+            trow[m][1] = a4[1];
+            trow[m][2] = a4[2];
+            trow[m][3] = a4[3];
+            trow[m][4] = a2[0];
+            trow[m][5] = a2[1];
+        }
+        if (m >= 2 && m < 8) {
+            const int i = m - 2;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(trow[i][j]));          // scalars: no packed-fp32 arithmetic on the loaded pairs
+            w4_row_pass(thh, trow[i], tX[i]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(tX[i][j]));
+        }
+        if (m >= 8 && m < 26) {
+            const int jj = (m - 8) / 6, st = (m - 8) % 6;
+            const float x0v = tX[0][jj], x1v = tX[1][jj], x2v = tX[2][jj], x3v = tX[3][jj], x4v = tX[4][jj], x5v = tX[5][jj];
+            // (te, to, ue, uo are recomputed in the step that consumes them: two operations per step either way)
+            if (st == 0) tv[jj] = (kP0 * x0v - kS2 * x2v) + x4v;
+            if (st == 1) {
+                const float te = x4v - kB2 * x2v, to = x3v - kB2 * x1v;
+                tv[3 + jj] = te + kA * to;
+                tv[6 + jj] = te - kA * to;
+            }
+            if (st == 2) {
+                const float ue = x4v - kA2 * x2v, uo = x3v - kA2 * x1v;
+                tv[9 + jj] = ue + kB * uo;
+                tv[12 + jj] = ue - kB * uo;
+            }
+            if (st == 3) tv[15 + jj] = (kP0 * x1v - kS2 * x3v) + x5v;
+            if (st == 5) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(tv[3 * i + jj]));
+            }
+        }
+        if (m >= 26 && m < 31) {
+            const int g = m - 26;          // thh = 0: quads 0..3 then the low half of quad 4; thh = 1: the high half of quad 4 then quads 5..8
+            if (thh == 0) {
+                if (g < 4) dst[g * NT] = f32x4{tv[4 * g], tv[4 * g + 1], tv[4 * g + 2], tv[4 * g + 3]};
+                else *(f32x2 *)(dst + 4 * NT) = f32x2{tv[16], tv[17]};
+            } else {
+                if (g == 0) *((f32x2 *)(dst + 4 * NT) + 1) = f32x2{tv[0], tv[1]};
+                else dst[(4 + g) * NT] = f32x4{tv[4 * g - 2], tv[4 * g - 1], tv[4 * g], tv[4 * g + 1]};
+            }
+        }
+    };
+
+    // chunk 0: wait for its DMAs, expand (UPS), transform without overlap
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    expand(0);
+    {
+        const float *src = lds + (UPS ? L::HOFF : L::DOFF) + t_rel;
+        f32x4 *dst = (f32x4 *)lds + L::VOFF / 4 + t_dst;
+#pragma unroll
+        for (int m = 0; m < 31; ++m) tstep(m, src, dst);
+    }
+
+    f32x4 a[2], bq[2];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int st = ch & 1;
+        // U(ch) and the patch of chunk ch+1 have landed (this wave's share); V(ch) is complete and every wave is done with chunk ch-1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool more = ch + 1 < nchunks, more2 = ch + 2 < nchunks;
+        if constexpr (UPS) {
+            if (more) expand(st ^ 1);          // raw patch of chunk ch+1 -> hi-res patch (the transform of chunk ch has finished with it)
+        }
+        const float *tsrc = lds + (UPS ? L::HOFF : L::DOFF + (st ^ 1) * L::DCAP) + t_rel;
+        f32x4 *tdst = (f32x4 *)lds + L::VOFF / 4 + (st ^ 1) * (C::VSZ / 4) + t_dst;
+        const int ai = aBase + st * (C::USZ / 4), bi = bBase + st * (C::VSZ / 4);
+        a[0] = lds4[ai];
+        bq[0] = lds4[bi];
+#pragma unroll
+        for (int m = 0; m < 36; ++m) {
+            const int g = m >> 2, e = m & 3, cur = g & 1;
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (e == 0 && g + 1 < 9) {          // operands of the next group: a whole group (128 cycles) + this slot's work ahead of their use
+                a[cur ^ 1] = lds4[ai + (g + 1) * BN];
+                bq[cur ^ 1] = lds4[bi + (g + 1) * NT];
+            }
+            if (more && !W4ABL(4)) tstep(m, tsrc, tdst);
+            // DMA: filter of chunk ch+1 into the other stage, patch of chunk ch+2 into the buffer the transform of chunk ch read
+            if (m >= 9 && (m - 9) % 5 == 0 && !W4ABL(1)) {
+                const int k = (m - 9) / 5;          // 0..5 at slots 9, 14, 19, 24, 29, 34
+                if (k < L::NIU) {
+                    if (more) issue_u(ch + 1, k);
+                } else if (k < L::NI) {
+                    if (more2) issue_p(ch + 2, k - L::NIU);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+#ifdef SSM_WINO_ABLATE
+    if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
+#endif
+    {
+        const int gx = l15 % C::GTX, gy = l15 / C::GTX;
+        const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
+        w4_epilogue(p, acc, bv, b, nb * BN + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
+    }
+}
+
 // ---- tile configurations ---------------------------------------------------------------------------------------------------------
 //                     GTX WTY WTX          tiles of 4x4 px     TH   TW
 using X4A = W4Cfg<8, 2, 1>;      //          8 x 4                16   32
@@ -505,26 +820,27 @@ using X4C = W4Cfg<4, 1, 2>;      //          8 x 4 (4x4 groups)   16   32
 // (row tiles stay <= 16: a tile that overshoots the map reads TH - 2 rows past the plane's frame, which the 64 Ki floats of slack behind
 // every tensor cover up to 4K-wide planes)
 
-#define SSM_W4_KINDS(X) X(X4A_, X4A) X(X4B_, X4B) X(X4C_, X4C)
+// pipelined form: 32 couts x 64 tiles per workgroup of 8 waves
+//                     GTX WTY WTX          tiles of 4x4 px     TH   TW
+using P8A = W8Cfg<8, 2, 2>;      //         16 x 4                16   64
+using P8B = W8Cfg<16, 4, 1>;     //         16 x 4 (16x1 groups)  16   64
+using P8C = W8Cfg<4, 1, 4>;      //         16 x 4 (4x4 groups)   16   64
+
+#define SSM_W4_KINDS(X) X(X4A_, X4A, 0) X(X4B_, X4B, 0) X(X4C_, X4C, 0) X(P8A_, P8A, 1) X(P8B_, P8B, 1) X(P8C_, P8C, 1)
 
 enum W4Kind {
-#define X(name, cfg) name,
+#define X(name, cfg, pipe) name,
     SSM_W4_KINDS(X)
 #undef X
         NW4KIND
 };
 
 struct W4KindInfo {
-    int th, tw;
+    int th, tw, pipe;
 };
 
-template <class C>
-constexpr W4KindInfo w4info_of() {
-    return W4KindInfo{C::TH, C::TW};
-}
-
 constexpr W4KindInfo kW4Info[NW4KIND] = {
-#define X(name, cfg) w4info_of<cfg>(),
+#define X(name, cfg, pipe) W4KindInfo{cfg::TH, cfg::TW, pipe},
     SSM_W4_KINDS(X)
 #undef X
 };
@@ -540,6 +856,10 @@ double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W,
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * (Cout / 32);
     const double chunks = (double)Cin / 4.0;
+    if (ki.pipe) {          // one workgroup per CU: 2 x 36 MFMAs per chunk and SIMD behind one barrier (+ the expansion phase), exposed prologue / epilogue
+        const double per = chunks * (2900.0 + (ups ? 600.0 : 0.0)) + 9000.0;
+        return (double)((nwg + 255) / 256) * per;
+    }
     const double per = chunks * (5300.0 + (ups ? 300.0 : 0.0)) + 14000.0;
     const long long full = nwg / 512, rem = nwg % 512;
     double t = (double)full * per;
@@ -550,9 +870,14 @@ double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W,
 int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     const int forced = g_force_w4kind.load();
     if (forced >= 0 && forced < NW4KIND) return forced;
+    static const int allow_pipe = [] {
+        const char *e = getenv("SSM_WINO4_PIPE");
+        return e ? atoi(e) : 1;
+    }();
     int best = -1;
     double bt = 0.0;
     for (int i = 0; i < NW4KIND; ++i) {
+        if (kW4Info[i].pipe && !allow_pipe) continue;
         const double t = estimate_w4(kW4Info[i], Cin, Cout, B, H, W, ups);
         if (best < 0 || t < bt * 0.999) {
             best = i;
@@ -562,7 +887,7 @@ int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     return best;
 }
 
-template <class C, bool UPS>
+template <class C, bool UPS, int PIPE>
 int w4launch(W4Params &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
@@ -572,8 +897,17 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
         ssm::set_error("wino4 conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
-    constexpr int lds_bytes = W4Lds<C, UPS>::BYTES;
-    auto kern = wino4_kernel<C, UPS>;
+    void (*kern)(const W4Params);
+    int lds_bytes, threads;
+    if constexpr (PIPE) {
+        kern = wino4p_kernel<C, UPS>;
+        lds_bytes = W8Lds<C, UPS>::BYTES;
+        threads = 512;
+    } else {
+        kern = wino4_kernel<C, UPS>;
+        lds_bytes = W4Lds<C, UPS>::BYTES;
+        threads = 256;
+    }
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
@@ -581,15 +915,15 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
         ssm::set_error("wino4 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds_bytes, st, p);
     return ssm::check_launch(UPS ? "ssm_wino4_conv2d_ups_fwd" : "ssm_wino4_conv2d_fwd");
 }
 
 template <bool UPS>
 int w4dispatch(int kind, W4Params &p, int B, hipStream_t st) {
     switch (kind) {
-#define X(name, cfg) \
-    case name: return w4launch<cfg, UPS>(p, B, st);
+#define X(name, cfg, pipe) \
+    case name: return w4launch<cfg, UPS, pipe>(p, B, st);
         SSM_W4_KINDS(X)
 #undef X
     }
@@ -597,7 +931,7 @@ int w4dispatch(int kind, W4Params &p, int B, hipStream_t st) {
 }
 
 // U = G g G^T with G[f] = [1 p p^2] / prod_{q != p} (p - q) over the finite points p = 0, +a, -a, +b, -b and G[inf] = [0 0 1], evaluated in
-// float64 and rounded once; packed index -> (nb, cin, fq, n, e), frequency f = 4 fq + e = 6 i + j
+// float64 and rounded once; packed index -> (nb, cin, fq, n, e), frequency f = 4 fq + e = w4_freq(i, j)
 __global__ void wino4_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ wp,
                                   float *__restrict__ bp, int Cout, int Cin, long long total, int nbias) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -611,7 +945,7 @@ __global__ void wino4_pack_kernel(const float *__restrict__ w, const float *__re
         r /= 9;
         const int cin = (int)(r % Cin);
         const int nb = (int)(r / Cin);
-        const int co = nb * 32 + n, f = 4 * fq + e, i = f / 6, j = f % 6;
+        const int co = nb * 32 + n, f = 4 * fq + e, i = (f % 18) / 3, j = 3 * (f / 18) + f % 3;          // f = w4_freq(i, j)
         double val = 0.0;
         if (co < Cout) {
             const double pt[5] = {0.0, W4_PA, -W4_PA, W4_PB, -W4_PB};

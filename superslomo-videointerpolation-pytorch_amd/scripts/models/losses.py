@@ -60,7 +60,7 @@ class SSMLosses(nn.Module):
             return None
         # the model's training precision (FullModel._train_engine stores it here), else $SSM_TRAIN_PRECISION, else exact fp32
         mode = self.__dict__.get("train_precision") or os.environ.get("SSM_TRAIN_PRECISION", "f32")
-        mode = "f32" if mode == "f32w" else mode          # the VGG16 extractor has the direct fp32 form and the f16f8 form
+        # (f32w: the extractor's 3x3 layers with 8+ input channels run as Winograd F(2x2,3x3) like the U-Nets' - fp32 throughout)
         key = (B, H, W, str(device), mode)
         if self._pterm is None or self._pterm[0] != key:
             from ssm_amd.perceptual import PerceptualTerm

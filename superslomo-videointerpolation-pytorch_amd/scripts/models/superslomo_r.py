@@ -257,7 +257,7 @@ class FullModel(nn.Module):
         from ssm_amd.backward import PairGrad
         mode = self.train_precision or os.environ.get("SSM_TRAIN_PRECISION", DEFAULT_TRAIN_PRECISION)
         assert mode in ("f16f8", "f32", "f32w"), "training precision must be f32, f32w or f16f8"
-        self.loss.__dict__["train_precision"] = "f32" if mode == "f32w" else mode        # the VGG16 term runs in the same arithmetic (direct form)
+        self.loss.__dict__["train_precision"] = mode        # the VGG16 term runs in the same arithmetic
         key = (B, H, W, str(device), mode)
         if getattr(self, "_train", None) is None or self._train[0] != key:
             sd1 = {k: v.detach() for k, v in self.stage1_model.state_dict().items()}

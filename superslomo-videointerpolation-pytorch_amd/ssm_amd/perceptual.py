@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import hipbind as hb
+from .engine import conv_fn
 from .backward import transposed_filter
 from .weights import _hash_uniform
 
@@ -43,9 +44,10 @@ class VGGFeatures:
         """mode f16f8: the convolutions run on the fp16 + fp8 matrix path (Q8 operands; the fp32 planes the ReLU mask, the max
         pooling and the feature loss read are written by the same launches); mode f32: exact-fp32 MFMA kernels."""
         assert H % 8 == 0 and W % 8 == 0, "VGG16 conv4_3 pools three times: H, W must be multiples of 8"
-        assert mode in ("f16f8", "f32")
+        assert mode in ("f16f8", "f32", "f32w")
         self.B, self.H, self.W, self.device = B, H, W, device
         self.q8 = mode == "f16f8"
+        self.wino = mode == "f32w"        # fp32 throughout, the 3x3 layers with 8+ input channels as Winograd F(2x2,3x3) (csrc/ssm_wino.hip)
         self.steps = []          # ("conv", idx, cin, cout, src, dst) | ("pool", src, dst)
         self.t, self.pk, self.w, self.q = {}, {}, {}, {}        # q: Q8 twins of the conv inputs (mode f16f8)
         self.b, self.pk_nb = {}, {}
@@ -65,7 +67,7 @@ class VGGFeatures:
             assert tuple(wt.shape) == (cout, cin, 3, 3), "features.%d.weight has shape %s" % (idx, tuple(wt.shape))
             self.w[idx] = wt
             self.b[idx] = bs
-            self.pk[idx] = hb.PackedConv16(wt, bs, w, q8=True) if self.q8 else hb.PackedConv(wt, bs, B, h, w)
+            self.pk[idx] = hb.PackedConv16(wt, bs, w, q8=True) if self.q8 else self._cls(cin, cout, h, w)(wt, bs, B, h, w)
             if name == "x":
                 self.t["x"] = hb.Planes(B, max(8, self.pk[idx].cin_p), h, w, device)     # 3 channels padded to the largest conv chunk
                 if self.q8:
@@ -79,17 +81,21 @@ class VGGFeatures:
         self.out = name
         self.g, self.pk_t = {}, {}
 
+    def _cls(self, cin, cout, h, w):
+        return hb.PackedWino if (self.wino and hb.wino_supported(cin, cout, h, w)) else hb.PackedConv
+
     def _pk(self, idx, nb, src):
         """Packed filter of conv `idx` for a launch over nb batch entries: the fp32 kernel's tile plan (and with it the packing)
         depends on the batch, and forward() runs on sub-batches (prediction and target separately)."""
         if self.q8:
             return self.pk[idx]
         pk = self.pk[idx]
-        if hb.conv_plan(3, pk.cin_p, pk.cout, nb, src.H, src.W)[1:] == (pk.bn, pk.ck):
+        plan = hb.wino_plan(pk.cin, pk.cout, nb, src.H, src.W) if pk.algo == "wino" else hb.conv_plan(3, pk.cin_p, pk.cout, nb, src.H, src.W)
+        if plan[1:] == (pk.bn, pk.ck):
             return pk
         key = (idx, nb)
         if key not in self.pk_nb:
-            self.pk_nb[key] = hb.PackedConv(self.w[idx], self.b[idx], nb, src.H, src.W)
+            self.pk_nb[key] = type(pk)(self.w[idx], self.b[idx], nb, src.H, src.W)
         return self.pk_nb[key]
 
     def _span(self, fam, name, flops):
@@ -127,7 +133,7 @@ class VGGFeatures:
                 hb.conv2d_hl8(self.q[sname].view(b0=b0), pk.cin_p, None, 0, pk, self.q[dname].view(b0=b0), dst.view(b0=b0), None, nb,
                               src.H, src.W, lrelu=True, slope=0.0)
             else:
-                hb.conv2d(src.view(b0=b0), pk.cin_p, None, 0, pk, dst.view(b0=b0), None, nb, src.H, src.W, lrelu=True, slope=0.0)
+                conv_fn(pk)(src.view(b0=b0), pk.cin_p, None, 0, pk, dst.view(b0=b0), None, nb, src.H, src.W, lrelu=True, slope=0.0)
             if e1 is not None:
                 e1.record()
         return self.t[self.out]
@@ -155,7 +161,7 @@ class VGGFeatures:
             Y = self.t[dname]
             if idx not in self.pk_t:
                 wt_t, zb = transposed_filter(self.w[idx]), torch.zeros(cin, device=self.device)
-                self.pk_t[idx] = (nb, hb.PackedConv16(wt_t, zb, Y.W, q8=True) if self.q8 else hb.PackedConv(wt_t, zb, nb, Y.H, Y.W))
+                self.pk_t[idx] = (nb, hb.PackedConv16(wt_t, zb, Y.W, q8=True) if self.q8 else self._cls(cout, cin, Y.H, Y.W)(wt_t, zb, nb, Y.H, Y.W))
             assert self.pk_t[idx][0] == nb, "input_grad was planned for %d batch entries" % self.pk_t[idx][0]
             pk = self.pk_t[idx][1]
             key = "dz%d" % idx
@@ -172,7 +178,7 @@ class VGGFeatures:
                 hb.conv2d_hl8(dzq.view(), pk.cin_p, None, 0, pk, None, dx.view(), None, nb, Y.H, Y.W, lrelu=False)
             else:
                 hb.check(lib.ssm_lrelu_bwd(dy.view(), hb.NULL_VIEW, Y.view(), dzp.view(), nb, cout, Y.H, Y.W, 0.0, 1, st))
-                hb.conv2d(dzp.view(), pk.cin_p, None, 0, pk, dx.view(), None, nb, Y.H, Y.W, lrelu=False)
+                conv_fn(pk)(dzp.view(), pk.cin_p, None, 0, pk, dx.view(), None, nb, Y.H, Y.W, lrelu=False)
             if e1 is not None:
                 e1.record()
             dy = dx

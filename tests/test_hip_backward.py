@@ -604,7 +604,7 @@ def _cos(a, b):
     return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
 
 
-@pytest.mark.parametrize("mode,tv,tg", [("f32", 1e-4, 1e-3), ("f16f8", 5e-4, 1.5e-1)])
+@pytest.mark.parametrize("mode,tv,tg", [("f32", 1e-4, 1e-3), ("f32w", 1e-4, 1e-3), ("f16f8", 5e-4, 1.5e-1)])
 def test_vgg_features_and_input_gradient_vs_oracle(dev, mode, tv, tg):
     """phi = vgg16.features[:23] on the HIP kernels and d<phi, R>/dx against the CPU oracle + autograd (f16f8: features within
     fp8-compensation noise; its input gradient sees the ReLU branch flips of elements within that noise of zero)."""

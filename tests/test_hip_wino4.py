@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["X4A", "X4B", "X4C"]
+KINDS = ["X4A", "X4B", "X4C", "P8A", "P8B", "P8C"]      # P8*: the software-pipelined 512-thread form
 
 
 @pytest.fixture(scope="module")
