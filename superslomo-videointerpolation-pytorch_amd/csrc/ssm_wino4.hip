@@ -856,8 +856,8 @@ double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W,
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * (Cout / 32);
     const double chunks = (double)Cin / 4.0;
-    if (ki.pipe) {          // one workgroup per CU: 2 x 36 MFMAs per chunk and SIMD behind one barrier (+ the expansion phase), exposed prologue / epilogue
-        const double per = chunks * (2900.0 + (ups ? 600.0 : 0.0)) + 9000.0;
+    if (ki.pipe) {          // one workgroup per CU: measured ~6200 cycles per chunk (tools/bench_layers_wino.py W4KIND=3), exposed prologue / epilogue
+        const double per = chunks * (6200.0 + (ups ? 300.0 : 0.0)) + 9000.0;
         return (double)((nwg + 255) / 256) * per;
     }
     const double per = chunks * (5300.0 + (ups ? 300.0 : 0.0)) + 14000.0;
@@ -871,8 +871,8 @@ int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     const int forced = g_force_w4kind.load();
     if (forced >= 0 && forced < NW4KIND) return forced;
     static const int allow_pipe = [] {
-        const char *e = getenv("SSM_WINO4_PIPE");
-        return e ? atoi(e) : 1;
+        const char *e = getenv("SSM_WINO4_PIPE");          // the pipelined kinds take part in the automatic choice: off by default - measured
+        return e ? atoi(e) : 0;                            // 8-12 % slower than the 256-thread form on every layer (profiles/r6_*)
     }();
     int best = -1;
     double bt = 0.0;
