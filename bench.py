@@ -191,6 +191,29 @@ def family_rooflines(by_name, n_pairs, precision, peak, batch=14, H=736, W=1280)
                 "algorithmic_achieved_in_kernel": round(d["alg"] / d["ms"] / 1e9, 2)} for k, d in fams.items()}
 
 
+def warp_kernel_rate(dev, H, W, B=7, reps=20):
+    """layers.warp as its own launch (torch.ops.ssm.warp -> warp_kernel; the pipeline uses the fused gather kernels): SURVEY 8d's
+    32 B/px (3 channels gathered + 2 flow channels read + 3 channels written, fp32) over its HIP-event time, flows of a few pixels."""
+    import ssm_amd.ops  # noqa: F401  (registers torch.ops.ssm.*)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, 3, H, W, generator=g).to(dev)
+    flo = (torch.randn(B, 2, H, W, generator=g) * 3.0).to(dev)
+    for _ in range(3):
+        torch.ops.ssm.warp(img, flo)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(reps):
+        torch.ops.ssm.warp(img, flo)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    gbs = 32.0 * B * H * W / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "warp_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "ms_per_launch": round(ms, 4), "bytes_per_launch": 32.0 * B * H * W,
+            "note": "batch %d of %dx%d; the op allocates its output (torch.empty) inside the bracket" % (B, H, W)}
+
+
 def family_clocks(eng, dev, peak, fams):
     """Shader clock under each conv family of the headline mode (one resident wave on a side stream comparing s_memtime with the
     100 MHz s_memrealtime, tools/clock_probe.hip, while stage 2's layers of that family run back to back on resident inputs):
@@ -697,6 +720,8 @@ def infer_bench(args):
             res["roofline_warp"] = {"bound": "hbm", "kernel": ", ".join(sorted(wk["by_name"])), "achieved": round(wach, 1),
                                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(wach / PEAK_HBM_GBS, 4), "traffic": wt,
                                     "bytes_per_pair": wk["bytes"] / n_solo, "ms_per_pair_in_kernel": round(wms, 3)}
+            if precision == headline:
+                res["roofline_warp"]["standalone_warp_kernel"] = warp_kernel_rate(dev, Hp, Wp)
             up = summ.get("upsample_cat", {"ms": 0.0})
             res["time_split_ms_per_pair"] = {"conv": round(conv_ms, 3), "warp_blend": round(wms, 3),
                                              "upsample_cat": round(up["ms"] / n_solo, 3), "wall_single_stream": round(solo_ms, 3),

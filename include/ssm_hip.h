@@ -349,6 +349,10 @@ int ssm_warp_bilinear_fwd(ssm_view img, ssm_view flow, ssm_view out, int B, int 
  * out16 [B,16,H,W] in the reference's channel order.                        */
 int ssm_flowinterp_inputs_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_view out16, int B,
                               int H, int W, void *stream);
+/* The same, writing only the ten t-dependent channels 3:13 of out16 (warped frames + approximated flows): for plans that convolve
+ * the frame channels 0:3 / 13:16 (flow_interpolation.py:364-367) once per pair from the pair itself and never read them from out16
+ * (ssm_amd.engine.UNetPlan.hoist) - 80 instead of 104 B/px of algorithmic traffic.                                              */
+int ssm_flowinterp_inputs_t_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_view out16, int B, int H, int W, void *stream);
 
 /* extract_outputs + compute_output_image (scripts/models/flow_interpolation.py:
  * 374-429), fused: sigmoid visibility, refined flows, 2 warps, blend.

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void warp_kernel(ssm_view img, ssm_view flow, 
 }
 
 // FlowInterpolationModel.compute_inputs, scripts/models/flow_interpolation.py:338-372
+// IMG = false: only the ten t-dependent channels 3:13 are written (hoisted stage-2 plans convolve the frame channels 0:3 / 13:16
+// once per pair from the pair itself and never read them here)
+template <bool IMG>
 __global__ __launch_bounds__(256) void flowinterp_inputs_kernel(ssm_view img6, ssm_view flow4, const float *__restrict__ tarr,
                                                                 ssm_view out16, int H, int W) {
     SSM_PIXEL_INDEX();
@@ -89,10 +92,10 @@ __global__ __launch_bounds__(256) void flowinterp_inputs_kernel(ssm_view img6, s
     // channel order is ABI (:364-367): I1, g(I1,Ft1), Ft1, Ft0, g(I0,Ft0), I0
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        vp(out16, b, c, y)[x] = vp(img6, b, 3 + c, y)[x];
+        if constexpr (IMG) vp(out16, b, c, y)[x] = vp(img6, b, 3 + c, y)[x];
         vp(out16, b, 3 + c, y)[x] = sample(vp(img6, b, 3 + c, 0), t1);
         vp(out16, b, 10 + c, y)[x] = sample(vp(img6, b, c, 0), t0);
-        vp(out16, b, 13 + c, y)[x] = vp(img6, b, c, y)[x];
+        if constexpr (IMG) vp(out16, b, 13 + c, y)[x] = vp(img6, b, c, y)[x];
     }
     vp(out16, b, 6, y)[x] = ft1u;
     vp(out16, b, 7, y)[x] = ft1v;
@@ -593,8 +596,16 @@ extern "C" int ssm_flowinterp_inputs_fwd(ssm_view img6, ssm_view flow4, const fl
     SSM_CHECK_DIMS("flowinterp_inputs");
     SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && t, "flowinterp_inputs: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs: plane too large");
-    hipLaunchKernelGGL(flowinterp_inputs_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, H, W);
+    hipLaunchKernelGGL(flowinterp_inputs_kernel<true>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, H, W);
     return ssm::check_launch("ssm_flowinterp_inputs_fwd");
+}
+
+extern "C" int ssm_flowinterp_inputs_t_fwd(ssm_view img6, ssm_view flow4, const float *t, ssm_view out16, int B, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("flowinterp_inputs_t");
+    SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && t, "flowinterp_inputs_t: null pointer");
+    SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_t: plane too large");
+    hipLaunchKernelGGL(flowinterp_inputs_kernel<false>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, H, W);
+    return ssm::check_launch("ssm_flowinterp_inputs_t_fwd");
 }
 
 extern "C" int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, const float *t, ssm_view y3, ssm_view aux, int B, int H, int W, void *stream) {

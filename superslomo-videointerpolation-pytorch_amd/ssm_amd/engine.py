@@ -755,8 +755,9 @@ class PairEngine:
         tm = UNetPlan.timer
         px = float(self.B2 * self.H * self.W)
         tptr = self.t_dev.data_ptr()
-        if tm is not None:   # 104 B/px (read 10 ch, write 16 ch)
-            e0, e1 = tm.span("warp", "flowinterp_inputs", nbytes=104.0 * px)
+        t_only = bool(self.s2.hoist) and not self.hl8      # hoisted plan: the frame channels of the 16-channel tensor are never read
+        if tm is not None:   # 104 B/px (read 10 ch, write 16 ch); 80 B/px without the six pass-through frame channels
+            e0, e1 = tm.span("warp", "flowinterp_inputs", nbytes=(80.0 if t_only else 104.0) * px)
             e0.record()
         for p, b0, n, bc in self._groups():
             i6 = self._img6_view(p, bc)
@@ -767,7 +768,8 @@ class PairEngine:
                 if self.twins:      # fp32 copy of the 16-channel stage-2 input for the weight gradient of conv1a
                     hb.check(lib.ssm_flowinterp_inputs_fwd(i6, f4, tptr + 4 * b0, self.s2.f32["in"].view(b0=b0), n, self.H, self.W, st))
             else:
-                hb.check(lib.ssm_flowinterp_inputs_fwd(i6, f4, tptr + 4 * b0, in16.view(b0=b0), n, self.H, self.W, st))
+                fn = lib.ssm_flowinterp_inputs_t_fwd if t_only else lib.ssm_flowinterp_inputs_fwd
+                hb.check(fn(i6, f4, tptr + 4 * b0, in16.view(b0=b0), n, self.H, self.W, st))
         if tm is not None:
             e1.record()
         cross, cbc = self._cross_planes()

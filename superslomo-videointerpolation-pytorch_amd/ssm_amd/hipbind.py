@@ -147,6 +147,7 @@ SIGNATURES = {
     "ssm_warp_bilinear_fwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_flowinterp_inputs_fwd": (_c_int, [SsmView, SsmView, _vp, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_final_conv_fwd": (_c_int, [SsmView, _vp, _vp, _c_int, SsmView, SsmView, SsmView, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _vp]),
+    "ssm_flowinterp_inputs_t_fwd": (_c_int, [SsmView, SsmView, _vp, SsmView, _c_int, _c_int, _c_int, _vp]),
     "ssm_synthesize_fwd": (_c_int, [SsmView, SsmView, SsmView, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _vp]),
 }
 

@@ -213,3 +213,21 @@ def test_dispatcher_ops_pass_opcheck(dev):
     in16 = torch.ops.ssm.flowinterp_inputs(img6, flow4, t)
     out5 = torch.randn(1, 5, 12, 20, generator=g).to(dev)
     torch.library.opcheck(torch.ops.ssm.synthesize.default, (img6, in16.clone().requires_grad_(), out5.clone().requires_grad_(), t), test_utils=tests)
+
+
+def test_flowinterp_inputs_t_only_variant(dev):
+    """ssm_flowinterp_inputs_t_fwd writes exactly channels 3:13 of compute_inputs' 16-channel tensor (the ten t-dependent ones,
+    scripts/models/flow_interpolation.py:364-367) - bit-identical to the full kernel - and leaves the six frame channels alone."""
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 3, 37, 50
+    img6 = torch.randn(B, 6, H, W, generator=g).to(dev)
+    flow4 = (torch.randn(B, 4, H, W, generator=g) * 3).to(dev)
+    t = torch.tensor([0.125, 0.5, 0.875], device=dev)
+    full = torch.empty(B, 16, H, W, device=dev)
+    part = torch.full((B, 16, H, W), 7.0, device=dev)
+    lib = hb.load()
+    hb.check(lib.ssm_flowinterp_inputs_fwd(hb.view_of(img6), hb.view_of(flow4), t.data_ptr(), hb.view_of(full), B, H, W, hb.stream_ptr()))
+    hb.check(lib.ssm_flowinterp_inputs_t_fwd(hb.view_of(img6), hb.view_of(flow4), t.data_ptr(), hb.view_of(part), B, H, W, hb.stream_ptr()))
+    assert torch.equal(part[:, 3:13], full[:, 3:13])
+    assert float((part[:, :3] - 7.0).abs().max()) == 0.0 and float((part[:, 13:] - 7.0).abs().max()) == 0.0
