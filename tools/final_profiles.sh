@@ -1,0 +1,22 @@
+#!/bin/bash
+# Artefacts behind the numbers of a round (run on the MI355X box from the repo root): default bench line + per-launch table, rocprofv3
+# kernel stats of the same command (3 streams, and 1 stream for attribution), PMC traffic of the conv kernels (separate passes),
+# per-layer tables of the Winograd kernels, train / recurrent / 4K lines.      tools/final_profiles.sh <tag>
+set -x
+T=${1:-r6}
+mkdir -p gpurun_out/$T
+python bench.py --detail gpurun_out/$T/detail.json > gpurun_out/$T/bench_line.json 2> gpurun_out/$T/bench_err.log && cut -c1-200 gpurun_out/$T/bench_line.json
+R=$(pwd); cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/prof -o f32w -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-io --modes '' > $R/gpurun_out/$T/prof_bench.json 2> $R/gpurun_out/$T/prof_err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/prof_s1 -o f32w_s1 -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-io --modes '' > $R/gpurun_out/$T/prof_s1_bench.json 2> $R/gpurun_out/$T/prof_s1_err.log
+cd $R
+bash tools/pmc_traffic.sh gpurun_out/$T/pmc f32w > gpurun_out/$T/pmc.log 2>&1; tail -8 gpurun_out/$T/pmc.log
+W4=1 timeout -k 10 200 python tools/bench_layers_wino.py 7 > gpurun_out/$T/wino4_layers_b7.txt 2>&1; tail -2 gpurun_out/$T/wino4_layers_b7.txt
+timeout -k 10 200 python tools/bench_layers_wino.py 7 > gpurun_out/$T/wino2_layers_b7.txt 2>&1; tail -2 gpurun_out/$T/wino2_layers_b7.txt
+timeout -k 10 200 python tools/bench_layers_wino1d.py 14 > gpurun_out/$T/wino1d_layers_b14.txt 2>&1; tail -3 gpurun_out/$T/wino1d_layers_b14.txt
+python bench.py --mode train --precision f32w > gpurun_out/$T/train_f32w_line.json 2>> gpurun_out/$T/bench_err.log
+python bench.py --mode train > gpurun_out/$T/train_f32_line.json 2>> gpurun_out/$T/bench_err.log
+python bench.py --mode recurrent > gpurun_out/$T/recurrent_f32w_line.json 2>> gpurun_out/$T/bench_err.log
+python bench.py --size 4k --precision f32w --streams 1 --pairs-per-batch 1 --pairs-per-step 1 --steps 4 --warmup 1 --no-kernel-timers > gpurun_out/$T/4k_f32w_line.json 2>> gpurun_out/$T/bench_err.log
+python bench.py --size 4k --precision f16 --streams 1 --pairs-per-batch 1 --pairs-per-step 1 --steps 4 --warmup 1 --no-kernel-timers > gpurun_out/$T/4k_f16_line.json 2>> gpurun_out/$T/bench_err.log
+ls gpurun_out/$T
