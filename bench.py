@@ -192,26 +192,32 @@ def family_rooflines(by_name, n_pairs, precision, peak, batch=14, H=736, W=1280)
 
 
 def warp_kernel_rate(dev, H, W, B=7, reps=20):
-    """layers.warp as its own launch (torch.ops.ssm.warp -> warp_kernel; the pipeline uses the fused gather kernels): SURVEY 8d's
+    """layers.warp as its own launch (ssm_warp_bilinear_fwd -> warp_kernel; the pipeline uses the fused gather kernels): SURVEY 8d's
     32 B/px (3 channels gathered + 2 flow channels read + 3 channels written, fp32) over its HIP-event time, flows of a few pixels."""
-    import ssm_amd.ops  # noqa: F401  (registers torch.ops.ssm.*)
+    from ssm_amd import hipbind as hb
     g = torch.Generator().manual_seed(5)
     img = torch.randn(B, 3, H, W, generator=g).to(dev)
     flo = (torch.randn(B, 2, H, W, generator=g) * 3.0).to(dev)
+    out = torch.empty_like(img)
+    lib = hb.load()
+
+    def call():
+        hb.check(lib.ssm_warp_bilinear_fwd(hb.view_of(img), hb.view_of(flo), hb.view_of(out), B, 3, H, W, hb.stream_ptr()))
+
     for _ in range(3):
-        torch.ops.ssm.warp(img, flo)
+        call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     e0.record()
     for _ in range(reps):
-        torch.ops.ssm.warp(img, flo)
+        call()
     e1.record()
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / reps
     gbs = 32.0 * B * H * W / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "warp_kernel", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(gbs / PEAK_HBM_GBS, 4), "ms_per_launch": round(ms, 4), "bytes_per_launch": 32.0 * B * H * W,
-            "note": "batch %d of %dx%d; the op allocates its output (torch.empty) inside the bracket" % (B, H, W)}
+            "note": "batch %d of %dx%d, C-ABI call with a preallocated output, back-to-back launches" % (B, H, W)}
 
 
 def family_clocks(eng, dev, peak, fams):
@@ -632,7 +638,7 @@ def infer_bench(args):
         for _ in range(warmup):
             step()
         sync()
-        clk = start_clock_probe(dev, 2.0) if (rank == 0 and precision == headline) else None
+        clk = start_clock_probe(dev, 2.0) if (rank == 0 and precision == headline and not args.no_clock_probes) else None
         elapsed = sdist.timed_steps(step, steps, 0, sync)
         ms_step = 1e3 * elapsed / steps
         res = {"value": N_T * P * world * steps / elapsed, "ms_per_step": ms_step, "ms_per_pair": ms_step / P, "elapsed_s": elapsed}
@@ -709,7 +715,7 @@ def infer_bench(args):
                                          "wall_ms_per_pair_single_stream": round(solo_ms, 3)}
             if precision in flops_issued:
                 res["roofline"]["families"] = family_rooflines(conv["by_name"], n_solo, precision, peak, PB * N_T, Hp, Wp)
-                if precision == headline:
+                if precision == headline and not args.no_clock_probes:
                     res["roofline"]["family_clocks"] = family_clocks(solo, dev, peak, res["roofline"]["families"])
             wk = summ["warp"]
             wms = wk["ms"] / n_solo
@@ -816,6 +822,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-io", action="store_true", help="skip the measured H2D / D2H legs")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the HIP-event brackets (no roofline.detail)")
+    ap.add_argument("--no-clock-probes", action="store_true",
+                    help="skip the shader-clock probes (the per-family probe re-runs every conv family for 0.7 s: leave it out of "
+                         "rocprofv3 kernel-stats runs, whose per-kernel sums are divided by the number of pairs)")
     ap.add_argument("--precision", default=None, choices=["f32", "f32w", "f16x3", "f16", "f16f8"],
                     help="headline conv arithmetic (default f32 = the reference's arithmetic)")
     ap.add_argument("--modes", default="f32,f16x3,f16f8", help="comma list of further modes reported under `modes` (N=1, 720p only); '' = none")
