@@ -193,11 +193,15 @@ def family_rooflines(by_name, n_pairs, precision, peak, batch=14, H=736, W=1280)
 
 def warp_kernel_rate(dev, H, W, B=7, reps=20):
     """layers.warp as its own launch (ssm_warp_bilinear_fwd -> warp_kernel; the pipeline uses the fused gather kernels): SURVEY 8d's
-    32 B/px (3 channels gathered + 2 flow channels read + 3 channels written, fp32) over its HIP-event time, flows of a few pixels."""
+    32 B/px (3 channels gathered + 2 flow channels read + 3 channels written, fp32) over its HIP-event time, smooth flows of a few pixels."""
     from ssm_amd import hipbind as hb
     g = torch.Generator().manual_seed(5)
     img = torch.randn(B, 3, H, W, generator=g).to(dev)
-    flo = (torch.randn(B, 2, H, W, generator=g) * 3.0).to(dev)
+    # a smooth flow field like the network's (a few pixels of translation + a slow spatial variation): neighbouring pixels sample
+    # neighbouring taps.  (Independent random flows per pixel scatter every wave-level gather over ~10 rows: 1.9-2.1 TB/s.)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flo = torch.stack([3.0 + 2.0 * torch.sin(xx / 97.0) * torch.cos(yy / 131.0), 2.0 + 1.5 * torch.cos(xx / 113.0 + yy / 89.0)], 0)
+    flo = flo.unsqueeze(0).expand(B, -1, -1, -1).contiguous().to(dev)
     out = torch.empty_like(img)
     lib = hb.load()
 
