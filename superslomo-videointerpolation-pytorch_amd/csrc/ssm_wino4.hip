@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         const int c0 = ch * CK;
         if (k < L::NIU) {
             const int g = 4 * k + wid;
-            if (g < L::NGU) {
+            if (4 * k + 3 < L::NGU || g < L::NGU) {          // (the first part is a compile-time fact: no branch)
                 const float *base = wbase + (long long)c0 * (9 * BN * 4) + g * 256;
                 const unsigned m0v = lds0 + (unsigned)(L::UOFF + stage * C::USZ) * 4u + (unsigned)g * 1024u;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         } else {
             const int kk = k - L::NIU;
             const int g = 4 * kk + wid;
-            if (g < L::NGP) {
+            if (4 * kk + 3 < L::NGP || g < L::NGP) {
                 const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
                 const unsigned m0v = lds0 + (unsigned)L::DOFF * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
@@ -337,8 +337,13 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
+    // DMA order of a chunk: the patch pieces first (the transform needs them at the top of the chunk), then the filter pieces (needed
+    // only by the matrix phase): the waits are counted - vmcnt(filter pieces of this wave) at the top, vmcnt(0) before the mid barrier
+    static_assert(L::NI <= 9, "one DMA issue slot per frequency group of the matrix loop");
+    auto issue_n = [&](int ch, int stage, int n) { issue_k(ch, stage, n < L::NIP ? L::NIU + n : n - L::NIP); };
+    const bool u_full = wid < L::NGU - 4 * (L::NIU - 1);          // this wave brings NIU filter pieces per chunk (else NIU - 1)
 #pragma unroll
-    for (int k = 0; k < L::NI; ++k) issue_k(0, 0, k);
+    for (int n = 0; n < L::NI; ++n) issue_n(0, 0, n);
     // bias of this lane's four couts (cb*16 + 4q + r): added after the output transform
     float bv[4];
 #pragma unroll
@@ -442,23 +447,18 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     for (int ch = 0; ch < nchunks; ++ch) {
         const int stage = ch & 1;
         // chunk ch has landed for every wave; every wave is done with the MFMAs of chunk ch-1 (V and the other filter stage are free)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the patch of) chunk ch has landed for every wave; every wave is done with the MFMAs of chunk ch-1 (V is free)
+        if (u_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU - 1) : "memory");
         __syncthreads();
         W4STAMP(0)
         const bool dma_next = ch + 1 < nchunks && !(W4ABL(1) && ch >= 1);
-        if (dma_next) {          // filter of chunk ch+1 into the stage the matrix loop of chunk ch-1 has just released
-#pragma unroll
-            for (int k = 0; k < L::NIU; ++k) issue_k(ch + 1, stage ^ 1, k);
-        }
         expand();
         if (!W4ABL(4) || ch == 0) transform();
         W4STAMP(1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the filter of chunk ch
         __syncthreads();
         W4STAMP(2)
-        if (dma_next) {          // patch of chunk ch+1 into the buffer the transform has just finished with
-#pragma unroll
-            for (int k = L::NIU; k < L::NI; ++k) issue_k(ch + 1, stage ^ 1, k);
-        }
 
         // ---- matrix phase: 9 groups of 4 frequencies = 36 MFMAs of 32 cycles; the operands of group g+2 are fetched behind the first
         // MFMA of group g (a ring of three register sets: a group of four MFMAs alone is shorter than the LDS latency) ---------------
@@ -479,6 +479,13 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
                         a[nxt] = lds4[ai + (g + 2) * BN];
                         bq[nxt] = lds4[bi + (g + 2) * NT];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // chunk ch+1, one DMA instruction per group behind its second MFMA (an LDS-DMA issued in a burst at a phase boundary
+                // costs ~200 cycles a piece, among MFMAs a few tens): the patch into the buffer the transform has finished with,
+                // the filter into the stage the matrix loop of chunk ch-1 has released
+                if (e == 1 && g < L::NI && dma_next) {
+                    issue_n(ch + 1, stage ^ 1, g);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
