@@ -648,8 +648,8 @@ def infer_bench(args):
         res = {"value": N_T * P * world * steps / elapsed, "ms_per_step": ms_step, "ms_per_pair": ms_step / P, "elapsed_s": elapsed}
         peak = PEAK_F32_MFMA_TFLOPS if precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
-        kname = {"f32w": "wino4_kernel<*, ups 0|1> (3x3 layers, F(4x4,3x3), v_mfma_f32_16x16x4_f32) + wino2_kernel<*> (3x3 layers on the 1/32 maps and the "
-                         "512+-channel fused-upsample layers, F(2x2,3x3)) + wino1d_kernel<*> (7x7 / 5x5 layers, F(2,7) / F(4,5) along x) "
+        kname = {"f32w": "wino4_kernel<*, ups 0|1> (3x3 layers, F(4x4,3x3), v_mfma_f32_16x16x4_f32) + wino2_kernel<*> (3x3 layers on the 1/32 maps, "
+                         "F(2x2,3x3)) + wino1d_kernel<*> (7x7 / 5x5 layers, F(2,7) / F(4,5) along x) "
                          "(v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "

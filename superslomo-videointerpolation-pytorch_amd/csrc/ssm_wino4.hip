@@ -69,23 +69,27 @@ struct W4Params {
     int ash, adiv;
 };
 
-// 2 cout halves x 2 tile groups = 4 waves; a tile group = GTX x GTY tiles of 4x4 pixels (16 tiles); the groups sit WTY x WTX
-template <int GTX_, int WTY_, int WTX_>
+// NCB cout blocks of 32 x 2 cout halves x 2 tile groups = 4 NCB waves; a tile group = GTX x GTY tiles of 4x4 pixels (16 tiles); the
+// groups sit WTY x WTX.  NCB = 1: 256 threads, two workgroups per CU.  NCB = 2 (64 couts): 512 threads, one workgroup per CU - the
+// transform of a (cin, tile) serves twice the MFMAs and is split over four threads instead of two (the vector pipe, not the matrix
+// pipe, is what a 32-cout workgroup saturates first: ~1000 cycles of vector issue per wave and chunk beside 1152 of MFMA).
+template <int GTX_, int WTY_, int WTX_, int NCB_ = 1>
 struct W4Cfg {
-    static constexpr int GTX = GTX_, GTY = 16 / GTX_, WTY = WTY_, WTX = WTX_;
-    static constexpr int CK = 4, BN = 32, NT = 32;                             // chunk = one MFMA k-step of 4 input channels
+    static constexpr int GTX = GTX_, GTY = 16 / GTX_, WTY = WTY_, WTX = WTX_, NCB = NCB_;
+    static constexpr int NW = 4 * NCB, THREADS = 64 * NW;
+    static constexpr int CK = 4, BN = 32 * NCB, NT = 32;                       // chunk = one MFMA k-step of 4 input channels
     static constexpr int NTX = GTX * WTX, NTY = GTY * WTY;                     // tiles per workgroup, by axis
     static constexpr int TH = 4 * NTY, TW = 4 * NTX;                           // output pixels per workgroup
     static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;               // patch rows y0-1 .., columns x0-4 .. x0+TW+3
     static constexpr int SHIFT = 1;                                            // floats: a tile's window starts at patch column 4 Tx + 3 + SHIFT
-    static constexpr int USZ = CK * 9 * BN * 4;                                // filter floats per chunk
+    static constexpr int USZ1 = CK * 9 * 32 * 4, USZ = NCB * USZ1;             // filter floats per chunk: per 32-cout block, per workgroup
     static constexpr int PSZ = CK * PH * PW;                                   // patch floats per chunk
     static constexpr int VSZ = CK * 9 * NT * 4;                                // transformed patch
     static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;       // fused upsample: low-res raw patch
     static constexpr int RSZ = CK * LH * LW;
     static constexpr int NPOS = (TH / 2 + 1) * (TW / 2 + 1);                   // 2x2 hi-res block positions of the expander
-    static_assert(WTY * WTX == 2 && (GTX == 4 || GTX == 8 || GTX == 16), "two tile groups of 16 tiles");
-    static_assert(USZ % 256 == 0 && NPOS <= 256, "filter stage = whole 1-KiB DMA groups; expander: one position per thread");
+    static_assert(WTY * WTX == 2 && (GTX == 4 || GTX == 8 || GTX == 16) && (NCB == 1 || NCB == 2), "two tile groups of 16 tiles");
+    static_assert(USZ1 % 256 == 0 && NPOS <= 256, "filter stage = whole 1-KiB DMA groups; expander: one position per thread");
 };
 
 template <class C, bool UPS>
@@ -95,7 +99,8 @@ struct W4Lds {
     static constexpr int NGU = C::USZ / 256;                    // 1-KiB groups of filter per chunk
     static constexpr int NDQ = DSZ / 4;                         // 16-byte pieces of (raw) patch per chunk
     static constexpr int NGP = (NDQ + 63) / 64;
-    static constexpr int NIU = (NGU + 3) / 4, NIP = (NGP + 3) / 4, NI = NIU + NIP;   // DMA instructions per wave per chunk
+    static constexpr int NW = C::NW;
+    static constexpr int NIU = (NGU + NW - 1) / NW, NIP = (NGP + NW - 1) / NW, NI = NIU + NIP;   // DMA instructions per wave per chunk
     static constexpr int UOFF = 0;                              // two filter stages
     static constexpr int DOFF = 2 * C::USZ;                     // the DMA'd patch (plain: lands SHIFT floats in; UPS: the low-res raw patch)
     static constexpr int DCAP = NGP * 256 + 256;
@@ -104,7 +109,7 @@ struct W4Lds {
     static constexpr int VOFF = HOFF + (UPS ? C::PSZ + 4 : 0);  // transformed patch
     static constexpr int BYTES = (VOFF + C::VSZ) * 4;
     static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0, "16-byte aligned regions");
-    static_assert(BYTES <= 80 * 1024, "LDS budget (two workgroups per CU)");
+    static_assert(BYTES <= (C::NCB == 1 ? 80 : 160) * 1024, "LDS budget (two workgroups of 256 or one of 512 per CU)");
 };
 
 // interpolation points 0, +-PA, +-PB, inf (PA * PB = 1); the transform matrices in the monic form:
@@ -145,6 +150,47 @@ __device__ __forceinline__ void w4_col_pass(float x0, float x1, float x2, float 
     v[3 * stride] = ue + kB * uo;
     v[4 * stride] = ue - kB * uo;
     v[5 * stride] = (kP0 * x1 - kS2 * x3) + x5;
+}
+
+// half of the column pass: the row-frequencies 3 hq .. 3 hq + 2 (same expressions as w4_col_pass)
+__device__ __forceinline__ void w4_col_pass_half(int hq, float x0, float x1, float x2, float x3, float x4, float x5, float *v, int stride) {
+    if (hq == 0) {
+        const float te = x4 - kB2 * x2, to = x3 - kB2 * x1;
+        v[0] = (kP0 * x0 - kS2 * x2) + x4;
+        v[stride] = te + kA * to;
+        v[2 * stride] = te - kA * to;
+    } else {
+        const float ue = x4 - kA2 * x2, uo = x3 - kA2 * x1;
+        v[0] = ue + kB * uo;
+        v[stride] = ue - kB * uo;
+        v[2 * stride] = (kP0 * x1 - kS2 * x3) + x5;
+    }
+}
+
+// four threads per (cin, tile): thread part = 2 hh + hq holds the 9 consecutive frequencies 9 part .. 9 part + 8 (v[3 ii + jj], row-
+// frequency 3 hq + ii, column-frequency 3 hh + jj) -> V [fq][NT tiles][4] at vo (f32x4 units, this tile's column)
+template <int NT>
+__device__ __forceinline__ void w4_store_v9(int part, const float *v, f32x4 *vo) {
+    float *vf = (float *)vo;
+    if (part == 0) {                 // f 0..8: quads 0, 1, element 0 of quad 2
+        vo[0] = f32x4{v[0], v[1], v[2], v[3]};
+        vo[NT] = f32x4{v[4], v[5], v[6], v[7]};
+        vf[2 * NT * 4] = v[8];
+    } else if (part == 1) {          // f 9..17: elements 1..3 of quad 2, quad 3, elements 0, 1 of quad 4
+        vf[2 * NT * 4 + 1] = v[0];
+        *(f32x2 *)(vf + 2 * NT * 4 + 2) = f32x2{v[1], v[2]};
+        vo[3 * NT] = f32x4{v[3], v[4], v[5], v[6]};
+        *(f32x2 *)(vf + 4 * NT * 4) = f32x2{v[7], v[8]};
+    } else if (part == 2) {          // f 18..26: elements 2, 3 of quad 4, quad 5, elements 0..2 of quad 6
+        *(f32x2 *)(vf + 4 * NT * 4 + 2) = f32x2{v[0], v[1]};
+        vo[5 * NT] = f32x4{v[2], v[3], v[4], v[5]};
+        *(f32x2 *)(vf + 6 * NT * 4) = f32x2{v[6], v[7]};
+        vf[6 * NT * 4 + 2] = v[8];
+    } else {                         // f 27..35: element 3 of quad 6, quads 7, 8
+        vf[6 * NT * 4 + 3] = v[0];
+        vo[7 * NT] = f32x4{v[1], v[2], v[3], v[4]};
+        vo[8 * NT] = f32x4{v[5], v[6], v[7], v[8]};
+    }
 }
 
 // a thread's 18 frequencies v[3 i + jj] of half hh -> V [fq][NT tiles][4] at vo (f32x4 units, this tile's column): quads 0..3 whole
@@ -263,15 +309,15 @@ __device__ __forceinline__ void w4_epilogue(const W4Params &p, const f32x4 (&acc
 }
 
 template <class C, bool UPS>
-__global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
+__global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = W4Lds<C, UPS>;
-    constexpr int BN = C::BN, PH = C::PH, PW = C::PW, CK = C::CK, NT = C::NT;
+    constexpr int BN = C::BN, PH = C::PH, PW = C::PW, CK = C::CK, NT = C::NT, NW = C::NW, NCB = C::NCB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cb = wid & 1, tg = wid >> 1;          // cout half, tile group of this wave
+    const int cb = wid & 1, tg = (wid >> 1) & 1, blk = wid >> 2;          // cout half, tile group, 32-cout block of this wave
 
     int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
     const int nb = id % p.NB;
@@ -285,13 +331,13 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
     const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
     const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
-    const float *wbase = p.wpk + (long long)nb * p.Cin * (9 * BN * 4);
+    const float *wbase = p.wpk + (long long)nb * NCB * p.Cin * (9 * 32 * 4);          // the packed filter is in 32-cout blocks
 
     // per-lane source offsets (bytes) of the patch pieces this wave brings per chunk; the filter pieces are linear
     int poff[L::NIP];
 #pragma unroll
     for (int i = 0; i < L::NIP; ++i) {
-        const int qq = (i * 4 + wid) * 64 + lane;
+        const int qq = (i * NW + wid) * 64 + lane;
         if (qq < L::NDQ) {
             const int c = qq / (L::DH * L::DW4);
             const int rem = qq - c * (L::DH * L::DW4);
@@ -309,16 +355,18 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     auto issue_k = [&](int ch, int stage, int k) {
         const int c0 = ch * CK;
         if (k < L::NIU) {
-            const int g = 4 * k + wid;
-            if (4 * k + 3 < L::NGU || g < L::NGU) {          // (the first part is a compile-time fact: no branch)
-                const float *base = wbase + (long long)c0 * (9 * BN * 4) + g * 256;
+            const int g = NW * k + wid;
+            if (NW * k + NW - 1 < L::NGU || g < L::NGU) {          // (the first part is a compile-time fact: no branch)
+                constexpr int G1 = C::USZ1 / 256;                  // 1-KiB pieces per 32-cout block
+                const int gb = NCB == 1 ? 0 : g / G1;
+                const float *base = wbase + ((long long)gb * p.Cin + c0) * (9 * 32 * 4) + (g - gb * G1) * 256;
                 const unsigned m0v = lds0 + (unsigned)(L::UOFF + stage * C::USZ) * 4u + (unsigned)g * 1024u;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
             }
         } else {
             const int kk = k - L::NIU;
-            const int g = 4 * kk + wid;
-            if (4 * kk + 3 < L::NGP || g < L::NGP) {
+            const int g = NW * kk + wid;
+            if (NW * kk + NW - 1 < L::NGP || g < L::NGP) {
                 const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
                 const unsigned m0v = lds0 + (unsigned)L::DOFF * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
@@ -341,16 +389,17 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     // only by the matrix phase): the waits are counted - vmcnt(filter pieces of this wave) at the top, vmcnt(0) before the mid barrier
     static_assert(L::NI <= 9, "one DMA issue slot per frequency group of the matrix loop");
     auto issue_n = [&](int ch, int stage, int n) { issue_k(ch, stage, n < L::NIP ? L::NIU + n : n - L::NIP); };
-    const bool u_full = wid < L::NGU - 4 * (L::NIU - 1);          // this wave brings NIU filter pieces per chunk (else NIU - 1)
+    const bool u_full = wid < L::NGU - NW * (L::NIU - 1);          // this wave brings NIU filter pieces per chunk (else NIU - 1)
 #pragma unroll
     for (int n = 0; n < L::NI; ++n) issue_n(0, 0, n);
     // bias of this lane's four couts (cb*16 + 4q + r): added after the output transform
     float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * BN + cb * 16 + 4 * q + r];
+    for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * BN + blk * 32 + cb * 16 + 4 * q + r];
 
     // ---- per-thread constants of the transform phase: unit = (cin, tile), two threads per unit (frequency rows 0..2 | 3..5) -------
-    const int thh = wid >> 1;                        // wave-uniform: which three frequency rows this thread computes
+    const int thh = (wid >> 1) & 1;                  // wave-uniform: which three column-frequencies this thread computes
+    const int thq = wid >> 2;                        // NCB = 2: ... and which three row-frequencies of them
     const int tu = tid & 127;                        // unit: cin = tu / 32, tile = tu % 32
     const int tcin = tu >> 5, ttile = tu & 31;
     // tile index -> position inside the workgroup's tile: group g2 = tile / 16, (gy, gx) inside the group
@@ -361,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
 
     // ---- the matrix loop's operand bases (f32x4 units): U of (cin = 4cp + q, fq, cout = cb*16 + l15), V of (cin, fq, tile) ---------
     const f32x4 *lds4 = (const f32x4 *)lds;
-    const int aBase = L::UOFF / 4 + q * (9 * BN) + cb * 16 + l15;
+    const int aBase = L::UOFF / 4 + blk * (C::USZ1 / 4) + q * (9 * 32) + cb * 16 + l15;
     const int bBase = L::VOFF / 4 + q * (9 * NT) + tg * 16 + l15;
 
     // fused upsample: low-res raw chunk -> hi-res patch; one thread = one 2x2 hi-res block position, walking the chunk's channels
@@ -409,24 +458,53 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         }
     };
 
-    // V = B^T d B of one (cin, tile): this thread's three column-frequencies (row pass first, then the six row-frequencies of each)
-    auto transform = [&]() {
+    // V = B^T d B of one (cin, tile): this thread's three column-frequencies (row pass first, then the row-frequencies of each).  The
+    // halves (HH: column-frequencies 0..2 | 3..5; NCB = 2 also HQ: row-frequencies 0..2 | 3..5) are wave-uniform, and each combination
+    // is its own straight-line instance: with the selection inside, every row's window read sat behind a scalar branch and waited
+    // out its LDS latency alone - six exposed latencies per chunk, ~1450 cycles for 80 vector instructions.
+    auto transform_as = [&](auto HH, auto HQ) {
+        constexpr int hh = decltype(HH)::value, hq = decltype(HQ)::value;
         const float *rp = lds + t_src;
+        f32x4 a4[6];
+        f32x2 a2[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            a4[i] = *(const f32x4 *)(rp + i * PW);
+            a2[i] = *(const f32x2 *)(rp + i * PW + 4);
+        }
         float X[6][3];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const f32x4 a4 = *(const f32x4 *)(rp + i * PW);
-            const f32x2 a2 = *(const f32x2 *)(rp + i * PW + 4);
-            float d[6] = {a4[0], a4[1], a4[2], a4[3], a2[0], a2[1]};
-            // the values arrive as 16- / 8-byte pieces: pin each as a scalar so that no packed-fp32 arithmetic is formed (DESIGN 3.3 fence)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(d[j]));
-            w4_row_pass(thh, d, X[i]);
+            const float d[6] = {a4[i][0], a4[i][1], a4[i][2], a4[i][3], a2[i][0], a2[i][1]};       // (scalar arithmetic only: check_isa.sh fences v_pk_*)
+            w4_row_pass(hh, d, X[i]);
         }
-        float v[18];            // frequency w4_freq(i, 3 thh + jj) - 18 thh = 3 i + jj
+        if constexpr (NCB == 1) {
+            float v[18];            // frequency w4_freq(i, 3 hh + jj) - 18 hh = 3 i + jj
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj) w4_col_pass(X[0][jj], X[1][jj], X[2][jj], X[3][jj], X[4][jj], X[5][jj], v + jj, 3);
-        w4_store_v<NT>(thh, v, (f32x4 *)lds + t_dst);
+            for (int jj = 0; jj < 3; ++jj) w4_col_pass(X[0][jj], X[1][jj], X[2][jj], X[3][jj], X[4][jj], X[5][jj], v + jj, 3);
+            w4_store_v<NT>(hh, v, (f32x4 *)lds + t_dst);
+        } else {
+            float v[9];             // frequency w4_freq(3 hq + ii, 3 hh + jj) - 18 hh - 9 hq = 3 ii + jj
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) w4_col_pass_half(hq, X[0][jj], X[1][jj], X[2][jj], X[3][jj], X[4][jj], X[5][jj], v + jj, 3);
+            w4_store_v9<NT>(2 * hh + hq, v, (f32x4 *)lds + t_dst);
+        }
+    };
+    auto transform = [&]() {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        if constexpr (NCB == 1) {
+            if (thh == 0) transform_as(I0{}, I0{});
+            else transform_as(I1{}, I0{});
+        } else {
+            if (thh == 0) {
+                if (thq == 0) transform_as(I0{}, I0{});
+                else transform_as(I0{}, I1{});
+            } else {
+                if (thq == 0) transform_as(I1{}, I0{});
+                else transform_as(I1{}, I1{});
+            }
+        }
     };
 
 #ifdef SSM_WINO_ABLATE
@@ -465,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
         const int ai = aBase + stage * (C::USZ / 4), bi = bBase;
         a[0] = lds4[ai];
         bq[0] = lds4[bi];
-        a[1] = lds4[ai + BN];
+        a[1] = lds4[ai + 32];
         bq[1] = lds4[bi + NT];
 #pragma unroll
         for (int g = 0; g < 9; ++g) {
@@ -476,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
                 if (e == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (g + 2 < 9) {
-                        a[nxt] = lds4[ai + (g + 2) * BN];
+                        a[nxt] = lds4[ai + (g + 2) * 32];
                         bq[nxt] = lds4[bi + (g + 2) * NT];
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -502,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void wino4_kernel(const W4Params p) {
     {
         const int gx = l15 % C::GTX, gy = l15 / C::GTX;
         const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
-        w4_epilogue(p, acc, bv, b, nb * BN + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
+        w4_epilogue(p, acc, bv, b, nb * BN + blk * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
     }
 #ifdef SSM_WINO_ABLATE
     if (stamp) {
@@ -833,7 +911,13 @@ using P8A = W8Cfg<8, 2, 2>;      //         16 x 4                16   64
 using P8B = W8Cfg<16, 4, 1>;     //         16 x 4 (16x1 groups)  16   64
 using P8C = W8Cfg<4, 1, 4>;      //         16 x 4 (4x4 groups)   16   64
 
-#define SSM_W4_KINDS(X) X(X4A_, X4A, 0) X(X4B_, X4B, 0) X(X4C_, X4C, 0) X(P8A_, P8A, 1) X(P8B_, P8B, 1) X(P8C_, P8C, 1)
+// 64 couts x 32 tiles per workgroup of 8 waves (same tile shapes as X4*)
+using Y4A = W4Cfg<8, 2, 1, 2>;
+using Y4B = W4Cfg<16, 2, 1, 2>;
+using Y4C = W4Cfg<4, 1, 2, 2>;
+
+#define SSM_W4_KINDS(X) \
+    X(X4A_, X4A, 0) X(X4B_, X4B, 0) X(X4C_, X4C, 0) X(P8A_, P8A, 1) X(P8B_, P8B, 1) X(P8C_, P8C, 1) X(Y4A_, Y4A, 0) X(Y4B_, Y4B, 0) X(Y4C_, Y4C, 0)
 
 enum W4Kind {
 #define X(name, cfg, pipe) name,
@@ -843,11 +927,11 @@ enum W4Kind {
 };
 
 struct W4KindInfo {
-    int th, tw, pipe;
+    int th, tw, pipe, bn;
 };
 
 constexpr W4KindInfo kW4Info[NW4KIND] = {
-#define X(name, cfg, pipe) W4KindInfo{cfg::TH, cfg::TW, pipe},
+#define X(name, cfg, pipe) W4KindInfo{cfg::TH, cfg::TW, pipe, cfg::BN},
     SSM_W4_KINDS(X)
 #undef X
 };
@@ -856,21 +940,26 @@ std::atomic<int> g_force_w4kind{-1};
 std::atomic<unsigned long long *> g_w4dbg{nullptr};      // diagnostics (ssm_wino4_debug_buffer)
 
 // Estimated duration (cycles) of a launch, fitted to tools/bench_layers_wino.py at batch 7 and the in-kernel phase timers
-// (tools/wino4_phase_probe.py): a CU-round of two co-resident workgroups costs ~5300 cycles per chunk of 4 input channels - 2 x 36 MFMAs
-// of 32 cycles are 2304 of them; the rest is the issue cost of the chunk's 32 LDS-DMA instructions, the transform and two barriers,
-// which the two waves of a SIMD cannot hide from each other - plus prologue + epilogue; whole rounds of 512 workgroups.
+// (tools/wino4_phase_probe.py).  256-thread form: a CU-round of two co-resident workgroups costs ~4300 cycles per chunk of 4 input
+// channels (2 x 36 MFMAs of 32 cycles are 2304 of them; the rest: transform phase, two barriers, and what the two waves of a SIMD
+// cannot hide from each other), ~900 more with the fused-upsample expander; whole rounds of 512 workgroups.  64-cout
+// form: one workgroup per CU, ~3800 (+800) cycles per chunk for twice the couts, rounds of 256, prologue and epilogue exposed.
 double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W, int ups) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
-    const long long nwg = tiles * (Cout / 32);
+    const long long nwg = tiles * (Cout / ki.bn);
     const double chunks = (double)Cin / 4.0;
+    if (ki.bn == 64) {
+        const double per = chunks * (3800.0 + (ups ? 800.0 : 0.0)) + 16000.0;
+        return (double)((nwg + 255) / 256) * per;
+    }
     if (ki.pipe) {          // one workgroup per CU: measured ~6200 cycles per chunk (tools/bench_layers_wino.py W4KIND=3), exposed prologue / epilogue
         const double per = chunks * (6200.0 + (ups ? 300.0 : 0.0)) + 9000.0;
         return (double)((nwg + 255) / 256) * per;
     }
-    const double per = chunks * (5300.0 + (ups ? 300.0 : 0.0)) + 14000.0;
+    const double per = chunks * (4300.0 + (ups ? 900.0 : 0.0)) + 14000.0;
     const long long full = nwg / 512, rem = nwg % 512;
     double t = (double)full * per;
-    if (rem) t += rem > 256 ? per : chunks * (3200.0 + (ups ? 300.0 : 0.0)) + 12000.0;     // a last round of lone workgroups
+    if (rem) t += rem > 256 ? per : chunks * (2900.0 + (ups ? 700.0 : 0.0)) + 12000.0;     // a last round of lone workgroups
     return t;
 }
 
@@ -883,8 +972,13 @@ int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     }();
     int best = -1;
     double bt = 0.0;
+    static const int allow_wide = [] {
+        const char *e = getenv("SSM_WINO4_WIDE");
+        return e ? atoi(e) : 1;
+    }();
     for (int i = 0; i < NW4KIND; ++i) {
         if (kW4Info[i].pipe && !allow_pipe) continue;
+        if (kW4Info[i].bn == 64 && (!allow_wide || Cout % 64)) continue;
         const double t = estimate_w4(kW4Info[i], Cin, Cout, B, H, W, ups);
         if (best < 0 || t < bt * 0.999) {
             best = i;
@@ -898,6 +992,10 @@ template <class C, bool UPS, int PIPE>
 int w4launch(W4Params &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
+    if (p.Cout % C::BN) {
+        ssm::set_error("wino4 conv: tile configuration of %d couts per workgroup, Cout = %d", C::BN, p.Cout);
+        return SSM_E_UNSUPPORTED;
+    }
     p.NB = p.Cout / C::BN;
     const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
@@ -913,8 +1011,12 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
     } else {
         kern = wino4_kernel<C, UPS>;
         lds_bytes = W4Lds<C, UPS>::BYTES;
-        threads = 256;
+        threads = C::THREADS;
     }
+#ifdef SSM_WINO_ABLATE
+    if (const char *e = getenv("SSM_WINO4_SOLO"))          // diagnostics: one workgroup per CU (the LDS request leaves no room for a second)
+        if (atoi(e) && lds_bytes < 100 * 1024) lds_bytes = 100 * 1024;
+#endif
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
@@ -1071,14 +1173,12 @@ extern "C" int ssm_wino4_debug_buffer(unsigned long long *dev_counters) {
 }
 
 // 1 when the plan should run this 3x3 layer as F(4x4,3x3) rather than F(2x2,3x3).  Measured per layer at 736x1280, batch 7
-// (tools/bench_layers_wino.py, W4=1 against the default): F(4x4) is 5-25 % faster everywhere except on the 23x40 maps (32 tiles of 16
-// pixels per workgroup: half of every tile row is overshoot; 0.24 vs 0.15 ms) and on the fused-upsample layers with 512+ input channels
-// (conv7a / conv8a / conv9a: 128-256 chunks of expander + transform; 2-5 % slower).  The two cost models are not calibrated against each
+// (tools/bench_layers_wino.py, W4=1 against the default): F(4x4) is 5-35 % faster everywhere except on the 23x40 maps (32 tiles of 16
+// pixels per workgroup: half of every tile row is overshoot; 0.21 vs 0.15 ms).  The two cost models are not calibrated against each
 // other, so the rule is stated directly.
 extern "C" int ssm_wino4_preferred(int Cin, int Cout, int B, int H, int W, int ups) {
     if (Cin % 4 || Cout % 32 || Cin <= 0 || Cout <= 0) return 0;
     if ((long long)H * W < 2048) return 0;
-    if (ups && Cin >= 512) return 0;
     return 1;
 }
 

@@ -26,8 +26,9 @@ def main():
     dev = torch.device("cuda:0")
     lib = hb.load()
     lib.ssm_wino4_debug_buffer.argtypes = [ctypes.c_void_p]
-    cnt = torch.zeros(8, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(16, dtype=torch.int64, device=dev)
     lib.ssm_wino4_debug_buffer(ctypes.c_void_p(cnt.data_ptr()))
+    lib.ssm_wino4_force_kind(int(os.environ.get("W4KIND", "-1")))          # tile configuration (csrc/ssm_wino4.hip: SSM_W4_KINDS)
     H, W = 736, 1280
     print("%-10s %6s | per workgroup (wave 0), shader cycles: %9s %9s %9s %9s %9s | %9s | chunks" % (
         "layer", "ms", "wait+bar", "transform", "mid bar", "matrix", "epilogue", "total"))
@@ -66,8 +67,11 @@ def main():
         torch.cuda.synchronize()
         c = [int(v) for v in cnt.cpu()]
         n = max(c[6], 1)
-        print("%-10s %6.3f | %44s %9d %9d %9d %9d %9d | %9d | %d" % (name, e0.elapsed_time(e1), "", c[0] // n, c[1] // n, c[2] // n, c[3] // n, c[4] // n,
-                                                                  c[5] // n, cin // 4), flush=True)
+        nc = cin // 4
+        print("%-10s %6.3f | %44s %9d %9d %9d %9d %9d | %9d | %d   per chunk: %d %d %d %d = %d" % (
+            name, e0.elapsed_time(e1), "", c[0] // n, c[1] // n, c[2] // n, c[3] // n, c[4] // n, c[5] // n, nc,
+            c[0] // n // nc, c[1] // n // nc, c[2] // n // nc, c[3] // n // nc, (c[0] + c[1] + c[2] + c[3]) // n // nc) + (
+            "   transform: reads %d arithmetic %d stores %d" % (c[8] // n // nc, c[9] // n // nc, c[10] // n // nc) if c[8] else ""), flush=True)
 
 
 if __name__ == "__main__":
