@@ -219,41 +219,47 @@ __global__ __launch_bounds__(256, 2) void wino1d_kernel(const W1Params p) {
         if (!W1ABL(4) || ch == 0) {
             const float *raw = lds + stage * L::STAGE + L::NGU * 256 + C::SHIFT;
             f32x4 *vout = (f32x4 *)(lds + L::VOFF);
+            // (all window reads of a thread's units first, then the arithmetic: one LDS latency per chunk, not one per unit)
+            constexpr int NUI = (C::NU + 255) / 256;
+            float d[NUI][8];
 #pragma unroll
-            for (int u0 = 0; u0 < C::NU; u0 += 256) {
-                const int u = u0 + tid;
-                if (u0 + 256 <= C::NU || u < C::NU) {
+            for (int ui = 0; ui < NUI; ++ui) {
+                const int u = ui * 256 + tid;
+                if (ui * 256 + 256 <= C::NU || u < C::NU) {
                     const int t = u % NTX, cr = u / NTX;          // cr = cin * PH + row
                     const float *rp = raw + cr * PW + M * t + (4 - C::PAD);
-                    float d[8];
                     if constexpr (M == 2) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const f32x2 q = *(const f32x2 *)(rp + 2 * j);
-                            d[2 * j] = q[0];
-                            d[2 * j + 1] = q[1];
+                            d[ui][2 * j] = q[0];
+                            d[ui][2 * j + 1] = q[1];
                         }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const f32x4 q = *(const f32x4 *)(rp + 4 * j);
-                            d[4 * j] = q[0];
-                            d[4 * j + 1] = q[1];
-                            d[4 * j + 2] = q[2];
-                            d[4 * j + 3] = q[3];
+                            d[ui][4 * j] = q[0];
+                            d[ui][4 * j + 1] = q[1];
+                            d[ui][4 * j + 2] = q[2];
+                            d[ui][4 * j + 3] = q[3];
                         }
                     }
-                    // the values arrive as 8- / 16-byte pieces: pin each as a scalar so that no packed-fp32 arithmetic is formed on
-                    // them (DESIGN 3.3 fence)
+                }
+            }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(d[j]));
+            for (int ui = 0; ui < NUI; ++ui) {
+                const int u = ui * 256 + tid;
+                if (ui * 256 + 256 <= C::NU || u < C::NU) {
+                    const int t = u % NTX, cr = u / NTX;
+                    const float *e = d[ui];
                     // BT of the points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (the F(6,3) matrix of Lavin & Gray; it depends on the
-                    // points only, not on the split of the 8 points into outputs and taps)
-                    const float v0 = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
-                    const float v7 = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
-                    const float t1 = (d[2] + d[6]) - 4.25f * d[4], t2 = (d[1] + d[5]) - 4.25f * d[3];
-                    const float t3 = (d[6] + 0.25f * d[2]) - 1.25f * d[4], t4 = (0.5f * d[1] - 2.5f * d[3]) + 2.f * d[5];
-                    const float t5 = (d[6] + 4.f * d[2]) - 5.f * d[4], t6 = (2.f * d[1] - 2.5f * d[3]) + 0.5f * d[5];
+                    // points only, not on the split of the 8 points into outputs and taps); scalar arithmetic (check_isa.sh fences v_pk_*)
+                    const float v0 = (e[0] - e[6]) + 5.25f * (e[4] - e[2]);
+                    const float v7 = (e[7] - e[1]) + 5.25f * (e[3] - e[5]);
+                    const float t1 = (e[2] + e[6]) - 4.25f * e[4], t2 = (e[1] + e[5]) - 4.25f * e[3];
+                    const float t3 = (e[6] + 0.25f * e[2]) - 1.25f * e[4], t4 = (0.5f * e[1] - 2.5f * e[3]) + 2.f * e[5];
+                    const float t5 = (e[6] + 4.f * e[2]) - 5.f * e[4], t6 = (2.f * e[1] - 2.5f * e[3]) + 0.5f * e[5];
                     const f32x4 o0 = {v0, t1 + t2, t1 - t2, t3 + t4};
                     const f32x4 o1 = {t3 - t4, t5 + t6, t5 - t6, v7};
                     vout[cr * (2 * NTX) + t] = o0;

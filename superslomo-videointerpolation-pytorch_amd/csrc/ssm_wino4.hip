@@ -101,20 +101,26 @@ struct W4Lds {
     static constexpr int NGP = (NDQ + 63) / 64;
     static constexpr int NW = C::NW;
     static constexpr int NIU = (NGU + NW - 1) / NW, NIP = (NGP + NW - 1) / NW, NI = NIU + NIP;   // DMA instructions per wave per chunk
+    static constexpr int NBUF = C::NCB == 2 ? 2 : 1;            // 512-thread form: patch, hi-res patch and V double-buffered (one barrier per chunk)
     static constexpr int UOFF = 0;                              // two filter stages
     static constexpr int DOFF = 2 * C::USZ;                     // the DMA'd patch (plain: lands SHIFT floats in; UPS: the low-res raw patch)
     static constexpr int DCAP = NGP * 256 + 256;
-    static constexpr int HOFF = DOFF + DCAP;                    // UPS: the expanded hi-res patch
+    static constexpr int HOFF = DOFF + NBUF * DCAP;             // UPS: the expanded hi-res patch
+    static constexpr int HCAP = C::PSZ + 4;
     static constexpr int POFF = UPS ? HOFF : DOFF;              // the patch the transform reads (its floats start at + SHIFT in the plain form)
-    static constexpr int VOFF = HOFF + (UPS ? C::PSZ + 4 : 0);  // transformed patch
-    static constexpr int BYTES = (VOFF + C::VSZ) * 4;
-    static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0, "16-byte aligned regions");
+    static constexpr int PCAP = UPS ? HCAP : DCAP;              // ... and the distance between its two buffers
+    static constexpr int VOFF = HOFF + (UPS ? NBUF * HCAP : 0); // transformed patch
+    static constexpr int BYTES = (VOFF + NBUF * C::VSZ) * 4;
+    static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0 && HCAP % 4 == 0 && DCAP % 4 == 0, "16-byte aligned regions");
     static_assert(BYTES <= (C::NCB == 1 ? 80 : 160) * 1024, "LDS budget (two workgroups of 256 or one of 512 per CU)");
 };
 
 // interpolation points 0, +-PA, +-PB, inf (PA * PB = 1); the transform matrices in the monic form:
 //   B^T rows: [a2b2 0 -(a2+b2) 0 1 0], [0 -+a b2  -b2  +-a 1 0], [0 -+b a2  -a2  +-b 1 0], [0 a2b2 0 -(a2+b2) 0 1]
 //   A^T[k][f] = p_f^k (k = 0..3; the point at infinity contributes to k = 3 only);  G[f] = [1 p p^2] / prod_{q != p}(p - q), G[inf] = [0 0 1]
+#ifndef W4_INTERLEAVE
+#define W4_INTERLEAVE 1      // 512-thread form: the next chunk's transform in the slots of the matrix loop (0: as one block behind the loop)
+#endif
 #define W4_PA 0.625
 #define W4_PB 1.6
 constexpr float kA = (float)W4_PA, kB = (float)W4_PB, kA2 = (float)(W4_PA * W4_PA), kB2 = (float)(W4_PB * W4_PB);
@@ -190,6 +196,32 @@ __device__ __forceinline__ void w4_store_v9(int part, const float *v, f32x4 *vo)
         vf[6 * NT * 4 + 3] = v[0];
         vo[7 * NT] = f32x4{v[1], v[2], v[3], v[4]};
         vo[8 * NT] = f32x4{v[5], v[6], v[7], v[8]};
+    }
+}
+
+// the k-th store instruction of w4_store_v9 (k = 0..3; parts 0 and 3 have three), for the form that spreads the transform over the
+// slots of the matrix loop
+template <int NT>
+__device__ __forceinline__ void w4_store_v9_step(int part, int k, const float *v, f32x4 *vo) {
+    float *vf = (float *)vo;
+    if (part == 0) {
+        if (k == 0) vo[0] = f32x4{v[0], v[1], v[2], v[3]};
+        if (k == 1) vo[NT] = f32x4{v[4], v[5], v[6], v[7]};
+        if (k == 2) vf[2 * NT * 4] = v[8];
+    } else if (part == 1) {
+        if (k == 0) vf[2 * NT * 4 + 1] = v[0];
+        if (k == 1) *(f32x2 *)(vf + 2 * NT * 4 + 2) = f32x2{v[1], v[2]};
+        if (k == 2) vo[3 * NT] = f32x4{v[3], v[4], v[5], v[6]};
+        if (k == 3) *(f32x2 *)(vf + 4 * NT * 4) = f32x2{v[7], v[8]};
+    } else if (part == 2) {
+        if (k == 0) *(f32x2 *)(vf + 4 * NT * 4 + 2) = f32x2{v[0], v[1]};
+        if (k == 1) vo[5 * NT] = f32x4{v[2], v[3], v[4], v[5]};
+        if (k == 2) *(f32x2 *)(vf + 6 * NT * 4) = f32x2{v[6], v[7]};
+        if (k == 3) vf[6 * NT * 4 + 2] = v[8];
+    } else {
+        if (k == 0) vf[6 * NT * 4 + 3] = v[0];
+        if (k == 1) vo[7 * NT] = f32x4{v[1], v[2], v[3], v[4]};
+        if (k == 2) vo[8 * NT] = f32x4{v[5], v[6], v[7], v[8]};
     }
 }
 
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
 
     // k-th DMA instruction of this wave for chunk `ch`: k < NIU filter group 4k + wave into filter stage `stage`, else the patch
-    auto issue_k = [&](int ch, int stage, int k) {
+    auto issue_k = [&](int ch, int stage, int k, int pbuf = 0) {
         const int c0 = ch * CK;
         if (k < L::NIU) {
             const int g = NW * k + wid;
@@ -360,7 +392,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                 constexpr int G1 = C::USZ1 / 256;                  // 1-KiB pieces per 32-cout block
                 const int gb = NCB == 1 ? 0 : g / G1;
                 const float *base = wbase + ((long long)gb * p.Cin + c0) * (9 * 32 * 4) + (g - gb * G1) * 256;
-                const unsigned m0v = lds0 + (unsigned)(L::UOFF + stage * C::USZ) * 4u + (unsigned)g * 1024u;
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(L::UOFF + stage * C::USZ) * 4u + (unsigned)g * 1024u);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
             }
         } else {
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             const int g = NW * kk + wid;
             if (NW * kk + NW - 1 < L::NGP || g < L::NGP) {
                 const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
-                const unsigned m0v = lds0 + (unsigned)L::DOFF * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT);
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(L::DOFF + pbuf * L::DCAP) * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT));
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
             }
         }
@@ -390,8 +422,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     static_assert(L::NI <= 9, "one DMA issue slot per frequency group of the matrix loop");
     auto issue_n = [&](int ch, int stage, int n) { issue_k(ch, stage, n < L::NIP ? L::NIU + n : n - L::NIP); };
     const bool u_full = wid < L::NGU - NW * (L::NIU - 1);          // this wave brings NIU filter pieces per chunk (else NIU - 1)
+    if constexpr (NCB == 1) {
 #pragma unroll
-    for (int n = 0; n < L::NI; ++n) issue_n(0, 0, n);
+        for (int n = 0; n < L::NI; ++n) issue_n(0, 0, n);
+    }
     // bias of this lane's four couts (cb*16 + 4q + r): added after the output transform
     float bv[4];
 #pragma unroll
@@ -414,11 +448,14 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     const int bBase = L::VOFF / 4 + q * (9 * NT) + tg * 16 + l15;
 
     // fused upsample: low-res raw chunk -> hi-res patch; one thread = one 2x2 hi-res block position, walking the chunk's channels
-    auto expand = [&]() {
+    // (CB, CN: the channels of the chunk this call expands - the 512-thread form splits them between its two halves of 256 threads)
+    auto expand = [&](int rbuf, int hbuf, auto CB, auto CN) {
         if constexpr (UPS) {
             constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, LH = C::LH, LW = C::LW;
-            const float *raw = lds + L::DOFF;
-            float *hip = lds + L::HOFF;
+            constexpr int cbeg = decltype(CB)::value, cnum = decltype(CN)::value;
+            const float *raw = lds + L::DOFF + rbuf * L::DCAP + cbeg * LH * LW;
+            float *hip = lds + L::HOFF + hbuf * L::HCAP + cbeg * PH * PW;
+            const int tid = threadIdx.x & 255;
             if (tid < NPOS) {
                 const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
                 const int pi = tid / PRW, pj = tid - pi * PRW;
@@ -436,16 +473,16 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                 const float *r0 = raw + (i0 - ly0) * LW + 3 - lx0 + j0;
                 const float *r1 = raw + (i1 - ly0) * LW + 3 - lx0 + j0;
                 float *dd = hip + (2 * pi) * PW + 2 * pj + 3 + C::SHIFT;       // hi-res pixel x0 + 2pj - 1 -> patch column 2pj + 3 (+ SHIFT)
-                float v00[CK], v01[CK], v10[CK], v11[CK];
+                float v00[cnum], v01[cnum], v10[cnum], v11[cnum];
 #pragma unroll
-                for (int cc = 0; cc < CK; ++cc) {
+                for (int cc = 0; cc < cnum; ++cc) {
                     v00[cc] = r0[cc * LH * LW];
                     v01[cc] = r0[cc * LH * LW + 1];
                     v10[cc] = r1[cc * LH * LW];
                     v11[cc] = r1[cc * LH * LW + 1];
                 }
 #pragma unroll
-                for (int cc = 0; cc < CK; ++cc) {
+                for (int cc = 0; cc < cnum; ++cc) {
                     const float h00 = xa * v00[cc] + xb * v01[cc], h01 = ca * v00[cc] + cbw * v01[cc];
                     const float h10 = xa * v10[cc] + xb * v11[cc], h11 = ca * v10[cc] + cbw * v11[cc];
                     dd[cc * PH * PW] = m00 * (ya * h00 + yb * h10);
@@ -454,7 +491,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                     dd[cc * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
                 }
             }
-            __syncthreads();
         }
     };
 
@@ -462,9 +498,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     // halves (HH: column-frequencies 0..2 | 3..5; NCB = 2 also HQ: row-frequencies 0..2 | 3..5) are wave-uniform, and each combination
     // is its own straight-line instance: with the selection inside, every row's window read sat behind a scalar branch and waited
     // out its LDS latency alone - six exposed latencies per chunk, ~1450 cycles for 80 vector instructions.
-    auto transform_as = [&](auto HH, auto HQ) {
+    auto transform_as = [&](auto HH, auto HQ, int sbuf, int vbuf) {
         constexpr int hh = decltype(HH)::value, hq = decltype(HQ)::value;
-        const float *rp = lds + t_src;
+        const float *rp = lds + t_src + sbuf * L::PCAP;
+        f32x4 *vo = (f32x4 *)lds + t_dst + vbuf * (C::VSZ / 4);
         f32x4 a4[6];
         f32x2 a2[6];
 #pragma unroll
@@ -482,27 +519,27 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             float v[18];            // frequency w4_freq(i, 3 hh + jj) - 18 hh = 3 i + jj
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) w4_col_pass(X[0][jj], X[1][jj], X[2][jj], X[3][jj], X[4][jj], X[5][jj], v + jj, 3);
-            w4_store_v<NT>(hh, v, (f32x4 *)lds + t_dst);
+            w4_store_v<NT>(hh, v, vo);
         } else {
             float v[9];             // frequency w4_freq(3 hq + ii, 3 hh + jj) - 18 hh - 9 hq = 3 ii + jj
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) w4_col_pass_half(hq, X[0][jj], X[1][jj], X[2][jj], X[3][jj], X[4][jj], X[5][jj], v + jj, 3);
-            w4_store_v9<NT>(2 * hh + hq, v, (f32x4 *)lds + t_dst);
+            w4_store_v9<NT>(2 * hh + hq, v, vo);
         }
     };
-    auto transform = [&]() {
+    auto transform = [&](int sbuf = 0, int vbuf = 0) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         if constexpr (NCB == 1) {
-            if (thh == 0) transform_as(I0{}, I0{});
-            else transform_as(I1{}, I0{});
+            if (thh == 0) transform_as(I0{}, I0{}, sbuf, vbuf);
+            else transform_as(I1{}, I0{}, sbuf, vbuf);
         } else {
             if (thh == 0) {
-                if (thq == 0) transform_as(I0{}, I0{});
-                else transform_as(I0{}, I1{});
+                if (thq == 0) transform_as(I0{}, I0{}, sbuf, vbuf);
+                else transform_as(I0{}, I1{}, sbuf, vbuf);
             } else {
-                if (thq == 0) transform_as(I1{}, I0{});
-                else transform_as(I1{}, I1{});
+                if (thq == 0) transform_as(I1{}, I0{}, sbuf, vbuf);
+                else transform_as(I1{}, I1{}, sbuf, vbuf);
             }
         }
     };
@@ -518,29 +555,22 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
         tph[i] += tn - tk;                                      \
         tk = tn;                                                \
     }
+    // $SSM_WINO4_ABL & 128: timeline of workgroup 0 - every wave writes s_memtime at its phase boundaries of the first 16 chunks to
+    // dbg[16 + (wave * 16 + chunk) * 4 + point]
+    const bool trace = (p.abl & 128) && p.dbg && blockIdx.x == 0;
+#define W4TRACE(chv, pt)                                                                                             \
+    if (trace && (chv) < 16 && lane == 0) p.dbg[16 + (wid * 16 + (chv)) * 4 + (pt)] = __builtin_amdgcn_s_memtime();
 #else
 #define W4STAMP(i)
+#define W4TRACE(chv, pt)
 #endif
     f32x4 a[3], bq[3];
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int stage = ch & 1;
-        // chunk ch has landed for every wave; every wave is done with the MFMAs of chunk ch-1 (V and the other filter stage are free)
-        // (the patch of) chunk ch has landed for every wave; every wave is done with the MFMAs of chunk ch-1 (V is free)
-        if (u_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU - 1) : "memory");
-        __syncthreads();
-        W4STAMP(0)
-        const bool dma_next = ch + 1 < nchunks && !(W4ABL(1) && ch >= 1);
-        expand();
-        if (!W4ABL(4) || ch == 0) transform();
-        W4STAMP(1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the filter of chunk ch
-        __syncthreads();
-        W4STAMP(2)
-
-        // ---- matrix phase: 9 groups of 4 frequencies = 36 MFMAs of 32 cycles; the operands of group g+2 are fetched behind the first
-        // MFMA of group g (a ring of three register sets: a group of four MFMAs alone is shorter than the LDS latency) ---------------
-        const int ai = aBase + stage * (C::USZ / 4), bi = bBase;
+    // ---- matrix phase of one chunk: 9 groups of 4 frequencies = 36 MFMAs of 32 cycles; the operands of group g+2 are fetched behind the
+    // first MFMA of group g (a ring of three register sets: a group of four MFMAs alone is shorter than the LDS latency); dma(g): the
+    // g-th LDS-DMA instruction of a later chunk, one per group behind its second MFMA (an LDS-DMA issued in a burst at a phase boundary
+    // costs ~200 cycles a piece, among MFMAs a few tens)
+    auto matrix = [&](int stage, int vbuf, auto dma, auto slot) __attribute__((always_inline)) {
+        const int ai = aBase + stage * (C::USZ / 4), bi = bBase + vbuf * (C::VSZ / 4);
         a[0] = lds4[ai];
         bq[0] = lds4[bi];
         a[1] = lds4[ai + 32];
@@ -559,17 +589,172 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // chunk ch+1, one DMA instruction per group behind its second MFMA (an LDS-DMA issued in a burst at a phase boundary
-                // costs ~200 cycles a piece, among MFMAs a few tens): the patch into the buffer the transform has finished with,
-                // the filter into the stage the matrix loop of chunk ch-1 has released
-                if (e == 1 && g < L::NI && dma_next) {
-                    issue_n(ch + 1, stage ^ 1, g);
+                if constexpr (NCB == 2) {          // slot(m): the m-th piece of the next chunk's transform, behind MFMA m
+                    slot(4 * g + e);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (e == 1 && g < L::NI) {
+                    dma(g);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        W4STAMP(3)
+    };
+
+    if constexpr (NCB == 1) {
+        // Two barriers per chunk: [patch of chunk ch landed | V free] expand, transform [filter of chunk ch landed | V complete] matrix
+        // loop, which carries the DMA of chunk ch+1: the patch into the buffer the transform has finished with, the filter into the stage
+        // the matrix loop of chunk ch-1 has released.
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int stage = ch & 1;
+            if (u_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU - 1) : "memory");
+            __syncthreads();
+            W4STAMP(0)
+            const bool dma_next = ch + 1 < nchunks && !(W4ABL(1) && ch >= 1);
+            if constexpr (UPS) {
+                expand(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, CK>{});
+                __syncthreads();
+            }
+            if (!W4ABL(4) || ch == 0) transform();
+            W4STAMP(1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the filter of chunk ch
+            __syncthreads();
+            W4STAMP(2)
+            matrix(stage, 0, [&](int g) {
+                if (dma_next) issue_n(ch + 1, stage ^ 1, g);
+            }, [](int) {});
+            W4STAMP(3)
+        }
+    } else {
+        // One barrier per chunk (patch, hi-res patch and V double-buffered): behind its MFMAs of chunk ch a wave transforms chunk ch+1
+        // (and, fused upsample, expands chunk ch+2) while the other wave of its SIMD is still feeding the matrix pipe - the two waves
+        // of a SIMD belong to the same workgroup here, and with two barriers per chunk they would sit in the same phase all the time.
+        //   plain:  the DMA inside matrix(ch) brings the filter of chunk ch+1 and the patch of chunk ch+2
+        //   UPS:    ... the filter of chunk ch+1 and the raw patch of chunk ch+3 (raw ch+2 is expanded behind transform(ch+1))
+        using T = std::true_type;
+        using F = std::false_type;
+#pragma unroll
+        for (int k = 0; k < L::NI; ++k) issue_k(0, 0, k, 0);
+        if (nchunks > 1) {
+#pragma unroll
+            for (int k = L::NIU; k < L::NI; ++k) issue_k(1, 0, k, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        using C0 = std::integral_constant<int, 0>;
+        using C2 = std::integral_constant<int, 2>;
+        auto expand_half = [&](int rbuf, int hbuf) {          // waves 0..3: channels 0, 1 of the chunk; waves 4..7: channels 2, 3
+            if (blk == 0) expand(rbuf, hbuf, C0{}, C2{});
+            else expand(rbuf, hbuf, C2{}, C2{});
+        };
+        if constexpr (UPS) {
+            expand_half(0, 0);
+            if (nchunks > 1) expand_half(1, 1);
+            __syncthreads();
+            if (nchunks > 2) {
+#pragma unroll
+                for (int k = L::NIU; k < L::NI; ++k) issue_k(2, 0, k, 0);
+            }
+        }
+        transform(0, 0);
+        // The transform of chunk ch+1 (this thread's quarter of a (cin, tile): 9 frequencies) rides in the slots of the matrix loop of chunk
+        // ch, one or two LDS / up to seven vector instructions behind an MFMA:
+        //   slots 0..5    window row i (one ds_read_b128 + one ds_read_b64)
+        //   slots 3..8    row pass of row i - 3 (its read is three MFMAs old)
+        //   slots 9..17   the three column passes, three slots each
+        //   slots 18..21  the V stores
+        // so that a wave never leaves the matrix pipe without queued work for a whole vector phase.  The quarter (HH, HQ) is wave-
+        // uniform: the loop is instantiated per quarter and carries no branch.
+        f32x4 r4[6];
+        f32x2 r2[6];
+        float tX[6][3], tE[3], tO[3], tv[9];
+        auto tstep = [&](auto HH, auto HQ, int m, const float *src, f32x4 *vo) __attribute__((always_inline)) {
+            constexpr int hh = decltype(HH)::value, hq = decltype(HQ)::value;
+            if (m < 6) {
+                r4[m] = *(const f32x4 *)(src + m * PW);
+                r2[m] = *(const f32x2 *)(src + m * PW + 4);
+            }
+            if (m >= 3 && m < 9) {
+                const int i = m - 3;
+                const float d[6] = {r4[i][0], r4[i][1], r4[i][2], r4[i][3], r2[i][0], r2[i][1]};
+                w4_row_pass(hh, d, tX[i]);
+            }
+            if (m >= 9 && m < 18) {
+                const int jj = (m - 9) / 3, st3 = (m - 9) % 3;
+                const float x0v = tX[0][jj], x1v = tX[1][jj], x2v = tX[2][jj], x3v = tX[3][jj], x4v = tX[4][jj], x5v = tX[5][jj];
+                if constexpr (hq == 0) {          // (the expressions of w4_col_pass_half)
+                    if (st3 == 0) {
+                        tE[jj] = x4v - kB2 * x2v;
+                        tO[jj] = x3v - kB2 * x1v;
+                    }
+                    if (st3 == 1) tv[jj] = (kP0 * x0v - kS2 * x2v) + x4v;
+                    if (st3 == 2) {
+                        tv[3 + jj] = tE[jj] + kA * tO[jj];
+                        tv[6 + jj] = tE[jj] - kA * tO[jj];
+                    }
+                } else {
+                    if (st3 == 0) {
+                        tE[jj] = x4v - kA2 * x2v;
+                        tO[jj] = x3v - kA2 * x1v;
+                    }
+                    if (st3 == 1) tv[6 + jj] = (kP0 * x1v - kS2 * x3v) + x5v;
+                    if (st3 == 2) {
+                        tv[jj] = tE[jj] + kB * tO[jj];
+                        tv[3 + jj] = tE[jj] - kB * tO[jj];
+                    }
+                }
+            }
+            if (m >= 18 && m < 22) w4_store_v9_step<NT>(2 * hh + hq, m - 18, tv, vo);
+        };
+        // one chunk; STEADY: chunks ch+1 .. ch+3 exist (compile-time: the steady state carries no per-slot branch on the tail conditions)
+        auto chunk = [&](int ch, auto STEADY, auto HH, auto HQ) __attribute__((always_inline)) {
+            constexpr bool steady = decltype(STEADY)::value;
+            const bool m1 = steady || ch + 1 < nchunks, m2 = steady || ch + 2 < nchunks, m3 = steady || ch + 3 < nchunks;
+            const int st = ch & 1;
+            // V(ch) complete, filter of chunk ch and (raw) patch of the next chunk(s) landed, every wave done with chunk ch-1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            W4STAMP(0)
+            W4TRACE(ch, 0)
+            const float *tsrc = lds + t_src + (st ^ 1) * L::PCAP;
+            f32x4 *tdst = (f32x4 *)lds + t_dst + (st ^ 1) * (C::VSZ / 4);
+            matrix(st, st, [&](int g) {
+                if (W4ABL(1)) return;
+                if (g < L::NIU) {
+                    if (m1) issue_k(ch + 1, st ^ 1, g, 0);
+                } else if constexpr (UPS) {
+                    if (m3) issue_k(ch + 3, 0, g, st ^ 1);
+                } else {
+                    if (m2) issue_k(ch + 2, 0, g, st);
+                }
+            }, [&](int m) {
+                if (W4_INTERLEAVE && m1 && !W4ABL(4)) tstep(HH, HQ, m, tsrc, tdst);
+            });
+            W4STAMP(3)
+            W4TRACE(ch, 2)
+            if (!W4_INTERLEAVE && m1 && !W4ABL(4)) transform_as(HH, HQ, st ^ 1, st ^ 1);
+            if constexpr (UPS) {
+                if (m2) expand_half(st, st);
+            }
+            W4STAMP(1)
+            W4TRACE(ch, 3)
+        };
+        auto chunks = [&](auto HH, auto HQ) __attribute__((always_inline)) {
+            int ch = 0;
+            for (; ch + 3 < nchunks; ++ch) chunk(ch, T{}, HH, HQ);
+            for (; ch < nchunks; ++ch) chunk(ch, F{}, HH, HQ);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        if (thh == 0) {
+            if (thq == 0) chunks(I0{}, I0{});
+            else chunks(I0{}, I1{});
+        } else {
+            if (thq == 0) chunks(I1{}, I0{});
+            else chunks(I1{}, I1{});
+        }
     }
 
     // ---- epilogue: Y = A^T M A per accumulator register (4 couts per lane), addend, LeakyReLU, stores, fused 2x2 mean -------------
@@ -682,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
     // chunk `chp` into patch buffer chp & 1 (the two are issued for different chunks: the patch runs one chunk further ahead)
     auto issue_u = [&](int chu, int k) {
         const int g = 8 * k + wid;
-        if (g < L::NGU) {
+        if (8 * k + 7 < L::NGU || g < L::NGU) {
             const float *base = wbase + (long long)(chu * CK) * (9 * BN * 4) + g * 256;
             const unsigned m0v = lds0 + (unsigned)(L::UOFF + (chu & 1) * C::USZ) * 4u + (unsigned)g * 1024u;
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
@@ -690,7 +875,7 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
     };
     auto issue_p = [&](int chp, int kk) {
         const int g = 8 * kk + wid;
-        if (g < L::NGP) {
+        if (8 * kk + 7 < L::NGP || g < L::NGP) {
             const int c0 = chp * CK;
             const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
             const unsigned m0v = lds0 + (unsigned)(L::DOFF + (chp & 1) * L::DCAP) * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT);
@@ -785,8 +970,11 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
     //   steps 2..7   row pass of row i - 2 (its load is two MFMAs + their slots old; three rows in flight = 18 registers)
     //   steps 8..25  the three column passes, six steps each
     //   steps 26..30 the five V stores
+    // (the column-frequency half is wave-uniform: the whole pipelined loop is instantiated per half, so that no step carries a branch)
+    auto pipeline = [&](auto HH) __attribute__((always_inline)) {
+    constexpr int hh = decltype(HH)::value;
     float trow[6][6], tX[6][3], tv[18];
-    auto tstep = [&](int m, const float *src, f32x4 *dst) {
+    auto tstep = [&](int m, const float *src, f32x4 *dst) __attribute__((always_inline)) {
         if (m < 6) {
             const f32x4 a4 = *(const f32x4 *)(src + m * PW);
             const f32x2 a2 = *(const f32x2 *)(src + m * PW + 4);
@@ -799,9 +987,7 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
         }
         if (m >= 2 && m < 8) {
             const int i = m - 2;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(trow[i][j]));          // scalars: no packed-fp32 arithmetic on the loaded pairs
-            w4_row_pass(thh, trow[i], tX[i]);
+            w4_row_pass(hh, trow[i], tX[i]);
 #pragma unroll
             for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(tX[i][j]));
         }
@@ -827,8 +1013,8 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
             }
         }
         if (m >= 26 && m < 31) {
-            const int g = m - 26;          // thh = 0: quads 0..3 then the low half of quad 4; thh = 1: the high half of quad 4 then quads 5..8
-            if (thh == 0) {
+            const int g = m - 26;          // hh = 0: quads 0..3 then the low half of quad 4; hh = 1: the high half of quad 4 then quads 5..8
+            if constexpr (hh == 0) {
                 if (g < 4) dst[g * NT] = f32x4{tv[4 * g], tv[4 * g + 1], tv[4 * g + 2], tv[4 * g + 3]};
                 else *(f32x2 *)(dst + 4 * NT) = f32x2{tv[16], tv[17]};
             } else {
@@ -850,12 +1036,13 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
     }
 
     f32x4 a[2], bq[2];
-    for (int ch = 0; ch < nchunks; ++ch) {
+    // one chunk; MORE / MORE2: chunks ch+1 / ch+2 exist (compile-time: the steady state carries no per-slot branch)
+    auto chunk = [&](int ch, auto MORE, auto MORE2) __attribute__((always_inline)) {
+        constexpr bool more = decltype(MORE)::value, more2 = decltype(MORE2)::value;
         const int st = ch & 1;
         // U(ch) and the patch of chunk ch+1 have landed (this wave's share); V(ch) is complete and every wave is done with chunk ch-1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const bool more = ch + 1 < nchunks, more2 = ch + 2 < nchunks;
         if constexpr (UPS) {
             if (more) expand(st ^ 1);          // raw patch of chunk ch+1 -> hi-res patch (the transform of chunk ch has finished with it)
         }
@@ -885,7 +1072,14 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+    int ch = 0;
+    for (; ch + 2 < nchunks; ++ch) chunk(ch, std::true_type{}, std::true_type{});
+    if (ch + 1 < nchunks) chunk(ch++, std::true_type{}, std::false_type{});
+    chunk(ch, std::false_type{}, std::false_type{});
+    };
+    if (thh == 0) pipeline(std::integral_constant<int, 0>{});
+    else pipeline(std::integral_constant<int, 1>{});
 
 #ifdef SSM_WINO_ABLATE
     if ((p.abl & 2) && acc[0][0] != 12345.678f) return;

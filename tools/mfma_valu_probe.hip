@@ -1,0 +1,77 @@
+// Diagnostic: do vector instructions of one wave issue beside the fp32 MFMAs of the other wave of the same SIMD?  One 512-thread
+// workgroup per CU (two waves per SIMD: w and w + 4).  Modes:
+//   0  all 8 waves: 36 independent v_mfma_f32_16x16x4_f32 per iteration
+//   1  waves 0..3 MFMA only, waves 4..7 vector only (144 v_fma_f32 per iteration, 8 independent chains)
+//   2  all 8 waves: 36 MFMAs with 2 v_fma_f32 behind each (72 per iteration)
+//   3  waves 4..7 vector only, waves 0..3 idle
+//   4  waves 0..3 MFMA only, waves 4..7 idle
+//   5  all 8 waves: 36 MFMAs with 4 v_fma_f32 behind each (144 per iteration)
+// Each wave reports its shader cycles per iteration (s_memtime) into out[block][wave].
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, unsigned long long *out, float *sink) {
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool mf = mode == 0 || mode == 2 || mode == 5 || ((mode == 1 || mode == 4) && wid < 4);
+    const bool va = mode == 2 || mode == 5 || ((mode == 1 || mode == 3) && wid >= 4);
+    const int nv = mode == 2 ? 2 : mode == 5 ? 4 : 0;
+    f32x4 acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 0.5f;
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = (float)i;
+    asm volatile("" : "+v"(a), "+v"(b));
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (mf && nv == 0) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+    } else if (mf && nv == 2) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                c[(2 * i) & 7] = __builtin_fmaf(c[(2 * i) & 7], 1.0001f, 0.5f);
+                c[(2 * i + 1) & 7] = __builtin_fmaf(c[(2 * i + 1) & 7], 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (mf && nv == 4) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[(4 * i + k) & 7] = __builtin_fmaf(c[(4 * i + k) & 7], 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (va) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 144; ++i) {
+                c[i & 7] = __builtin_fmaf(c[i & 7], 1.0001f, 0.5f);
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += c[i];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + wid] = (t1 - t0);
+}
+
+extern "C" int mfma_valu_launch(int mode, int iters, int blocks, unsigned long long *out, float *sink, void *stream) {
+    hipLaunchKernelGGL(mfma_valu_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, mode, iters, out, sink);
+    return (int)hipGetLastError();
+}
