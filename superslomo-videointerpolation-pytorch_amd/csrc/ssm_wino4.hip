@@ -22,12 +22,21 @@
 // the 2x2 mean is lane-local too), and two workgroups share a CU (<= 256 registers per wave).  The bias is added after the output
 // transform (sum of products, then + bias: the reference's order).
 //
-// Data movement as in ssm_conv.hip / ssm_wino.hip: padded planes, per chunk of 4 input channels the [4][9][32][4] filter values (double-
-// buffered) and the [4][TH+2][TW+8] patch (or, fused upsample, the low-res [4][TH/2+2][TW/2+8] patch, expanded in LDS by the same
-// expander) arrive by LDS-DMA.  The filter DMA of chunk c+1 is issued right behind the barrier that opens chunk c (its stage was freed
-// by the matrix loop of chunk c-1), so it has the transform and the matrix loop of chunk c to land; the patch is single-buffered: its DMA
-// for chunk c+1 is issued as one burst at the start of the matrix loop of chunk c, when the transform of chunk c - the patch's only
-// reader - is complete.
+// Data movement as in ssm_conv.hip / ssm_wino.hip: padded planes, per chunk of 4 input channels the [4][9][32][4] filter values per
+// 32-cout block (double-buffered) and the [4][TH+2][TW+8] patch (or, fused upsample, the low-res [4][TH/2+2][TW/2+8] patch, expanded in
+// LDS) arrive by LDS-DMA, one instruction per frequency group INSIDE the matrix loop of the chunk before (a burst at a phase boundary
+// costs ~200 issue cycles a piece, among MFMAs a few tens).
+//
+// Three kernel forms (DESIGN.md 3.2f-g has the measurements behind them):
+//   wino4_kernel<W4Cfg<.., NCB = 1>>  256 threads, 32 couts x 32 tiles, two workgroups per CU, two barriers per chunk
+//                                     [patch landed] expand, transform [filter landed] matrix loop; single-buffered patch and V.
+//   wino4_kernel<W4Cfg<.., NCB = 2>>  512 threads, 64 couts x 32 tiles, one workgroup per CU: the transform serves twice the MFMAs
+//                                     (a vector instruction beside the fp32 MFMA costs ~3 matrix cycles - tools/mfma_valu_probe.py -
+//                                     so fewer of them per MFMA is the only thing that hides a transform); patch, hi-res patch and V
+//                                     double-buffered, ONE barrier per chunk, the next chunk's transform in the slots of the matrix loop.
+//   wino4p_kernel<W8Cfg>              512 threads, 32 couts x 64 tiles, the first pipelined form (opt-in, $SSM_WINO4_PIPE; slower).
+// Whatever is wave-uniform at run time (which part of a (cin, tile) a thread transforms, whether later chunks exist) selects a
+// straight-line INSTANCE of the loop instead of being tested inside it: a scalar branch in front of an LDS read exposes its latency.
 #include "ssm_common.h"
 
 #include <atomic>
@@ -242,6 +251,8 @@ __device__ __forceinline__ void w4_store_v(int hh, const float *v, f32x4 *vo) {
 
 #ifdef SSM_WINO_ABLATE
 #define W4ABL(bit) (p.abl & (bit))
+#elif defined(W4_CT_ABL)          // compile-time ablation (tuning builds: no per-slot branches, unlike the run-time switch)
+#define W4ABL(bit) (W4_CT_ABL & (bit))
 #else
 #define W4ABL(bit) 0
 #endif
@@ -1133,27 +1144,27 @@ constexpr W4KindInfo kW4Info[NW4KIND] = {
 std::atomic<int> g_force_w4kind{-1};
 std::atomic<unsigned long long *> g_w4dbg{nullptr};      // diagnostics (ssm_wino4_debug_buffer)
 
-// Estimated duration (cycles) of a launch, fitted to tools/bench_layers_wino.py at batch 7 and the in-kernel phase timers
-// (tools/wino4_phase_probe.py).  256-thread form: a CU-round of two co-resident workgroups costs ~4300 cycles per chunk of 4 input
-// channels (2 x 36 MFMAs of 32 cycles are 2304 of them; the rest: transform phase, two barriers, and what the two waves of a SIMD
-// cannot hide from each other), ~900 more with the fused-upsample expander; whole rounds of 512 workgroups.  64-cout
-// form: one workgroup per CU, ~3800 (+800) cycles per chunk for twice the couts, rounds of 256, prologue and epilogue exposed.
+// Estimated duration (cycles) of a launch, fitted to tools/bench_layers_wino.py at batch 7 (profiles/r7b_wino4_layers_b7.txt: time x clock
+// / rounds = chunks x c + e per workgroup).  256-thread form: two co-resident workgroups per CU, c = 4500 cycles per chunk of 4 input
+// channels (2 x 36 MFMAs of 32 cycles are 2304 of them), e = 11 k of prologue + epilogue (the other workgroup of the CU covers most of
+// it); whole rounds of 512 workgroups.  64-cout form: one workgroup per CU, c = 3600 for twice the couts, e = 26 k (nothing covers its
+// first loads and its stores), rounds of 256 - the better form from ~20 chunks on.
 double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W, int ups) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * (Cout / ki.bn);
     const double chunks = (double)Cin / 4.0;
     if (ki.bn == 64) {
-        const double per = chunks * (3800.0 + (ups ? 800.0 : 0.0)) + 16000.0;
+        const double per = chunks * 3600.0 + 26000.0;
         return (double)((nwg + 255) / 256) * per;
     }
-    if (ki.pipe) {          // one workgroup per CU: measured ~6200 cycles per chunk (tools/bench_layers_wino.py W4KIND=3), exposed prologue / epilogue
-        const double per = chunks * (6200.0 + (ups ? 300.0 : 0.0)) + 9000.0;
+    if (ki.pipe) {          // one workgroup per CU: measured ~5400 cycles per chunk (tools/bench_layers_wino.py W4KIND=3), exposed prologue / epilogue
+        const double per = chunks * (5400.0 + (ups ? 300.0 : 0.0)) + 20000.0;
         return (double)((nwg + 255) / 256) * per;
     }
-    const double per = chunks * (4300.0 + (ups ? 900.0 : 0.0)) + 14000.0;
+    const double per = chunks * (4500.0 + (ups ? 250.0 : 0.0)) + 11000.0;
     const long long full = nwg / 512, rem = nwg % 512;
     double t = (double)full * per;
-    if (rem) t += rem > 256 ? per : chunks * (2900.0 + (ups ? 700.0 : 0.0)) + 12000.0;     // a last round of lone workgroups
+    if (rem) t += rem > 256 ? per : chunks * (3300.0 + (ups ? 250.0 : 0.0)) + 11000.0;     // a last round of lone workgroups
     return t;
 }
 
