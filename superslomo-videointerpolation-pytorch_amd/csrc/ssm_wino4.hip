@@ -571,6 +571,14 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     const bool trace = (p.abl & 128) && p.dbg && blockIdx.x == 0;
 #define W4TRACE(chv, pt)                                                                                             \
     if (trace && (chv) < 16 && lane == 0) p.dbg[16 + (wid * 16 + (chv)) * 4 + (pt)] = __builtin_amdgcn_s_memtime();
+#elif defined(W4_TRACE)
+    // tuning build (-DW4_TRACE): the same timeline without run-time switches in the loop - the stamps of workgroup 0 go to 4 KiB of
+    // LDS behind the kernel's regions (no vector-memory traffic that the loop's vmcnt waits would see) and to dbg[16 ..] at the end
+#define W4STAMP(i)
+    unsigned long long *ltrace = (unsigned long long *)(lds + L::BYTES / 4);
+    const bool trace = p.dbg && blockIdx.x == 0;
+#define W4TRACE(chv, pt) \
+    if (trace && (chv) < 16 && lane == 0) ltrace[(wid * 16 + (chv)) * 4 + (pt)] = __builtin_amdgcn_s_memtime();
 #else
 #define W4STAMP(i)
 #define W4TRACE(chv, pt)
@@ -778,6 +786,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
         const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
         w4_epilogue(p, acc, bv, b, nb * BN + blk * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
     }
+#if defined(W4_TRACE) && !defined(SSM_WINO_ABLATE)
+    if (trace) {
+        __syncthreads();
+        for (int i = tid; i < NW * 64; i += C::THREADS) p.dbg[16 + i] = ltrace[i];
+    }
+#endif
 #ifdef SSM_WINO_ABLATE
     if (stamp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1218,6 +1232,9 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
         lds_bytes = W4Lds<C, UPS>::BYTES;
         threads = C::THREADS;
     }
+#ifdef W4_TRACE
+    lds_bytes += 4096;
+#endif
 #ifdef SSM_WINO_ABLATE
     if (const char *e = getenv("SSM_WINO4_SOLO"))          // diagnostics: one workgroup per CU (the LDS request leaves no room for a second)
         if (atoi(e) && lds_bytes < 100 * 1024) lds_bytes = 100 * 1024;

@@ -6,6 +6,10 @@
 //   3  waves 4..7 vector only, waves 0..3 idle
 //   4  waves 0..3 MFMA only, waves 4..7 idle
 //   5  all 8 waves: 36 MFMAs with 4 v_fma_f32 behind each (144 per iteration)
+//   6  waves 0..3 MFMA only, waves 4..7 LDS-DMA only (12 global_load_lds_dwordx4 of 1 KiB per iteration from an L2-resident buffer)
+//   7  waves 4..7 LDS-DMA only, waves 0..3 idle
+//   8  all 8 waves: 36 MFMAs with one LDS-DMA behind every sixth (6 per iteration)
+//   9  waves 0..3 MFMA only, waves 4..7 LDS reads only (36 ds_read_b128 per iteration)
 // Each wave reports its shader cycles per iteration (s_memtime) into out[block][wave].
 #include <hip/hip_runtime.h>
 
@@ -13,7 +17,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, unsigned long long *out, float *sink) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool mf = mode == 0 || mode == 2 || mode == 5 || ((mode == 1 || mode == 4) && wid < 4);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const bool mf = mode == 0 || mode == 2 || mode == 5 || mode == 8 || ((mode == 1 || mode == 4 || mode == 6 || mode == 9) && wid < 4);
+    const bool dm = (mode == 6 || mode == 7) && wid >= 4;
+    const bool lr = mode == 9 && wid >= 4;
+    const float *gsrc = sink + 4096 + wid * 4096;          // 16 KiB per wave, L2-resident after the first pass
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds + wid * 16384;
+    const int voff = (threadIdx.x & 63) * 16;
     const bool va = mode == 2 || mode == 5 || ((mode == 1 || mode == 3) && wid >= 4);
     const int nv = mode == 2 ? 2 : mode == 5 ? 4 : 0;
     f32x4 acc[36];
@@ -25,7 +35,45 @@ __global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, 
     for (int i = 0; i < 8; ++i) c[i] = (float)i;
     asm volatile("" : "+v"(a), "+v"(b));
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (mf && nv == 0) {
+    if (mode == 8) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                if (i % 6 == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned m0v = lds0 + (i / 6) * 1024;
+                    const float *base = gsrc + (i / 6) * 256;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(m0v) : "memory", "m0");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else if (dm) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const unsigned m0v = lds0 + i * 1024;
+                const float *base = gsrc + i * 256;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(m0v) : "memory", "m0");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else if (lr) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 r = {0.f, 0.f, 0.f, 0.f};
+        const f4 *l4 = (const f4 *)lds + wid * 1024 + (threadIdx.x & 63);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                f4 t = l4[(i & 15) * 64];
+                asm volatile("" : "+v"(t));
+                r += t;
+            }
+        }
+        c[0] += r[0] + r[1] + r[2] + r[3];
+    } else if (mf && nv == 0) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int i = 0; i < 36; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
@@ -72,6 +120,11 @@ __global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, 
 }
 
 extern "C" int mfma_valu_launch(int mode, int iters, int blocks, unsigned long long *out, float *sink, void *stream) {
-    hipLaunchKernelGGL(mfma_valu_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, mode, iters, out, sink);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void *)mfma_valu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        attr = true;
+    }
+    hipLaunchKernelGGL(mfma_valu_kernel, dim3(blocks), dim3(512), 8 * 16384, (hipStream_t)stream, mode, iters, out, sink);
     return (int)hipGetLastError();
 }

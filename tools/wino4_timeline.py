@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Timeline of ONE wino4 workgroup (diagnostics build, make wabl; $SSM_WINO4_ABL bit 128): every wave of workgroup 0 stamps s_memtime at
-its phase boundaries of the first 16 chunks - after the chunk's barrier | before the matrix loop | after it | after the transform.
-usage: W4KIND=6 SSM_WINO4_STAGGER=3 python tools/wino4_timeline.py [layer]"""
+"""Timeline of ONE wino4 workgroup (tuning build `make wtrace` in csrc: -DW4_TRACE, no run-time switches in the loop): every wave of
+workgroup 0 stamps s_memtime at its phase boundaries of the first 16 chunks - after the chunk's barrier | (unused) | after the matrix loop |
+after the work behind it.   usage: W4KIND=6 python tools/wino4_timeline.py [layer]"""
 import ctypes
 import os
 import sys
@@ -9,8 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd")
 sys.path[:0] = [ROOT, PKG, os.path.join(PKG, "scripts")]
-os.environ.setdefault("SSM_HIP_LIB", os.path.join(ROOT, "tools", "wabl_libssm_hip.so"))
-os.environ["SSM_WINO4_ABL"] = str(int(os.environ.get("SSM_WINO4_ABL", "0")) | 128)
+os.environ.setdefault("SSM_HIP_LIB", os.path.join(ROOT, "tools", "w4trace_libssm_hip.so"))          # csrc: make wtrace
 import torch  # noqa: E402
 
 from ssm_amd import hipbind as hb  # noqa: E402
