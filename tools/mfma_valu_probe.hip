@@ -10,6 +10,8 @@
 //   7  waves 4..7 LDS-DMA only, waves 0..3 idle
 //   8  all 8 waves: 36 MFMAs with one LDS-DMA behind every sixth (6 per iteration)
 //   9  waves 0..3 MFMA only, waves 4..7 LDS reads only (36 ds_read_b128 per iteration)
+//  10  waves 0..3: 36 MFMAs with 4 v_fma_f32 behind each, waves 4..7: 36 MFMAs only   (all the vector work on the favoured wave)
+//  11  waves 0..3: 36 MFMAs only, waves 4..7: 36 MFMAs with 4 v_fma_f32 behind each
 // Each wave reports its shader cycles per iteration (s_memtime) into out[block][wave].
 #include <hip/hip_runtime.h>
 
@@ -18,6 +20,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, unsigned long long *out, float *sink) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (mode == 10) mode = wid < 4 ? 5 : 0;
+    if (mode == 11) mode = wid < 4 ? 0 : 5;
     const bool mf = mode == 0 || mode == 2 || mode == 5 || mode == 8 || ((mode == 1 || mode == 4 || mode == 6 || mode == 9) && wid < 4);
     const bool dm = (mode == 6 || mode == 7) && wid >= 4;
     const bool lr = mode == 9 && wid >= 4;

@@ -16,8 +16,9 @@ sink = torch.zeros(4096 * 10, device=dev)
 names = {0: "8 waves MFMA only (36 / iteration)", 1: "waves 0-3 MFMA, waves 4-7 vector (144 fma / iteration)", 2: "8 waves: 36 MFMA + 72 fma interleaved",
          3: "waves 4-7 vector only", 4: "waves 0-3 MFMA only", 5: "8 waves: 36 MFMA + 144 fma interleaved",
          6: "waves 0-3 MFMA, waves 4-7 LDS-DMA (12 x 1 KiB / iteration)", 7: "waves 4-7 LDS-DMA only", 8: "8 waves: 36 MFMA + 6 LDS-DMA interleaved",
-         9: "waves 0-3 MFMA, waves 4-7 36 ds_read_b128 / iteration"}
-for mode in (4, 3, 0, 1, 2, 5, 7, 6, 8, 9):
+         9: "waves 0-3 MFMA, waves 4-7 36 ds_read_b128 / iteration", 10: "waves 0-3: 36 MFMA + 144 fma, waves 4-7: 36 MFMA",
+         11: "waves 0-3: 36 MFMA, waves 4-7: 36 MFMA + 144 fma"}
+for mode in (4, 3, 0, 1, 2, 5, 7, 6, 8, 9, 10, 11):
     for _ in range(2):
         out.zero_()
         lib.mfma_valu_launch(mode, iters, blocks, out.data_ptr(), sink.data_ptr(), None)
