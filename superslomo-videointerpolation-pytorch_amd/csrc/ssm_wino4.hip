@@ -778,8 +778,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
 
     // ---- epilogue: Y = A^T M A per accumulator register (4 couts per lane), addend, LeakyReLU, stores, fused 2x2 mean -------------
     // A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]
-#ifdef SSM_WINO_ABLATE
-    if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
+#if defined(SSM_WINO_ABLATE) || defined(W4_CT_ABL)
+    if (W4ABL(2) && acc[0][0] != 12345.678f) return;
 #endif
     {
         const int gx = l15 % C::GTX, gy = l15 / C::GTX;

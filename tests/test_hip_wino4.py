@@ -102,6 +102,31 @@ def test_every_wino4_configuration_fused_upsample(dev, kind):
         assert _err(y.to_nchw().cpu(), want1) < 5e-5, "%s %dx%d: single-source" % (kind, h, wd)
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_wino4_short_channel_counts(dev, kind):
+    """1..5 chunks of 4 input channels: the double-buffered forms prefetch two (fused upsample: three) chunks ahead and run their last
+    three chunks in a copy of the loop with run-time tail conditions - every tail length, plain and fused-upsample."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(400 + KINDS.index(kind))
+    _force(kind)
+    B, H, W, cout = 2, 20, 36, 64
+    for cin in (4, 8, 12, 16, 20):
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        a = torch.randn(B, cin, H, W, generator=g)
+        y = hb.Planes(B, cout, H, W, dev)
+        pk = hb.PackedWino4(w.to(dev), bias.to(dev), B, H, W)
+        hb.conv2d_wino4(hb.Planes(B, cin, H, W, dev).load(a.to(dev)).view(), cin, None, 0, pk, y.view(), None, B, H, W, lrelu=True)
+        e = _err(y.to_nchw().cpu(), O.conv2d_lrelu(a, w, bias))
+        assert e < 5e-5, "%s cin %d: %.3e" % (kind, cin, e)
+        al = torch.randn(B, cin, H // 2, W // 2, generator=g)
+        pku = hb.PackedWino4(w.to(dev), bias.to(dev), B, H, W, ups=True)
+        hb.conv2d_ups_wino4(hb.Planes(B, cin, H // 2, W // 2, dev).load(al.to(dev)).view(), cin, None, 0, pku, y.view(), B, H, W)
+        e = _err(y.to_nchw().cpu(), O.conv2d_lrelu(O.upsample2x_bilinear(al), w, bias))
+        assert e < 5e-5, "%s cin %d fused upsample: %.3e" % (kind, cin, e)
+
+
 def test_wino4_deep_channels_and_scale_invariance(dev):
     """512 input channels (128 chunks through the filter double buffer) at the 1/16 map, and the same problem with activations x 2^12
     and filters x 2^-9: the form is linear fp32 arithmetic - no operand range in which it degrades (unlike the split-fp16 modes)."""
