@@ -240,6 +240,9 @@ class UNetGrad:
                 # runs in the Winograd form like the forward (its "input channels" are the layer's output channels)
                 use_w = getattr(self.plan, "wino", False) and hb.wino_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
                 cls = hb.PackedWino if use_w else hb.PackedConv
+                if (use_w and getattr(self.plan, "wino4", False) and hb.wino4_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
+                        and hb.wino4_preferred(co, ci, self.B, self.plan.H // s, self.plan.W // s, False)):
+                    cls = hb.PackedWino4
                 from .engine import wino1d_enabled
                 if getattr(self.plan, "wino1d", False) and wino1d_enabled(k) and hb.wino1d_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
                     cls = hb.PackedWino1d          # data gradient of a 7x7 / 5x5 layer: the same convolution on the transposed filter

@@ -82,6 +82,13 @@ WINO1D = os.environ.get("SSM_WINO1D", "57")
 WINO4 = os.environ.get("SSM_WINO4", "1")
 
 
+# ... and in the TRAINING plans (forward and data-gradient convolutions on the 46x46+ maps): $SSM_TRAIN_WINO4=1.  Gradient parity holds
+# (tests/test_hip_backward.py green with it: 1.8e-6 from the reference's gradient fixture, 6.8e-4 worst at 2x352x352 like mode f32),
+# but the step is not faster at 2 samples of 352x352: forward 4.97 -> 4.88 ms and data gradients 7.87 -> 7.26 ms in kernel, wall 20.8 ->
+# 21.3 ms per step (the 64-cout form holds a whole CU's LDS, and the weight-gradient stream runs beside it) - off by default.
+TRAIN_WINO4 = os.environ.get("SSM_TRAIN_WINO4", "0")
+
+
 def wino4_enabled(name):
     return WINO4 not in ("0", "") and (WINO4 == "1" or name in WINO4.split(","))
 
@@ -91,16 +98,17 @@ def wino1d_enabled(k):
     return k in (5, 7) and str(k) in WINO1D
 
 
-def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d):
+def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d, wino4=None):
     """Algorithm of one convolution of an fp32 plan: "direct" (csrc/ssm_conv.hip), "wino" = F(2x2,3x3) (ssm_wino.hip), "wino4" =
     F(4x4,3x3) (ssm_wino4.hip), "wino1d" = F(2,7) / F(4,5) along x (ssm_wino1d.hip).  wino: the plan is mode f32w; wino1d: it is an
     inference plan (the 8-frequency forms stay out of the training plans).  Pure function of the problem: bench.py uses it to count the
     multiply-adds the matrix cores issue."""
     skip = name in WINO_SKIP or "all" in WINO_SKIP or name == "final_conv"
+    wino4 = wino1d if wino4 is None else wino4
     if wino1d and not skip and wino1d_enabled(k) and hb.wino1d_supported(ci, co, h, w, k):
         return "wino1d"
     if wino and not skip and hb.wino_supported(ci, co, h, w, k):
-        if (wino1d and wino4_enabled(name) and hb.wino4_supported(ci, co, h, w, k)
+        if (wino4 and wino4_enabled(name) and hb.wino4_supported(ci, co, h, w, k)
                 and (WINO4 != "1" or hb.wino4_preferred(ci, co, nb, h, w, ups))):
             return "wino4"
         return "wino"
@@ -175,6 +183,7 @@ class UNetPlan:
         # direct: the 8-point transforms round ~5x coarser than an fmaf chain, which moves more pre-activations across the LeakyReLU /
         # |.| kinks of the loss - the parameter gradients at 64x64 then sit 4e-4 from CPU autograd instead of 6e-5 (bar 3e-4)
         self.wino1d = self.wino and self.fuse_up and not twins
+        self.wino4 = self.wino and (self.wino1d or TRAIN_WINO4 == "1")          # F(4x4,3x3) for the 3x3 layers
         # hoist = (B1, G): stage-2 inference plan whose batch holds G interpolation times for each of B1 pairs (entry p*G + i).  The
         # parts of two convolutions' inputs that do not depend on t - the image channels 0:3 / 13:16 of conv1a's 16-channel input
         # (flow_interpolation.py:364-367) and the stage-1 half of the cross-skip concat in front of conv7a (:98-101,224-231) - are
@@ -288,7 +297,7 @@ class UNetPlan:
             else:
                 nb = self.Bd if name in self.DECODER else self.B
                 ups = self.fuse_up and name in self.UPS
-                cls = _ALGO_CLASS[choose_algo(name, ci, co, k, nb, self.H // s, self.W // s, ups, self.wino, self.wino1d)]()
+                cls = _ALGO_CLASS[choose_algo(name, ci, co, k, nb, self.H // s, self.W // s, ups, self.wino, self.wino1d, self.wino4)]()
                 if self.hoist and name == "conv1a":
                     # per-t part: channels 3:13 (warped frames + estimated flows); per-pair part: the frames themselves in stage 1's
                     # input order (I0 = channels 13:16, I1 = channels 0:3), no bias, no activation
