@@ -14,6 +14,8 @@
 //                   two stage-1 warp-loss terms
 #include "ssm_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ float *vp(const ssm_view &v, int b, int c, int y) {
@@ -106,30 +108,38 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__re
 
 // Weight gradient on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
 //     dW[co][col] = sum_pixels dZ[co][p] * X[ci(col)][p + tap(col)],      col = ci*k*k + tap  (OIHW order)
-// GEMM with M = couts, N = (ci, tap) columns, K = pixels.  A operand = dZ (32 couts x 2 pixels) from an LDS tile
-// [co][pixel] with an odd row stride; B operand = 32 columns x 2 pixels: every lane owns one column and reads the
-// staged activation rows at a constant per-lane offset (its channel, filter row and filter column) plus the running
-// pixel index.  The accumulator has the column on the lane, so a register is 32 consecutive floats of one
-// filter row of dW.  A workgroup (4 waves) owns NTC*32 couts x 128 columns, walks image rows (b, y) strided by
-// gridDim.z in 64-pixel segments and adds its partial sums with fp32 atomics.
+// GEMM with M = couts, N = (ci, tap) columns, K = pixels.  A workgroup (4 waves) owns NTC*32 couts x 256 columns (a wave: CT = 2
+// column tiles of 32), walks the image in steps of RR rows x SEG pixels (strided by gridDim.z over the batch's steps) and adds its
+// partial sums with fp32 atomics.  Per step the dZ tile [co][RR*SEG] and the XR = KS+RR-1 activation rows of the XC input channels the
+// 256 columns touch are staged in LDS (register-prefetched: the loads of step s+1 are issued before the MFMAs of step s).
+//   A operand (dZ): rows of 132 floats (33 quads: odd, so the 16 lanes of a ds_read_b128 group hit 16 different quads) - a lane reads
+//     FOUR k-steps at once: within a group of 8 pixels MFMA m (0..3) takes pixel m as k = 0 (lanes 0..31) and pixel 4 + m as k = 1
+//     (lanes 32..63), so each half-wave reads 4 consecutive pixels (any pairing of pixels with k is a valid order of the sum).
+//   B operand (X): every lane owns one column = (channel, filter row, filter column) and reads the staged rows at its constant offset
+//     + the pixel: four ds_read_b32 with immediate offsets per group (the filter column shifts the alignment, so no wide read);
+//     columns past Cin*k*k read a zeroed row instead of being masked.
+// Everything that depends only on the thread (which float4 of a tile it stages, where it lands in LDS, its validity) is computed ONCE:
+// the first version recomputed that index arithmetic every step - 5-11 vector instructions per MFMA on the training step's layers
+// (tools/pmc_wgrad.sh), and a vector instruction beside the fp32 MFMA costs ~3 matrix cycles.  SEG x RR = 64x2,
+// 32x4 or 16x8 by the map's width: the deep layers' 22- and 11-pixel rows fill a step with more rows instead of padding.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float wg_f4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int XC, int NTC>
+template <int KS, int XC, int NTC, int SEG, int RR>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
                                                             int H, int W, int cin_total, int ci_offset) {
-    // CT column tiles per wave (256 columns per workgroup), RR image rows per staging step.
-    // Staging is register-prefetched: the float4 loads of step s+1 are issued before the MFMAs of step s and written
-    // to LDS after them, so global latency hides under 1024 MFMAs instead of standing between two barriers.
-    constexpr int KS2 = KS * KS, PAD = (KS - 1) / 2, SEG = 64, RR = 2, CT = 2;
-    constexpr int DS = RR * SEG + 1;                 // dZ tile row stride (odd: conflict-free across couts)
+    constexpr int KS2 = KS * KS, PAD = (KS - 1) / 2, CT = 2;
+    static_assert(RR * SEG == 128 && SEG % 8 == 0, "a step stages 128 pixels per cout");
+    constexpr int DS = RR * SEG + 4;                 // dZ tile row stride: 33 quads
     constexpr int XR = KS + RR - 1;                  // staged activation rows
     constexpr int XV = SEG / 4 + 2;                  // float4 per staged row: columns [xs-4, xs+SEG+4)
-    constexpr int RS = 4 * XV + 1;                   // odd row stride
+    constexpr int RS = 4 * XV + 1;                   // odd row stride (the lanes of a B read differ in row and filter column)
     constexpr int NDZ = NTC * 32 * RR * (SEG / 4);   // float4 in a dZ tile
     constexpr int NX = XC * XR * XV;                 // float4 in an activation tile
     constexpr int LDZ = (NDZ + 255) / 256, LX = (NX + 255) / 256;
-    __shared__ float sdz[NTC * 32 * DS];
-    __shared__ float sx[XC * XR * RS + 8];
+    constexpr int ZROW = XC * XR * RS;               // a zeroed row behind the activation tile (columns that do not exist)
+    __shared__ __attribute__((aligned(16))) float sdz[NTC * 32 * DS];
+    __shared__ float sx[ZROW + SEG + 16];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = tid >> 6;
     const int co0 = blockIdx.y * (NTC * 32);
@@ -145,8 +155,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
         cci[t] = cvalid[t] ? col / KS2 : c_lo;
         tap[t] = cvalid[t] ? col - cci[t] * KS2 : 0;
         const int ky = tap[t] / KS, kx = tap[t] - ky * KS;
-        colOff[t] = ((cci[t] - c_lo) * XR + ky) * RS + kx + (4 - PAD) + half;   // + row*RS + pixel = LDS address of this lane's B value
+        // + row*RS + pixel = LDS index of this lane's B value of MFMA 0 of a pixel group (k = half: pixels +0 / +4)
+        colOff[t] = cvalid[t] ? ((cci[t] - c_lo) * XR + ky) * RS + kx + (4 - PAD) + 4 * half : ZROW;
     }
+    for (int i = tid; i < SEG + 16; i += 256) sx[ZROW + i] = 0.f;
     f32x16 acc[NTC][CT];
 #pragma unroll
     for (int n = 0; n < NTC; ++n)
@@ -155,9 +167,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][t][r] = 0.f;
 
+    // ---- what this thread stages, fixed for the whole launch ------------------------------------------------------------------
+    int dzo[LDZ], dzl[LDZ], dzq[LDZ];        // global element offset from the step's (b, y, xs) origin | LDS float index | rr + (4 x4 << 8), -1: nothing
+#pragma unroll
+    for (int i = 0; i < LDZ; ++i) {
+        const int f = tid + 256 * i;
+        const int c = f / (RR * (SEG / 4)), rem = f - c * (RR * (SEG / 4));
+        const int rr = rem / (SEG / 4), x4 = rem - rr * (SEG / 4);
+        const bool ok = f < NDZ && co0 + c < Cout;
+        dzo[i] = (int)((long long)c * dz.sc) + rr * dz.sh + 4 * x4;
+        dzl[i] = c * DS + rr * SEG + 4 * x4;
+        dzq[i] = ok ? (rr | ((4 * x4) << 8)) : -1;
+        if (!(f < NDZ)) dzl[i] = -1;         // (a cout past Cout still gets its zeros written: the tile row exists)
+    }
+    int xo[LX], xl[LX], xq[LX];              // the same for the activation rows; xq = ry, -1: nothing to load (zeros are written)
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+        const int f = tid + 256 * i;
+        const int c = f / (XR * XV), rem = f - c * (XR * XV);
+        const int ry = rem / XV, x4 = rem - ry * XV;
+        const bool ok = f < NX && c_lo + c < Cin;
+        xo[i] = (int)((long long)c * x.sc) + (ry - PAD) * x.sh + 4 * x4 - 4;
+        xl[i] = f < NX ? (c * XR + ry) * RS + 4 * x4 : -1;
+        xq[i] = ok ? ry : -1;
+    }
+    const float *dzb0 = dz.ptr + (long long)co0 * dz.sc;
+    const float *xb0 = x.ptr + (long long)c_lo * x.sc;
+
     const int rgroups = (H + RR - 1) / RR, nseg = (W + SEG - 1) / SEG;
     const int nsteps_total = B * rgroups * nseg;     // staging steps of the whole image batch; this workgroup takes every gridDim.z-th
-    float4 pdz[LDZ], px[LX];
+    wg_f4 pdz[LDZ], px[LX];
     auto decode = [&](int s, int &b, int &y, int &xs) {
         const int rp = s / nseg;
         xs = (s - rp * nseg) * SEG;
@@ -167,56 +206,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
     auto prefetch = [&](int s) {
         int b, y, xs;
         decode(s, b, y, xs);
+        const float *dzb = dzb0 + (long long)b * dz.sb + (long long)y * dz.sh + xs;
+        const float *xb = xb0 + (long long)b * x.sb + (long long)y * x.sh + xs;
 #pragma unroll
         for (int i = 0; i < LDZ; ++i) {
-            const int f = tid + 256 * i;
-            const int c = f / (RR * (SEG / 4)), rem = f - c * (RR * (SEG / 4));
-            const int rr = rem / (SEG / 4), x4 = rem - rr * (SEG / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < NDZ && co0 + c < Cout && y + rr < H && xs + 4 * x4 < W) {
-                v = *reinterpret_cast<const float4 *>(vp(dz, b, co0 + c, y + rr) + xs + 4 * x4);
-                const int left = W - (xs + 4 * x4);        // zero tail: those products vanish
-                if (left < 4) {
-                    if (left < 2) v.y = 0.f;
-                    if (left < 3) v.z = 0.f;
-                    v.w = 0.f;
+            wg_f4 v = {0.f, 0.f, 0.f, 0.f};
+            const int rr = dzq[i] & 255, xq4 = dzq[i] >> 8;
+            const int left = W - xs - xq4;            // pixels of this float4 inside the row
+            if (dzq[i] >= 0 && y + rr < H && left > 0) {
+                v = *reinterpret_cast<const wg_f4 *>(dzb + dzo[i]);
+                if (left < 4) {                       // zero tail: those products vanish
+                    if (left < 2) v[1] = 0.f;
+                    if (left < 3) v[2] = 0.f;
+                    v[3] = 0.f;
                 }
             }
             pdz[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < LX; ++i) {
-            const int f = tid + 256 * i;
-            const int c = f / (XR * XV), rem = f - c * (XR * XV);
-            const int ry = rem / XV, x4 = rem - ry * XV;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            wg_f4 v = {0.f, 0.f, 0.f, 0.f};
             // rows / columns outside the image come from the padded-plane zero frame; columns past the frame only meet zeroed dZ
-            if (f < NX && c_lo + c < Cin && y + ry - PAD < H + PAD)
-                v = *reinterpret_cast<const float4 *>(vp(x, b, c_lo + c, y + ry - PAD) + xs - 4 + 4 * x4);
+            if (xq[i] >= 0 && y + xq[i] - PAD < H + PAD) v = *reinterpret_cast<const wg_f4 *>(xb + xo[i]);
             px[i] = v;
         }
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < LDZ; ++i) {
-            const int f = tid + 256 * i;
-            if (f < NDZ) {
-                const int c = f / (RR * (SEG / 4)), rem = f - c * (RR * (SEG / 4));
-                float *d = sdz + c * DS + 4 * rem;          // rem = rr*(SEG/4) + x4  ->  rr*SEG + 4*x4
-                d[0] = pdz[i].x; d[1] = pdz[i].y; d[2] = pdz[i].z; d[3] = pdz[i].w;
-            }
-        }
+        for (int i = 0; i < LDZ; ++i)
+            if (dzl[i] >= 0) *reinterpret_cast<wg_f4 *>(sdz + dzl[i]) = pdz[i];
 #pragma unroll
-        for (int i = 0; i < LX; ++i) {
-            const int f = tid + 256 * i;
-            if (f < NX) {
-                const int rowi = f / XV, x4 = f - rowi * XV;        // rowi = c*XR + ry
-                float *d = sx + rowi * RS + 4 * x4;
-                d[0] = px[i].x; d[1] = px[i].y; d[2] = px[i].z; d[3] = px[i].w;
+        for (int i = 0; i < LX; ++i)
+            if (xl[i] >= 0) {
+                float *d = sx + xl[i];
+                d[0] = px[i][0];
+                d[1] = px[i][1];
+                d[2] = px[i][2];
+                d[3] = px[i][3];
             }
-        }
     };
 
+    const wg_f4 *sdz4 = reinterpret_cast<const wg_f4 *>(sdz);
+    const int aBase = (l31 * DS) / 4 + half;          // quad index of this lane's A values of pixel group 0 (row n*32 + l31)
     int s = blockIdx.z;
     if (s < nsteps_total) prefetch(s);
     for (; s < nsteps_total; s += gridDim.z) {
@@ -226,21 +257,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
         if (s + (int)gridDim.z < nsteps_total) prefetch(s + gridDim.z);
         int b, y, xs;
         decode(s, b, y, xs);
-        const int wseg = min(SEG, W - xs);
-        const int nsteps = (wseg + 1) >> 1;
+        const int ngrp = (min(SEG, W - xs) + 7) >> 3;          // groups of 8 pixels = 4 MFMA k-steps
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr) {
-            for (int st = 0; st < nsteps; ++st) {
-                const int pp = 2 * st;
-                float bv[CT];
+            const float *bp0 = sx + colOff[0] + rr * RS, *bp1 = sx + colOff[1] + rr * RS;
+            const wg_f4 *ap = sdz4 + aBase + (rr * SEG) / 4;
+            for (int g = 0; g < ngrp; ++g) {
+                wg_f4 av[NTC];
 #pragma unroll
-                for (int t = 0; t < CT; ++t) bv[t] = cvalid[t] ? sx[colOff[t] + rr * RS + pp] : 0.f;
+                for (int n = 0; n < NTC; ++n) av[n] = ap[n * (32 * DS / 4) + 2 * g];
+                float bv[CT][4];
 #pragma unroll
-                for (int n = 0; n < NTC; ++n) {
-                    const float av = sdz[(n * 32 + l31) * DS + rr * SEG + pp + half];
-#pragma unroll
-                    for (int t = 0; t < CT; ++t) acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[n][t], 0, 0, 0);
+                for (int m = 0; m < 4; ++m) {
+                    bv[0][m] = bp0[8 * g + m];
+                    bv[1][m] = bp1[8 * g + m];
                 }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTC; ++n)
+#pragma unroll
+                        for (int t = 0; t < CT; ++t) acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n][m], bv[t][m], acc[n][t], 0, 0, 0);
             }
         }
     }
@@ -830,19 +867,32 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
     const int ntc = Cout > 32 ? 2 : 1;
     const int gx = (Cin * k * k + 255) / 256, gy = (Cout + ntc * 32 - 1) / (ntc * 32);
     const int tiles = gx * gy;
-    int split = (1024 + tiles - 1) / tiles;          // aim for >= 1024 workgroups
-    const int rows = B * ((H + 1) / 2) * ((W + 63) / 64);       // staging steps (2 image rows x 64 pixels)
+    const int seg = W > 32 ? 64 : (W > 16 ? 32 : 16), rr = 128 / seg;       // a step = rr image rows x seg pixels
+    // Workgroups of one launch: at most `target` = one round of two co-resident workgroups per CU (measured per layer of the training
+    // step, tools/bench_wgrad.py with $SSM_WGRAD_TARGET: 512 -> 4.8 ms per step, 768 -> 6.0, 1024 -> 5.5, 1536 -> 6.0; rounding the
+    // split UP, as the first version did, put 1029 workgroups on 1024 slots and a third, almost empty round behind them - and every
+    // extra slice multiplies the atomic adds)
+    static const int target_env = [] {
+        const char *e = getenv("SSM_WGRAD_TARGET");          // tuning knob
+        return e ? atoi(e) : 0;
+    }();
+    const int target = target_env > 0 ? target_env : 512;
+    int split = target / tiles;
+    const int rows = B * ((H + rr - 1) / rr) * ((W + seg - 1) / seg);       // staging steps
     if (split > rows) split = rows;
     if (split < 1) split = 1;
     if (split > 65535) split = 65535;
     const dim3 grid(gx, gy, split);
-#define SSM_WGRAD(KS_, XC_)                                                                                                       \
-    if (ntc == 2)                                                                                                                 \
-        hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, 2>), grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total,  \
-                           ci_offset);                                                                                            \
-    else                                                                                                                          \
-        hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, 1>), grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, cin_total,  \
-                           ci_offset);
+#define SSM_WGRAD_L(KS_, XC_, NTC_, SEG_, RR_)                                                                                       \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, NTC_, SEG_, RR_>), grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, \
+                       cin_total, ci_offset)
+#define SSM_WGRAD_S(KS_, XC_, NTC_)                              \
+    if (seg == 64) SSM_WGRAD_L(KS_, XC_, NTC_, 64, 2);           \
+    else if (seg == 32) SSM_WGRAD_L(KS_, XC_, NTC_, 32, 4);      \
+    else SSM_WGRAD_L(KS_, XC_, NTC_, 16, 8)
+#define SSM_WGRAD(KS_, XC_)                 \
+    if (ntc == 2) { SSM_WGRAD_S(KS_, XC_, 2); } \
+    else { SSM_WGRAD_S(KS_, XC_, 1); }
     switch (k) {          // XC = input channels a 256-column workgroup can touch: ceil((256 + k*k - 1) / (k*k))
         case 3: SSM_WGRAD(3, 30) break;
         case 5: SSM_WGRAD(5, 12) break;
@@ -850,6 +900,8 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
         default: ssm::set_error("wgrad: kernel size %d unsupported", k); return SSM_E_UNSUPPORTED;
     }
 #undef SSM_WGRAD
+#undef SSM_WGRAD_S
+#undef SSM_WGRAD_L
     return ssm::check_launch("ssm_conv2d_wgrad");
 }
 
