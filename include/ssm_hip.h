@@ -417,6 +417,11 @@ int ssm_bias_grad(ssm_view dz, float *db, int B, int C, int H, int W, void *stre
 int ssm_bias_grad_acc(ssm_view dz, float *db, int B, int C, int H, int W, void *stream);
 int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
                      int ci_offset, int zero_first, void *stream);
+/* ssm_conv2d_wgrad that also ACCUMULATES the bias gradient db_acc[co] += sum_{b,y,x} dz (what autograd computes for nn.Conv2d.bias,
+ * scripts/models/layers.py:21-33): the sum over pixels is one more column of the same GEMM (dZ times a row of ones), so the separate
+ * ssm_bias_grad pass over dZ - 48 launches of a training step - disappears.  Call it for ONE of a two-source layer's sources.        */
+int ssm_conv2d_wgrad_bias(ssm_view x, ssm_view dz, float *dw_oihw, float *db_acc, int B, int Cin, int Cout, int H, int W, int k,
+                          int cin_total, int ci_offset, int zero_first, void *stream);
 /* Same contract as ssm_conv2d_wgrad (what autograd computes for nn.Conv2d.weight, scripts/models/layers.py:21-33 trained by
  * scripts/main.py:138-197) on the bf16 matrix cores with split operands: v = bf16(v) + bf16(v - bf16(v)) + r, products
  * hi*hi + hi*lo + lo*hi accumulated in fp32 (dropped terms ~2^-17 relative; no scaling needed, bf16 has fp32's exponent).

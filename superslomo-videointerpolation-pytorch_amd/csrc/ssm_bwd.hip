@@ -126,8 +126,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float wg_f4 __attribute__((ext_vector_type(4)));
 
 template <int KS, int XC, int NTC, int SEG, int RR>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
-                                                            int H, int W, int cin_total, int ci_offset) {
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, float *__restrict__ db, int B,
+                                                            int Cin, int Cout, int H, int W, int cin_total, int ci_offset) {
     constexpr int KS2 = KS * KS, PAD = (KS - 1) / 2, CT = 2;
     static_assert(RR * SEG == 128 && SEG % 8 == 0, "a step stages 128 pixels per cout");
     constexpr int DS = RR * SEG + 4;                 // dZ tile row stride: 33 quads
@@ -138,27 +138,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
     constexpr int NX = XC * XR * XV;                 // float4 in an activation tile
     constexpr int LDZ = (NDZ + 255) / 256, LX = (NX + 255) / 256;
     constexpr int ZROW = XC * XR * RS;               // a zeroed row behind the activation tile (columns that do not exist)
+    constexpr int OROW = ZROW + SEG + 16;            // ... and a row of ones: the column Cin*k*k of the GEMM is the bias gradient (db != null)
     __shared__ __attribute__((aligned(16))) float sdz[NTC * 32 * DS];
-    __shared__ float sx[ZROW + SEG + 16];
+    __shared__ float sx[OROW + SEG + 16];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wid = tid >> 6;
     const int co0 = blockIdx.y * (NTC * 32);
     const int colbase = blockIdx.x * (128 * CT);
     const int ncols = Cin * KS2;
     const int c_lo = colbase / KS2;                  // first input channel this workgroup touches
-    int colOff[CT], cci[CT], tap[CT];
-    bool cvalid[CT];
+    int colOff[CT], cci[CT], tap[CT], rstride[CT];
+    bool cvalid[CT], cbias[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
         const int col = colbase + (wid * CT + t) * 32 + l31;      // this lane's (ci, tap) columns
         cvalid[t] = col < ncols;
+        cbias[t] = db != nullptr && col == ncols;                 // sum_p dZ[co][p] * 1: no extra MFMA, the lane would idle otherwise
         cci[t] = cvalid[t] ? col / KS2 : c_lo;
         tap[t] = cvalid[t] ? col - cci[t] * KS2 : 0;
         const int ky = tap[t] / KS, kx = tap[t] - ky * KS;
         // + row*RS + pixel = LDS index of this lane's B value of MFMA 0 of a pixel group (k = half: pixels +0 / +4)
-        colOff[t] = cvalid[t] ? ((cci[t] - c_lo) * XR + ky) * RS + kx + (4 - PAD) + 4 * half : ZROW;
+        colOff[t] = cvalid[t] ? ((cci[t] - c_lo) * XR + ky) * RS + kx + (4 - PAD) + 4 * half : (cbias[t] ? OROW : ZROW);
+        rstride[t] = cvalid[t] ? RS : 0;
     }
-    for (int i = tid; i < SEG + 16; i += 256) sx[ZROW + i] = 0.f;
+    for (int i = tid; i < SEG + 16; i += 256) {
+        sx[ZROW + i] = 0.f;
+        sx[OROW + i] = 1.f;
+    }
     f32x16 acc[NTC][CT];
 #pragma unroll
     for (int n = 0; n < NTC; ++n)
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
         const int ngrp = (min(SEG, W - xs) + 7) >> 3;          // groups of 8 pixels = 4 MFMA k-steps
 #pragma unroll
         for (int rr = 0; rr < RR; ++rr) {
-            const float *bp0 = sx + colOff[0] + rr * RS, *bp1 = sx + colOff[1] + rr * RS;
+            const float *bp0 = sx + colOff[0] + rr * rstride[0], *bp1 = sx + colOff[1] + rr * rstride[1];
             const wg_f4 *ap = sdz4 + aBase + (rr * SEG) / 4;
             for (int g = 0; g < ngrp; ++g) {
                 wg_f4 av[NTC];
@@ -290,6 +296,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(ssm_view x, ssm_view
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + n * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (co < Cout) atomicAdd(dw + ((long long)co * cin_total + ci_offset + cci[t]) * KS2 + tap[t], acc[n][t][r]);
+                }
+        } else if (cbias[t]) {
+#pragma unroll
+            for (int n = 0; n < NTC; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + n * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < Cout) atomicAdd(db + co, acc[n][t][r]);
                 }
         }
 }
@@ -847,8 +861,8 @@ extern "C" int ssm_bias_grad_acc(ssm_view dz, float *db, int B, int C, int H, in
     return bias_grad_launch(dz, db, B, C, H, W, 0, stream);
 }
 
-extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
-                                int ci_offset, int zero_first, void *stream) {
+static int wgrad_launch(ssm_view x, ssm_view dz, float *dw_oihw, float *db, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
+                        int ci_offset, int zero_first, void *stream) {
     SSM_REQUIRE(x.ptr && dz.ptr && dw_oihw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "wgrad: bad arguments");
     SSM_REQUIRE(ci_offset >= 0 && ci_offset + Cin <= cin_total, "wgrad: channel range [%d,%d) outside the filter's %d inputs", ci_offset,
                 ci_offset + Cin, cin_total);
@@ -865,7 +879,7 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
         }
     }
     const int ntc = Cout > 32 ? 2 : 1;
-    const int gx = (Cin * k * k + 255) / 256, gy = (Cout + ntc * 32 - 1) / (ntc * 32);
+    const int gx = (Cin * k * k + (db ? 1 : 0) + 255) / 256, gy = (Cout + ntc * 32 - 1) / (ntc * 32);
     const int tiles = gx * gy;
     const int seg = W > 32 ? 64 : (W > 16 ? 32 : 16), rr = 128 / seg;       // a step = rr image rows x seg pixels
     // Workgroups of one launch: at most `target` = one round of two co-resident workgroups per CU (measured per layer of the training
@@ -884,7 +898,7 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
     if (split > 65535) split = 65535;
     const dim3 grid(gx, gy, split);
 #define SSM_WGRAD_L(KS_, XC_, NTC_, SEG_, RR_)                                                                                       \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, NTC_, SEG_, RR_>), grid, dim3(256), 0, st, x, dz, dw_oihw, B, Cin, Cout, H, W, \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, NTC_, SEG_, RR_>), grid, dim3(256), 0, st, x, dz, dw_oihw, db, B, Cin, Cout, H, W, \
                        cin_total, ci_offset)
 #define SSM_WGRAD_S(KS_, XC_, NTC_)                              \
     if (seg == 64) SSM_WGRAD_L(KS_, XC_, NTC_, 64, 2);           \
@@ -903,6 +917,17 @@ extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, 
 #undef SSM_WGRAD_S
 #undef SSM_WGRAD_L
     return ssm::check_launch("ssm_conv2d_wgrad");
+}
+
+extern "C" int ssm_conv2d_wgrad(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
+                                int ci_offset, int zero_first, void *stream) {
+    return wgrad_launch(x, dz, dw_oihw, nullptr, B, Cin, Cout, H, W, k, cin_total, ci_offset, zero_first, stream);
+}
+
+extern "C" int ssm_conv2d_wgrad_bias(ssm_view x, ssm_view dz, float *dw_oihw, float *db_acc, int B, int Cin, int Cout, int H, int W, int k,
+                                     int cin_total, int ci_offset, int zero_first, void *stream) {
+    SSM_REQUIRE(db_acc, "wgrad_bias: null bias-gradient pointer");
+    return wgrad_launch(x, dz, dw_oihw, db_acc, B, Cin, Cout, H, W, k, cin_total, ci_offset, zero_first, stream);
 }
 
 extern "C" int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,

@@ -38,12 +38,19 @@ def bias_grad(dz, out, zero_first=True):
     return out
 
 
-def wgrad(x, dz, out, k, ci_offset=0, zero_first=True, split=False):
+def wgrad(x, dz, out, k, ci_offset=0, zero_first=True, split=False, bias_acc=None):
     """out[:, ci_offset:ci_offset+x.C] (OIHW fp32, contiguous) = sum_{b,y,x} dz * x(shifted).
     x, dz: hb.Planes (or slices) of the layer's input / dZ; two-source convs call this once per source.
-    split: the bf16 matrix path with hi/lo-split operands (ssm_conv2d_wgrad_bf16x3) instead of the fp32 one."""
+    split: the bf16 matrix path with hi/lo-split operands (ssm_conv2d_wgrad_bf16x3) instead of the fp32 one.
+    bias_acc (fp32 path): [Cout] tensor that ALSO receives += sum dz - the bias gradient as one more column of the same GEMM
+    (ssm_conv2d_wgrad_bias); pass it with one source of a two-source layer."""
     assert out.is_contiguous() and out.shape[0] == dz.C and out.shape[2] == k and ci_offset + x.C <= out.shape[1]
     lib = hb.load()
+    if bias_acc is not None:
+        assert not split and bias_acc.is_contiguous() and bias_acc.numel() == dz.C and bias_acc.dtype == torch.float32
+        hb.check(lib.ssm_conv2d_wgrad_bias(x.view(), dz.view(), out.data_ptr(), bias_acc.data_ptr(), x.B, x.C, dz.C, x.H, x.W, k,
+                                           out.shape[1], ci_offset, 1 if zero_first else 0, hb.stream_ptr()))
+        return out
     fn = lib.ssm_conv2d_wgrad_bf16x3 if split else lib.ssm_conv2d_wgrad
     hb.check(fn(x.view(), dz.view(), out.data_ptr(), x.B, x.C, dz.C, x.H, x.W, k, out.shape[1],
                 ci_offset, 1 if zero_first else 0, hb.stream_ptr()))
@@ -288,10 +295,13 @@ class UNetGrad:
                 off = 0
                 for sname in srcs:
                     X = self.act(sname)
-                    wgrad(X, dz, self.grads[wk], k, ci_offset=off, zero_first=False, split=self.split_wgrad)
+                    # fp32 path: the bias gradient rides in the first source's GEMM as one more column (no pass of its own over dZ)
+                    wgrad(X, dz, self.grads[wk], k, ci_offset=off, zero_first=False, split=self.split_wgrad,
+                          bias_acc=self.grads[bk] if off == 0 and not self.split_wgrad else None)
                     off += X.C
                 assert off == ci, "%s: inputs cover %d of %d channels" % (name, off, ci)
-                bias_grad(dz, self.grads[bk], zero_first=False)
+                if self.split_wgrad:
+                    bias_grad(dz, self.grads[bk], zero_first=False)
                 if tm is not None:
                     e1.record()
                 self._layer_done(name)

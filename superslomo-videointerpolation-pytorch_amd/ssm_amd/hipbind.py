@@ -111,6 +111,7 @@ SIGNATURES = {
     "ssm_lrelu_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_lrelu_bwd_q8": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_bias_grad": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_conv2d_wgrad_bias": (_c_int, [SsmView, SsmView, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv_plan": (_c_int, [_c_int] * 8 + [ctypes.POINTER(ctypes.c_int)] * 3),
     "ssm_conv_force_kind": (_c_int, [_c_int]),
     "ssm_conv2d_ups_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,

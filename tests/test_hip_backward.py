@@ -20,7 +20,8 @@ def rel_err(got, want):
 
 @pytest.mark.parametrize("k,cin,cout,B,H,W,act", [(7, 6, 32, 2, 16, 40, True), (5, 32, 64, 1, 12, 32, True),
                                                    (3, 64, 32, 2, 9, 33, True), (3, 32, 5, 1, 16, 64, False),
-                                                   (3, 128, 256, 1, 8, 16, True), (3, 64, 32, 1, 70, 130, True)])
+                                                   (3, 128, 256, 1, 8, 16, True), (3, 64, 32, 1, 70, 130, True),
+                                                   (3, 256, 64, 1, 11, 11, True), (5, 64, 64, 2, 22, 22, True)])
 def test_conv_backward(dev, k, cin, cout, B, H, W, act):
     """dX (forward kernel on the transposed filter), dW (wgrad), db, through LeakyReLU', vs autograd."""
     from oracle import ssm_oracle as O
@@ -54,6 +55,11 @@ def test_conv_backward(dev, k, cin, cout, B, H, W, act):
     assert rel_err(dx.cpu(), x.grad) < 2e-4, "dX"
     assert rel_err(dw.cpu(), w.grad) < 2e-4, "dW"
     assert rel_err(db.cpu(), bias.grad) < 2e-4, "db"
+    # the bias gradient as one more column of the weight-gradient GEMM (ssm_conv2d_wgrad_bias), accumulating like the training step
+    dw2, db2 = torch.zeros(cout, cin, k, k, device=dev), torch.full((cout,), 0.25, device=dev)
+    Bk.wgrad(xp, dzp.slice(0, cout), dw2, k, zero_first=False, bias_acc=db2)
+    assert rel_err(dw2.cpu(), w.grad) < 2e-4, "dW (fused bias column)"
+    assert rel_err(db2.cpu() - 0.25, bias.grad) < 2e-4, "db (fused bias column)"
 
 
 @pytest.mark.parametrize("k,cin,cout,B,H,W,gscale", [
