@@ -221,6 +221,7 @@ typedef struct {
     int Cout, Cin, CinP, k, BN, algo, transposed, nbias;
     long long first, total;
 } ssm_pack32_job;
+/* (a thread stores four packed elements: every job's `first` and `total` are multiples of 4 - BN is - and `wp` is 16-byte aligned) */
 int ssm_pack32_weights_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_elements, void *stream);
 
 /* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------

@@ -649,7 +649,9 @@ class PackBatch32:
             j.Cout, j.Cin, j.CinP, j.k, j.BN = pk.cout, pk.cin, pk.cin_p, pk.k, pk.bn
             j.algo, j.transposed, j.nbias = self.ALGO[pk.algo], 1 if transposed else 0, pk.b.numel()
             j.first, j.total = off, pk.w.numel()
-            off += max(pk.w.numel(), pk.b.numel())
+            # the kernel stores 4 packed elements per thread: whole quads per job, 16-byte aligned buffers
+            assert pk.w.numel() % 4 == 0 and pk.bn % 4 == 0 and pk.w.data_ptr() % 16 == 0, "packed filter is not made of whole quads"
+            off += (max(pk.w.numel(), pk.b.numel()) + 3) // 4 * 4
             self.keep.append((pk, w, b))
         self.n, self.total = len(entries), off
         self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
