@@ -13,12 +13,14 @@ for o in "$@"; do
     objcopy -O binary --only-section=.hip_fatbin "$o" $tmp/fat.bin 2>/dev/null || continue
     [ -s $tmp/fat.bin ] || continue                     # host-only object
     $LLVM/clang-offload-bundler --unbundle --type=o --input=$tmp/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$tmp/dev.co
-    n=$($LLVM/llvm-objdump -d $tmp/dev.co | grep -c 'v_pk_[a-z0-9]*_f32' || true)
+    $LLVM/llvm-objdump -d $tmp/dev.co > $tmp/dev.s
+    python3 "$(dirname "$0")/check_hazard.py" "$o" < $tmp/dev.s || bad=1          # VALU-written SGPR -> vector-memory base (see the script)
+    n=$(grep -c 'v_pk_[a-z0-9]*_f32' $tmp/dev.s || true)
     if [ "$n" != "0" ]; then
         echo "check_isa: $o contains $n packed-fp32 instructions (v_pk_*_f32):" >&2
-        $LLVM/llvm-objdump -d $tmp/dev.co | grep 'v_pk_[a-z0-9]*_f32' | head -5 >&2
+        grep 'v_pk_[a-z0-9]*_f32' $tmp/dev.s | head -5 >&2
         bad=1
     fi
 done
-[ $bad = 0 ] && echo "check_isa: no packed-fp32 instructions in $# object(s)"
+[ $bad = 0 ] && echo "check_isa: no packed-fp32 instructions and no scalar-base hazards in $# object(s)"
 exit $bad

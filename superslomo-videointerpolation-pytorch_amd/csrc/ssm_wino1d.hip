@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256, 2) void wino1d_kernel(const W1Params p) {
     }
     const int uoff = lane * 16;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
-
     // k-th DMA instruction of this wave for chunk `ch` into stage `stage`: k < NIU filter group 4k + wave, else raw patch
     auto issue_k = [&](int ch, int stage, int k) {
         const int c0 = ch * CK;
@@ -319,9 +318,24 @@ __global__ __launch_bounds__(256, 2) void wino1d_kernel(const W1Params p) {
             asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
         };
         const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * half) * p.asc + (long long)py * p.ash + px : nullptr;
+        // M = 2: the addend pair of output register r + 4 is fetched at the top of iteration r (the stores below are ordered asm
+        // statements: a load issued behind one cannot move above it, and fetched in its own iteration every addend would wait out its
+        // whole latency - 16 exposed latencies per workgroup, 0.2 ms per pair on stage 2's conv1a)
+        constexpr int AQD = 4;
+        f32x2 addq[M == 2 ? 16 : 1];
+        auto addr_of = [&](int r) { return addb + (long long)(cu0 + (r & 3) + 8 * (r >> 2)) * p.asc; };
+        if constexpr (M == 2) {
+            if (addb && vok) {
+#pragma unroll
+                for (int r = 0; r < AQD; ++r) addq[r] = *(const f32x2 *)addr_of(r);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cu = cu0 + (r & 3) + 8 * (r >> 2);          // uniform; this lane's cout = cu + 4 * half
+            if constexpr (M == 2) {
+                if (addb && vok && r + AQD < 16) addq[r + AQD] = *(const f32x2 *)addr_of(r + AQD);
+            }
             float y[M];
             {
                 const float s12p = acc[1][r] + acc[2][r], s12m = acc[1][r] - acc[2][r];
@@ -340,9 +354,8 @@ __global__ __launch_bounds__(256, 2) void wino1d_kernel(const W1Params p) {
                 const float *ap = addb + (long long)cu * p.asc;
                 if (vok) {
                     if constexpr (M == 2) {
-                        const f32x2 q = *(const f32x2 *)ap;
-                        y[0] += q[0];
-                        y[1] += q[1];
+                        y[0] += addq[r][0];
+                        y[1] += addq[r][1];
                     } else {
                         const f32x4 q = *(const f32x4 *)ap;
                         y[0] += q[0];
