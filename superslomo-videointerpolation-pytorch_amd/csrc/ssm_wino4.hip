@@ -1087,8 +1087,8 @@ __global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
             }
             if (more && !W4ABL(4)) tstep(m, tsrc, tdst);
             // DMA: filter of chunk ch+1 into the other stage, patch of chunk ch+2 into the buffer the transform of chunk ch read
-            if (m >= 9 && (m - 9) % 5 == 0 && !W4ABL(1)) {
-                const int k = (m - 9) / 5;          // 0..5 at slots 9, 14, 19, 24, 29, 34
+            if (m % 4 == 1 && m / 4 < L::NI && !W4ABL(1)) {
+                const int k = m / 4;                // 0..5 at slots 1, 5, 9, 13, 17, 21: early, so that they have landed by the chunk's barrier
                 if (k < L::NIU) {
                     if (more) issue_u(ch + 1, k);
                 } else if (k < L::NI) {
@@ -1171,8 +1171,8 @@ double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W,
         const double per = chunks * 3600.0 + 26000.0;
         return (double)((nwg + 255) / 256) * per;
     }
-    if (ki.pipe) {          // one workgroup per CU: measured ~5400 cycles per chunk (tools/bench_layers_wino.py W4KIND=3), exposed prologue / epilogue
-        const double per = chunks * (5400.0 + (ups ? 300.0 : 0.0)) + 20000.0;
+    if (ki.pipe) {          // 32 couts x 64 tiles, one workgroup per CU (tools/bench_layers_wino.py W4KIND=3): c = 3700 (fused upsample 4600), e = 23 k
+        const double per = chunks * (ups ? 4600.0 : 3700.0) + 23000.0;
         return (double)((nwg + 255) / 256) * per;
     }
     const double per = chunks * (4500.0 + (ups ? 250.0 : 0.0)) + 11000.0;
@@ -1186,8 +1186,9 @@ int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     const int forced = g_force_w4kind.load();
     if (forced >= 0 && forced < NW4KIND) return forced;
     static const int allow_pipe = [] {
-        const char *e = getenv("SSM_WINO4_PIPE");          // the pipelined kinds take part in the automatic choice: off by default - measured
-        return e ? atoi(e) : 0;                            // 8-12 % slower than the 256-thread form on every layer (profiles/r6_*)
+        const char *e = getenv("SSM_WINO4_PIPE");          // the 32-cout pipelined kinds take part in the automatic choice: off by default.  With
+        return e ? atoi(e) : 0;                            // their DMA moved to the early slots they win 3-5 % on the 16-chunk plain layers only
+                                                           // (fuse_conv 0.89 vs 0.94 ms, conv10b 0.44 vs 0.45) and lose on the fused-upsample ones
     }();
     int best = -1;
     double bt = 0.0;
