@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, 
 extern "C" int mfma_valu_launch(int mode, int iters, int blocks, unsigned long long *out, float *sink, void *stream) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void *)mfma_valu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        (void)hipFuncSetAttribute((const void *)mfma_valu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
         attr = true;
     }
     hipLaunchKernelGGL(mfma_valu_kernel, dim3(blocks), dim3(512), 8 * 16384, (hipStream_t)stream, mode, iters, out, sink);
