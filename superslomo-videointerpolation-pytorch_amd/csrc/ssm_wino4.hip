@@ -108,8 +108,11 @@ struct W4Lds {
     static constexpr int NGU = C::USZ / 256;                    // 1-KiB groups of filter per chunk
     static constexpr int NDQ = DSZ / 4;                         // 16-byte pieces of (raw) patch per chunk
     static constexpr int NGP = (NDQ + 63) / 64;
-    static constexpr int NW = C::NW;
-    static constexpr int NIU = (NGU + NW - 1) / NW, NIP = (NGP + NW - 1) / NW, NI = NIU + NIP;   // DMA instructions per wave per chunk
+    // Waves that issue the chunk's LDS-DMA.  512-thread form: only waves 0..3 - the SIMD's issue arbitration favours the older wave of
+    // a pair (w, w + 4), waves 0..3 reach the chunk's barrier ~600 cycles before waves 4..7 (tools/wino4_timeline.py) and would idle
+    // there; with the whole DMA issue on them the pair finishes together.
+    static constexpr int NW = C::NCB == 2 ? 4 : C::NW;
+    static constexpr int NIU = (NGU + NW - 1) / NW, NIP = (NGP + NW - 1) / NW, NI = NIU + NIP;   // DMA instructions per issuing wave per chunk
     static constexpr int NBUF = C::NCB == 2 ? 2 : 1;            // 512-thread form: patch, hi-res patch and V double-buffered (one barrier per chunk)
     static constexpr int UOFF = 0;                              // two filter stages
     static constexpr int DOFF = 2 * C::USZ;                     // the DMA'd patch (plain: lands SHIFT floats in; UPS: the low-res raw patch)
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     int poff[L::NIP];
 #pragma unroll
     for (int i = 0; i < L::NIP; ++i) {
-        const int qq = (i * NW + wid) * 64 + lane;
+        const int qq = (i * L::NW + (wid & (L::NW - 1))) * 64 + lane;
         if (qq < L::NDQ) {
             const int c = qq / (L::DH * L::DW4);
             const int rem = qq - c * (L::DH * L::DW4);
@@ -396,6 +399,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
 
     // k-th DMA instruction of this wave for chunk `ch`: k < NIU filter group 4k + wave into filter stage `stage`, else the patch
     auto issue_k = [&](int ch, int stage, int k, int pbuf = 0) {
+        constexpr int NW = L::NW;          // (the issuing waves)
+        if (NCB == 2 && wid >= NW) return;
         const int c0 = ch * CK;
         if (k < L::NIU) {
             const int g = NW * k + wid;
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     }
     // DMA order of a chunk: the patch pieces first (the transform needs them at the top of the chunk), then the filter pieces (needed
     // only by the matrix phase): the waits are counted - vmcnt(filter pieces of this wave) at the top, vmcnt(0) before the mid barrier
-    static_assert(L::NI <= 9, "one DMA issue slot per frequency group of the matrix loop");
+    static_assert(L::NI <= (NCB == 2 ? 18 : 9), "DMA issue slots of the matrix loop: one per frequency group (two in the 512-thread form)");
     auto issue_n = [&](int ch, int stage, int n) { issue_k(ch, stage, n < L::NIP ? L::NIU + n : n - L::NIP); };
     const bool u_full = wid < L::NGU - NW * (L::NIU - 1);          // this wave brings NIU filter pieces per chunk (else NIU - 1)
     if constexpr (NCB == 1) {
@@ -612,7 +617,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                     slot(4 * g + e);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (e == 1 && g < L::NI) {
+                if constexpr (NCB == 2) {          // two DMA slots per group (behind its second and fourth MFMA)
+                    if ((e == 1 || e == 3) && 2 * g + (e == 3) < L::NI) {
+                        dma(2 * g + (e == 3));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (e == 1 && g < L::NI) {
                     dma(g);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -740,7 +750,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             const float *tsrc = lds + t_src + (st ^ 1) * L::PCAP;
             f32x4 *tdst = (f32x4 *)lds + t_dst + (st ^ 1) * (C::VSZ / 4);
             matrix(st, st, [&](int g) {
-                if (W4ABL(1)) return;
+                if (W4ABL(1) || decltype(HQ)::value != 0) return;          // (HQ = wave >> 2: waves 4..7 issue no DMA)
                 if (g < L::NIU) {
                     if (m1) issue_k(ch + 1, st ^ 1, g, 0);
                 } else if constexpr (UPS) {
