@@ -427,9 +427,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = p.Cin / CK;
-    // Two workgroups share a CU and run the same program: started together they reach their barriers, transform phases and epilogues
-    // together, and nothing overlaps.  The second workgroup of every CU (dispatch order: workgroup i + 256) starts late; all
-    // workgroups of a launch take equally long, so the offset persists through the launch.
+    // Tuning knob ($SSM_WINO4_STAGGER, 256-thread form): the second workgroup of every CU (dispatch order: workgroup i + 256) starts
+    // late, so that the two co-resident workgroups are out of phase.  Measured: no effect (profiles/r6g_w4_stagger_b7.txt) - the two
+    // waves of a SIMD serialise on the issue port whatever their phases are.
     if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
