@@ -1172,13 +1172,13 @@ std::atomic<unsigned long long *> g_w4dbg{nullptr};      // diagnostics (ssm_win
 // / rounds = chunks x c + e per workgroup).  256-thread form: two co-resident workgroups per CU, c = 4500 cycles per chunk of 4 input
 // channels (2 x 36 MFMAs of 32 cycles are 2304 of them), e = 11 k of prologue + epilogue (the other workgroup of the CU covers most of
 // it); whole rounds of 512 workgroups.  64-cout form: one workgroup per CU, c = 3600 for twice the couts, e = 26 k (nothing covers its
-// first loads and its stores), rounds of 256 - the better form from ~20 chunks on.
+// first loads and its stores), rounds of 256 - the better form from ~16 chunks on.
 double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W, int ups) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * (Cout / ki.bn);
     const double chunks = (double)Cin / 4.0;
-    if (ki.bn == 64) {
-        const double per = chunks * 3600.0 + 26000.0;
+    if (ki.bn == 64) {          // (with the DMA issue on waves 0..3: c = 3500, e = 24 k; ahead of the 256-thread form from 16 chunks on)
+        const double per = chunks * 3500.0 + 24000.0;
         return (double)((nwg + 255) / 256) * per;
     }
     if (ki.pipe) {          // 32 couts x 64 tiles, one workgroup per CU (tools/bench_layers_wino.py W4KIND=3): c = 3700 (fused upsample 4600), e = 23 k
