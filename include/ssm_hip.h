@@ -152,7 +152,6 @@ int ssm_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *
  * ssm_wino_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/BN][Cin][4][BN][4] (+ bias padded to BN).          */
 int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK);
 int ssm_wino_force_kind(int kind);       /* tests / tuning only (-1 = automatic); returns the number of configurations */
-int ssm_wino_deep_ring(int on);          /* process-wide: let the 4-stage DMA-ring configurations take part in ssm_wino_plan; returns the old setting */
 size_t ssm_wino_packed_weight_floats(int Cout, int Cin, int BN);
 int ssm_wino_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin,
                           int BN, void *stream);
@@ -174,7 +173,9 @@ int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const fl
  * fp32 a single layer sits ~1e-5 from a float64 evaluation at unit output scale (per-layer bar 5e-5), the pair -> frame path at
  * 736x1280 is unchanged within its fp32 noise (tests/emulate_winograd_f44_precision.py).
  * Cin and the first cat source multiples of 4, Cout a multiple of 32; any H, W (fused upsample: even).
- * ssm_wino4_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/32][Cin][9][32][4] (+ bias).                              */
+ * ssm_wino4_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/32][Cin][9][32][4] (+ bias).
+ * Inputs must be padded planes with SSM_TAIL_SLACK_FLOATS readable floats behind them: a 16-row tile that overshoots the map reads 14
+ * rows past the frame, so row strides beyond (SSM_TAIL_SLACK_FLOATS - 72) / 14 floats (~4.6 K pixels) are refused (SSM_E_UNSUPPORTED). */
 int ssm_wino4_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK);
 int ssm_wino4_preferred(int Cin, int Cout, int B, int H, int W, int ups);   /* 1: modelled faster than F(2x2,3x3) for this problem */
 double ssm_wino_estimate(int Cin, int Cout, int B, int H, int W, int ups);     /* modelled cycles of ssm_wino_conv2d_*_fwd (-1: unsupported) */

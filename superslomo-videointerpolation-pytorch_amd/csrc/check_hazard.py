@@ -28,8 +28,11 @@ for idx, text in enumerate(ins):
     ws = 0
     for j in range(idx - 1, max(idx - 12, -1), -1):
         p = ins[j]
+        if re.match(r"(s_branch|s_setpc|s_swappc|s_endpgm)\b", p):
+            break          # unconditional jump: the code behind it is reached through a label only - its predecessors are not in this listing order
+                           # (a conditional branch is scanned across: the fall-through path is the straight line)
         rf = re.match(r"v_readfirstlane_b32 s(\d+),", p)
-        if rf and int(rf.group(1)) in regs:
+        if rf and regs[0] <= int(rf.group(1)) <= regs[1]:          # any register of the s[lo:hi] operand (a 4-SGPR buffer descriptor too)
             if ws < 5:
                 bad += 1
                 print("check_hazard: %s: `%s` reads s%s %d wait state(s) after `%s`" % (sys.argv[1], text, rf.group(1), ws, p), file=sys.stderr)

@@ -878,14 +878,10 @@ using V32H = WCfg<1, 2, 1, 16, 8, 2>;     //    32    8  32
 using V32G = WCfg<1, 2, 1, 8, 8, 2>;      //    32   16  16
 using V64A = WCfg<2, 1, 1, 32, 4, 2>;     //    64    2  64
 using V64G = WCfg<2, 1, 1, 8, 4, 2>;      //    64    8  16
-// ... with 4-channel chunks in a ring of four stages (DMA lookahead of three chunks = six k-steps instead of three)
-using V32A4 = WCfg<1, 2, 1, 32, 4, 2, 4>;
-using V32H4 = WCfg<1, 2, 1, 16, 4, 2, 4>;
-using V32G4 = WCfg<1, 2, 1, 8, 4, 2, 4>;
 
 #define SSM_WINO_KINDS(X)                                                                                          \
     X(W64A_, W64A) X(W32A_, W32A) X(W128A_, W128A) X(W64G_, W64G) X(W128G_, W128G) X(W64H_, W64H) X(W128H_, W128H) \
-    X(V32A_, V32A) X(V32H_, V32H) X(V32G_, V32G) X(V64A_, V64A) X(V64G_, V64G) X(V32A4_, V32A4) X(V32H4_, V32H4) X(V32G4_, V32G4)
+    X(V32A_, V32A) X(V32H_, V32H) X(V32G_, V32G) X(V64A_, V64A) X(V64G_, V64G)
 
 enum WinoKind {
 #define X(name, cfg) name,
@@ -910,7 +906,6 @@ constexpr WKindInfo kWInfo[NWKIND] = {
 };
 
 std::atomic<int> g_force_wkind{-1};
-std::atomic<int> g_deep_ring{0};       // the 4-stage kinds take part in the automatic choice (ssm_wino_deep_ring; $SSM_WINO_RING=4)
 
 // Estimated duration (cycles) of a launch.  The matrix work of one CU-round is mf = Cin/2 k-steps x 16 MFMAs x 64 cycles: one
 // workgroup of the first form (all 16 frequencies per wave, 256 resident workgroups), or two co-resident workgroups of the second
@@ -942,8 +937,7 @@ int pick_wkind(int Cin, int Cout, int B, int H, int W, int ups) {
         const WKindInfo &ki = kWInfo[i];
         if (ki.bn > 32 && ki.bn / 2 >= ((Cout + 31) / 32) * 32) continue;      // over half of the cout block would be padding
         if (Cin % ki.ck) continue;
-        if (ki.nst > 2 && !g_deep_ring.load()) continue;
-        const double t = estimate_wino(ki, Cin, Cout, B, H, W, ups) * (ki.nst > 2 ? 0.99 : 1.0);
+        const double t = estimate_wino(ki, Cin, Cout, B, H, W, ups);
         if (best < 0 || t < bt * 0.999) {
             best = i;
             bt = t;
@@ -1101,11 +1095,6 @@ extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, in
 extern "C" double ssm_wino_estimate(int Cin, int Cout, int B, int H, int W, int ups) {
     const int kd = (W % 2 == 0 && Cin % 8 == 0) ? pick_wkind(Cin, Cout, B, H, W, ups) : -1;
     return kd < 0 ? -1.0 : estimate_wino(kWInfo[kd], Cin, Cout, B, H, W, ups);
-}
-
-extern "C" int ssm_wino_deep_ring(int on) {
-    const int was = g_deep_ring.exchange(on ? 1 : 0);
-    return was;
 }
 
 extern "C" int ssm_wino_force_kind(int kind) {

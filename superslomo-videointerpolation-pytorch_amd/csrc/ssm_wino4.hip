@@ -27,14 +27,13 @@
 // LDS) arrive by LDS-DMA, one instruction per frequency group INSIDE the matrix loop of the chunk before (a burst at a phase boundary
 // costs ~200 issue cycles a piece, among MFMAs a few tens).
 //
-// Three kernel forms (DESIGN.md 3.2f-g has the measurements behind them):
+// Two kernel forms (DESIGN.md 3.2f-g has the measurements behind them):
 //   wino4_kernel<W4Cfg<.., NCB = 1>>  256 threads, 32 couts x 32 tiles, two workgroups per CU, two barriers per chunk
 //                                     [patch landed] expand, transform [filter landed] matrix loop; single-buffered patch and V.
 //   wino4_kernel<W4Cfg<.., NCB = 2>>  512 threads, 64 couts x 32 tiles, one workgroup per CU: the transform serves twice the MFMAs
 //                                     (a vector instruction beside the fp32 MFMA costs ~3 matrix cycles - tools/mfma_valu_probe.py -
 //                                     so fewer of them per MFMA is the only thing that hides a transform); patch, hi-res patch and V
 //                                     double-buffered, ONE barrier per chunk, the next chunk's transform in the slots of the matrix loop.
-//   wino4p_kernel<W8Cfg>              512 threads, 32 couts x 64 tiles, the first pipelined form (opt-in, $SSM_WINO4_PIPE; slower).
 // Whatever is wave-uniform at run time (which part of a (cin, tile) a thread transforms, whether later chunks exist) selects a
 // straight-line INSTANCE of the loop instead of being tested inside it: a scalar branch in front of an LDS read exposes its latency.
 #include "ssm_common.h"
@@ -815,317 +814,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
 #endif
 }
 
-// =====================================================================================================================================
-// Second form: ONE 512-thread workgroup per CU, software-pipelined.  The in-kernel phase timers of the first form (tools/
-// wino4_phase_probe.py) show where a 32-cout x 32-tile workgroup loses: per chunk of 4 input channels a wave issues 8 LDS-DMA
-// instructions (~150 cycles of issue each) and spends ~1100 cycles in the transform phase, against 1152 cycles of MFMAs - and the two
-// waves of a SIMD cannot hide that from each other.  Here a workgroup owns 32 couts x 64 tiles (8 waves: the filter DMA per MFMA
-// halves), everything is double-buffered in the 160 KiB of LDS (filter 2 x 18 KiB, patch 2 x 22 KiB, V 2 x 36 KiB), and the transform
-// of chunk c+1 - row loads, row pass, column passes, V stores - is spread over the 36 MFMA slots of chunk c, one or two LDS / six
-// vector instructions per slot, next to the operand fetches and the DMA issue: one barrier per chunk, and no phase in which the
-// matrix pipe has nothing queued.  (Fused upsample: the expansion of chunk c+1 keeps its own phase in front of the matrix loop - two
-// barriers per chunk - with the low-res raw patch double-buffered and one hi-res patch.)
-template <int GTX_, int WTY_, int WTX_>
-struct W8Cfg {
-    static constexpr int GTX = GTX_, GTY = 16 / GTX_, WTY = WTY_, WTX = WTX_;
-    static constexpr int CK = 4, BN = 32, NT = 64;
-    static constexpr int NTX = GTX * WTX, NTY = GTY * WTY;
-    static constexpr int TH = 4 * NTY, TW = 4 * NTX;
-    static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;
-    static constexpr int SHIFT = 1;
-    static constexpr int USZ = CK * 9 * BN * 4, PSZ = CK * PH * PW, VSZ = CK * 9 * NT * 4;
-    static constexpr int LH = TH / 2 + 2, LW = TW / 2 + 8, LW4 = LW / 4;
-    static constexpr int RSZ = CK * LH * LW;
-    static constexpr int NPOS = (TH / 2 + 1) * (TW / 2 + 1);
-    static_assert(WTY * WTX == 4 && (GTX == 4 || GTX == 8 || GTX == 16), "four tile groups of 16 tiles");
-    static_assert(USZ % 256 == 0 && NPOS <= 512 && TH <= 16, "filter stage = whole 1-KiB DMA groups; expander: one position per thread");
-};
-
-template <class C, bool UPS>
-struct W8Lds {
-    static constexpr int DSZ = UPS ? C::RSZ : C::PSZ;
-    static constexpr int DH = UPS ? C::LH : C::PH, DW4 = UPS ? C::LW4 : C::PW4;
-    static constexpr int NGU = C::USZ / 256, NDQ = DSZ / 4, NGP = (NDQ + 63) / 64;
-    static constexpr int NIU = (NGU + 7) / 8, NIP = (NGP + 7) / 8, NI = NIU + NIP;      // DMA instructions per wave per chunk
-    static constexpr int DCAP = NGP * 256 + 256;                // one DMA'd (raw) patch buffer
-    static constexpr int UOFF = 0, DOFF = 2 * C::USZ;           // two filter stages, two DMA'd patch buffers
-    static constexpr int HOFF = DOFF + 2 * DCAP;                // UPS: the one expanded hi-res patch
-    static constexpr int VOFF = HOFF + (UPS ? C::PSZ + 4 : 0);  // two transformed patches
-    static constexpr int BYTES = (VOFF + 2 * C::VSZ) * 4;
-    static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0 && DCAP % 4 == 0, "16-byte aligned regions");
-    static_assert(BYTES <= 160 * 1024 && NI <= 6, "LDS budget (one workgroup per CU); DMA issue slots of the matrix loop");
-};
-
-template <class C, bool UPS>
-__global__ __launch_bounds__(512, 2) void wino4p_kernel(const W4Params p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    using L = W8Lds<C, UPS>;
-    constexpr int BN = C::BN, PH = C::PH, PW = C::PW, CK = C::CK, NT = C::NT;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, l15 = lane & 15, q = lane >> 4;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cb = wid & 1, tg = wid >> 1;          // cout half, tile group (0..3) of this wave
-
-    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
-    const int nb = id % p.NB;
-    id /= p.NB;
-    const int tx = id % p.tilesX;
-    id /= p.tilesX;
-    const int ty = id % p.tilesY;
-    const int b = id / p.tilesY;
-    const int x0 = tx * C::TW, y0 = ty * C::TH;
-
-    const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
-    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
-    const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
-    const float *wbase = p.wpk + (long long)nb * p.Cin * (9 * BN * 4);
-
-    int poff[L::NIP];
-#pragma unroll
-    for (int i = 0; i < L::NIP; ++i) {
-        const int qq = (i * 8 + wid) * 64 + lane;
-        if (qq < L::NDQ) {
-            const int c = qq / (L::DH * L::DW4);
-            const int rem = qq - c * (L::DH * L::DW4);
-            const int r = rem / L::DW4;
-            const int j = rem - r * L::DW4;
-            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
-        } else {
-            poff[i] = 0;
-        }
-    }
-    const int uoff = lane * 16;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
-
-    // k-th DMA instruction of this wave: k < NIU filter group 8k + wave of chunk `chu` into filter stage chu & 1; else patch group of
-    // chunk `chp` into patch buffer chp & 1 (the two are issued for different chunks: the patch runs one chunk further ahead)
-    auto issue_u = [&](int chu, int k) {
-        const int g = 8 * k + wid;
-        if (8 * k + 7 < L::NGU || g < L::NGU) {
-            const float *base = wbase + (long long)(chu * CK) * (9 * BN * 4) + g * 256;
-            const unsigned m0v = lds0 + (unsigned)(L::UOFF + (chu & 1) * C::USZ) * 4u + (unsigned)g * 1024u;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff), "s"(base), "s"(m0v) : "memory", "m0");
-        }
-    };
-    auto issue_p = [&](int chp, int kk) {
-        const int g = 8 * kk + wid;
-        if (8 * kk + 7 < L::NGP || g < L::NGP) {
-            const int c0 = chp * CK;
-            const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
-            const unsigned m0v = lds0 + (unsigned)(L::DOFF + (chp & 1) * L::DCAP) * 4u + (unsigned)g * 1024u + (UPS ? 0u : 4u * C::SHIFT);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(poff[kk]), "s"(base), "s"(m0v) : "memory", "m0");
-        }
-    };
-
-    f32x4 acc[36];
-#pragma unroll
-    for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = p.Cin / CK;
-    // prologue: filter of chunk 0, patches of chunks 0 and 1
-#pragma unroll
-    for (int k = 0; k < L::NIU; ++k) issue_u(0, k);
-#pragma unroll
-    for (int k = 0; k < L::NIP; ++k) issue_p(0, k);
-    if (nchunks > 1) {
-#pragma unroll
-        for (int k = 0; k < L::NIP; ++k) issue_p(1, k);
-    }
-    float bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * BN + cb * 16 + 4 * q + r];
-
-    // transform unit of this thread: (cin, tile), column-frequency half thh (wave-uniform)
-    const int thh = wid >> 2;
-    const int tu = tid & 255;
-    const int tcin = tu >> 6, ttile = tu & 63;
-    const int tgx = (ttile & 15) % C::GTX, tgy = (ttile & 15) / C::GTX, tg2 = ttile >> 4;
-    const int tTx = (tg2 % C::WTX) * C::GTX + tgx, tTy = (tg2 / C::WTX) * C::GTY + tgy;
-    const int t_rel = C::SHIFT + (tcin * PH + 4 * tTy) * PW + 4 * tTx + 3;      // floats from the start of a patch buffer (plain: DOFF + buf * DCAP; UPS: HOFF)
-    const int t_dst = (tcin * 9) * NT + ttile;                                  // f32x4 units from the start of a V buffer
-
-    const f32x4 *lds4 = (const f32x4 *)lds;
-    const int aBase = L::UOFF / 4 + q * (9 * BN) + cb * 16 + l15;
-    const int bBase = L::VOFF / 4 + q * (9 * NT) + tg * 16 + l15;
-
-    // fused upsample: low-res raw patch buffer `buf` -> the hi-res patch; one thread = one 2x2 hi-res block position
-    auto expand = [&](int buf) {
-        if constexpr (UPS) {
-            constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, LH = C::LH, LW = C::LW;
-            const float *raw = lds + L::DOFF + buf * L::DCAP;
-            float *hip = lds + L::HOFF;
-            // (the geometry is recomputed per chunk: hoisted out of the loop it would hold ~15 registers across the matrix phase, and
-            // the pipelined loop has none to spare)
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-            if (tl < NPOS) {
-                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
-                const int pi = tl / PRW, pj = tl - pi * PRW;
-                const int i = ly0 + pi, j = lx0 + pj;
-                const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
-                const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
-                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;
-                const float ca = j0 == j1 ? 1.f : 0.25f, cbw = j0 == j1 ? 0.f : 0.75f;
-                const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
-                const int Y = 2 * i + 1, X = 2 * j + 1;
-                const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
-                const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
-                const float *r0 = raw + (i0 - ly0) * LW + 3 - lx0 + j0;
-                const float *r1 = raw + (i1 - ly0) * LW + 3 - lx0 + j0;
-                float *dd = hip + (2 * pi) * PW + 2 * pj + 3 + C::SHIFT;
-                // two channels at a time: the pipelined loop leaves ~40 registers for this phase
-#pragma unroll 1
-                for (int c2 = 0; c2 < CK; c2 += 2) {
-                    float v00[2], v01[2], v10[2], v11[2];
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        v00[cc] = r0[(c2 + cc) * LH * LW];
-                        v01[cc] = r0[(c2 + cc) * LH * LW + 1];
-                        v10[cc] = r1[(c2 + cc) * LH * LW];
-                        v11[cc] = r1[(c2 + cc) * LH * LW + 1];
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        const float h00 = xa * v00[cc] + xb * v01[cc], h01 = ca * v00[cc] + cbw * v01[cc];
-                        const float h10 = xa * v10[cc] + xb * v11[cc], h11 = ca * v10[cc] + cbw * v11[cc];
-                        dd[(c2 + cc) * PH * PW] = m00 * (ya * h00 + yb * h10);
-                        dd[(c2 + cc) * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
-                        dd[(c2 + cc) * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
-                        dd[(c2 + cc) * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    };
-
-    // The transform of one (cin, tile, half) as 36 micro-steps, so that the matrix loop can place one behind every MFMA:
-    //   steps 0..5   load patch row i (one ds_read_b128 + one ds_read_b64)
-    //   steps 2..7   row pass of row i - 2 (its load is two MFMAs + their slots old; three rows in flight = 18 registers)
-    //   steps 8..25  the three column passes, six steps each
-    //   steps 26..30 the five V stores
-    // (the column-frequency half is wave-uniform: the whole pipelined loop is instantiated per half, so that no step carries a branch)
-    auto pipeline = [&](auto HH) __attribute__((always_inline)) {
-    constexpr int hh = decltype(HH)::value;
-    float trow[6][6], tX[6][3], tv[18];
-    auto tstep = [&](int m, const float *src, f32x4 *dst) __attribute__((always_inline)) {
-        if (m < 6) {
-            const f32x4 a4 = *(const f32x4 *)(src + m * PW);
-            const f32x2 a2 = *(const f32x2 *)(src + m * PW + 4);
-            trow[m][0] = a4[0];
-            trow[m][1] = a4[1];
-            trow[m][2] = a4[2];
-            trow[m][3] = a4[3];
-            trow[m][4] = a2[0];
-            trow[m][5] = a2[1];
-        }
-        if (m >= 2 && m < 8) {
-            const int i = m - 2;
-            w4_row_pass(hh, trow[i], tX[i]);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(tX[i][j]));
-        }
-        if (m >= 8 && m < 26) {
-            const int jj = (m - 8) / 6, st = (m - 8) % 6;
-            const float x0v = tX[0][jj], x1v = tX[1][jj], x2v = tX[2][jj], x3v = tX[3][jj], x4v = tX[4][jj], x5v = tX[5][jj];
-            // (te, to, ue, uo are recomputed in the step that consumes them: two operations per step either way)
-            if (st == 0) tv[jj] = (kP0 * x0v - kS2 * x2v) + x4v;
-            if (st == 1) {
-                const float te = x4v - kB2 * x2v, to = x3v - kB2 * x1v;
-                tv[3 + jj] = te + kA * to;
-                tv[6 + jj] = te - kA * to;
-            }
-            if (st == 2) {
-                const float ue = x4v - kA2 * x2v, uo = x3v - kA2 * x1v;
-                tv[9 + jj] = ue + kB * uo;
-                tv[12 + jj] = ue - kB * uo;
-            }
-            if (st == 3) tv[15 + jj] = (kP0 * x1v - kS2 * x3v) + x5v;
-            if (st == 5) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(tv[3 * i + jj]));
-            }
-        }
-        if (m >= 26 && m < 31) {
-            const int g = m - 26;          // hh = 0: quads 0..3 then the low half of quad 4; hh = 1: the high half of quad 4 then quads 5..8
-            if constexpr (hh == 0) {
-                if (g < 4) dst[g * NT] = f32x4{tv[4 * g], tv[4 * g + 1], tv[4 * g + 2], tv[4 * g + 3]};
-                else *(f32x2 *)(dst + 4 * NT) = f32x2{tv[16], tv[17]};
-            } else {
-                if (g == 0) *((f32x2 *)(dst + 4 * NT) + 1) = f32x2{tv[0], tv[1]};
-                else dst[(4 + g) * NT] = f32x4{tv[4 * g - 2], tv[4 * g - 1], tv[4 * g], tv[4 * g + 1]};
-            }
-        }
-    };
-
-    // chunk 0: wait for its DMAs, expand (UPS), transform without overlap
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    expand(0);
-    {
-        const float *src = lds + (UPS ? L::HOFF : L::DOFF) + t_rel;
-        f32x4 *dst = (f32x4 *)lds + L::VOFF / 4 + t_dst;
-#pragma unroll
-        for (int m = 0; m < 31; ++m) tstep(m, src, dst);
-    }
-
-    f32x4 a[2], bq[2];
-    // one chunk; MORE / MORE2: chunks ch+1 / ch+2 exist (compile-time: the steady state carries no per-slot branch)
-    auto chunk = [&](int ch, auto MORE, auto MORE2) __attribute__((always_inline)) {
-        constexpr bool more = decltype(MORE)::value, more2 = decltype(MORE2)::value;
-        const int st = ch & 1;
-        // U(ch) and the patch of chunk ch+1 have landed (this wave's share); V(ch) is complete and every wave is done with chunk ch-1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if constexpr (UPS) {
-            if (more) expand(st ^ 1);          // raw patch of chunk ch+1 -> hi-res patch (the transform of chunk ch has finished with it)
-        }
-        const float *tsrc = lds + (UPS ? L::HOFF : L::DOFF + (st ^ 1) * L::DCAP) + t_rel;
-        f32x4 *tdst = (f32x4 *)lds + L::VOFF / 4 + (st ^ 1) * (C::VSZ / 4) + t_dst;
-        const int ai = aBase + st * (C::USZ / 4), bi = bBase + st * (C::VSZ / 4);
-        a[0] = lds4[ai];
-        bq[0] = lds4[bi];
-#pragma unroll
-        for (int m = 0; m < 36; ++m) {
-            const int g = m >> 2, e = m & 3, cur = g & 1;
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[m], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (e == 0 && g + 1 < 9) {          // operands of the next group: a whole group (128 cycles) + this slot's work ahead of their use
-                a[cur ^ 1] = lds4[ai + (g + 1) * BN];
-                bq[cur ^ 1] = lds4[bi + (g + 1) * NT];
-            }
-            if (more && !W4ABL(4)) tstep(m, tsrc, tdst);
-            // DMA: filter of chunk ch+1 into the other stage, patch of chunk ch+2 into the buffer the transform of chunk ch read
-            if (m % 4 == 1 && m / 4 < L::NI && !W4ABL(1)) {
-                const int k = m / 4;                // 0..5 at slots 1, 5, 9, 13, 17, 21: early, so that they have landed by the chunk's barrier
-                if (k < L::NIU) {
-                    if (more) issue_u(ch + 1, k);
-                } else if (k < L::NI) {
-                    if (more2) issue_p(ch + 2, k - L::NIU);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    int ch = 0;
-    for (; ch + 2 < nchunks; ++ch) chunk(ch, std::true_type{}, std::true_type{});
-    if (ch + 1 < nchunks) chunk(ch++, std::true_type{}, std::false_type{});
-    chunk(ch, std::false_type{}, std::false_type{});
-    };
-    if (thh == 0) pipeline(std::integral_constant<int, 0>{});
-    else pipeline(std::integral_constant<int, 1>{});
-
-#ifdef SSM_WINO_ABLATE
-    if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
-#endif
-    {
-        const int gx = l15 % C::GTX, gy = l15 / C::GTX;
-        const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
-        w4_epilogue(p, acc, bv, b, nb * BN + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
-    }
-}
-
 // ---- tile configurations ---------------------------------------------------------------------------------------------------------
 //                     GTX WTY WTX          tiles of 4x4 px     TH   TW
 using X4A = W4Cfg<8, 2, 1>;      //          8 x 4                16   32
@@ -1134,39 +822,34 @@ using X4C = W4Cfg<4, 1, 2>;      //          8 x 4 (4x4 groups)   16   32
 // (row tiles stay <= 16: a tile that overshoots the map reads TH - 2 rows past the plane's frame, which the 64 Ki floats of slack behind
 // every tensor cover up to 4K-wide planes)
 
-// pipelined form: 32 couts x 64 tiles per workgroup of 8 waves
-//                     GTX WTY WTX          tiles of 4x4 px     TH   TW
-using P8A = W8Cfg<8, 2, 2>;      //         16 x 4                16   64
-using P8B = W8Cfg<16, 4, 1>;     //         16 x 4 (16x1 groups)  16   64
-using P8C = W8Cfg<4, 1, 4>;      //         16 x 4 (4x4 groups)   16   64
-
 // 64 couts x 32 tiles per workgroup of 8 waves (same tile shapes as X4*)
 using Y4A = W4Cfg<8, 2, 1, 2>;
 using Y4B = W4Cfg<16, 2, 1, 2>;
 using Y4C = W4Cfg<4, 1, 2, 2>;
 
-#define SSM_W4_KINDS(X) \
-    X(X4A_, X4A, 0) X(X4B_, X4B, 0) X(X4C_, X4C, 0) X(P8A_, P8A, 1) X(P8B_, P8B, 1) X(P8C_, P8C, 1) X(Y4A_, Y4A, 0) X(Y4B_, Y4B, 0) X(Y4C_, Y4C, 0)
+#define SSM_W4_KINDS(X) X(X4A_, X4A) X(X4B_, X4B) X(X4C_, X4C) X(Y4A_, Y4A) X(Y4B_, Y4B) X(Y4C_, Y4C)
 
 enum W4Kind {
-#define X(name, cfg, pipe) name,
+#define X(name, cfg) name,
     SSM_W4_KINDS(X)
 #undef X
         NW4KIND
 };
 
 struct W4KindInfo {
-    int th, tw, pipe, bn;
+    int th, tw, bn;
 };
 
 constexpr W4KindInfo kW4Info[NW4KIND] = {
-#define X(name, cfg, pipe) W4KindInfo{cfg::TH, cfg::TW, pipe, cfg::BN},
+#define X(name, cfg) W4KindInfo{cfg::TH, cfg::TW, cfg::BN},
     SSM_W4_KINDS(X)
 #undef X
 };
 
 std::atomic<int> g_force_w4kind{-1};
-std::atomic<unsigned long long *> g_w4dbg{nullptr};      // diagnostics (ssm_wino4_debug_buffer)
+#if defined(SSM_WINO_ABLATE) || defined(W4_TRACE)
+std::atomic<unsigned long long *> g_w4dbg{nullptr};      // diagnostics builds only (ssm_wino4_debug_buffer; `make wabl` / `make wtrace`)
+#endif
 
 // Estimated duration (cycles) of a launch, fitted to tools/bench_layers_wino.py at batch 7 (profiles/r7b_wino4_layers_b7.txt: time x clock
 // / rounds = chunks x c + e per workgroup).  256-thread form: two co-resident workgroups per CU, c = 4500 cycles per chunk of 4 input
@@ -1181,10 +864,6 @@ double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W,
         const double per = chunks * 3500.0 + 24000.0;
         return (double)((nwg + 255) / 256) * per;
     }
-    if (ki.pipe) {          // 32 couts x 64 tiles, one workgroup per CU (tools/bench_layers_wino.py W4KIND=3): c = 3700 (fused upsample 4600), e = 23 k
-        const double per = chunks * (ups ? 4600.0 : 3700.0) + 23000.0;
-        return (double)((nwg + 255) / 256) * per;
-    }
     const double per = chunks * (4500.0 + (ups ? 250.0 : 0.0)) + 11000.0;
     const long long full = nwg / 512, rem = nwg % 512;
     double t = (double)full * per;
@@ -1195,11 +874,6 @@ double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W,
 int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     const int forced = g_force_w4kind.load();
     if (forced >= 0 && forced < NW4KIND) return forced;
-    static const int allow_pipe = [] {
-        const char *e = getenv("SSM_WINO4_PIPE");          // the 32-cout pipelined kinds take part in the automatic choice: off by default.  With
-        return e ? atoi(e) : 0;                            // their DMA moved to the early slots they win 3-5 % on the 16-chunk plain layers only
-                                                           // (fuse_conv 0.89 vs 0.94 ms, conv10b 0.44 vs 0.45) and lose on the fused-upsample ones
-    }();
     int best = -1;
     double bt = 0.0;
     static const int allow_wide = [] {
@@ -1207,7 +881,6 @@ int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
         return e ? atoi(e) : 1;
     }();
     for (int i = 0; i < NW4KIND; ++i) {
-        if (kW4Info[i].pipe && !allow_pipe) continue;
         if (kW4Info[i].bn == 64 && (!allow_wide || Cout % 64)) continue;
         const double t = estimate_w4(kW4Info[i], Cin, Cout, B, H, W, ups);
         if (best < 0 || t < bt * 0.999) {
@@ -1218,7 +891,7 @@ int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     return best;
 }
 
-template <class C, bool UPS, int PIPE>
+template <class C, bool UPS>
 int w4launch(W4Params &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
@@ -1227,22 +900,25 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
         return SSM_E_UNSUPPORTED;
     }
     p.NB = p.Cout / C::BN;
+    // The patch DMA is not predicated in y: a tile that overshoots the map reads up to TH - 2 rows (fused upsample: TH / 2 - 1 low-res
+    // rows) past the plane's frame, into the SSM_TAIL_SLACK_FLOATS every conv input carries (include/ssm_hip.h).  Rows wider than ~4K
+    // floats outgrow that slack: refuse them here instead of reading out of bounds (the plan then keeps the layer on F(2x2,3x3)).
+    {
+        const long long over = (long long)(UPS ? C::TH / 2 - 1 : C::TH - 2) * p.sh + (UPS ? C::TW / 2 : C::TW) + 8;
+        if (over > SSM_TAIL_SLACK_FLOATS) {
+            ssm::set_error("wino4 conv: row stride %d: a %d-row tile overshoot reads %lld floats past the plane (slack %d)", p.sh, C::TH, over,
+                           SSM_TAIL_SLACK_FLOATS);
+            return SSM_E_UNSUPPORTED;
+        }
+    }
     const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("wino4 conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
-    void (*kern)(const W4Params);
-    int lds_bytes, threads;
-    if constexpr (PIPE) {
-        kern = wino4p_kernel<C, UPS>;
-        lds_bytes = W8Lds<C, UPS>::BYTES;
-        threads = 512;
-    } else {
-        kern = wino4_kernel<C, UPS>;
-        lds_bytes = W4Lds<C, UPS>::BYTES;
-        threads = C::THREADS;
-    }
+    void (*kern)(const W4Params) = wino4_kernel<C, UPS>;
+    int lds_bytes = W4Lds<C, UPS>::BYTES;
+    const int threads = C::THREADS;
 #ifdef W4_TRACE
     lds_bytes += 4096;
 #endif
@@ -1264,8 +940,8 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
 template <bool UPS>
 int w4dispatch(int kind, W4Params &p, int B, hipStream_t st) {
     switch (kind) {
-#define X(name, cfg, pipe) \
-    case name: return w4launch<cfg, UPS, pipe>(p, B, st);
+#define X(name, cfg) \
+    case name: return w4launch<cfg, UPS>(p, B, st);
         SSM_W4_KINDS(X)
 #undef X
     }
@@ -1358,7 +1034,11 @@ int w4fill(W4Params &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w
 #ifdef SSM_WINO_ABLATE
     if (const char *e = getenv("SSM_WINO4_ABL")) p.abl = atoi(e);
 #endif
+#if defined(SSM_WINO_ABLATE) || defined(W4_TRACE)
     p.dbg = g_w4dbg.load();
+#else
+    p.dbg = nullptr;
+#endif
     static const int stagger = [] {
         const char *e = getenv("SSM_WINO4_STAGGER");
         return e ? atoi(e) : 0;
@@ -1399,11 +1079,14 @@ extern "C" int ssm_wino4_plan(int Cin, int Cout, int B, int H, int W, int ups, i
     return SSM_OK;
 }
 
-// diagnostics only (not in include/ssm_hip.h): 7 device counters that the ablation build fills when $SSM_WINO4_ABL has bit 32 set
+#if defined(SSM_WINO_ABLATE) || defined(W4_TRACE)
+// diagnostics builds only (tools/wabl_libssm_hip.so, tools/w4trace_libssm_hip.so - never lib/libssm_hip.so, whose exports are exactly
+// include/ssm_hip.h): 7 device counters that the ablation build fills when $SSM_WINO4_ABL has bit 32 set / the wave timeline
 extern "C" int ssm_wino4_debug_buffer(unsigned long long *dev_counters) {
     g_w4dbg.store(dev_counters);
     return SSM_OK;
 }
+#endif
 
 // 1 when the plan should run this 3x3 layer as F(4x4,3x3) rather than F(2x2,3x3).  Measured per layer at 736x1280, batch 7
 // (tools/bench_layers_wino.py, W4=1 against the default): F(4x4) is 5-35 % faster everywhere except on the 23x40 maps (32 tiles of 16
@@ -1412,6 +1095,7 @@ extern "C" int ssm_wino4_debug_buffer(unsigned long long *dev_counters) {
 extern "C" int ssm_wino4_preferred(int Cin, int Cout, int B, int H, int W, int ups) {
     if (Cin % 4 || Cout % 32 || Cin <= 0 || Cout <= 0) return 0;
     if ((long long)H * W < 2048) return 0;
+    if (14LL * ((ups ? W / 2 : W) + 2 * SSM_PADX + 4) + 72 > SSM_TAIL_SLACK_FLOATS) return 0;      // tile overshoot would outrun the input's tail slack (w4launch refuses it)
     return 1;
 }
 

@@ -60,7 +60,6 @@ SIGNATURES = {
                                              _c_int, _c_float, _c_int, _vp]),
     "ssm_wino_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino_force_kind": (_c_int, [_c_int]),
-    "ssm_wino_deep_ring": (_c_int, [_c_int]),
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "ssm_pack32_weights_batch": (_c_int, [_vp, _c_int, ctypes.c_longlong, _vp]),
@@ -169,8 +168,6 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if os.environ.get("SSM_WINO_RING") == "4":       # the 4-stage DMA-ring Winograd configurations join the automatic plan
-            lib.ssm_wino_deep_ring(1)
         _lib = lib
     return _lib
 

@@ -34,3 +34,18 @@ def test_scalar_alu_written_base_passes():
     r = run("\ts_add_u32 s4, s4, s6                                       // 0: 80040604\n"
             "\tglobal_store_dword v1, v2, s[4:5]                          // 4: DC708000 00040201\n")
     assert r.returncode == 0, r.stderr
+
+
+def test_middle_register_of_a_descriptor_is_flagged():
+    """A v_readfirstlane into a MIDDLE register of a 4-SGPR buffer descriptor s[8:11] (the scanner once tested the two end registers only)."""
+    r = run("\tv_readfirstlane_b32 s9, v3                                 // 0: 7E120503\n"
+            "\tbuffer_load_dwordx4 v[4:7], v1, s[8:11], 0 offen lds        // 4: E05D1000 80020401\n")
+    assert r.returncode == 1 and "reads s9" in r.stderr, r.stderr
+
+
+def test_scan_stops_at_an_unconditional_branch_but_crosses_a_conditional_one():
+    base = ("\tv_readfirstlane_b32 s4, v170                               // 0: 7E0805AA\n"
+            "%s"
+            "\tglobal_store_dword v1, v2, s[4:5]                          // 8: DC708000 00040201\n")
+    assert run(base % "\ts_cbranch_scc0 12                                           // 4: BF84000C\n").returncode == 1
+    assert run(base % "\ts_branch 12                                                 // 4: BF82000C\n").returncode == 0

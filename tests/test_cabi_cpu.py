@@ -28,6 +28,16 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert lib.ssm_abi_version() == 1
 
 
+def test_exported_symbols_are_exactly_the_header():
+    """`nm -D` of the product library == include/ssm_hip.h, both ways: no diagnostics hook or undeclared entry point in the shipped ABI
+    (r3: ssm_wino4_debug_buffer was exported and undeclared; it now exists in the `make wabl` / `make wtrace` builds only)."""
+    import subprocess
+    from ssm_amd import hipbind as hb
+    out = subprocess.run(["nm", "-D", "--defined-only", hb.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("ssm_"))
+    assert exported == declared_symbols(), (sorted(set(exported) - set(declared_symbols())), sorted(set(declared_symbols()) - set(exported)))
+
+
 def test_plane_dims_and_conv_config():
     from ssm_amd import hipbind as hb
     lib = hb.load()

@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["W64A", "W32A", "W128A", "W64G", "W128G", "W64H", "W128H", "V32A", "V32H", "V32G", "V64A", "V64G", "V32A4", "V32H4", "V32G4"]
+KINDS = ["W64A", "W32A", "W128A", "W64G", "W128G", "W64H", "W128H", "V32A", "V32H", "V32G", "V64A", "V64G"]
 
 
 @pytest.fixture(scope="module")

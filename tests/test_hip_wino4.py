@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["X4A", "X4B", "X4C", "P8A", "P8B", "P8C", "Y4A", "Y4B", "Y4C"]      # P8*: the software-pipelined 512-thread form; Y4*: 64 couts per workgroup
+KINDS = ["X4A", "X4B", "X4C", "Y4A", "Y4B", "Y4C"]      # X4*: 32 couts per workgroup (256 threads); Y4*: 64 couts per workgroup (512 threads)
 
 
 @pytest.fixture(scope="module")
