@@ -208,13 +208,31 @@ int ssm_wino1d_pack_weights(const float *w_oihw, const float *bias, float *w_pac
 int ssm_wino1d_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const float *bias_packed, ssm_view y, ssm_view pool,
                               ssm_view add, int add_div, int B, int H, int W, int Cout, int k, float slope, int flags, void *stream);
 
+/* ---- the 7x7 convolutions as a blocked two-dimensional Winograd form, all arithmetic fp32 (v_mfma_f32_16x16x4_f32) ----------
+ * Same operator and operand layout as ssm_wino1d_conv2d_add_fwd for k = 7 (layers.conv, scripts/models/layers.py:21-33; conv1a /
+ * conv1b of both U-Nets, scripts/models/flow_computation.py:36-45 and flow_interpolation.py:36-45; fused 2x2 mean, layers.py:60-63;
+ * pre-activation addend for the hoisted part of stage 2's conv1a).  The 7x7 filter (zero-padded to 8x8) is 2x2 blocks of 4x4 taps;
+ * each block is a F(4x4,4x4) Winograd filter over the seven points {0, +-1, +-1/2, +-2}, and because the blocks of a 4x4 output tile
+ * read input windows that are whole tiles apart, one input transform per window position serves all four: 4 x 49 multiplies per 16
+ * outputs and (cin, cout) = 12.25 per output against 28 for F(2,7) and 49 for the direct form (csrc/ssm_wino7.hip).
+ * In fp32 the result differs from the direct form by rounding only (a 32-channel layer: 2e-6 rms / 3e-5 max at unit output scale).
+ * One input source, any Cin >= 1 (a k-step is the four blocks of one channel: no channel padding); Cout a multiple of 32.
+ * Inputs are padded planes with SSM_TAIL_SLACK_FLOATS readable floats behind them (tile overshoot; refused if it would outrun them).
+ * ssm_wino7_pack_weights: OIHW fp32 7x7 filter -> U_b = G g_b G^T as [Cout/32][Cin][14 quads][4 blocks][32][4] (+ bias).            */
+int ssm_wino7_plan(int Cin, int Cout, int B, int H, int W, int *kind);
+int ssm_wino7_force_kind(int kind);      /* tests / tuning only (-1 = automatic); returns the number of configurations */
+size_t ssm_wino7_packed_weight_floats(int Cout, int Cin);
+int ssm_wino7_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin, void *stream);
+int ssm_wino7_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const float *bias_packed, ssm_view y, ssm_view pool,
+                             ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+
 /* ---- every fp32 filter of a U-Net repacked by one launch (training: the parameters change each optimizer step) ------------
  * A job = one convolution's OIHW parameter -> its packed form (algo: the per-layer pack entry point it replaces, same arithmetic,
  * same layout).  transposed: pack the DATA-GRADIENT filter of the forward parameter, W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx]
  * (the adjoint of layers.conv, scripts/models/layers.py:21-33, is the same convolution on it), read straight from the forward
  * tensor; Cout / Cin are then the data-gradient convolution's (Cout = the forward layer's input channels), bias NULL = zeros.
  * first = sum of max(total, nbias) over the preceding jobs.                                                                   */
-enum { SSM_PACK_DIRECT = 0, SSM_PACK_WINO = 1, SSM_PACK_WINO1D = 2, SSM_PACK_WINO4 = 3 };
+enum { SSM_PACK_DIRECT = 0, SSM_PACK_WINO = 1, SSM_PACK_WINO1D = 2, SSM_PACK_WINO4 = 3, SSM_PACK_WINO7 = 4 };
 typedef struct {
     const float *w;      /* OIHW parameter */
     const float *bias;   /* or NULL */

@@ -78,6 +78,11 @@ WINO_SKIP = frozenset(n for n in os.environ.get("SSM_WINO_SKIP", "").split(",") 
 WINO1D = os.environ.get("SSM_WINO1D", "57")
 
 
+# 7x7 layers of an f32w inference plan as 2x2 blocks of F(4x4,4x4) (csrc/ssm_wino7.hip: 12.25 multiplies per output instead of F(2,7)'s 28);
+# $SSM_WINO7=0 keeps them on the 1-D form
+WINO7 = os.environ.get("SSM_WINO7", "1")
+
+
 # 3x3 layers of an f32w plan as F(4x4,3x3) (csrc/ssm_wino4.hip) instead of F(2x2,3x3): $SSM_WINO4=0 keeps F(2x2); a comma list names layers
 WINO4 = os.environ.get("SSM_WINO4", "1")
 
@@ -100,11 +105,13 @@ def wino1d_enabled(k):
 
 def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d, wino4=None):
     """Algorithm of one convolution of an fp32 plan: "direct" (csrc/ssm_conv.hip), "wino" = F(2x2,3x3) (ssm_wino.hip), "wino4" =
-    F(4x4,3x3) (ssm_wino4.hip), "wino1d" = F(2,7) / F(4,5) along x (ssm_wino1d.hip).  wino: the plan is mode f32w; wino1d: it is an
+    F(4x4,3x3) (ssm_wino4.hip), "wino1d" = F(2,7) / F(4,5) along x (ssm_wino1d.hip), "wino7" = the 7x7 layers as 2x2 blocks of F(4x4,4x4) (ssm_wino7.hip).  wino: the plan is mode f32w; wino1d: it is an
     inference plan (the 8-frequency forms stay out of the training plans).  Pure function of the problem: bench.py uses it to count the
     multiply-adds the matrix cores issue."""
     skip = name in WINO_SKIP or "all" in WINO_SKIP or name == "final_conv"
     wino4 = wino1d if wino4 is None else wino4
+    if wino1d and not skip and k == 7 and WINO7 not in ("0", "") and hb.wino7_supported(ci, co, h, w, k):
+        return "wino7"
     if wino1d and not skip and wino1d_enabled(k) and hb.wino1d_supported(ci, co, h, w, k):
         return "wino1d"
     if wino and not skip and hb.wino_supported(ci, co, h, w, k):
@@ -115,14 +122,17 @@ def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d, wino4=None):
     return "direct"
 
 
-_ALGO_CLASS = {"direct": lambda: hb.PackedConv, "wino": lambda: hb.PackedWino, "wino4": lambda: hb.PackedWino4, "wino1d": lambda: hb.PackedWino1d}
+_ALGO_CLASS = {"direct": lambda: hb.PackedConv, "wino": lambda: hb.PackedWino, "wino4": lambda: hb.PackedWino4, "wino1d": lambda: hb.PackedWino1d,
+               "wino7": lambda: hb.PackedWino7}
 # multiply-adds issued on the matrix cores per direct-form multiply-add, by algorithm and kernel size
 ISSUED_FACTOR = {"direct": lambda k: 1.0, "wino": lambda k: 16.0 / 36.0, "wino4": lambda k: 36.0 / 144.0,
-                 "wino1d": lambda k: 8.0 / 14.0 if k == 7 else 8.0 / 20.0}
+                 "wino1d": lambda k: 8.0 / 14.0 if k == 7 else 8.0 / 20.0, "wino7": lambda k: 196.0 / 784.0}
 
 
 def conv_fn(pk, ups=False):
     """The launcher that goes with a packed filter's algorithm."""
+    if pk.algo == "wino7":
+        return hb.conv2d_wino7
     if pk.algo == "wino1d":
         return hb.conv2d_wino1d
     if pk.algo == "wino4":

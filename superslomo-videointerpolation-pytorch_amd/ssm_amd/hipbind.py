@@ -79,6 +79,12 @@ SIGNATURES = {
     "ssm_wino1d_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_wino1d_conv2d_add_fwd": (_c_int, [SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int,
                                            _c_int, _c_float, _c_int, _vp]),
+    "ssm_wino7_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _ip]),
+    "ssm_wino7_force_kind": (_c_int, [_c_int]),
+    "ssm_wino7_packed_weight_floats": (_sz, [_c_int, _c_int]),
+    "ssm_wino7_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _vp]),
+    "ssm_wino7_conv2d_add_fwd": (_c_int, [SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                          _c_float, _c_int, _vp]),
     "ssm_wino_conv2d_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int,
                                      _c_float, _c_int, _vp]),
     "ssm_wino_conv2d_ups_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int,
@@ -116,7 +122,7 @@ SIGNATURES = {
     "ssm_conv2d_ups_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, ctypes.c_float,
                                     _c_int, _vp]),
     "ssm_conv2d_hl8_subpixel_fwd": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, _vp, _vp, ctypes.c_float, SsmHView, _c_int, _c_int, _c_int,
-                                              _c_int, _c_int, ctypes.c_float, _c_int, _vp]),
+                                              _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_hl8_gather_cols": (_c_int, [SsmHView, _c_int, SsmHView, _c_int, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv16_subpixel_table_bytes": (ctypes.c_size_t, [_c_int]),
     "ssm_conv16_subpixel_plan": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int, _vp, ctypes.c_size_t,
@@ -489,6 +495,43 @@ def conv2d_wino1d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, a
                                         SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
+# ---- 7x7 convolutions as 2x2 blocks of F(4x4,4x4) Winograd filters in fp32 (csrc/ssm_wino7.hip) ---------------------
+def wino7_supported(cin, cout, H, W, k):
+    """Can this layer run in the blocked two-dimensional Winograd form?  (7x7, 32-channel output blocks; any Cin)"""
+    return k == 7 and cout % 32 == 0
+
+
+class PackedWino7:
+    """7x7 filter as four pre-transformed 4x4 blocks (U_b = G g_b G^T) packed for csrc/ssm_wino7.hip; an explicit handle owned by the
+    Python side like PackedConv."""
+
+    algo = "wino7"
+
+    def __init__(self, weight, bias, B, H, W, pool=False, ups=False):
+        require_device(weight, "conv weight")
+        require_device(bias, "conv bias")
+        assert not ups, "the 7x7 layers have no fused-upsample form"
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        assert self.k == 7 and weight.shape[3] == 7 and self.cout % 32 == 0, "the blocked Winograd form is for 7x7 filters, Cout a multiple of 32"
+        self.ups = False
+        self.bn, self.ck, self.cin_p = 32, 1, self.cin
+        lib = load()
+        self.w = torch.empty(lib.ssm_wino7_packed_weight_floats(self.cout, self.cin), dtype=torch.float32, device=weight.device)
+        self.b = torch.empty(self.cout, dtype=torch.float32, device=weight.device)
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        check(lib.ssm_wino7_pack_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout, self.cin, stream_ptr()))
+
+
+def conv2d_wino7(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+    """Same call shape as conv2d / conv2d_wino1d; these layers take one source (x2 must be None)."""
+    lib = load()
+    assert x2 is None and c2 == 0, "the 7x7 layers have no concatenated source"
+    assert pk.cin == c1, "packed filter expects %d input channels, got %d" % (pk.cin, c1)
+    check(lib.ssm_wino7_conv2d_add_fwd(x1, c1, pk.w.data_ptr(), pk.b.data_ptr(), y, pool if pool is not None else NULL_VIEW,
+                                       add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
+                                       SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
 # ---- HL8 (fp16 hi/lo) tensors and the fp16-MFMA convolution ------------------------------------
 class HPlanes:
     """A [B,C,H,W] activation in the HL8 layout (include/ssm_hip.h): [B][G][hi|lo][Hp][Wp][8 x fp16],
@@ -632,7 +675,7 @@ class PackBatch32:
     transposed packs the data-gradient filter of the forward parameter (no torch flip / permute / copy).  The job table holds raw
     pointers: rebuild it when `PackBatch.key()` of the parameters changes."""
 
-    ALGO = {"direct": 0, "wino": 1, "wino1d": 2, "wino4": 3}
+    ALGO = {"direct": 0, "wino": 1, "wino1d": 2, "wino4": 3, "wino7": 4}
 
     def __init__(self, entries, device):
         jobs = (SsmPack32Job * len(entries))()
