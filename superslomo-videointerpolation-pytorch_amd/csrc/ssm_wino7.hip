@@ -68,6 +68,7 @@ struct W7Params {
     const float *add;    // optional pre-activation addend [B / adiv][Cout][H][W]
     long long asb, asc;
     int ash, adiv;
+    unsigned long long *dbg;   // tuning build (-DW7_TRACE) only: per-wave phase sums of workgroup 0
 };
 
 // 2 cout halves x 2 tile groups = 4 waves; a tile group = GTX x GTY tiles of 4x4 pixels (16 tiles), the groups sit WTY x WTX.
@@ -221,6 +222,12 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
     }
 }
 
+#ifndef W7_ABL
+#define W7_ABL 0             // tuning builds (make w7alt W7FLAGS=-DW7_ABL=n): 1 no LDS-DMA, 2 no transform in the steady-state loop; 4 no epilogue
+#endif
+#ifndef W7_UNROLL2
+#define W7_UNROLL2 0
+#endif
 #ifndef W7_INTERLEAVE
 #define W7_INTERLEAVE 1      // the transform pieces and the DMA issue ride in the slots of the matrix loop (0: as blocks in front of it)
 #endif
@@ -264,17 +271,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto dma = [](const float *base, int voff_bytes, unsigned m0v) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(m0v) : "memory", "m0");
     };
-    // k-th filter piece of this wave for channel c into stage c & 1 (k = 0 .. NIU-1); the patch piece of channel c into buffer c & 1
-    auto dma_u = [&](int c, int k) {
+    // k-th filter piece of this wave for channel c into stage buf (= c & 1; k = 0 .. NIU-1); the patch piece of channel c into buffer buf
+    auto dma_u = [&](int c, int k, int buf) {
         const int g = 4 * k + wid;
         const float *base = wbase + (long long)c * C::USZ + g * 256;
-        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::UOFF + (c & 1) * C::USZ) * 4u + (unsigned)g * 1024u);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::UOFF + buf * C::USZ) * 4u + (unsigned)g * 1024u);
         dma(base, uoff, m0v);
     };
-    auto dma_p = [&](int c) {
+    auto dma_p = [&](int c, int buf) {
         if (wid < C::NGP) {
             const float *base = pbase + (long long)c * p.sc;
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::POFF + (c & 1) * C::PCAP + C::SHIFT) * 4u + (unsigned)wid * 1024u);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::POFF + buf * C::PCAP + C::SHIFT) * 4u + (unsigned)wid * 1024u);
             dma(base, poff, m0v);
         }
     };
@@ -288,15 +295,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * 32 + cb * 16 + 4 * q + r];
 
     // ---- row pass: unit = (patch row, position column); 2 x 16-byte reads, 21 vector operations, 2 x 16-byte writes -------------------
-    const bool r_on = tid < C::NRU;
-    const int r_row = tid / NPX, r_px = tid - r_row * NPX;
+    // (no predicates in the loop: the threads / lanes beyond the last unit repeat it - same reads, same values written to the same place.
+    // Exec-masked pieces between the MFMAs split the loop into basic blocks, and the register allocator then copied all 196 accumulator
+    // registers once per channel: 195 v_accvgpr_mov per 49 MFMAs.)
+    const int r_unit = min(tid, C::NRU - 1);
+    const int r_row = r_unit / NPX, r_px = r_unit - r_row * NPX;
     const int r_src = C::POFF + C::SHIFT + r_row * PW + 4 * r_px + 1;           // floats; 16-byte aligned
     const int r_dst = C::XOFF + (r_row * NPX + r_px) * 4;                        // plane h = 0; plane 1 at + PH * NPX * 4
     // ---- column pass: unit = (position, pair j of column-frequencies), j = wave; 7 x 8-byte reads, 2 x 21 operations, 7 x 8-byte writes
-    const bool c_on = lane < NP;
-    const int c_py = lane / NPX, c_px = lane - c_py * NPX;
+    const int c_pos = min(lane, NP - 1);
+    const int c_py = c_pos / NPX, c_px = c_pos - c_py * NPX;
     const int c_src = C::XOFF + ((wid >> 1) * PH * NPX + (4 * c_py) * NPX + c_px) * 4 + (wid & 1) * 2;
-    const int c_dst = C::VOFF + ((wid >> 1) * NP + lane) * 4 + (wid & 1) * 2;    // + rf * 2 * NP * 4 per row-frequency
+    const int c_dst = C::VOFF + ((wid >> 1) * NP + c_pos) * 4 + (wid & 1) * 2;    // + rf * 2 * NP * 4 per row-frequency
 
     // ---- operand bases of the matrix loop (f32x4 units): U of (quad, block q, cout cb*16 + l15), V of (quad, position of the tile + block q)
     const f32x4 *lds4 = (const f32x4 *)lds;
@@ -317,28 +327,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //   piece 5, 6     column pass: the seven reads       piece 7 .. 12  column pass: arithmetic, two frequencies x 3; piece 13, 14: writes
     auto tpiece = [&](auto J, int k, bool doR, bool doC, int rbuf, int xrbuf, int xcbuf, int vbuf) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;          // this wave's pair of column-frequencies (j = 3: the single frequency 6)
-        if (k == 0 && doR && r_on) {
+        if (k == 0 && doR) {
             const float *src = lds + r_src + rbuf * C::PCAP;
             ra[0] = *(const f32x4 *)src;
             ra[1] = *(const f32x4 *)(src + 4);
         }
-        if (k >= 1 && k <= 3 && doR && r_on) {
+        if (k >= 1 && k <= 3 && doR) {
             const float d[7] = {ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[1][0], ra[1][1], ra[1][2]};
             if (k == 1) w7_bt_e(d, re);
             if (k == 2) w7_bt_a(re, rc);
             if (k == 3) w7_bt_b(d, re, rc);
         }
-        if (k == 4 && doR && r_on) {
+        if (k == 4 && doR) {
             float *dst = lds + r_dst + xrbuf * C::XSZ;
             *(f32x4 *)dst = f32x4{rc[0], rc[1], rc[2], rc[3]};
             *(f32x4 *)(dst + PH * NPX * 4) = f32x4{rc[4], rc[5], rc[6], 0.f};
         }
-        if ((k == 5 || k == 6) && doC && c_on) {
+        if ((k == 5 || k == 6) && doC) {
             const float *src = lds + c_src + xcbuf * C::XSZ;
 #pragma unroll
             for (int i = (k == 5 ? 0 : 4); i < (k == 5 ? 4 : 7); ++i) cx[i] = *(const f32x2 *)(src + i * NPX * 4);
         }
-        if (k >= 7 && k <= 12 && doC && c_on) {
+        if (k >= 7 && k <= 12 && doC) {
             const int which = (k - 7) / 3, part = (k - 7) % 3;
             if (which == 0 || j < 3) {
                 const float d[7] = {cx[0][which], cx[1][which], cx[2][which], cx[3][which], cx[4][which], cx[5][which], cx[6][which]};
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
-        if ((k == 13 || k == 14) && doC && c_on) {
+        if ((k == 13 || k == 14) && doC) {
             float *dst = lds + c_dst + vbuf * C::VSZ;
 #pragma unroll
             for (int rf = (k == 13 ? 0 : 4); rf < (k == 13 ? 4 : 7); ++rf) {
@@ -417,56 +427,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
+#ifdef W7_TRACE
+    unsigned long long tph[4] = {0, 0, 0, 0};
+    unsigned long long tk = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tk;
+#define W7STAMP(i)                                                  \
+    {                                                               \
+        const unsigned long long tn = __builtin_amdgcn_s_memtime(); \
+        tph[i] += tn - tk;                                          \
+        tk = tn;                                                    \
+    }
+#else
+#define W7STAMP(i)
+#endif
     // ---- one iteration of the pipeline (c from -2): DMA U(c+1), patch(c+3) | row pass (c+2) | column pass (c+1) | matrix (c) ----------
-    auto iter = [&](auto J, int c, auto STEADY) __attribute__((always_inline)) {
+    // PAR: c & 1 as a compile-time fact (the steady-state loop runs two iterations per trip: every buffer then sits at an immediate offset
+    // from per-lane base addresses that never change - with a run-time parity each LDS access of the transform cost a vector add), or -1
+    auto iter = [&](auto J, int c, auto STEADY, auto PAR) __attribute__((always_inline)) {
         constexpr bool steady = decltype(STEADY)::value;
+        constexpr int par_ct = decltype(PAR)::value;
+        const int par = par_ct >= 0 ? par_ct : (c & 1);
         const bool doM = steady || c >= 0;
         const bool doC = steady || (c + 1 >= 0 && c + 1 < n);
         const bool doR = steady || c + 2 < n;
         const bool doP = steady || c + 3 < n;
+        W7STAMP(0)          // -> [0]: the iteration's work (matrix loop + transform pieces)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W7STAMP(1)          // -> [1]: waiting for this wave's LDS-DMA
         __syncthreads();
-        const int rbuf = c & 1, xrbuf = c & 1, xcbuf = (c + 1) & 1, vbuf = (c + 1) & 1;          // (c + 2) & 1 == c & 1
+        W7STAMP(2)          // -> [2]: waiting at the barrier
+        const int rbuf = par, xrbuf = par, xcbuf = par ^ 1, vbuf = par ^ 1;          // (c + 2) & 1 == c & 1
         auto slot = [&](int m) __attribute__((always_inline)) {
             const int d = dma_of_slot(m);
-            if (d >= 0) {
+            if (d >= 0 && !(steady && (W7_ABL & 1))) {
                 if (d < C::NIU) {
-                    if (doC) dma_u(c + 1, d);
+                    if (doC) dma_u(c + 1, d, par ^ 1);
                 } else if (doP) {
-                    dma_p(c + 3);
+                    dma_p(c + 3, par ^ 1);
                 }
             }
             const int k = piece_of_slot(m);
-            if (k >= 0) tpiece(J, k, doR, doC, rbuf, xrbuf, xcbuf, vbuf);
+            if (k >= 0 && !(steady && (W7_ABL & 2))) tpiece(J, k, doR, doC, rbuf, xrbuf, xcbuf, vbuf);
         };
         if (doM && W7_INTERLEAVE) {
-            matrix(c & 1, slot);
+            matrix(par, slot);
         } else {
 #pragma unroll
             for (int m = 0; m < 49; ++m) {
                 slot(m);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (doM) matrix(c & 1, [](int) {});
+            if (doM) matrix(par, [](int) {});
         }
     };
 
-    dma_p(0);
+    dma_p(0, 0);
     auto run = [&](auto J) __attribute__((always_inline)) {
         using T = std::true_type;
         using F = std::false_type;
-        iter(J, -2, F{});
-        iter(J, -1, F{});
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using PR = std::integral_constant<int, -1>;
+        iter(J, -2, F{}, P0{});
+        iter(J, -1, F{}, P1{});
         int c = 0;
-        for (; c + 3 < n; ++c) iter(J, c, T{});
-        for (; c < n; ++c) iter(J, c, F{});
+#if W7_UNROLL2          // two iterations per trip, buffer parity at compile time: saves ~8 vector adds per channel, but the register allocator then
+                        // routes 5 of the 49 accumulators through VGPRs every trip (40 v_accvgpr_read / _write per channel) - off
+        for (; c + 4 < n; c += 2) {
+            iter(J, c, T{}, P0{});
+            iter(J, c + 1, T{}, P1{});
+        }
+#else
+        for (; c + 3 < n; ++c) iter(J, c, T{}, PR{});
+#endif
+        for (; c < n; ++c) iter(J, c, F{}, PR{});
     };
     if (wid == 0) run(std::integral_constant<int, 0>{});
     else if (wid == 1) run(std::integral_constant<int, 1>{});
     else if (wid == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 3>{});
 
+    if ((W7_ABL & 4) && acc[0][0] != 12345.678f) return;
+    W7STAMP(0)
     w7_epilogue(p, acc, bv, b, nb * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
+#ifdef W7_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W7STAMP(3)          // -> [3]: epilogue
+    if (p.dbg && lane == 0 && (blockIdx.x % 64) == 0) {          // a sample of the workgroups
+        for (int i = 0; i < 4; ++i) atomicAdd(p.dbg + wid * 8 + i, tph[i]);
+        atomicAdd(p.dbg + wid * 8 + 4, tk - tstart);
+        atomicAdd(p.dbg + wid * 8 + 5, 1ULL);
+    }
+#endif
 }
 
 // ---- tile configurations ---------------------------------------------------------------------------------------------------------
@@ -494,6 +546,9 @@ constexpr W7KindInfo kW7Info[NW7KIND] = {
 };
 
 std::atomic<int> g_force_w7kind{-1};
+#ifdef W7_TRACE
+std::atomic<unsigned long long *> g_w7dbg{nullptr};
+#endif
 
 // the configuration with the fewest workgroup-rounds (tile overshoot included); ties go to the 16x32-pixel tile
 int pick_w7kind(int Cout, int B, int H, int W) {
@@ -580,6 +635,15 @@ extern "C" int ssm_wino7_plan(int Cin, int Cout, int B, int H, int W, int *kind)
     return SSM_OK;
 }
 
+#ifdef W7_TRACE
+// tuning build only (make w7alt W7FLAGS=-DW7_TRACE=1; never lib/libssm_hip.so): 4 x 8 device counters, per wave of the sampled workgroups
+// the shader cycles spent in [work, DMA wait, barrier wait, epilogue], the lifetime and the number of samples
+extern "C" int ssm_wino7_debug_buffer(unsigned long long *dev_counters) {
+    g_w7dbg.store(dev_counters);
+    return SSM_OK;
+}
+#endif
+
 extern "C" int ssm_wino7_force_kind(int kind) {
     g_force_w7kind.store(kind >= 0 && kind < NW7KIND ? kind : -1);
     return NW7KIND;
@@ -654,5 +718,10 @@ extern "C" int ssm_wino7_conv2d_add_fwd(ssm_view x, int Cin, const float *w_pack
         vec = vec && (reinterpret_cast<size_t>(pool.ptr) & 7) == 0 && pool.sh % 2 == 0 && pool.sc % 2 == 0 && pool.sb % 2 == 0;
     }
     p.vec = vec ? 1 : 0;
+#ifdef W7_TRACE
+    p.dbg = g_w7dbg.load();
+#else
+    p.dbg = nullptr;
+#endif
     return w7dispatch(kind, p, B, (hipStream_t)stream);
 }
