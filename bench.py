@@ -68,11 +68,11 @@ DTYPE_NOTE = {"f32": "f32",
                        "activations stored as f16 hi + e4m3 lo, f32 accumulate) - narrower than f32"}
 # rocprofv3 --pmc traffic summaries (tools/pmc_traffic.sh) per mode: (file under profiles/, conv kernel family keys)
 ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(4x4,3x3) (csrc/ssm_wino4.hip) or F(2x2,3x3) (csrc/ssm_wino.hip), 7x7 / 5x5 "
-                     "convolutions as 1-D Winograd F(2,7) / F(4,5) along x (csrc/ssm_wino1d.hip), final convolutions in the direct form "
+                     "convolutions as 2x2 blocks of F(4x4,4x4) (csrc/ssm_wino7.hip) / 1-D Winograd F(4,5) along x (csrc/ssm_wino1d.hip), final convolutions in the direct form "
                      "(csrc/ssm_elem.hip); the t-independent input channels of stage 2's conv1a / conv7a convolved once per pair",
              "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output; the t-independent input channels of "
                     "stage 2's conv1a / conv7a summed once per pair and added - SSM_HOIST=0 keeps one chain)"}
-PMC_FILES = {"f32w": ("r7r_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel")),
+PMC_FILES = {"f32w": ("r8_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel")),
              "f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "final_conv_kernel")),
              "f16x3": ("r1k_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel")),
              "f16f8": ("r1q_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel"))}
@@ -160,7 +160,7 @@ def layer_kernel_size(lname):
 
 def issued_factor(lname, precision, B=14, H=736, W=1280):
     """Multiply-adds the matrix cores issue per direct-form multiply-add of this layer in this precision mode: the plan's algorithm
-    for the layer (ssm_amd.engine.choose_algo: F(4x4,3x3) x 1/4, F(2x2,3x3) x 16/36, F(2,7) x 8/14, F(4,5) x 8/20, direct x 1).
+    for the layer (ssm_amd.engine.choose_algo: F(4x4,3x3) x 1/4, F(2x2,3x3) x 16/36, 7x7 as blocked F(4x4,4x4) x 1/4, F(4,5) x 8/20, direct x 1).
     B, H, W: batch and full-resolution size of the plan the layer belongs to."""
     if precision != "f32w" or lname.startswith("final"):
         return 1.0
@@ -335,27 +335,35 @@ def train_bench(args):
         out["time_split_ms_per_step"] = {fam: round(d["ms"] / 3, 3) for fam, d in summ.items()}
         out["tflops"] = {fam: round(d["flops"] / d["ms"] / 1e9, 1) for fam, d in summ.items() if d["flops"] > 0}
         # roofline of the step (forward 93.9 GMAC per sample, backward = data + weight gradients of the same
-        # convolutions, + the VGG16 conv4_3 passes): every MFMA-bound family against the MFMA peak.  `achieved` = the
-        # direct-form conv FLOP of one step (all families, as counted by the per-launch brackets) / the step's wall time in the
-        # timed region; families.* = the same FLOP / the summed HIP-event durations of that family's launches (in-kernel rate).
+        # convolutions, + the VGG16 conv4_3 passes): every MFMA-bound family against the MFMA peak.  `achieved` = the multiply-adds
+        # the matrix cores ISSUE in one step (Winograd launches count 16/36 or 36/144 of their direct-form FLOP: engine.ISSUED_FACTOR,
+        # recorded per launch by the brackets) / the step's wall time in the timed region - always <= peak; the direct-form figure the
+        # step corresponds to is under `algorithmic`.  families.* = the same / the summed HIP-event durations of that family (in-kernel).
         peak = PEAK_F16_MFMA_TFLOPS if train_mode == "f16f8" else PEAK_F32_MFMA_TFLOPS
         fl_step = sum(d["flops"] for d in summ.values()) / 3.0
-        ach = fl_step / (1e-3 * out["ms_per_step"]) / 1e12
+        is_step = sum(d["issued"] for d in summ.values()) / 3.0
+        wall = 1e-3 * out["ms_per_step"]
+        ach = is_step / wall / 1e12
         out["roofline"] = {
             "bound": "mfma",
             "kernel": ("conv16 / wgrad_bf16x3 kernels" if train_mode == "f16f8" else
                        "conv_mfma_kernel / wino2_kernel (forward, data gradients), wgrad kernels (weight gradients), VGG16 conv kernels: "
                        "all MFMA families of a step"),
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flop_per_step": fl_step,
-            "region": "the timed region: direct-form conv FLOP of %d steps / its wall time (launch gaps, elementwise kernels, Adam "
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "flop_per_step": is_step,
+            "algorithmic": {"achieved": round(fl_step / wall / 1e12, 2), "flop_per_step": fl_step,
+                            "note": "direct-form FLOP of the same convolutions / the same wall time (can exceed the peak where Winograd forms run)"},
+            "region": "the timed region: FLOP issued on the matrix cores in %d steps / its wall time (launch gaps, elementwise kernels, Adam "
                       "and the exchange count against it)" % args.steps,
-            "families": {fam: {"flop_per_step": d["flops"] / 3.0, "ms_per_step_in_kernel": round(d["ms"] / 3, 3),
-                               "achieved_in_kernel": round(d["flops"] / d["ms"] / 1e9, 2),
-                               "frac_in_kernel": round(d["flops"] / d["ms"] / 1e9 / peak, 4)}
+            "families": {fam: {"flop_per_step": d["issued"] / 3.0, "direct_form_flop_per_step": d["flops"] / 3.0,
+                               "ms_per_step_in_kernel": round(d["ms"] / 3, 3),
+                               "achieved_in_kernel": round(d["issued"] / d["ms"] / 1e9, 2),
+                               "frac_in_kernel": round(d["issued"] / d["ms"] / 1e9 / peak, 4),
+                               "algorithmic_in_kernel": round(d["flops"] / d["ms"] / 1e9, 2)}
                          for fam, d in summ.items() if d["flops"] > 0},
             "traffic": None,
-            "note": ("3x3 forward / data-gradient layers run as Winograd F(2x2,3x3): their matrix cores issue 16/36 of the direct-form "
-                     "FLOP counted here" if train_mode == "f32w" else "every product issued in the direct form: FLOP counted = FLOP issued")}
+            "note": ("3x3 forward / data-gradient / VGG layers run as Winograd F(2x2,3x3): 16/36 of their direct-form FLOP are issued; weight "
+                     "gradients, 7x7 / 5x5 / final layers run in the direct form" if train_mode == "f32w" else
+                     "every product issued in the direct form: FLOP counted = FLOP issued")}
         if args.detail:
             det = {fam: {n: {"ms_per_step": v[0] / 3, "tflops": (v[1] / v[0] / 1e9 if v[0] > 0 else 0.0)}
                          for n, v in d["by_name"].items()} for fam, d in summ.items()}
@@ -649,7 +657,8 @@ def infer_bench(args):
         peak = PEAK_F32_MFMA_TFLOPS if precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
         kname = {"f32w": "wino4_kernel<*, ups 0|1> (3x3 layers, F(4x4,3x3), v_mfma_f32_16x16x4_f32) + wino2_kernel<*> (3x3 layers on the 1/32 maps, "
-                         "F(2x2,3x3)) + wino1d_kernel<*> (7x7 / 5x5 layers, F(2,7) / F(4,5) along x) "
+                         "F(2x2,3x3)) + wino7_kernel<*> (7x7 layers, 2x2 blocks of F(4x4,4x4), v_mfma_f32_16x16x4_f32) + wino1d_kernel<*> (5x5 layers, "
+                         "F(4,5) along x) "
                          "(v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "
@@ -663,7 +672,7 @@ def infer_bench(args):
         if precision in flops_issued:
             issued_note = ("the multiply-adds the matrix cores execute: the t-independent input channels of stage 2's conv1a (6 of 16) and "
                            "conv7a (512 of 1024) are convolved once per pair instead of once per t" +
-                           ("; Winograd layers: direct-form FLOP x 1/4 (F(4x4,3x3)) or x 16/36 (F(2x2,3x3)), x 8/14 (7x7 as F(2,7) along x), "
+                           ("; Winograd layers: direct-form FLOP x 1/4 (F(4x4,3x3)) or x 16/36 (F(2x2,3x3)), x 1/4 (7x7 as 2x2 blocks of F(4x4,4x4)), "
                             "x 8/20 (5x5 as F(4,5) along x), per layer as the plan picks the form" if precision == "f32w" else ""))
         else:
             issued_note = "direct-form FLOP (each product costs %s narrow MFMA operations in this mode)" % \

@@ -396,16 +396,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // slot -> DMA instruction of this wave (NIU filter pieces, then the patch piece): slots 1, 3, 5, ...
     auto dma_of_slot = [](int m) constexpr -> int { return (m % 2 == 1 && m / 2 < C::NIU + 1) ? m / 2 : -1; };
 
-    // ---- 49 MFMAs of one input channel: 14 quads of frequencies (the odd quads hold three), operands of quad g+2 fetched behind the first
-    // MFMA of quad g (a ring of three register sets); slot(m) behind MFMA m
-    auto matrix = [&](int st, auto slot) __attribute__((always_inline)) {
+    // ---- 49 MFMAs per input channel: 14 quads of frequencies (the odd quads hold three), operands of quad g+2 fetched behind the first MFMA
+    // of quad g (a ring of three register sets); slot(m) behind the m-th MFMA of the iteration.  The loop is ROTATED by two quads: a wave
+    // alone on its SIMD would wait out a full LDS latency behind every barrier (its first operands can only be fetched once the barrier has
+    // released V), so the last two quads of channel c (7 MFMAs, operands fetched into ha / hb before the barrier) are issued behind the
+    // barrier of channel c+1, in front of its own quads, while its first operand fetches are in flight.
+    //   held: the previous channel left quads 12, 13 to do;  hold: leave this channel's quads 12, 13 to the next iteration
+    f32x4 ha[2], hb[2];
+    auto matrix = [&](int st, bool held, bool hold, auto slot) __attribute__((always_inline)) {
         const int ai = aBase + st * (C::USZ / 4), bi = bBase + st * (C::VSZ / 4);
         a[0] = lds4[ai];
         bq[0] = lds4[bi];
         a[1] = lds4[ai + 128];
         bq[1] = lds4[bi + NP];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < NFQ; ++g) {
+        for (int m = 0; m < 7; ++m) {
+            if (held) acc[42 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[m >> 2][m & 3], hb[m >> 2][m & 3], acc[42 + m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int g = 0; g < NFQ - 2; ++g) {
             const int cur = g % 3, nxt = (g + 2) % 3;
             const int rf = g >> 1, h = g & 1;
 #pragma unroll
@@ -415,15 +428,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[f], 0, 0, 0);
                 if (e == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (g + 2 < NFQ) {
+                    if (g + 2 < NFQ - 2) {
                         a[nxt] = lds4[ai + (g + 2) * 128];
                         bq[nxt] = lds4[bi + (g + 2) * NP];
+                    } else {          // g = 10, 11: the operands of quads 12, 13
+                        ha[g - (NFQ - 4)] = lds4[ai + (g + 2) * 128];
+                        hb[g - (NFQ - 4)] = lds4[bi + (g + 2) * NP];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                slot(f);
+                slot(7 + f);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (!hold) {
+#pragma unroll
+            for (int m = 0; m < 7; ++m) acc[42 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[m >> 2][m & 3], hb[m >> 2][m & 3], acc[42 + m], 0, 0, 0);
         }
     };
 
@@ -469,15 +489,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int k = piece_of_slot(m);
             if (k >= 0 && !(steady && (W7_ABL & 2))) tpiece(J, k, doR, doC, rbuf, xrbuf, xcbuf, vbuf);
         };
+        const bool held = steady || c >= 1, hold = steady || c + 1 < n;
         if (doM && W7_INTERLEAVE) {
-            matrix(par, slot);
+            matrix(par, held, hold, slot);
         } else {
 #pragma unroll
             for (int m = 0; m < 49; ++m) {
                 slot(m);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (doM) matrix(par, [](int) {});
+            if (doM) matrix(par, held, hold, [](int) {});
         }
     };
 
@@ -491,6 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         iter(J, -2, F{}, P0{});
         iter(J, -1, F{}, P1{});
         int c = 0;
+        if (n > 0) iter(J, c++, F{}, PR{});          // (the steady-state copy finishes the previous channel's last quads: from channel 1 on)
 #if W7_UNROLL2          // two iterations per trip, buffer parity at compile time: saves ~8 vector adds per channel, but the register allocator then
                         // routes 5 of the 49 accumulators through VGPRs every trip (40 v_accvgpr_read / _write per channel) - off
         for (; c + 4 < n; c += 2) {

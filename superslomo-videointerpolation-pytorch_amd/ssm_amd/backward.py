@@ -307,7 +307,8 @@ class UNetGrad:
                 self._layer_done(name)
         if dx is not None:
             if tm is not None:
-                e0, e1 = tm.span("dgrad", "s%d.%s" % (plan.stage, name), flops)
+                from .engine import issued_factor
+                e0, e1 = tm.span("dgrad", "s%d.%s" % (plan.stage, name), flops, issued=flops * (1.0 if self.hl8 else issued_factor(pk)))
                 e0.record()
             if self.hl8:
                 hb.conv2d_hl8(self.dzq[name].view(), cpad, None, 0, pk, None, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)

@@ -28,21 +28,23 @@ class KernelTimer:
     roofline figures; off by default."""
 
     def __init__(self):
-        self.spans = []      # (family, name, flops, bytes, ev0, ev1)
+        self.spans = []      # (family, name, flops, bytes, ev0, ev1, issued flops)
 
-    def span(self, family, name, flops=0.0, nbytes=0.0):
+    def span(self, family, name, flops=0.0, nbytes=0.0, issued=None):
+        """flops: direct-form FLOP of the launch; issued: the FLOP its matrix cores execute (Winograd forms issue fewer: ISSUED_FACTOR)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.spans.append((family, name, flops, nbytes, e0, e1))
+        self.spans.append((family, name, flops, nbytes, e0, e1, flops if issued is None else issued))
         return e0, e1
 
     def summary(self):
         """family -> dict(ms, flops, bytes, launches); call after torch.cuda.synchronize()."""
         out = {}
-        for fam, name, fl, nb, e0, e1 in self.spans:
-            d = out.setdefault(fam, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "by_name": {}})
+        for fam, name, fl, nb, e0, e1, isd in self.spans:
+            d = out.setdefault(fam, {"ms": 0.0, "flops": 0.0, "issued": 0.0, "bytes": 0.0, "launches": 0, "by_name": {}})
             ms = e0.elapsed_time(e1)
             d["ms"] += ms
             d["flops"] += fl
+            d["issued"] += isd
             d["bytes"] += nb
             d["launches"] += 1
             n = d["by_name"].setdefault(name, [0.0, 0.0, 0])
@@ -127,6 +129,11 @@ _ALGO_CLASS = {"direct": lambda: hb.PackedConv, "wino": lambda: hb.PackedWino, "
 # multiply-adds issued on the matrix cores per direct-form multiply-add, by algorithm and kernel size
 ISSUED_FACTOR = {"direct": lambda k: 1.0, "wino": lambda k: 16.0 / 36.0, "wino4": lambda k: 36.0 / 144.0,
                  "wino1d": lambda k: 8.0 / 14.0 if k == 7 else 8.0 / 20.0, "wino7": lambda k: 196.0 / 784.0}
+
+
+def issued_factor(pk):
+    """Multiply-adds the matrix cores execute per direct-form multiply-add for a packed filter's algorithm (fp32 plans; 1 otherwise)."""
+    return ISSUED_FACTOR.get(getattr(pk, "algo", "direct"), ISSUED_FACTOR["direct"])(pk.k)
 
 
 def conv_fn(pk, ups=False):
@@ -346,7 +353,8 @@ class UNetPlan:
         c2 = self.t[src2].C if src2 else 0
         tm = self.timer
         if tm is not None:
-            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * s.H * s.W * pk.cout * pk.cin * pk.k * pk.k)
+            fl = 2.0 * self._Bcur * s.H * s.W * pk.cout * pk.cin * pk.k * pk.k
+            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), fl, issued=fl * issued_factor(pk))
             e0.record()
         v = self._v
         if self.hl8:
@@ -407,7 +415,8 @@ class UNetPlan:
         d = self.t[dst]
         tm = self.timer
         if tm is not None:
-            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), 2.0 * self._Bcur * d.H * d.W * pk.cout * pk.cin * 9)
+            fl = 2.0 * self._Bcur * d.H * d.W * pk.cout * pk.cin * 9
+            e0, e1 = tm.span("conv", "s%d.%s" % (self.stage, name), fl, issued=fl * issued_factor(pk))
             e0.record()
         if self.hl8:
             hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
@@ -450,7 +459,8 @@ class UNetPlan:
         pk = self.pk_pair["conv1a"]
         P = self.t["pair1a"]
         if tm is not None:
-            e0, e1 = tm.span("conv", "s2.conv1a(pair)", 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * pk.k * pk.k)
+            fl = 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * pk.k * pk.k
+            e0, e1 = tm.span("conv", "s2.conv1a(pair)", fl, issued=fl * issued_factor(pk))
             e0.record()
         conv_fn(pk)(pair_planes.view(), 6, None, 0, pk, P.view(), None, B1, P.H, P.W, lrelu=False)
         if tm is not None:
@@ -459,7 +469,8 @@ class UNetPlan:
             pk = self.pk_pair["conv7a"]
             P = self.t["pair7a"]
             if tm is not None:
-                e0, e1 = tm.span("conv", "s2.conv7a(pair)", 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * 9)
+                fl = 2.0 * B1 * P.H * P.W * pk.cout * pk.cin * 9
+                e0, e1 = tm.span("conv", "s2.conv7a(pair)", fl, issued=fl * issued_factor(pk))
                 e0.record()
             conv_fn(pk, True)(c6_planes.view(), 512, None, 0, pk, P.view(), B1, P.H, P.W, lrelu=False)
             if tm is not None:

@@ -98,11 +98,12 @@ class VGGFeatures:
             self.pk_nb[key] = type(pk)(self.w[idx], self.b[idx], nb, src.H, src.W)
         return self.pk_nb[key]
 
-    def _span(self, fam, name, flops):
+    def _span(self, fam, name, flops, pk=None):
         tm = VGGFeatures.timer
         if tm is None:
             return None
-        e0, e1 = tm.span(fam, name, flops)
+        issued = flops * (16.0 / 36.0 if pk is not None and getattr(pk, "algo", "") == "wino" else 1.0)      # F(2x2,3x3) layers
+        e0, e1 = tm.span(fam, name, flops, issued=issued)
         e0.record()
         return e1
 
@@ -128,7 +129,7 @@ class VGGFeatures:
                 continue
             _, idx, cin, cout, sname, dname = s
             src, dst, pk = self.t[sname], self.t[dname], self._pk(idx, nb, self.t[sname])
-            e1 = self._span("vgg_fwd", "features.%d" % idx, 2.0 * nb * src.H * src.W * cin * cout * 9)
+            e1 = self._span("vgg_fwd", "features.%d" % idx, 2.0 * nb * src.H * src.W * cin * cout * 9, pk)
             if self.q8:
                 hb.conv2d_hl8(self.q[sname].view(b0=b0), pk.cin_p, None, 0, pk, self.q[dname].view(b0=b0), dst.view(b0=b0), None, nb,
                               src.H, src.W, lrelu=True, slope=0.0)
@@ -171,7 +172,7 @@ class VGGFeatures:
                     self.g[key + "q"] = hb.HPlanes(self.B, pk.cin_p, Y.H, Y.W, self.device, q8=True)
             dzp = self.g[key]
             dx = self._G(sname, C=cin)
-            e1 = self._span("vgg_bwd", "features.%d" % idx, 2.0 * nb * Y.H * Y.W * cin * cout * 9)
+            e1 = self._span("vgg_bwd", "features.%d" % idx, 2.0 * nb * Y.H * Y.W * cin * cout * 9, pk)
             if self.q8:
                 dzq = self.g[key + "q"]
                 hb.check(lib.ssm_lrelu_bwd_q8(dy.view(), hb.NULL_VIEW, Y.view(), dzp.view(), dzq.view(), nb, cout, Y.H, Y.W, 0.0, 1, st))

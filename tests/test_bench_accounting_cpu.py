@@ -32,7 +32,7 @@ def test_issued_flop_follows_from_hoisting_and_winograd():
     saved = 6 * (6 / 16) * c1a + 6 * 0.5 * c7a     # six of seven evaluations of the t-independent channels
     assert abs((alg - f32) - saved) / saved < 1e-9
     # mode f32w: every 3x3 layer except the final convs as F(4x4,3x3) (36 products per 16 outputs instead of 144) - or as F(2x2,3x3)
-    # (16 per 4 outputs instead of 36) on the 23x40 maps (csrc/ssm_wino4.hip, ssm_wino4_preferred); the 7x7 layers as F(2,7) along x (8 frequencies per 2 outputs and filter row instead of 14 products), the 5x5
+    # (16 per 4 outputs instead of 36) on the 23x40 maps (csrc/ssm_wino4.hip, ssm_wino4_preferred); the 7x7 layers as 2x2 blocks of F(4x4,4x4) (4 x 49 products per 16 outputs instead of 784: csrc/ssm_wino7.hip), the 5x5
     # layers as F(4,5) (8 per 4 outputs instead of 20)
     scale = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8, "conv9": 4, "fuse_": 1, "final": 1}
     want = 0.0
@@ -48,7 +48,7 @@ def test_issued_flop_follows_from_hoisting_and_winograd():
                 f22 = (736 // s) * (1280 // s) < 2048
                 fl *= 16 / 36 if f22 else 36 / 144
             elif k == 7:
-                fl *= 8 / 14
+                fl *= 196 / 784
             elif k == 5:
                 fl *= 8 / 20
             want += fl
