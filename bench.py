@@ -813,8 +813,31 @@ def infer_bench(args):
             par[m] = {"max_abs_vs_oracle": max(per_t), "per_t": [round(e, 7) for e in per_t]}
             if m != headline:
                 out["modes"][m]["parity"] = par[m]
-        out["parity"] = {"max_abs_vs_oracle": par[headline]["max_abs_vs_oracle"], "per_t": par[headline]["per_t"], "tolerance": 1e-3,
-                         "frames": N_T, "size": "%dx%d" % (Hp, Wp), "mode": headline}
+        # a second deterministic weight family through the same pair (the margin must not be a property of one weight
+        # distribution): He-normal values, Gaussian-windowed 7x7 / 5x5 filters, decoder at gain 1.25; `max_abs_vs_oracle` = the WORST family
+        fams = [{"weights": "uniform (index-hash He-uniform: the fixtures' and the timed family)", "frames": "low-pass texture, 3-px motion",
+                 "max_abs_vs_oracle": par[headline]["max_abs_vs_oracle"]}]
+        if not args.no_second_family:
+            sdA, sdB = synthetic_state_dict(1, family="smooth"), synthetic_state_dict(2, family="smooth")
+            model2 = FullModel(cfg)
+            model2.stage1_model.load_state_dict(sdA)
+            model2.stage2_model.load_state_dict(sdB)
+            model2 = model2.to(dev).eval()
+            model2.precision = headline
+            ts2 = [0.125, 0.5, 0.875]
+            from oracle import ssm_oracle as O
+            with torch.no_grad():
+                want2 = torch.cat(O.interpolate_pair(sdA, sdB, pair, ts2), 0)
+            got2 = model2.interpolate(xs[0].to(dev), ts2).cpu()
+            fams.append({"weights": "smooth (He-normal, windowed 7x7 / 5x5 filters, decoder gain 1.25)", "frames": "low-pass texture, 3-px motion",
+                         "max_abs_vs_oracle": float((got2 - want2).abs().max()), "t": ts2})
+            del model2
+        out["parity"] = {"max_abs_vs_oracle": max(f["max_abs_vs_oracle"] for f in fams), "per_t": par[headline]["per_t"], "tolerance": 1e-3,
+                         "frames": N_T, "size": "%dx%d" % (Hp, Wp), "mode": headline, "families": fams,
+                         "note": "hard-edged frames with 28-px motion put the reference's own CPU fp32 path 1.4e-3 from a float64 evaluation of "
+                                 "itself (profiles/r8h_parity_families_720p.txt): per-pixel max-abs between two fp32 evaluations is set by the "
+                                 "image gradient there, not by the arithmetic; the HIP path tracks the oracle's own rounding "
+                                 "(tests/test_hip_model.py::test_720p_hard_edge_frames_track_the_oracles_own_rounding)"}
     if rank == 0 and world == 1 and not args.no_io and args.size == "720p":
         out["io"] = io_legs(dev, h_in, w_in)
 
@@ -827,6 +850,7 @@ def infer_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-second-family", action="store_true", help="skip the parity leg on the second weight family (saves ~25 s of CPU oracle)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-step", type=int, default=8, help="frame pairs per step (infer mode); 20 steps x 8 = 160 pairs")

@@ -99,8 +99,23 @@ def _hash_uniform(tag, n):
     return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
 
 
-def synthetic_state_dict(stage, cross_skip=True, gain=1.0, bottleneck="CONV"):
-    """Deterministic OIHW fp32 state dict with the reference's keys."""
+def _hash_normal(tag, n):
+    """n standard-normal floats, a pure function of (tag, index): Box-Muller on two hash-uniform streams (float64 inside)."""
+    u1 = _hash_uniform(tag + "/u1", n).astype(np.float64)
+    u2 = _hash_uniform(tag + "/u2", n).astype(np.float64)
+    return (np.sqrt(-2.0 * np.log(u1 + 2.0 ** -25)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)
+
+
+def synthetic_state_dict(stage, cross_skip=True, gain=1.0, bottleneck="CONV", family="uniform"):
+    """Deterministic OIHW fp32 state dict with the reference's keys.
+
+    family "uniform" (the fixtures' and the benchmark's): index-hash He-uniform values.  family "smooth" (second family of the parity
+    tests, r4): He-NORMAL values (heavier tails, same variance), the 7x7 / 5x5 filters multiplied by a Gaussian window (low-pass,
+    spatially structured filters like trained first layers) and renormalised to the same variance, decoder layers at gain 1.25 -
+    another point of the parity margin than one weight distribution gives."""
+    assert family in ("uniform", "smooth"), family
+    if family == "smooth":
+        return _smooth_state_dict(stage, cross_skip, gain, bottleneck)
     sd = {}
     if bottleneck != "CONV":
         for prefix, cin, hid, cout in recurrent_convs(bottleneck):
@@ -122,6 +137,28 @@ def synthetic_state_dict(stage, cross_skip=True, gain=1.0, bottleneck="CONV"):
         b = (_hash_uniform(tag + "/b", cout) * 2.0 - 1.0) * 0.05
         sd[wkey] = torch.from_numpy(w.astype(np.float32).reshape(cout, cin, k, k).copy())
         sd[bkey] = torch.from_numpy(b.astype(np.float32).copy())
+    return sd
+
+
+def _smooth_state_dict(stage, cross_skip, gain, bottleneck):
+    assert bottleneck == "CONV", "the second weight family covers the convolutional U-Nets"
+    sd = {}
+    for name, cin, cout, k in unet_layers(stage, cross_skip, bottleneck):
+        fan_in = cin * k * k
+        std = gain * float(np.sqrt(2.0 / (1.01 * fan_in)))
+        if name == "final_conv":
+            std *= 2.0
+        elif name[:5] in ("conv7", "conv8", "conv9") or name[:6] in ("conv10", "conv11") or name == "fuse_conv":
+            std *= 1.25
+        tag = "smooth/stage%d/%s" % (stage, name)
+        w = _hash_normal(tag + "/w", cout * cin * k * k).reshape(cout, cin, k, k).astype(np.float64)
+        if k >= 5:
+            ax = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
+            win = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / (2.0 * (k / 4.0) ** 2))
+            w = w * (win / np.sqrt((win ** 2).mean()))
+        b = (_hash_uniform(tag + "/b", cout) * 2.0 - 1.0) * 0.05
+        sd[param_key(name, "weight")] = torch.from_numpy((w * std).astype(np.float32).copy())
+        sd[param_key(name, "bias")] = torch.from_numpy(b.astype(np.float32).copy())
     return sd
 
 
@@ -149,6 +186,36 @@ def synthetic_frames_u8(n_frames, h, w, seed=42):
     return torch.stack(frames)
 
 
+def synthetic_frames_edges_u8(n_frames, h, w, seed=7, motion=(28, 20)):
+    """Second frame family of the parity tests (r4): HARD edges - flat rectangles, bars and a checkerboard at full contrast over a
+    coarse gradient - translated `motion` (default 28, 20) px per frame: large motion and step edges instead of the low-pass texture
+    with 3-px motion of synthetic_frames_u8.  uint8 RGB [n_frames, 3, h, w]."""
+    rng = np.random.RandomState(seed)
+    mx, my = abs(motion[0]) * n_frames + 8, abs(motion[1]) * n_frames + 8
+    H, W = h + 2 * my, w + 2 * mx
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = np.stack([0.25 + 0.5 * xx / W, 0.25 + 0.5 * yy / H, 0.5 + 0.0 * xx]).astype(np.float32)
+    for _ in range(60):          # flat rectangles
+        y0, x0 = rng.randint(0, H - 8), rng.randint(0, W - 8)
+        hh, ww = rng.randint(8, max(9, H // 4)), rng.randint(8, max(9, W // 4))
+        img[:, y0:y0 + hh, x0:x0 + ww] = rng.rand(3, 1, 1).astype(np.float32)
+    for i in range(12):          # thin bars, both directions
+        p = rng.randint(0, W - 4)
+        img[:, :, p:p + 1 + i % 3] = float(i % 2)
+        p = rng.randint(0, H - 4)
+        img[:, p:p + 1 + i % 3, :] = float((i + 1) % 2)
+    cy, cx = H // 3, W // 3          # a one-pixel and an eight-pixel checkerboard
+    img[:, cy:cy + 96, cx:cx + 96] = (((yy[cy:cy + 96, cx:cx + 96] + xx[cy:cy + 96, cx:cx + 96]) % 2) > 0.5).astype(np.float32)
+    img[:, cy + 128:cy + 256, cx:cx + 128] = ((((yy[cy + 128:cy + 256, cx:cx + 128] // 8) + (xx[cy + 128:cy + 256, cx:cx + 128] // 8)) % 2) > 0.5)
+    t = torch.from_numpy(img)
+    frames = []
+    for i in range(n_frames):
+        dx, dy = motion[0] * i, motion[1] * i
+        crop = t[:, my + dy: my + dy + h, mx + dx: mx + dx + w]
+        frames.append(torch.round(crop * 255.0).clamp(0, 255).to(torch.uint8))
+    return torch.stack(frames)
+
+
 def normalize_and_pad(u8, pad_to=32):
     """Input contract of the path (SURVEY a-0): x/255, ImageNet-normalise
     (scripts/utils/dataloaders/augmentations.py:141-200), then zero-pad IN
@@ -167,6 +234,8 @@ def normalize_and_pad(u8, pad_to=32):
     return out
 
 
-def synthetic_frames(n_frames, h, w, seed=42, pad_to=32):
-    """normalize_and_pad(synthetic_frames_u8(...)): float32 [1,n_frames,3,Hp,Wp]."""
-    return normalize_and_pad(synthetic_frames_u8(n_frames, h, w, seed), pad_to)
+def synthetic_frames(n_frames, h, w, seed=42, pad_to=32, family="texture"):
+    """normalize_and_pad(synthetic_frames_u8(...)): float32 [1,n_frames,3,Hp,Wp].  family "edges": synthetic_frames_edges_u8."""
+    assert family in ("texture", "edges"), family
+    u8 = synthetic_frames_u8(n_frames, h, w, seed) if family == "texture" else synthetic_frames_edges_u8(n_frames, h, w, seed)
+    return normalize_and_pad(u8, pad_to)
