@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Parity of the HIP path against the CPU oracle at 736x1280 for other weight / frame families than the fixtures' (VERDICT r3 item 5):
+"""Study (GPU, not a test; the oracle is only imported under tests/): parity of the HIP path against the CPU oracle at 736x1280 for other weight / frame families than the fixtures' (VERDICT r3 item 5):
 weights "uniform" (index-hash He-uniform) | "smooth" (He-normal, windowed 7x7 / 5x5 filters, decoder gain 1.25); frames "texture"
 (low-pass texture, 3-px motion) | "edges" (full-contrast rectangles, bars, checkerboards, 28 x 20 px motion).  Beside max|HIP - oracle| it
 prints the oracle's OWN fp32 rounding (oracle fp32 vs oracle float64): what two correct fp32 evaluations can differ by on that input.
-usage: python tools/parity_families.py [mode=f32w] [--f64]"""
+usage: python tests/study_parity_families.py [mode=f32w] [--f64]"""
 import os
 import sys
 
