@@ -132,6 +132,9 @@ struct W4Lds {
 #ifndef W4_INTERLEAVE
 #define W4_INTERLEAVE 1      // 512-thread form: the next chunk's transform in the slots of the matrix loop (0: as one block behind the loop)
 #endif
+#ifndef W4_HALF_UNITS
+#define W4_HALF_UNITS 1      // 512-thread form: waves 4..7 transform half units (no row pass computed twice); 0: every wave a quarter unit
+#endif
 #define W4_PA 0.625
 #define W4_PB 1.6
 constexpr float kA = (float)W4_PA, kB = (float)W4_PB, kA2 = (float)(W4_PA * W4_PA), kB2 = (float)(W4_PB * W4_PB);
@@ -736,6 +739,51 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             }
             if (m >= 18 && m < 22) w4_store_v9_step<NT>(2 * hh + hq, m - 18, tv, vo);
         };
+        // Second arrangement of the same transform (W4_HALF_UNITS, default): only waves 4..7 transform - TWO threads per (cin, tile), each
+        // the row pass of its three column-frequencies (42 operations) and their whole column pass (42) = 84 per thread, 18 frequencies
+        // stored as 4 x 16 + 8 bytes.  The quarter form above computes every row pass twice (two threads share a column half): 126
+        // vector instructions per SIMD and chunk; this one 84, all of them in the wave whose partner (waves 0..3) issues the chunk's DMA.
+        float tv18[18];
+        auto tstep2 = [&](auto HH, int m, const float *src, f32x4 *vo) __attribute__((always_inline)) {
+            constexpr int hh = decltype(HH)::value;
+            if (m < 6) {
+                r4[m] = *(const f32x4 *)(src + m * PW);
+                r2[m] = *(const f32x2 *)(src + m * PW + 4);
+            }
+            if (m >= 3 && m < 9) {
+                const int i = m - 3;
+                const float d[6] = {r4[i][0], r4[i][1], r4[i][2], r4[i][3], r2[i][0], r2[i][1]};
+                w4_row_pass(hh, d, tX[i]);
+            }
+            if (m >= 9 && m < 18) {
+                const int jj = (m - 9) / 3, st3 = (m - 9) % 3;
+                const float x0v = tX[0][jj], x1v = tX[1][jj], x2v = tX[2][jj], x3v = tX[3][jj], x4v = tX[4][jj], x5v = tX[5][jj];
+                if (st3 == 0) {          // (the expressions of w4_col_pass)
+                    tv18[jj] = (kP0 * x0v - kS2 * x2v) + x4v;
+                    tv18[15 + jj] = (kP0 * x1v - kS2 * x3v) + x5v;
+                }
+                if (st3 == 1) {
+                    const float te = x4v - kB2 * x2v, to = x3v - kB2 * x1v;
+                    tv18[3 + jj] = te + kA * to;
+                    tv18[6 + jj] = te - kA * to;
+                }
+                if (st3 == 2) {
+                    const float ue = x4v - kA2 * x2v, uo = x3v - kA2 * x1v;
+                    tv18[9 + jj] = ue + kB * uo;
+                    tv18[12 + jj] = ue - kB * uo;
+                }
+            }
+            if (m >= 18 && m < 23) {          // the five stores of w4_store_v, one per slot
+                const int k = m - 18;
+                if (hh == 0) {
+                    if (k < 4) vo[k * NT] = f32x4{tv18[4 * k], tv18[4 * k + 1], tv18[4 * k + 2], tv18[4 * k + 3]};
+                    else *(f32x2 *)(vo + 4 * NT) = f32x2{tv18[16], tv18[17]};
+                } else {
+                    if (k == 0) *((f32x2 *)(vo + 4 * NT) + 1) = f32x2{tv18[0], tv18[1]};
+                    else vo[(4 + k) * NT] = f32x4{tv18[4 * k - 2], tv18[4 * k - 1], tv18[4 * k], tv18[4 * k + 1]};
+                }
+            }
+        };
         // one chunk; STEADY: chunks ch+1 .. ch+3 exist (compile-time: the steady state carries no per-slot branch on the tail conditions)
         auto chunk = [&](int ch, auto STEADY, auto HH, auto HQ) __attribute__((always_inline)) {
             constexpr bool steady = decltype(STEADY)::value;
@@ -758,13 +806,23 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                     if (m2) issue_k(ch + 2, 0, g, st);
                 }
             }, [&](int m) {
-                if (W4_INTERLEAVE && m1 && !W4ABL(4)) tstep(HH, HQ, m, tsrc, tdst);
+                if (W4_INTERLEAVE && m1 && !W4ABL(4)) {
+                    if constexpr (W4_HALF_UNITS) {
+                        if constexpr (decltype(HQ)::value == 1) tstep2(HH, m, tsrc, tdst);
+                    } else {
+                        tstep(HH, HQ, m, tsrc, tdst);
+                    }
+                }
             });
             W4STAMP(3)
             W4TRACE(ch, 2)
-            if (!W4_INTERLEAVE && m1 && !W4ABL(4)) transform_as(HH, HQ, st ^ 1, st ^ 1);
+            if (!W4_INTERLEAVE && m1 && !W4ABL(4)) transform_as(HH, HQ, st ^ 1, st ^ 1);          // (block form: always the quarter arrangement)
             if constexpr (UPS) {
-                if (m2) expand_half(st, st);
+                if constexpr (W4_HALF_UNITS) {          // waves 4..7 carried the whole transform: waves 0..3 expand all four channels
+                    if (m2 && decltype(HQ)::value == 0) expand(st, st, C0{}, std::integral_constant<int, CK>{});
+                } else {
+                    if (m2) expand_half(st, st);
+                }
             }
             W4STAMP(1)
             W4TRACE(ch, 3)
