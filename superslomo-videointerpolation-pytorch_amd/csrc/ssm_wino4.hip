@@ -132,9 +132,6 @@ struct W4Lds {
 #ifndef W4_INTERLEAVE
 #define W4_INTERLEAVE 1      // 512-thread form: the next chunk's transform in the slots of the matrix loop (0: as one block behind the loop)
 #endif
-#ifndef W4_HALF_UNITS
-#define W4_HALF_UNITS 1      // 512-thread form: waves 4..7 transform half units (no row pass computed twice); 0: every wave a quarter unit
-#endif
 #define W4_PA 0.625
 #define W4_PB 1.6
 constexpr float kA = (float)W4_PA, kB = (float)W4_PB, kA2 = (float)(W4_PA * W4_PA), kB2 = (float)(W4_PB * W4_PB);
@@ -210,32 +207,6 @@ __device__ __forceinline__ void w4_store_v9(int part, const float *v, f32x4 *vo)
         vf[6 * NT * 4 + 3] = v[0];
         vo[7 * NT] = f32x4{v[1], v[2], v[3], v[4]};
         vo[8 * NT] = f32x4{v[5], v[6], v[7], v[8]};
-    }
-}
-
-// the k-th store instruction of w4_store_v9 (k = 0..3; parts 0 and 3 have three), for the form that spreads the transform over the
-// slots of the matrix loop
-template <int NT>
-__device__ __forceinline__ void w4_store_v9_step(int part, int k, const float *v, f32x4 *vo) {
-    float *vf = (float *)vo;
-    if (part == 0) {
-        if (k == 0) vo[0] = f32x4{v[0], v[1], v[2], v[3]};
-        if (k == 1) vo[NT] = f32x4{v[4], v[5], v[6], v[7]};
-        if (k == 2) vf[2 * NT * 4] = v[8];
-    } else if (part == 1) {
-        if (k == 0) vf[2 * NT * 4 + 1] = v[0];
-        if (k == 1) *(f32x2 *)(vf + 2 * NT * 4 + 2) = f32x2{v[1], v[2]};
-        if (k == 2) vo[3 * NT] = f32x4{v[3], v[4], v[5], v[6]};
-        if (k == 3) *(f32x2 *)(vf + 4 * NT * 4) = f32x2{v[7], v[8]};
-    } else if (part == 2) {
-        if (k == 0) *(f32x2 *)(vf + 4 * NT * 4 + 2) = f32x2{v[0], v[1]};
-        if (k == 1) vo[5 * NT] = f32x4{v[2], v[3], v[4], v[5]};
-        if (k == 2) *(f32x2 *)(vf + 6 * NT * 4) = f32x2{v[6], v[7]};
-        if (k == 3) vf[6 * NT * 4 + 2] = v[8];
-    } else {
-        if (k == 0) vf[6 * NT * 4 + 3] = v[0];
-        if (k == 1) vo[7 * NT] = f32x4{v[1], v[2], v[3], v[4]};
-        if (k == 2) vo[8 * NT] = f32x4{v[5], v[6], v[7], v[8]};
     }
 }
 
@@ -690,59 +661,22 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             }
         }
         transform(0, 0);
-        // The transform of chunk ch+1 (this thread's quarter of a (cin, tile): 9 frequencies) rides in the slots of the matrix loop of chunk
-        // ch, one or two LDS / up to seven vector instructions behind an MFMA:
+        // The transform of chunk ch+1 rides in the slots of the matrix loop of chunk ch, one or two LDS / up to seven vector instructions
+        // behind an MFMA:
         //   slots 0..5    window row i (one ds_read_b128 + one ds_read_b64)
         //   slots 3..8    row pass of row i - 3 (its read is three MFMAs old)
         //   slots 9..17   the three column passes, three slots each
-        //   slots 18..21  the V stores
-        // so that a wave never leaves the matrix pipe without queued work for a whole vector phase.  The quarter (HH, HQ) is wave-
-        // uniform: the loop is instantiated per quarter and carries no branch.
+        //   slots 18..22  the V stores
+        // so that a wave never leaves the matrix pipe without queued work for a whole vector phase.  The role (HH, HQ) is wave-uniform:
+        // the loop is instantiated per role and carries no branch.
         f32x4 r4[6];
         f32x2 r2[6];
-        float tX[6][3], tE[3], tO[3], tv[9];
-        auto tstep = [&](auto HH, auto HQ, int m, const float *src, f32x4 *vo) __attribute__((always_inline)) {
-            constexpr int hh = decltype(HH)::value, hq = decltype(HQ)::value;
-            if (m < 6) {
-                r4[m] = *(const f32x4 *)(src + m * PW);
-                r2[m] = *(const f32x2 *)(src + m * PW + 4);
-            }
-            if (m >= 3 && m < 9) {
-                const int i = m - 3;
-                const float d[6] = {r4[i][0], r4[i][1], r4[i][2], r4[i][3], r2[i][0], r2[i][1]};
-                w4_row_pass(hh, d, tX[i]);
-            }
-            if (m >= 9 && m < 18) {
-                const int jj = (m - 9) / 3, st3 = (m - 9) % 3;
-                const float x0v = tX[0][jj], x1v = tX[1][jj], x2v = tX[2][jj], x3v = tX[3][jj], x4v = tX[4][jj], x5v = tX[5][jj];
-                if constexpr (hq == 0) {          // (the expressions of w4_col_pass_half)
-                    if (st3 == 0) {
-                        tE[jj] = x4v - kB2 * x2v;
-                        tO[jj] = x3v - kB2 * x1v;
-                    }
-                    if (st3 == 1) tv[jj] = (kP0 * x0v - kS2 * x2v) + x4v;
-                    if (st3 == 2) {
-                        tv[3 + jj] = tE[jj] + kA * tO[jj];
-                        tv[6 + jj] = tE[jj] - kA * tO[jj];
-                    }
-                } else {
-                    if (st3 == 0) {
-                        tE[jj] = x4v - kA2 * x2v;
-                        tO[jj] = x3v - kA2 * x1v;
-                    }
-                    if (st3 == 1) tv[6 + jj] = (kP0 * x1v - kS2 * x3v) + x5v;
-                    if (st3 == 2) {
-                        tv[jj] = tE[jj] + kB * tO[jj];
-                        tv[3 + jj] = tE[jj] - kB * tO[jj];
-                    }
-                }
-            }
-            if (m >= 18 && m < 22) w4_store_v9_step<NT>(2 * hh + hq, m - 18, tv, vo);
-        };
-        // Second arrangement of the same transform (W4_HALF_UNITS, default): only waves 4..7 transform - TWO threads per (cin, tile), each
-        // the row pass of its three column-frequencies (42 operations) and their whole column pass (42) = 84 per thread, 18 frequencies
-        // stored as 4 x 16 + 8 bytes.  The quarter form above computes every row pass twice (two threads share a column half): 126
-        // vector instructions per SIMD and chunk; this one 84, all of them in the wave whose partner (waves 0..3) issues the chunk's DMA.
+        float tX[6][3];
+        // In the loop only waves 4..7 transform - TWO threads per (cin, tile), each the row pass of its three column-frequencies (42
+        // operations) and their whole column pass (42) = 84 per thread, 18 frequencies stored as 4 x 16 + 8 bytes - while their SIMD
+        // partners, waves 0..3, issue the chunk's DMA and (fused upsample) expand all four channels.  (r3 gave every wave a quarter unit:
+        // each row pass was computed twice, 126 vector instructions per SIMD and chunk instead of 84; same-box A/B at batch 14: 3 % over
+        // the 3x3 layers, profiles/r8k_wino4_half_units_ab.txt.  The block-form transform of the prologue keeps the quarter units.)
         float tv18[18];
         auto tstep2 = [&](auto HH, int m, const float *src, f32x4 *vo) __attribute__((always_inline)) {
             constexpr int hh = decltype(HH)::value;
@@ -806,23 +740,16 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                     if (m2) issue_k(ch + 2, 0, g, st);
                 }
             }, [&](int m) {
-                if (W4_INTERLEAVE && m1 && !W4ABL(4)) {
-                    if constexpr (W4_HALF_UNITS) {
-                        if constexpr (decltype(HQ)::value == 1) tstep2(HH, m, tsrc, tdst);
-                    } else {
-                        tstep(HH, HQ, m, tsrc, tdst);
-                    }
+                if constexpr (decltype(HQ)::value == 1) {
+                    if (W4_INTERLEAVE && m1 && !W4ABL(4)) tstep2(HH, m, tsrc, tdst);
                 }
             });
             W4STAMP(3)
             W4TRACE(ch, 2)
             if (!W4_INTERLEAVE && m1 && !W4ABL(4)) transform_as(HH, HQ, st ^ 1, st ^ 1);          // (block form: always the quarter arrangement)
             if constexpr (UPS) {
-                if constexpr (W4_HALF_UNITS) {          // waves 4..7 carried the whole transform: waves 0..3 expand all four channels
-                    if (m2 && decltype(HQ)::value == 0) expand(st, st, C0{}, std::integral_constant<int, CK>{});
-                } else {
-                    if (m2) expand_half(st, st);
-                }
+                // (waves 4..7 carried the whole transform: waves 0..3 expand all four channels)
+                if (m2 && decltype(HQ)::value == 0) expand(st, st, C0{}, std::integral_constant<int, CK>{});
             }
             W4STAMP(1)
             W4TRACE(ch, 3)
