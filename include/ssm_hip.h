@@ -146,7 +146,7 @@ int ssm_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *
  * scripts/models/layers.py:21-33; decoder step scripts/models/flow_computation.py:244-247), evaluated as
  * Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A per 2x2 output tile: 16 instead of 36 multiplies per (cin, cout, 4 outputs),
  * i.e. 2.25x fewer matrix-core cycles; in fp32 the result differs from the direct form by rounding only (about as much as
- * a different summation order).  W must be even; Cin and the first cat source multiples of CK.
+ * a different summation order; profiles/DESIGN_history_r1-r3.md 3.2d).  W must be even; Cin and the first cat source multiples of CK.
  * ssm_wino_plan: tile configuration for the problem (ups: the fused-upsample entry point; BN = cout block to pack for, CK =
  * channel chunk); two kernel forms - one workgroup per CU with 16 frequency accumulators per wave, or two per CU with 8.
  * ssm_wino_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/BN][Cin][4][BN][4] (+ bias padded to BN).          */
@@ -171,7 +171,7 @@ int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const fl
  * decoder step scripts/models/flow_computation.py:244-247), evaluated per 4x4 output tile from its 6x6 input patch over the points
  * {0, +-1, +-2, inf}: 36 instead of 144 multiplies per (cin, cout, 16 outputs) - 1.78x fewer matrix-core cycles than F(2x2,3x3); in
  * fp32 a single layer sits ~1e-5 from a float64 evaluation at unit output scale (per-layer bar 5e-5), the pair -> frame path at
- * 736x1280 is unchanged within its fp32 noise (tests/emulate_winograd_f44_precision.py).
+ * 736x1280 is unchanged within its fp32 noise (tests/emulate_winograd_f44_precision.py; profiles/DESIGN_history_r1-r3.md 3.2f).
  * Cin and the first cat source multiples of 4, Cout a multiple of 32; any H, W (fused upsample: even).
  * ssm_wino4_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/32][Cin][9][32][4] (+ bias).
  * Inputs must be padded planes with SSM_TAIL_SLACK_FLOATS readable floats behind them: a 16-row tile that overshoots the map reads 14
@@ -194,7 +194,7 @@ int ssm_wino4_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const f
  * flow_interpolation.py:36-45; fused 2x2 mean, layers.py:60-63), evaluated as F(2,7) / F(4,5) along x - eight frequencies over the
  * points {0, +-1, +-2, +-1/2, inf} - and in the direct form along y: 8 multiplies per 2 (k = 7) / 4 (k = 5) outputs and filter
  * row instead of 14 / 20, i.e. 1.75x / 2.5x fewer matrix-core cycles; in fp32 the result differs from the direct form by
- * rounding only (a single layer: 5-8e-6 at unit output scale, tests/emulate_winograd_1d_precision.py).
+ * rounding only (a single layer: 5-8e-6 at unit output scale, tests/emulate_winograd_1d_precision.py; profiles/DESIGN_history_r1-r3.md 3.2e).
  * One input source (these layers have no concat); Cin a multiple of CK (= 2; pad the view), Cout a multiple of BN.
  * ssm_wino1d_plan: tile configuration (BN = cout block to pack for, CK = channel chunk).
  * ssm_wino1d_pack_weights: OIHW fp32 filter -> U[ky] = G g[ky] as [Cout/BN][CinP][k][2][BN][4] (+ bias padded to BN).
@@ -214,7 +214,7 @@ int ssm_wino1d_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const 
  * pre-activation addend for the hoisted part of stage 2's conv1a).  The 7x7 filter (zero-padded to 8x8) is 2x2 blocks of 4x4 taps;
  * each block is a F(4x4,4x4) Winograd filter over the seven points {0, +-1, +-1/2, +-2}, and because the blocks of a 4x4 output tile
  * read input windows that are whole tiles apart, one input transform per window position serves all four: 4 x 49 multiplies per 16
- * outputs and (cin, cout) = 12.25 per output against 28 for F(2,7) and 49 for the direct form (csrc/ssm_wino7.hip; DESIGN 3.2h).
+ * outputs and (cin, cout) = 12.25 per output against 28 for F(2,7) and 49 for the direct form (csrc/ssm_wino7.hip; DESIGN.md 3.2).
  * In fp32 the result differs from the direct form by rounding only (a 32-channel layer: 2e-6 rms / 3e-5 max at unit output scale).
  * One input source, any Cin >= 1 (a k-step is the four blocks of one channel: no channel padding); Cout a multiple of 32.
  * Inputs are padded planes with SSM_TAIL_SLACK_FLOATS readable floats behind them (tile overshoot; refused if it would outrun them).

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(ssm_view dz, float *__re
 //     columns past Cin*k*k read a zeroed row instead of being masked.
 // Everything that depends only on the thread (which float4 of a tile it stages, where it lands in LDS, its validity) is computed ONCE:
 // the first version recomputed that index arithmetic every step - 5-11 vector instructions per MFMA on the training step's layers
-// (tools/pmc_wgrad.sh), and a vector instruction beside the fp32 MFMA costs ~3 matrix cycles.  SEG x RR = 64x2,
+// (tools/pmc_wgrad.sh), and a vector instruction beside the fp32 MFMA costs ~3 matrix cycles (profiles/DESIGN_history_r1-r3.md 3.2g).  SEG x RR = 64x2,
 // 32x4 or 16x8 by the map's width: the deep layers' 22- and 11-pixel rows fill a step with more rows instead of padding.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float wg_f4 __attribute__((ext_vector_type(4)));

@@ -26,7 +26,7 @@
 // and the operands of its first k-step are fetched and transformed behind the remaining MFMAs - the matrix pipe never waits for LDS.
 //
 // Two kernel forms share this file: wino_kernel (this description: 16 frequencies per wave, one workgroup per CU) and wino2_kernel
-// (further down: 8 frequencies per wave, two workgroups per CU - what the plan picks for most layers; DESIGN.md 3.2d says why).
+// (further down: 8 frequencies per wave, two workgroups per CU - what the plan picks for most layers; profiles/DESIGN_history_r1-r3.md 3.2d says why).
 #include "ssm_common.h"
 
 #include <atomic>
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float t[16];
     auto transform_rows = [&]() {
         // the patch values arrive as 8-byte pairs: pin each as a scalar HERE (where the wait for the loads belongs anyway), so that no
-        // packed-fp32 arithmetic is formed on the pairs (DESIGN 3.3 fence).  Pinning at the load would put an s_waitcnt lgkmcnt(0)
+        // packed-fp32 arithmetic is formed on the pairs (profiles/DESIGN_history_r1-r3.md 3.3 fence).  Pinning at the load would put an s_waitcnt lgkmcnt(0)
         // behind every ds_read_b64 - the full LDS latency, eight times per k-step.
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(d[i]));

@@ -27,7 +27,7 @@
 // LDS) arrive by LDS-DMA, one instruction per frequency group INSIDE the matrix loop of the chunk before (a burst at a phase boundary
 // costs ~200 issue cycles a piece, among MFMAs a few tens).
 //
-// Two kernel forms (DESIGN.md 3.2f-g has the measurements behind them):
+// Two kernel forms (profiles/DESIGN_history_r1-r3.md 3.2f-g has the measurements behind them):
 //   wino4_kernel<W4Cfg<.., NCB = 1>>  256 threads, 32 couts x 32 tiles, two workgroups per CU, two barriers per chunk
 //                                     [patch landed] expand, transform [filter landed] matrix loop; single-buffered patch and V.
 //   wino4_kernel<W4Cfg<.., NCB = 2>>  512 threads, 64 couts x 32 tiles, one workgroup per CU: the transform serves twice the MFMAs
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     const int nchunks = p.Cin / CK;
     // Tuning knob ($SSM_WINO4_STAGGER, 256-thread form): the second workgroup of every CU (dispatch order: workgroup i + 256) starts
     // late, so that the two co-resident workgroups are out of phase.  Measured: no effect (profiles/r6g_w4_stagger_b7.txt) - the two
-    // waves of a SIMD serialise on the issue port whatever their phases are.
+    // waves of a SIMD serialise on the issue port whatever their phases are (profiles/DESIGN_history_r1-r3.md 3.2g).
     if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }

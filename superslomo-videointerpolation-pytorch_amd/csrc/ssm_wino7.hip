@@ -25,7 +25,7 @@
 // of its tile shifted by block q - a per-lane constant offset into V).  A wave owns 16 couts x 16 tiles for all 49 frequencies (49
 // accumulators of 4 registers), so the output transform A^T M A is lane-local and a lane finishes whole 4x4 pixel tiles.  One workgroup
 // of four waves (32 couts x 32 tiles of 4x4 pixels) per CU, one wave per SIMD: the fp32 MFMA and vector instructions share the issue
-// port, two waves on a SIMD only serialise.
+// port (profiles/DESIGN_history_r1-r3.md 3.2g), two waves on a SIMD only serialise.
 //
 // Input transform with the overlap of neighbouring windows used (7 rows at stride 4): a ROW pass per (patch row, position column) - each
 // patch row is transformed once although two vertically neighbouring windows read it - leaves X [h][row][px][4] in LDS, a COLUMN pass per

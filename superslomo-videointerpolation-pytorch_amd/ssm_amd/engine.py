@@ -260,7 +260,7 @@ class UNetPlan:
             t["pair1a"] = hb.Planes(self.hoist[0], 32, H, W, device)                  # conv1a's image-channel partial sums, per pair
             if self.cross:
                 t["pair7a"] = hb.Planes(self.hoist[0], 512, H // 16, W // 16, device)  # conv7a's stage-1 half, per pair
-        # (outer decoder levels run in the sub-pixel form on inference plans: _subpixel / ssm_amd.subpixel)
+        # (outer decoder levels run in the sub-pixel form on inference plans: _subpixel / ssm_amd.subpixel, profiles/DESIGN_history_r1-r3.md 3.1a)
         self.f32 = {}
         if self.twins:
             assert bottleneck == "CONV" and dec is None, "fp32 twins are for the training plan"

@@ -1,4 +1,4 @@
-"""conv3x3(upsample2x(cat[a, b])) in its sub-pixel form: a plain 3x3 convolution of the LOW-res tensors with
+"""conv3x3(upsample2x(cat[a, b])) in its sub-pixel form (profiles/DESIGN_history_r1-r3.md 3.1a): a plain 3x3 convolution of the LOW-res tensors with
 4*Cout outputs - the effective filter M_a W M_b^T of each output parity (a, b) - and a pixel-shuffle store.  The bilinear rule
 clamps at the border (scripts/models/flow_computation.py:215-289 via F.upsample, align_corners=False) while the convolution
 zero-pads the upsampled map, so low-res rows / columns 0 and last have their own effective filters: border strips (rows as H = 1

@@ -3,7 +3,7 @@
 emulation of: fp16 main product + correction products whose operands are quantised to block-scaled fp6 (e2m3, one E8M0 scale
 per 32 channels - the operand format of v_mfma_scale_f32_32x32x64_f8f6f4) or block-scaled int8.
 
-    python tests/emulate_correction_precision.py [size]     (default 128; result quoted in DESIGN.md section 7)
+    python tests/emulate_correction_precision.py [size]     (default 128; result quoted in DESIGN.md 7)
 """
 import sys, torch, math
 import os

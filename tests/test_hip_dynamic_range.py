@@ -6,7 +6,7 @@ compensation) against the exact-fp32 mode - the evidence behind their labels "na
 each mode IS fp32-grade, where it degrades to fp16-grade, and where it breaks (so nobody mistakes it for a drop-in fp32):
 
   activations / weights in 2^-4 .. 2^4   : f16x3 <= 5e-6, f16f8 <= 5e-4 of the output scale (2.4e-6 / 2.1e-4 measured)
-  activations down to 2^-10 / 2^-14      : lo parts go subnormal in fp16 -> fp16-grade (documented in DESIGN 3.1)
+  activations down to 2^-10 / 2^-14      : lo parts go subnormal in fp16 -> fp16-grade (documented in profiles/DESIGN_history_r1-r3.md 3.1)
   |activation| in (448, 65504)           : f16f8's e4m3 copies clamp (pack4_fp8) -> compensation lost, fp16-grade; f16x3 unaffected
   |activation| > 65504                   : fp16 hi overflows -> non-finite output in BOTH split modes; mode f32 is exact
   large motion (flows of 30-120 px)      : f16x3 frames within 1e-3 of mode f32 (1.1e-4 measured); f16f8 EXCEEDS the 1e-3
