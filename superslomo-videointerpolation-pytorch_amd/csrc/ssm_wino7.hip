@@ -152,9 +152,21 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
         asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
     };
     const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * q) * p.asc + (long long)py * p.ash + px : nullptr;
+    // the addend rows of cout r + 1 are requested while cout r is transformed (four independent 16-byte loads, one cout ahead): their
+    // latency runs beside the output transform instead of in front of each cout's stores
+    f32x4 zadd[2][4];
+    const bool zvec = addb && vok;
+    auto zload = [&](int r) {
+        if (zvec) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zadd[r & 1][i] = *(const f32x4 *)(addb + (long long)(cu0 + r) * p.asc + (long long)i * p.ash);
+        }
+    };
+    zload(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cu = cu0 + r;          // uniform; this lane's cout = cu + 4 * q
+        if (r + 1 < 4) zload(r + 1);
         float t[4][7];                   // A^T M: over the row-frequencies, for every column-frequency
 #pragma unroll
         for (int cf = 0; cf < 7; ++cf) {
@@ -176,7 +188,7 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (vok) {
-                    const f32x4 z = *(const f32x4 *)(ap + (long long)i * p.ash);
+                    const f32x4 z = zadd[r & 1][i];
                     y[i][0] += z[0];
                     y[i][1] += z[1];
                     y[i][2] += z[2];

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from ssm_amd import hipbind as hb  # noqa: E402
 
 # (name, cin, cout, pooled): stage 1 / stage 2 (per-t part of the hoisted conv1a: 10 channels; its per-pair part: 6) shapes
-LAYERS = [("s1.conv1a", 6, 32, False), ("s2.conv1a(t)", 10, 32, False), ("conv1b", 32, 32, True)]
+LAYERS = [("s1.conv1a", 6, 32, False), ("s2.conv1a(t)", 10, 32, False), ("s2.conv1a(t)+add", 10, 32, False), ("conv1b", 32, 32, True)]
 
 
 def timed(fn, n=5):
@@ -50,8 +50,12 @@ def main():
         y0, y1 = hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, H, W, dev)
         q0 = hb.Planes(B, cout, H // 2, W // 2, dev) if pooled else None
         q1 = hb.Planes(B, cout, H // 2, W // 2, dev) if pooled else None
-        f0 = lambda: hb.conv2d_wino1d(x.view(), p1.cin_p, None, 0, p1, y0.view(), q0.view() if pooled else None, B, H, W)  # noqa: E731
-        f1 = lambda: hb.conv2d_wino7(x.view(), cin, None, 0, p7, y1.view(), q1.view() if pooled else None, B, H, W)  # noqa: E731
+        add = hb.Planes(max(B // 7, 1), cout, H, W, dev) if name.endswith("+add") and B % 7 == 0 else None      # the hoisted plan's addend: one per pair
+        if add is not None:
+            add.interior.normal_()
+        akw = dict(add=add.view(), add_div=7) if add is not None else {}
+        f0 = lambda: hb.conv2d_wino1d(x.view(), p1.cin_p, None, 0, p1, y0.view(), q0.view() if pooled else None, B, H, W, **akw)  # noqa: E731
+        f1 = lambda: hb.conv2d_wino7(x.view(), cin, None, 0, p7, y1.view(), q1.view() if pooled else None, B, H, W, **akw)  # noqa: E731
         t0 = timed(f0)
         t1 = timed(f1)
         diff = float((y0.interior - y1.interior).abs().max())
