@@ -837,7 +837,7 @@ def infer_bench(args):
                          "note": "hard-edged frames with 28-px motion put the reference's own CPU fp32 path 1.4e-3 from a float64 evaluation of "
                                  "itself (profiles/r8h_parity_families_720p.txt): per-pixel max-abs between two fp32 evaluations is set by the "
                                  "image gradient there, not by the arithmetic; the HIP path tracks the oracle's own rounding "
-                                 "(tests/test_hip_model.py::test_720p_hard_edge_frames_track_the_oracles_own_rounding)"}
+                                 "(tests/test_hip_model.py::test_hard_edge_frames_track_the_oracles_own_rounding)"}
     if rank == 0 and world == 1 and not args.no_io and args.size == "720p":
         out["io"] = io_legs(dev, h_in, w_in)
 
