@@ -437,31 +437,47 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     const int bBase = L::VOFF / 4 + q * (9 * NT) + tg * 16 + l15;
 
     // fused upsample: low-res raw chunk -> hi-res patch; one thread = one 2x2 hi-res block position, walking the chunk's channels
-    // (CB, CN: the channels of the chunk this call expands - the 512-thread form splits them between its two halves of 256 threads)
+    // (CB, CN: the channels of the chunk this call expands - the 512-thread form splits them between its two halves of 256 threads).
+    // What depends on the position only - source offsets, the edge cases of ATen's half-pixel rule, the in-image masks - is computed once per
+    // thread; a call rebuilds the twelve weights from one word of flags (the masks folded into the row weights: a mask is 0 or 1, same
+    // values) and is then 2 reads, 16 multiply-adds and 4 writes per channel (r3: 218 vector instructions per call of 4 channels).
+    // (kept across the chunk loop: three offsets and one word of flags - holding the twelve weights themselves spilled the 64-cout kernels)
+    int ex_r0 = 0, ex_r1 = 0, ex_dd = 0, ex_fl = 0;          // flags: 1 j0 == j1, 2 i0 == i1, 4 / 8 / 16 / 32 the 2x2 block's pixels inside the map, 64 thread has a position
+    if constexpr (UPS) {
+        constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, LW = C::LW;
+        const int etid = threadIdx.x & 255;
+        const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
+        const int pi = etid / PRW, pj = etid - pi * PRW;
+        const int i = ly0 + pi, j = lx0 + pj;
+        const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
+        const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
+        const int Y = 2 * i + 1, X = 2 * j + 1;
+        const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
+        ex_fl = (j0 == j1 ? 1 : 0) | (i0 == i1 ? 2 : 0) | ((yt && xl) ? 4 : 0) | ((yt && xr) ? 8 : 0) | ((yb2 && xl) ? 16 : 0) | ((yb2 && xr) ? 32 : 0) |
+                (etid < NPOS ? 64 : 0);
+        // (the right neighbour is read at j0 + 1 even where the source index is clamped: its weight is then exactly 0 and the value -
+        // the zero frame or a neighbouring pixel - is finite)
+        ex_r0 = (i0 - ly0) * LW + 3 - lx0 + j0;
+        ex_r1 = (i1 - ly0) * LW + 3 - lx0 + j0;
+        ex_dd = (2 * pi) * PW + 2 * pj + 3 + C::SHIFT;       // hi-res pixel x0 + 2pj - 1 -> patch column 2pj + 3 (+ SHIFT)
+    }
     auto expand = [&](int rbuf, int hbuf, auto CB, auto CN) {
         if constexpr (UPS) {
-            constexpr int PRW = C::TW / 2 + 1, NPOS = C::NPOS, LH = C::LH, LW = C::LW;
+            constexpr int LH = C::LH, LW = C::LW;
             constexpr int cbeg = decltype(CB)::value, cnum = decltype(CN)::value;
             const float *raw = lds + L::DOFF + rbuf * L::DCAP + cbeg * LH * LW;
             float *hip = lds + L::HOFF + hbuf * L::HCAP + cbeg * PH * PW;
-            const int tid = threadIdx.x & 255;
-            if (tid < NPOS) {
-                const int ly0 = y0 / 2 - 1, lx0 = x0 / 2 - 1;
-                const int pi = tid / PRW, pj = tid - pi * PRW;
-                const int i = ly0 + pi, j = lx0 + pj;
-                const int i0 = min(max(i, 0), p.hs - 1), i1 = min(max(i + 1, 0), p.hs - 1);
-                const int j0 = min(max(j, 0), p.ws - 1), j1 = min(max(j + 1, 0), p.ws - 1);
-                const float xa = j0 == j1 ? 1.f : 0.75f, xb = j0 == j1 ? 0.f : 0.25f;      // column 2j+1 = xa x[j0] + xb x[j0+1]
-                const float ca = j0 == j1 ? 1.f : 0.25f, cbw = j0 == j1 ? 0.f : 0.75f;     // column 2j+2 = ca x[j0] + cbw x[j0+1]
-                const float ya = i0 == i1 ? 1.f : 0.75f, yb = i0 == i1 ? 0.f : 0.25f;
-                const int Y = 2 * i + 1, X = 2 * j + 1;
-                const bool yt = Y >= 0 && Y < p.H, yb2 = Y + 1 < p.H, xl = X >= 0 && X < p.W, xr = X + 1 < p.W;
-                const float m00 = (yt && xl) ? 1.f : 0.f, m01 = (yt && xr) ? 1.f : 0.f, m10 = (yb2 && xl) ? 1.f : 0.f, m11 = (yb2 && xr) ? 1.f : 0.f;
-                // (the right neighbour is read at j0 + 1 even where the source index is clamped: its weight is then exactly 0 and the
-                // value - the zero frame or a neighbouring pixel - is finite)
-                const float *r0 = raw + (i0 - ly0) * LW + 3 - lx0 + j0;
-                const float *r1 = raw + (i1 - ly0) * LW + 3 - lx0 + j0;
-                float *dd = hip + (2 * pi) * PW + 2 * pj + 3 + C::SHIFT;       // hi-res pixel x0 + 2pj - 1 -> patch column 2pj + 3 (+ SHIFT)
+            if (ex_fl & 64) {
+                const bool jeq = ex_fl & 1, ieq = ex_fl & 2;
+                const float ex_xa = jeq ? 1.f : 0.75f, ex_xb = jeq ? 0.f : 0.25f;      // column 2j+1 = xa x[j0] + xb x[j0+1]
+                const float ex_ca = jeq ? 1.f : 0.25f, ex_cw = jeq ? 0.f : 0.75f;      // column 2j+2 = ca x[j0] + cw x[j0+1]
+                const float ya = ieq ? 1.f : 0.75f, yb = ieq ? 0.f : 0.25f;
+                const float ex_a00 = (ex_fl & 4) ? ya : 0.f, ex_b00 = (ex_fl & 4) ? yb : 0.f;        // row 2i+1: ya (row i0) + yb (row i1)
+                const float ex_a01 = (ex_fl & 8) ? ya : 0.f, ex_b01 = (ex_fl & 8) ? yb : 0.f;
+                const float ex_a10 = (ex_fl & 16) ? yb : 0.f, ex_b10 = (ex_fl & 16) ? ya : 0.f;      // row 2i+2: yb (row i0) + ya (row i1)
+                const float ex_a11 = (ex_fl & 32) ? yb : 0.f, ex_b11 = (ex_fl & 32) ? ya : 0.f;
+                const float *r0 = raw + ex_r0, *r1 = raw + ex_r1;
+                float *dd = hip + ex_dd;
                 float v00[cnum], v01[cnum], v10[cnum], v11[cnum];
 #pragma unroll
                 for (int cc = 0; cc < cnum; ++cc) {
@@ -472,12 +488,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                 }
 #pragma unroll
                 for (int cc = 0; cc < cnum; ++cc) {
-                    const float h00 = xa * v00[cc] + xb * v01[cc], h01 = ca * v00[cc] + cbw * v01[cc];
-                    const float h10 = xa * v10[cc] + xb * v11[cc], h11 = ca * v10[cc] + cbw * v11[cc];
-                    dd[cc * PH * PW] = m00 * (ya * h00 + yb * h10);
-                    dd[cc * PH * PW + 1] = m01 * (ya * h01 + yb * h11);
-                    dd[cc * PH * PW + PW] = m10 * (yb * h00 + ya * h10);
-                    dd[cc * PH * PW + PW + 1] = m11 * (yb * h01 + ya * h11);
+                    const float h00 = ex_xa * v00[cc] + ex_xb * v01[cc], h01 = ex_ca * v00[cc] + ex_cw * v01[cc];
+                    const float h10 = ex_xa * v10[cc] + ex_xb * v11[cc], h11 = ex_ca * v10[cc] + ex_cw * v11[cc];
+                    dd[cc * PH * PW] = ex_a00 * h00 + ex_b00 * h10;
+                    dd[cc * PH * PW + 1] = ex_a01 * h01 + ex_b01 * h11;
+                    dd[cc * PH * PW + PW] = ex_a10 * h00 + ex_b10 * h10;
+                    dd[cc * PH * PW + PW + 1] = ex_a11 * h01 + ex_b11 * h11;
                 }
             }
         }
@@ -748,7 +764,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             W4TRACE(ch, 2)
             if (!W4_INTERLEAVE && m1 && !W4ABL(4)) transform_as(HH, HQ, st ^ 1, st ^ 1);          // (block form: always the quarter arrangement)
             if constexpr (UPS) {
-                // (waves 4..7 carried the whole transform: waves 0..3 expand all four channels)
+                // waves 4..7 carried the whole transform and are the longer role of a SIMD pair: waves 0..3 expand all four channels (a
+                // 3 : 1 or 2 : 2 split of the expansion between the halves measured 17-23 % SLOWER, profiles/r8z_wino4_expand_split.txt)
                 if (m2 && decltype(HQ)::value == 0) expand(st, st, C0{}, std::integral_constant<int, CK>{});
             }
             W4STAMP(1)
