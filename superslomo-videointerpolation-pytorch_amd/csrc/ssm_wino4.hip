@@ -772,6 +772,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             W4TRACE(ch, 3)
         };
         auto chunks = [&](auto HH, auto HQ) __attribute__((always_inline)) {
+            // Static priority for the transforming waves: they are the longer role of every SIMD pair (36 MFMAs + 76 interleaved vector
+            // instructions against 36 MFMAs + DMA), and at equal priority the arbiter serves the older wave 0..3 first.  -3.3 % on the
+            // 64-cout layers, same box, both run orders (profiles/r9b_wino4_static_priority.txt); priority 3 measures the same as 1.
+            if constexpr (decltype(HQ)::value == 1) __builtin_amdgcn_s_setprio(1);
             int ch = 0;
             for (; ch + 3 < nchunks; ++ch) chunk(ch, T{}, HH, HQ);
             for (; ch < nchunks; ++ch) chunk(ch, F{}, HH, HQ);
