@@ -226,13 +226,30 @@ int ssm_wino7_pack_weights(const float *w_oihw, const float *bias, float *w_pack
 int ssm_wino7_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const float *bias_packed, ssm_view y, ssm_view pool,
                              ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 
+/* ---- the 5x5 convolutions as two-dimensional Winograd F(4x4,5x5), all arithmetic fp32 (v_mfma_f32_16x16x4_f32) ------------------
+ * Same operator and operand layout as ssm_wino1d_conv2d_add_fwd for k = 5 (layers.conv, scripts/models/layers.py:21-33; conv2a /
+ * conv2b of both U-Nets, scripts/models/flow_computation.py:46-55; fused 2x2 mean, layers.py:60-63): the eight points
+ * {0, +-1, +-2, +-1/2, inf} of the 1-D F(4,5) form on BOTH axes - 64 multiplies per 16 outputs and (cin, cout) = 4 per output
+ * against 10 for F(4,5) along x and 25 for the direct form (csrc/ssm_wino5.hip).  In fp32 the result differs from the
+ * direct form by rounding only (a 64-channel layer: 3e-6 rms / 3e-5 max at unit output scale).
+ * One input source; Cin a multiple of 4 (pad the view; pack with CinP), Cout a multiple of 32.  Inputs are padded planes with
+ * SSM_TAIL_SLACK_FLOATS readable floats behind them.
+ * ssm_wino5_pack_weights: OIHW fp32 5x5 filter -> U = G g G^T as [Cout/32][CinP/4][16 quads][4 channels][32][4] (+ bias).          */
+int ssm_wino5_plan(int Cin, int Cout, int B, int H, int W, int *kind);
+int ssm_wino5_force_kind(int kind);      /* tests / tuning only (-1 = automatic); returns the number of configurations */
+size_t ssm_wino5_packed_weight_floats(int Cout, int CinP);
+int ssm_wino5_pack_weights(const float *w_oihw, const float *bias, float *w_packed, float *bias_packed, int Cout, int Cin, int CinP,
+                           void *stream);
+int ssm_wino5_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const float *bias_packed, ssm_view y, ssm_view pool,
+                             ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+
 /* ---- every fp32 filter of a U-Net repacked by one launch (training: the parameters change each optimizer step) ------------
  * A job = one convolution's OIHW parameter -> its packed form (algo: the per-layer pack entry point it replaces, same arithmetic,
  * same layout).  transposed: pack the DATA-GRADIENT filter of the forward parameter, W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx]
  * (the adjoint of layers.conv, scripts/models/layers.py:21-33, is the same convolution on it), read straight from the forward
  * tensor; Cout / Cin are then the data-gradient convolution's (Cout = the forward layer's input channels), bias NULL = zeros.
  * first = sum of max(total, nbias) over the preceding jobs.                                                                   */
-enum { SSM_PACK_DIRECT = 0, SSM_PACK_WINO = 1, SSM_PACK_WINO1D = 2, SSM_PACK_WINO4 = 3, SSM_PACK_WINO7 = 4 };
+enum { SSM_PACK_DIRECT = 0, SSM_PACK_WINO = 1, SSM_PACK_WINO1D = 2, SSM_PACK_WINO4 = 3, SSM_PACK_WINO7 = 4, SSM_PACK_WINO5 = 5 };
 typedef struct {
     const float *w;      /* OIHW parameter */
     const float *bias;   /* or NULL */

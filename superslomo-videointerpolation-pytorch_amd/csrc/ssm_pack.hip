@@ -5,11 +5,13 @@
 //   wino    (ssm_wino_pack_weights,   csrc/ssm_wino.hip)    [Cout/BN][Cin][4][BN][4]        U = G g G^T, F(2x2,3x3)
 //   wino1d  (ssm_wino1d_pack_weights, csrc/ssm_wino1d.hip)  [Cout/BN][CinP][k][2][BN][4]    U[ky] = G g[ky], F(2,7) / F(4,5)
 //   wino4   (ssm_wino4_pack_weights,  csrc/ssm_wino4.hip)   [Cout/32][Cin][9][32][4]        U = G g G^T, F(4x4,3x3)
+//   wino5   (ssm_wino5_pack_weights,  csrc/ssm_wino5.hip)   [Cout/32][CinP/4][16][4][32][4]  U = G g G^T, F(4x4,5x5)
 //   wino7   (ssm_wino7_pack_weights,  csrc/ssm_wino7.hip)   [Cout/32][Cin][14][4][32][4]    U_b = G g_b G^T, 2x2 blocks of F(4x4,4x4)
 // `transposed` packs the DATA-GRADIENT filter of the forward parameter, W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx] (what
 // ssm_amd.backward.transposed_filter materialises), read straight from the OIHW tensor; such jobs have no bias (zeros).  Every
 // element is computed by the same arithmetic as the per-layer kernels (tests/test_hip_pack_batch.py holds them bit-identical).
 #include "ssm_common.h"
+#include "ssm_wino5_pack.h"
 #include "ssm_wino7_pack.h"
 
 namespace {
@@ -159,6 +161,12 @@ __global__ void pack32_batch_kernel(const ssm_pack32_job *__restrict__ jobs, int
             case SSM_PACK_WINO: v = pack_wino_4(s, j, e); break;
             case SSM_PACK_WINO1D: v = pack_wino1d_4(s, j, e); break;
             case SSM_PACK_WINO4: v = pack_wino4_4(s, j, e); break;
+            case SSM_PACK_WINO5: {
+                float o4[4];
+                ssm_w5_pack_quad([&](int co, int ci, int ky, int kx) { return s.at(co, ci, ky, kx); }, j.Cout, j.Cin, j.CinP, e, o4);
+                v = pk_f4{o4[0], o4[1], o4[2], o4[3]};
+                break;
+            }
             case SSM_PACK_WINO7: {
                 float o4[4];
                 ssm_w7_pack_quad([&](int co, int ci, int ky, int kx) { return s.at(co, ci, ky, kx); }, j.Cout, j.Cin, e, o4);

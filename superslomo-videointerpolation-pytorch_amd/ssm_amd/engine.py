@@ -83,6 +83,9 @@ WINO1D = os.environ.get("SSM_WINO1D", "57")
 # 7x7 layers of an f32w inference plan as 2x2 blocks of F(4x4,4x4) (csrc/ssm_wino7.hip: 12.25 multiplies per output instead of F(2,7)'s 28);
 # $SSM_WINO7=0 keeps them on the 1-D form
 WINO7 = os.environ.get("SSM_WINO7", "1")
+# 5x5 layers of an f32w inference plan as two-dimensional F(4x4,5x5) (csrc/ssm_wino5.hip: 4 multiplies per output instead of F(4,5)'s 10);
+# $SSM_WINO5=0 keeps them on the 1-D form
+WINO5 = os.environ.get("SSM_WINO5", "1")
 
 
 # 3x3 layers of an f32w plan as F(4x4,3x3) (csrc/ssm_wino4.hip) instead of F(2x2,3x3): $SSM_WINO4=0 keeps F(2x2); a comma list names layers
@@ -114,6 +117,8 @@ def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d, wino4=None):
     wino4 = wino1d if wino4 is None else wino4
     if wino1d and not skip and k == 7 and WINO7 not in ("0", "") and hb.wino7_supported(ci, co, h, w, k):
         return "wino7"
+    if wino1d and not skip and k == 5 and WINO5 not in ("0", "") and ci % 4 == 0 and hb.wino5_supported(ci, co, h, w, k):
+        return "wino5"
     if wino1d and not skip and wino1d_enabled(k) and hb.wino1d_supported(ci, co, h, w, k):
         return "wino1d"
     if wino and not skip and hb.wino_supported(ci, co, h, w, k):
@@ -125,10 +130,11 @@ def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d, wino4=None):
 
 
 _ALGO_CLASS = {"direct": lambda: hb.PackedConv, "wino": lambda: hb.PackedWino, "wino4": lambda: hb.PackedWino4, "wino1d": lambda: hb.PackedWino1d,
-               "wino7": lambda: hb.PackedWino7}
+               "wino7": lambda: hb.PackedWino7, "wino5": lambda: hb.PackedWino5}
 # multiply-adds issued on the matrix cores per direct-form multiply-add, by algorithm and kernel size
 ISSUED_FACTOR = {"direct": lambda k: 1.0, "wino": lambda k: 16.0 / 36.0, "wino4": lambda k: 36.0 / 144.0,
-                 "wino1d": lambda k: 8.0 / 14.0 if k == 7 else 8.0 / 20.0, "wino7": lambda k: 196.0 / 784.0}
+                 "wino1d": lambda k: 8.0 / 14.0 if k == 7 else 8.0 / 20.0, "wino7": lambda k: 196.0 / 784.0,
+                 "wino5": lambda k: 64.0 / 400.0}
 
 
 def issued_factor(pk):
@@ -140,6 +146,8 @@ def conv_fn(pk, ups=False):
     """The launcher that goes with a packed filter's algorithm."""
     if pk.algo == "wino7":
         return hb.conv2d_wino7
+    if pk.algo == "wino5":
+        return hb.conv2d_wino5
     if pk.algo == "wino1d":
         return hb.conv2d_wino1d
     if pk.algo == "wino4":

@@ -79,6 +79,12 @@ SIGNATURES = {
     "ssm_wino1d_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_wino1d_conv2d_add_fwd": (_c_int, [SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int,
                                            _c_int, _c_float, _c_int, _vp]),
+    "ssm_wino5_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _ip]),
+    "ssm_wino5_force_kind": (_c_int, [_c_int]),
+    "ssm_wino5_packed_weight_floats": (_sz, [_c_int, _c_int]),
+    "ssm_wino5_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
+    "ssm_wino5_conv2d_add_fwd": (_c_int, [SsmView, _c_int, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                          _c_float, _c_int, _vp]),
     "ssm_wino7_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _ip]),
     "ssm_wino7_force_kind": (_c_int, [_c_int]),
     "ssm_wino7_packed_weight_floats": (_sz, [_c_int, _c_int]),
@@ -495,6 +501,45 @@ def conv2d_wino1d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, a
                                         SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
+# ---- 5x5 convolutions as two-dimensional Winograd F(4x4,5x5) in fp32 (csrc/ssm_wino5.hip) -----------------------------
+def wino5_supported(cin, cout, H, W, k):
+    """Can this layer run in the two-dimensional F(4x4,5x5) form?  (5x5, 32-channel output blocks; channels padded to 4)"""
+    return k == 5 and cout % 32 == 0
+
+
+class PackedWino5:
+    """5x5 filter pre-transformed on both axes (U = G g G^T, 64 frequencies) and packed for csrc/ssm_wino5.hip; an explicit handle
+    owned by the Python side like PackedConv."""
+
+    algo = "wino5"
+
+    def __init__(self, weight, bias, B, H, W, pool=False, ups=False):
+        require_device(weight, "conv weight")
+        require_device(bias, "conv bias")
+        assert not ups, "the 5x5 layers have no fused-upsample form"
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        assert self.k == 5 and weight.shape[3] == 5 and self.cout % 32 == 0, "the F(4x4,5x5) form is for 5x5 filters, Cout a multiple of 32"
+        self.ups = False
+        self.bn, self.ck = 32, 4
+        self.cin_p = (self.cin + 3) // 4 * 4
+        lib = load()
+        self.w = torch.empty(lib.ssm_wino5_packed_weight_floats(self.cout, self.cin_p), dtype=torch.float32, device=weight.device)
+        self.b = torch.empty(self.cout, dtype=torch.float32, device=weight.device)
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        check(lib.ssm_wino5_pack_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout, self.cin, self.cin_p,
+                                         stream_ptr()))
+
+
+def conv2d_wino5(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+    """Same call shape as conv2d / conv2d_wino1d; these layers take one source (x2 must be None)."""
+    lib = load()
+    assert x2 is None and c2 == 0, "the 5x5 layers have no concatenated source"
+    assert pk.cin_p == c1, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1)
+    check(lib.ssm_wino5_conv2d_add_fwd(x1, c1, pk.w.data_ptr(), pk.b.data_ptr(), y, pool if pool is not None else NULL_VIEW,
+                                       add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
+                                       SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
 # ---- 7x7 convolutions as 2x2 blocks of F(4x4,4x4) Winograd filters in fp32 (csrc/ssm_wino7.hip) ---------------------
 def wino7_supported(cin, cout, H, W, k):
     """Can this layer run in the blocked two-dimensional Winograd form?  (7x7, 32-channel output blocks; any Cin)"""
@@ -675,7 +720,7 @@ class PackBatch32:
     transposed packs the data-gradient filter of the forward parameter (no torch flip / permute / copy).  The job table holds raw
     pointers: rebuild it when `PackBatch.key()` of the parameters changes."""
 
-    ALGO = {"direct": 0, "wino": 1, "wino1d": 2, "wino4": 3, "wino7": 4}
+    ALGO = {"direct": 0, "wino": 1, "wino1d": 2, "wino4": 3, "wino7": 4, "wino5": 5}
 
     def __init__(self, entries, device):
         jobs = (SsmPack32Job * len(entries))()

@@ -33,7 +33,7 @@ def test_issued_flop_follows_from_hoisting_and_winograd():
     assert abs((alg - f32) - saved) / saved < 1e-9
     # mode f32w: every 3x3 layer except the final convs as F(4x4,3x3) (36 products per 16 outputs instead of 144) - or as F(2x2,3x3)
     # (16 per 4 outputs instead of 36) on the 23x40 maps (csrc/ssm_wino4.hip, ssm_wino4_preferred); the 7x7 layers as 2x2 blocks of F(4x4,4x4) (4 x 49 products per 16 outputs instead of 784: csrc/ssm_wino7.hip), the 5x5
-    # layers as F(4,5) (8 per 4 outputs instead of 20)
+    # layers as two-dimensional F(4x4,5x5) (64 products per 16 outputs instead of 400: csrc/ssm_wino5.hip)
     scale = {"conv1": 1, "conv2": 2, "conv3": 4, "conv4": 8, "conv5": 16, "conv6": 32, "conv7": 16, "conv8": 8, "conv9": 4, "fuse_": 1, "final": 1}
     want = 0.0
     for st, reps in ((1, 1), (2, 7)):
@@ -50,7 +50,7 @@ def test_issued_flop_follows_from_hoisting_and_winograd():
             elif k == 7:
                 fl *= 196 / 784
             elif k == 5:
-                fl *= 8 / 20
+                fl *= 64 / 400
             want += fl
     assert abs(f32w - want) / want < 1e-9
     assert f32w < f32 < alg

@@ -1,0 +1,142 @@
+"""GPU parity of the two-dimensional Winograd form of the 5x5 layers (csrc/ssm_wino5.hip: F(4x4,5x5), fp32 throughout) for EVERY tile
+configuration - forced one by one through ssm_wino5_force_kind - against the CPU oracle's direct convolution (layers.conv,
+scripts/models/layers.py:21-33): plain conv, fused 2x2 mean, pre-activation addend, plain NCHW outputs, channel counts that are not
+multiples of the k-step (padded on the host), 1 .. 5 k-steps, ragged sizes (tiles overshoot the map on both axes, odd sizes, maps smaller
+than one tile), the layer shapes of the plan and operand-scale invariance.
+Bar 5e-5 like the other kernels at unit output scale (tests/emulate_winograd_5x5_2d.py predicts 3e-6 rms / 3e-5 max for 64 channels)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["F5A", "F5B"]      # 16x32-pixel workgroup tiles: tile groups of 8x2 tiles stacked / of 4x4 tiles side by side
+BAR = 5e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _unforce():
+    yield
+    from ssm_amd import hipbind as hb
+    hb.load().ssm_wino5_force_kind(-1)
+
+
+def _force(kind):
+    from ssm_amd import hipbind as hb
+    n = hb.load().ssm_wino5_force_kind(KINDS.index(kind))
+    assert n == len(KINDS), "tile-configuration list of the test is out of date (%d in the library)" % n
+
+
+def _err(got, want):
+    return float((got - want).abs().max())
+
+
+def _planes(hb, x, cin_p, dev):
+    B, cin, H, W = x.shape
+    px = hb.Planes(B, cin_p, H, W, dev)
+    px.interior[:, :cin] = x.to(dev)
+    return px
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_every_wino5_configuration_plain_pool(dev, kind):
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(KINDS.index(kind))
+    _force(kind)
+    # (B, H, W, cin, cout): whole tiles; ragged both ways + a channel count that is padded to the k-step; smaller than a tile; odd sizes
+    for B, H, W, cin, cout in ((2, 16, 64, 8, 32), (1, 23, 40, 7, 64), (3, 6, 2, 2, 32), (1, 9, 131, 16, 32), (2, 34, 96, 32, 64), (1, 3, 5, 4, 32),
+                               (1, 1, 1, 1, 32)):
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 5, 5, generator=g) / (cin * 25) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        want = O.conv2d_lrelu(x, w, bias)
+        pool = H % 2 == 0 and W % 2 == 0
+        pk = hb.PackedWino5(w.to(dev), bias.to(dev), B, H, W, pool=pool)
+        px = _planes(hb, x, pk.cin_p, dev)
+        y, yp = hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, max(H // 2, 1), max(W // 2, 1), dev)
+        hb.conv2d_wino5(px.view(), pk.cin_p, None, 0, pk, y.view(), yp.view() if pool else None, B, H, W, lrelu=True)
+        got = y.to_nchw().cpu()
+        assert _err(got, want) < BAR, "%s %dx%dx%d cin %d: conv %.3e" % (kind, B, H, W, cin, _err(got, want))
+        if pool:
+            gp = yp.to_nchw().cpu()
+            assert _err(gp, O.avg_pool2(want)) < BAR, "%s: fused pool %.3e" % (kind, _err(gp, O.avg_pool2(want)))
+            fullp = yp.full.cpu().clone()
+            fullp[:, :, hb.SSM_PADY:hb.SSM_PADY + H // 2, hb.SSM_PADX:hb.SSM_PADX + W // 2] = 0
+            assert float(fullp.abs().max()) == 0.0, "%s wrote outside the pooled interior" % kind
+        full = y.full.cpu().clone()
+        full[:, :, hb.SSM_PADY:hb.SSM_PADY + H, hb.SSM_PADX:hb.SSM_PADX + W] = 0
+        assert float(full.abs().max()) == 0.0, "%s wrote outside the interior" % kind
+        # no activation, plain NCHW output tensor (rows not 16-byte aligned for most W: the element-wise store path)
+        yn = torch.full((B, cout, H, W), 7.0, device=dev)
+        hb.conv2d_wino5(px.view(), pk.cin_p, None, 0, pk, hb.view_of(yn), None, B, H, W, lrelu=False)
+        assert _err(yn.cpu(), O.conv2d(x, w, bias)) < BAR, "%s %dx%dx%d: NCHW output" % (kind, B, H, W)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_wino5_every_short_step_count(dev, kind):
+    """1 .. 5 k-steps of 4 channels (the filter and the patch of the next k-step arrive while the current one is transformed and
+    multiplied: first and last iterations), on a map of several workgroup tiles, with a pre-activation addend."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(50 + KINDS.index(kind))
+    _force(kind)
+    B, H, W, cout, div = 2, 40, 72, 32, 2
+    for cin in (4, 8, 12, 16, 20):
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 5, 5, generator=g) / (cin * 25) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        add = torch.randn(B // div, cout, H, W, generator=g)
+        z = O.conv2d(x, w, bias) + add.repeat_interleave(div, 0)
+        want = torch.where(z >= 0, z, z * 0.1)
+        pk = hb.PackedWino5(w.to(dev), bias.to(dev), B, H, W)
+        px = _planes(hb, x, pk.cin_p, dev)
+        pa = hb.Planes(B // div, cout, H, W, dev).load(add.to(dev))
+        y = hb.Planes(B, cout, H, W, dev)
+        hb.conv2d_wino5(px.view(), pk.cin_p, None, 0, pk, y.view(), None, B, H, W, add=pa.view(), add_div=div)
+        e = _err(y.to_nchw().cpu(), want)
+        assert e < BAR, "%s cin %d: %.3e" % (kind, cin, e)
+
+
+def test_wino5_layer_shapes_and_scale_invariance(dev):
+    """conv2a / conv2b as the plan runs them (32 -> 64; 64 -> 64 with the fused 2x2 mean) on a map of many workgroup tiles, and the same
+    problem with activations x 2^12 and filters x 2^-9: the form is linear fp32 arithmetic with dyadic transform constants."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(12)
+    B, H, W = 2, 48, 96
+    for cin, cout, pool in ((32, 64, False), (64, 64, True)):
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 5, 5, generator=g) / (cin * 25) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        for sx, sw in ((1.0, 1.0), (4096.0, 1.0 / 512)):
+            want = O.conv2d_lrelu(x * sx, w * sw, bias * sx * sw)
+            px = hb.Planes(B, cin, H, W, dev).load((x * sx).to(dev))
+            y, yp = hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, H // 2, W // 2, dev)
+            pk = hb.PackedWino5((w * sw).to(dev), (bias * sx * sw).to(dev), B, H, W, pool=pool)
+            hb.conv2d_wino5(px.view(), cin, None, 0, pk, y.view(), yp.view() if pool else None, B, H, W)
+            e = _err(y.to_nchw().cpu(), want)
+            print("wino5 %d -> %d scale %g x %g: max err %.3e" % (cin, cout, sx, sw, e))
+            assert e < BAR * sx * sw, "scale %g x %g: %.3e" % (sx, sw, e)
+            if pool:
+                assert _err(yp.to_nchw().cpu(), O.avg_pool2(want)) < BAR * sx * sw
+
+
+def test_wino5_batch_pack_is_bit_identical(dev):
+    """The one-launch repack (ssm_pack32_weights_batch, algo SSM_PACK_WINO5) fills the same bytes as ssm_wino5_pack_weights."""
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 30, 5, 5, generator=g).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    pk = hb.PackedWino5(w, b, 1, 32, 32)
+    ref_w, ref_b = pk.w.clone(), pk.b.clone()
+    pk.w.fill_(-1.0)
+    pk.b.fill_(-1.0)
+    hb.PackBatch32([(pk, w, b, False)], dev).run()
+    torch.cuda.synchronize()
+    assert torch.equal(pk.w, ref_w) and torch.equal(pk.b, ref_b)

@@ -15,6 +15,7 @@ W4=1 timeout -k 10 200 python tools/bench_layers_wino.py 7 > gpurun_out/$T/wino4
 timeout -k 10 200 python tools/bench_layers_wino.py 7 > gpurun_out/$T/wino2_layers_b7.txt 2>&1; tail -2 gpurun_out/$T/wino2_layers_b7.txt
 timeout -k 10 200 python tools/bench_layers_wino1d.py 14 > gpurun_out/$T/wino1d_layers_b14.txt 2>&1; tail -3 gpurun_out/$T/wino1d_layers_b14.txt
 timeout -k 10 200 python tools/bench_layers_wino7.py 14 > gpurun_out/$T/wino7_layers_b14.txt 2>&1; tail -2 gpurun_out/$T/wino7_layers_b14.txt
+timeout -k 10 200 python tools/bench_layers_wino5.py 14 > gpurun_out/$T/wino5_layers_b14.txt 2>&1; tail -2 gpurun_out/$T/wino5_layers_b14.txt
 bash tools/pmc_wino7.sh gpurun_out/$T/pmc_wino7 14 > gpurun_out/$T/pmc_wino7.log 2>&1; tail -6 gpurun_out/$T/pmc_wino7.log
 bash tools/pmc_wino4.sh gpurun_out/$T/pmc_wino4 7 > gpurun_out/$T/pmc_wino4.log 2>&1; tail -24 gpurun_out/$T/pmc_wino4.log
 python bench.py --mode train --precision f32w > gpurun_out/$T/train_f32w_line.json 2>> gpurun_out/$T/bench_err.log
