@@ -287,12 +287,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         r_src[k] = C::POFF + C::SHIFT + (c * PH + row) * PW + 4 * t + 2;          // floats; 16-byte aligned
         r_dst[k] = C::XOFF + c * 2 * C::XPL + row * C::XRW + t * 4;               // half 0; half 1 at + XPL
     }
-    // ---- column pass: unit = (channel, tile, pair j of column-frequencies), j = wave; two rounds: channels 2k + (lane >> 5) ----------
+    // ---- column pass: unit = (channel = wave, half h = lane >> 5 of the column-frequencies, tile): one unit per thread.  16-byte reads
+    // and writes: the 8-byte form (a pair of column-frequencies per thread) used half of the banks per instruction and cost ~500 of the
+    // pass's 1580 cycles (profiles/r9i_wino5_first_phases_and_layers.txt) ------------------------------------------------------------
     const int c_tile = lane & 31;
     const int c_gx = (c_tile & 15) % C::GTX, c_gy = (c_tile & 15) / C::GTX, c_g2 = c_tile >> 4;
     const int c_Tx = (c_g2 % C::WTX) * C::GTX + c_gx, c_Ty = (c_g2 / C::WTX) * C::GTY + c_gy;
-    const int c_src = C::XOFF + ((lane >> 5) * 2 + (wid >> 1)) * C::XPL + (4 * c_Ty) * C::XRW + c_Tx * 4 + (wid & 1) * 2;      // + 2 k * 2 * XPL
-    const int c_dst = C::VOFF + (((wid >> 1) * CK + (lane >> 5)) * C::NTP + c_tile) * 4 + (wid & 1) * 2;                      // + rf * 2 * CK * NTP * 4, + 2 k * NTP * 4
+    const int c_src = C::XOFF + (wid * 2 + (lane >> 5)) * C::XPL + (4 * c_Ty) * C::XRW + c_Tx * 4;
+    const int c_dst = C::VOFF + (((lane >> 5) * CK + wid) * C::NTP + c_tile) * 4;                      // + rf * 2 * CK * NTP * 4
 
     // ---- operand bases of the matrix phase (f32x4 units): U of (quad, channel q, cout cb*16 + l15), V of (quad, channel q, tile) ------
     const f32x4 *lds4 = (const f32x4 *)lds;
@@ -347,29 +349,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W5STAMP(4)          // [4] barrier behind the row pass
         // ---- column pass ------------------------------------------------------------------------------------------------------------
         {
-            f32x2 cx[2][8];
+            f32x4 cx[8];
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < 8; ++i) cx[i] = *(const f32x4 *)(lds + c_src + i * C::XRW);
+            float f[4][8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) cx[k][i] = *(const f32x2 *)(lds + c_src + k * 4 * C::XPL + i * C::XRW);
+            for (int e = 0; e < 4; ++e) {
+                float d[8] = {cx[0][e], cx[1][e], cx[2][e], cx[3][e], cx[4][e], cx[5][e], cx[6][e], cx[7][e]};
+                // the values arrive as 16-byte quads: pin each as a scalar so that no packed-fp32 arithmetic is formed on neighbours
+                // (check_isa.sh fences v_pk_*_f32; the four passes are the same arithmetic on the four elements of every quad)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float e0[8] = {cx[k][0][0], cx[k][1][0], cx[k][2][0], cx[k][3][0], cx[k][4][0], cx[k][5][0], cx[k][6][0], cx[k][7][0]};
-                float e1[8] = {cx[k][0][1], cx[k][1][1], cx[k][2][1], cx[k][3][1], cx[k][4][1], cx[k][5][1], cx[k][6][1], cx[k][7][1]};
-                // the values arrive as 8-byte pairs: pin each as a scalar so that no packed-fp32 arithmetic is formed on the pairs
-                // (check_isa.sh fences v_pk_*_f32; the two passes below are the same arithmetic on the two halves of every pair)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    asm volatile("" : "+v"(e0[i]));
-                    asm volatile("" : "+v"(e1[i]));
-                }
-                float f0[8], f1[8];
-                w5_bt(e0, f0);
-                w5_bt(e1, f1);
-                float *dst = lds + c_dst + k * 2 * C::NTP * 4;
-#pragma unroll
-                for (int rf = 0; rf < 8; ++rf) *(f32x2 *)(dst + rf * 2 * CK * C::NTP * 4) = f32x2{f0[rf], f1[rf]};
+                for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(d[i]));
+                w5_bt(d, f[e]);
             }
+#pragma unroll
+            for (int rf = 0; rf < 8; ++rf) *(f32x4 *)(lds + c_dst + rf * 2 * CK * C::NTP * 4) = f32x4{f[0][rf], f[1][rf], f[2][rf], f[3][rf]};
         }
         W5STAMP(2)          // [2] column pass
         __syncthreads();
