@@ -14,11 +14,16 @@
 // GEMM per frequency f: M_f[cout][tile] = sum_cin U_f[cout][cin] V_f[cin][tile], k-step = 4 input channels; a wave owns 16 couts x 16
 // tiles for all 64 frequencies (64 accumulators of 4 registers: one wave per SIMD), the output transform is lane-local.  One workgroup
 // of four waves = 32 couts x 32 tiles of 4x4 pixels.  Input transform with the overlap of neighbouring windows used (8 rows at stride
-// 4): a ROW pass per (channel, patch row, tile column) leaves X in LDS, a COLUMN pass per (channel, tile, pair of column-frequencies;
-// the pair = the wave) writes V [16 quads][4 channels][32 tiles][4].  26 vector operations per 8-point pass.
+// 4): a ROW pass per (channel, patch row, tile column) leaves X in LDS, a COLUMN pass per (channel, half of the column-frequencies,
+// tile) writes V [16 quads][4 channels][32 tiles][4]; wave w does both passes of channel w, every LDS access of the passes is 16 bytes
+// wide.  26 vector operations per 8-point pass.
 //
-// Per k-step three phases, three barriers (the 160 KiB of LDS hold two filter stages of 32 KiB, two patches, ONE X and ONE V):
-//   [barrier] row pass [barrier] column pass [barrier] 64 MFMAs, the DMA of the next k-step's filter and patch one instruction per quad
+// Per k-step three phases, two barriers (the 160 KiB of LDS hold two filter stages of 32 KiB, two patches, ONE X and ONE V):
+//   [barrier] row pass, column pass [barrier] 64 MFMAs, the DMA of the next k-step's filter and patch one instruction per quad
+// The phases are serial on purpose: 256 accumulator registers leave no second wave per SIMD and no second V / X in LDS to run them beside
+// the MFMAs.  A lone wave issues one vector instruction per ~5 cycles (tools/valu_rate_probe.py), so the two passes (182 vector + 44 LDS
+// instructions) cost ~2000 cycles per k-step beside 2048 of MFMA: the form runs at ~0.33 of the matrix pipe and still beats F(4,5)
+// along x (0.71 of the pipe at 2.5 x the multiplies) by 1.27 x.
 #include "ssm_common.h"
 #include "ssm_wino5_pack.h"
 
@@ -78,7 +83,7 @@ struct W5Cfg {
     static constexpr int NDQ = CK * PH * PW / 4, NGP = (NDQ + 63) / 64;        // 16-byte pieces / 1-KiB DMA groups of the patch
     static constexpr int PCAP = NGP * 256 + 256;
     static constexpr int NGU = USZ / 256, NIU = NGU / 4, NIP = (NGP + 3) / 4;  // DMA instructions per wave and k-step
-    static constexpr int NRU = CK * PH * NTX, NRR = (NRU + 255) / 256;         // row-pass units, rounds of 256 threads
+    static constexpr int NRU = PH * NTX, NRR = (NRU + 63) / 64;                // row-pass units of a channel, rounds of one wave
     static constexpr int UOFF = 0, VOFF = 2 * USZ, XOFF = VOFF + VSZ, POFF = XOFF + XSZ;
     static constexpr int BYTES = (POFF + 2 * PCAP) * 4;
     static_assert(WTY * WTX == 2 && (GTX == 4 || GTX == 8 || GTX == 16), "two tile groups of 16 tiles");
@@ -112,13 +117,16 @@ __device__ __forceinline__ void w5_at(float m0, float m1, float m2, float m3, fl
 
 // ---- epilogue: Y = A^T M A per accumulator register (4 couts per lane), + bias, addend, LeakyReLU, stores, fused 2x2 mean.
 // cu0: first cout of the wave's 16-cout block (this lane holds couts cu0 + 4 q + r), (px, py): the lane's 4x4 output tile.
+// FAST (chosen per wave): every tile of the wave lies inside the map and rows move as aligned 16-byte pieces - the element-wise edge
+// path, a branch per element even when no lane takes it, is not compiled in (ssm_wino7.hip: - 2.7 % on a full-resolution layer)
+template <bool FAST>
 __device__ __forceinline__ void w5_epilogue(const W5Params &p, const f32x4 (&acc)[64], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
     const float sl = p.lrelu ? p.slope : 1.f;
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
     const unsigned pb = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
     const unsigned qb = 4u * ((unsigned)(4 * q) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
-    const bool vok = py + 4 <= p.H && px + 4 <= p.W && p.vec;          // whole tile inside the map, rows as aligned 16-byte pieces
+    const bool vok = FAST || (py + 4 <= p.H && px + 4 <= p.W && p.vec);          // whole tile inside the map, rows as aligned 16-byte pieces
     auto st4 = [](const float *base, unsigned off_bytes, f32x4 val) {
         asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
     };
@@ -132,7 +140,7 @@ __device__ __forceinline__ void w5_epilogue(const W5Params &p, const f32x4 (&acc
     // the addend rows of cout r + 1 are requested while cout r is transformed (four independent 16-byte loads, one cout ahead): their
     // latency runs beside the output transform instead of in front of each cout's stores
     f32x4 zadd[2][4];
-    const bool zvec = addb && vok;
+    const bool zvec = p.add && vok;
     auto zload = [&](int r) {
         if (zvec) {
 #pragma unroll
@@ -160,7 +168,7 @@ __device__ __forceinline__ void w5_epilogue(const W5Params &p, const f32x4 (&acc
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[i][e] = y4[e] + bv[r];
         }
-        if (addb) {
+        if (p.add) {          // (uniform; addb is a per-lane pointer)
             const float *ap = addb + (long long)cu * p.asc;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -181,6 +189,12 @@ __device__ __forceinline__ void w5_epilogue(const W5Params &p, const f32x4 (&acc
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[i][e] = fmaxf(y[i][e], y[i][e] * sl);
+        // the wait for the prefetched addend rows of cout r + 1 goes in front of the inline-assembly stores, which the compiler's wait-count
+        // pass does not see (ssm_wino7.hip, w7_epilogue)
+        if (zvec && r + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(zadd[(r + 1) & 1][i]));
+        }
         float *bp = dstb + (long long)cu * p.dsc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -199,8 +213,8 @@ __device__ __forceinline__ void w5_epilogue(const W5Params &p, const f32x4 (&acc
             for (int i = 0; i < 2; ++i) {
                 const float o0 = ((y[2 * i][0] + y[2 * i + 1][0]) + (y[2 * i][1] + y[2 * i + 1][1])) * 0.25f;
                 const float o1 = ((y[2 * i][2] + y[2 * i + 1][2]) + (y[2 * i][3] + y[2 * i + 1][3])) * 0.25f;
-                const bool rok = py + 2 * i < p.H;
-                if (rok && px + 4 <= p.W && p.vec) st2(qp + (long long)i * p.psh, qb, f32x2{o0, o1});
+                const bool rok = FAST || py + 2 * i < p.H;
+                if (FAST || (rok && px + 4 <= p.W && p.vec)) st2(qp + (long long)i * p.psh, qb, f32x2{o0, o1});
                 else if (rok) {
                     if (px + 2 <= p.W) st1(qp + (long long)i * p.psh, qb, o0);
                     if (px + 4 <= p.W) st1(qp + (long long)i * p.psh + 1, qb, o1);
@@ -277,13 +291,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * 32 + cb * 16 + 4 * q + r];
 
-    // ---- row pass: unit = (channel, patch row, tile column), NRR rounds of 256 threads (threads beyond the last unit repeat it) --------
+    // ---- row pass: wave w transforms the rows of channel w of the k-step - the rows its own column pass reads, so no barrier stands
+    // between the two passes; unit = (patch row, tile column), NRR rounds of 64 lanes (lanes beyond the last unit repeat it) -----------
     int r_src[C::NRR], r_dst[C::NRR];
 #pragma unroll
     for (int k = 0; k < C::NRR; ++k) {
-        const int u = min(tid + 256 * k, C::NRU - 1);
-        const int c = u / (PH * NTX), rem = u - c * (PH * NTX);
-        const int row = rem / NTX, t = rem - row * NTX;
+        const int u = min(lane + 64 * k, C::NRU - 1);
+        const int c = wid, row = u / NTX, t = u - row * NTX;
         r_src[k] = C::POFF + C::SHIFT + (c * PH + row) * PW + 4 * t + 2;          // floats; 16-byte aligned
         r_dst[k] = C::XOFF + c * 2 * C::XPL + row * C::XRW + t * 4;               // half 0; half 1 at + XPL
     }
@@ -345,8 +359,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         W5STAMP(1)          // [1] row pass
-        __syncthreads();
-        W5STAMP(4)          // [4] barrier behind the row pass
+        __builtin_amdgcn_wave_barrier();          // X of channel w is written and read by wave w only: the LDS serves a wave's accesses in order
+        W5STAMP(4)          // [4] (no barrier behind the row pass)
         // ---- column pass ------------------------------------------------------------------------------------------------------------
         {
             f32x4 cx[8];
@@ -402,7 +416,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     W5STAMP(3)
-    w5_epilogue(p, acc, bv, b, nb * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
+    {
+        const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
+        // one copy only: with 256 accumulator registers a second inlined copy of the epilogue (the FAST split of ssm_wino7.hip) spills 8
+        // vector registers, and the epilogue is 9 % of a 64-channel workgroup's life
+        w5_epilogue<false>(p, acc, bv, b, nb * 32 + cb * 16, q, px, py);
+    }
 #ifdef W5_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (p.dbg && lane == 0 && (blockIdx.x % 64) == 0) {          // a sample of the workgroups

@@ -135,13 +135,19 @@ __device__ __forceinline__ void w7_at(float m0, float m1, float m2, float m3, fl
 
 // ---- epilogue: Y = A^T M A per accumulator register (4 couts per lane), + bias, addend, LeakyReLU, stores, fused 2x2 mean.
 // cu0: first cout of the wave's 16-cout block (this lane holds couts cu0 + 4 q + r), (px, py): the lane's 4x4 output tile.
+// FAST: every tile of the wave lies inside the map and rows move as aligned 16-byte pieces - the element-wise edge path (a branch per
+// element even when no lane takes it) is not compiled in.  HOLD (FAST with an addend): the 16 output rows of the lane's four couts stay in
+// registers and are stored after the last addend row has been used.  The stores are inline assembly (scalar base + 32-bit lane offset),
+// invisible to the compiler's wait-count pass: a compiler-placed wait for an addend load also waits for every store issued before it, so
+// stores between the loads cost store round trips (tools/bench_layers_wino7.py, conv1a with the addend: 2.11 -> 2.01 ms at batch 14).
+template <bool FAST, bool HOLD>
 __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc)[49], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
     const float sl = p.lrelu ? p.slope : 1.f;
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
     const unsigned pb = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
     const unsigned qb = 4u * ((unsigned)(4 * q) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
-    const bool vok = py + 4 <= p.H && px + 4 <= p.W && p.vec;          // whole tile inside the map, rows as aligned 16-byte pieces
+    const bool vok = FAST || (py + 4 <= p.H && px + 4 <= p.W && p.vec);          // whole tile inside the map, rows as aligned 16-byte pieces
     auto st4 = [](const float *base, unsigned off_bytes, f32x4 val) {
         asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
     };
@@ -154,19 +160,56 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
     const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * q) * p.asc + (long long)py * p.ash + px : nullptr;
     // the addend rows of cout r + 1 are requested while cout r is transformed (four independent 16-byte loads, one cout ahead): their
     // latency runs beside the output transform instead of in front of each cout's stores
-    f32x4 zadd[2][4];
-    const bool zvec = addb && vok;
+    constexpr int ZN = HOLD ? 4 : 2;          // HOLD: all 16 addend rows are requested up front (no store stands between them and their use)
+    f32x4 zadd[ZN][4];
+    const bool hasadd = p.add != nullptr;          // uniform (addb is a per-lane pointer: a test of it compiles to a divergent branch)
+    const bool zvec = hasadd && vok;
     auto zload = [&](int r) {
         if (zvec) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) zadd[r & 1][i] = *(const f32x4 *)(addb + (long long)(cu0 + r) * p.asc + (long long)i * p.ash);
+            for (int i = 0; i < 4; ++i) zadd[r % ZN][i] = *(const f32x4 *)(addb + (long long)(cu0 + r) * p.asc + (long long)i * p.ash);
         }
     };
     zload(0);
+    if (HOLD) {
+        zload(1);
+        zload(2);
+        zload(3);
+    }
+    f32x4 yk[HOLD ? 4 : 1][4];
+    auto emit = [&](int r, const float (&y)[4][4]) {
+        const int cu = cu0 + r;
+        float *bp = dstb + (long long)cu * p.dsc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (vok) {
+                st4(bp + (long long)i * p.dsh, pb, f32x4{y[i][0], y[i][1], y[i][2], y[i][3]});
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)      // edge path: one scalar base per cout (16 (row, element) bases at once overflow the scalar registers)
+                    if (py + i < p.H && px + e < p.W) st1(bp, pb + 4u * ((unsigned)i * (unsigned)p.dsh + (unsigned)e), y[i][e]);
+            }
+        }
+        if (poolb) {
+            // 2x2 mean, vertical pairs first then the horizontal pair (the association of the direct kernel); H, W even (host check)
+            float *qp = poolb + (long long)cu * p.psc;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float o0 = ((y[2 * i][0] + y[2 * i + 1][0]) + (y[2 * i][1] + y[2 * i + 1][1])) * 0.25f;
+                const float o1 = ((y[2 * i][2] + y[2 * i + 1][2]) + (y[2 * i][3] + y[2 * i + 1][3])) * 0.25f;
+                const bool rok = FAST || py + 2 * i < p.H;
+                if (FAST || (rok && px + 4 <= p.W && p.vec)) st2(qp + (long long)i * p.psh, qb, f32x2{o0, o1});
+                else if (rok) {
+                    if (px + 2 <= p.W) st1(qp, qb + 4u * (unsigned)i * (unsigned)p.psh, o0);
+                    if (px + 4 <= p.W) st1(qp, qb + 4u * ((unsigned)i * (unsigned)p.psh + 1u), o1);
+                }
+            }
+        }
+    };
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int cu = cu0 + r;          // uniform; this lane's cout = cu + 4 * q
-        if (r + 1 < 4) zload(r + 1);
+        if (!HOLD && r + 1 < 4) zload(r + 1);
         float t[4][7];                   // A^T M: over the row-frequencies, for every column-frequency
 #pragma unroll
         for (int cf = 0; cf < 7; ++cf) {
@@ -183,12 +226,12 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[i][e] = y4[e] + bv[r];
         }
-        if (addb) {
+        if (hasadd) {
             const float *ap = addb + (long long)cu * p.asc;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (vok) {
-                    const f32x4 z = zadd[r & 1][i];
+                    const f32x4 z = zadd[r % ZN][i];
                     y[i][0] += z[0];
                     y[i][1] += z[1];
                     y[i][2] += z[2];
@@ -204,33 +247,21 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[i][e] = fmaxf(y[i][e], y[i][e] * sl);
-        float *bp = dstb + (long long)cu * p.dsc;
+        if (HOLD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (vok) {
-                st4(bp + (long long)i * p.dsh, pb, f32x4{y[i][0], y[i][1], y[i][2], y[i][3]});
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (py + i < p.H && px + e < p.W) st1(bp + (long long)i * p.dsh + e, pb, y[i][e]);
-            }
-        }
-        if (poolb) {
-            // 2x2 mean, vertical pairs first then the horizontal pair (the association of the direct kernel); H, W even (host check)
-            float *qp = poolb + (long long)cu * p.psc;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float o0 = ((y[2 * i][0] + y[2 * i + 1][0]) + (y[2 * i][1] + y[2 * i + 1][1])) * 0.25f;
-                const float o1 = ((y[2 * i][2] + y[2 * i + 1][2]) + (y[2 * i][3] + y[2 * i + 1][3])) * 0.25f;
-                const bool rok = py + 2 * i < p.H;
-                if (rok && px + 4 <= p.W && p.vec) st2(qp + (long long)i * p.psh, qb, f32x2{o0, o1});
-                else if (rok) {
-                    if (px + 2 <= p.W) st1(qp + (long long)i * p.psh, qb, o0);
-                    if (px + 4 <= p.W) st1(qp + (long long)i * p.psh + 1, qb, o1);
-                }
-            }
+            for (int i = 0; i < 4; ++i) yk[r][i] = f32x4{y[i][0], y[i][1], y[i][2], y[i][3]};
+        } else {
+            emit(r, y);
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (HOLD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y[4][4] = {{yk[r][0][0], yk[r][0][1], yk[r][0][2], yk[r][0][3]}, {yk[r][1][0], yk[r][1][1], yk[r][1][2], yk[r][1][3]},
+                                   {yk[r][2][0], yk[r][2][1], yk[r][2][2], yk[r][2][3]}, {yk[r][3][0], yk[r][3][1], yk[r][3][2], yk[r][3][3]}};
+            emit(r, y);
+        }
     }
 }
 
@@ -543,7 +574,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     if ((W7_ABL & 4) && acc[0][0] != 12345.678f) return;
     W7STAMP(0)
-    w7_epilogue(p, acc, bv, b, nb * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
+    {
+        const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
+        const bool edge = !(py + 4 <= p.H && px + 4 <= p.W && p.vec);
+        if (__builtin_amdgcn_ballot_w64(edge) != 0) w7_epilogue<false, false>(p, acc, bv, b, nb * 32 + cb * 16, q, px, py);
+        else if (p.add) w7_epilogue<true, true>(p, acc, bv, b, nb * 32 + cb * 16, q, px, py);
+        else w7_epilogue<true, false>(p, acc, bv, b, nb * 32 + cb * 16, q, px, py);
+    }
 #ifdef W7_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W7STAMP(3)          // -> [3]: epilogue

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-wave phase sums of the blocked 7x7 kernel (tuning build: make -C csrc w7alt W7TAG=tr W7FLAGS=-DW7_TRACE=1).
-usage: SSM_HIP_LIB=$PWD/tools/w7tr_libssm_hip.so python tools/wino7_phase_probe.py [cin] [B]"""
+usage: SSM_HIP_LIB=$PWD/tools/w7tr_libssm_hip.so python tools/wino7_phase_probe.py [cin] [B] [add]      (add: with the per-pair addend, B % 7 == 0)"""
 import ctypes
 import os
 import sys
@@ -27,13 +27,18 @@ def main():
     x = hb.Planes(B, cin, H, W, dev)
     x.interior.normal_()
     y = hb.Planes(B, cout, H, W, dev)
+    akw = {}
+    if len(sys.argv) > 3 and sys.argv[3] == "add":
+        add = hb.Planes(B // 7, cout, H, W, dev)
+        add.interior.normal_()
+        akw = dict(add=add.view(), add_div=7)
     for _ in range(3):
-        hb.conv2d_wino7(x.view(), cin, None, 0, pk, y.view(), None, B, H, W)
+        hb.conv2d_wino7(x.view(), cin, None, 0, pk, y.view(), None, B, H, W, **akw)
     torch.cuda.synchronize()
     lib.ssm_wino7_debug_buffer(ctypes.c_void_p(cnt.data_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    hb.conv2d_wino7(x.view(), cin, None, 0, pk, y.view(), None, B, H, W)
+    hb.conv2d_wino7(x.view(), cin, None, 0, pk, y.view(), None, B, H, W, **akw)
     e1.record()
     torch.cuda.synchronize()
     c = cnt.cpu().view(4, 8)
