@@ -228,7 +228,7 @@ int ssm_wino7_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const f
 
 /* ---- the 5x5 convolutions as two-dimensional Winograd F(4x4,5x5), all arithmetic fp32 (v_mfma_f32_16x16x4_f32) ------------------
  * Same operator and operand layout as ssm_wino1d_conv2d_add_fwd for k = 5 (layers.conv, scripts/models/layers.py:21-33; conv2a /
- * conv2b of both U-Nets, scripts/models/flow_computation.py:46-55; fused 2x2 mean, layers.py:60-63): the eight points
+ * conv2b of both U-Nets, scripts/models/flow_computation.py:43-45; fused 2x2 mean, layers.py:60-63): the eight points
  * {0, +-1, +-2, +-1/2, inf} of the 1-D F(4,5) form on BOTH axes - 64 multiplies per 16 outputs and (cin, cout) = 4 per output
  * against 10 for F(4,5) along x and 25 for the direct form (csrc/ssm_wino5.hip).  In fp32 the result differs from the
  * direct form by rounding only (a 64-channel layer: 3e-6 rms / 3e-5 max at unit output scale).

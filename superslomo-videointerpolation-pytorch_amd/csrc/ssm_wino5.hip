@@ -2,7 +2,7 @@
 //
 // Same operator as the k = 5 case of ssm_conv.hip / ssm_wino1d.hip (layers.conv of the reference, scripts/models/layers.py:21-33: stride-1
 // 'same' cross-correlation, zero padding, bias, LeakyReLU; fused 2x2 mean, scripts/models/layers.py:60-63) - conv2a / conv2b of both U-Nets
-// (scripts/models/flow_computation.py:46-55), 32 -> 64 and 64 -> 64 channels at half resolution.
+// (scripts/models/flow_computation.py:43-45), 32 -> 64 and 64 -> 64 channels at half resolution.
 //
 //      Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      per 4x4 output tile (d = its 8x8 input window, g = the 5x5 filter)
 //
