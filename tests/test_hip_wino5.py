@@ -103,6 +103,29 @@ def test_wino5_every_short_step_count(dev, kind):
         assert e < BAR, "%s cin %d: %.3e" % (kind, cin, e)
 
 
+def test_wino5_addend_with_fused_pool(dev):
+    """Pre-activation addend AND fused 2x2 mean in one launch (whole tiles and a ragged edge; add_div 2 and 1): a combination the plan never
+    asks for and the entry point allows."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(78)
+    for (B, div, H, W) in ((4, 2, 48, 96), (2, 1, 38, 76)):
+        cin, cout = 8, 32
+        w = torch.randn(cout, cin, 5, 5, generator=g) / (cin * 25) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        x = torch.randn(B, cin, H, W, generator=g)
+        add = torch.randn(B // div, cout, H, W, generator=g)
+        z = O.conv2d(x, w, bias) + add.repeat_interleave(div, 0)
+        want = torch.where(z >= 0, z, z * 0.1)
+        px = hb.Planes(B, cin, H, W, dev).load(x.to(dev))
+        pa = hb.Planes(B // div, cout, H, W, dev).load(add.to(dev))
+        y, yp = hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, H // 2, W // 2, dev)
+        pk = hb.PackedWino5(w.to(dev), bias.to(dev), B, H, W, pool=True)
+        hb.conv2d_wino5(px.view(), cin, None, 0, pk, y.view(), yp.view(), B, H, W, add=pa.view(), add_div=div)
+        assert _err(y.to_nchw().cpu(), want) < BAR, "%dx%d: %.3e" % (H, W, _err(y.to_nchw().cpu(), want))
+        assert _err(yp.to_nchw().cpu(), O.avg_pool2(want)) < BAR, "%dx%d: pooled" % (H, W)
+
+
 def test_wino5_layer_shapes_and_scale_invariance(dev):
     """conv2a / conv2b as the plan runs them (32 -> 64; 64 -> 64 with the fused 2x2 mean) on a map of many workgroup tiles, and the same
     problem with activations x 2^12 and filters x 2^-9: the form is linear fp32 arithmetic with dyadic transform constants."""

@@ -119,6 +119,30 @@ def test_wino7_pre_activation_addend(dev, kind):
         assert _err(y.to_nchw().cpu(), want) < BAR, "%s %dx%d: %.3e" % (kind, H, W, _err(y.to_nchw().cpu(), want))
 
 
+def test_wino7_addend_with_fused_pool(dev):
+    """Pre-activation addend AND fused 2x2 mean in one launch, on a map whose workgroups take the epilogue's three paths: whole tiles
+    (outputs held in registers until the last addend row is used, then stored and pooled), a ragged right / bottom edge (element-wise
+    path), and add_div = 1.  The plan never asks for the combination; the entry point allows it."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(77)
+    for (B, div, H, W) in ((4, 2, 48, 96), (2, 1, 38, 76)):
+        cin, cout = 5, 32
+        w = torch.randn(cout, cin, 7, 7, generator=g) / (cin * 49) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        x = torch.randn(B, cin, H, W, generator=g)
+        add = torch.randn(B // div, cout, H, W, generator=g)
+        z = O.conv2d(x, w, bias) + add.repeat_interleave(div, 0)
+        want = torch.where(z >= 0, z, z * 0.1)
+        px = hb.Planes(B, cin, H, W, dev).load(x.to(dev))
+        pa = hb.Planes(B // div, cout, H, W, dev).load(add.to(dev))
+        y, yp = hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, H // 2, W // 2, dev)
+        pk = hb.PackedWino7(w.to(dev), bias.to(dev), B, H, W, pool=True)
+        hb.conv2d_wino7(px.view(), cin, None, 0, pk, y.view(), yp.view(), B, H, W, add=pa.view(), add_div=div)
+        assert _err(y.to_nchw().cpu(), want) < BAR, "%dx%d: %.3e" % (H, W, _err(y.to_nchw().cpu(), want))
+        assert _err(yp.to_nchw().cpu(), O.avg_pool2(want)) < BAR, "%dx%d: pooled" % (H, W)
+
+
 def test_wino7_layer_shape_and_scale_invariance(dev):
     """conv1b as the plan runs it (32 -> 32, fused 2x2 mean) on a map of many workgroup tiles, and the same problem with activations
     x 2^12 and filters x 2^-9: the form is linear fp32 arithmetic with dyadic transform constants, no operand range degrades it."""
