@@ -596,7 +596,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
                 acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[4 * g + e], 0, 0, 0);
                 if (e == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (g + 2 < 9) {
+                    if (g + 2 < 9 && !W4ABL(8)) {          // (tuning builds, bit 8: the matrix loop re-uses the operands it holds)
                         a[nxt] = lds4[ai + (g + 2) * 32];
                         bq[nxt] = lds4[bi + (g + 2) * NT];
                     }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             const int st = ch & 1;
             // V(ch) complete, filter of chunk ch and (raw) patch of the next chunk(s) landed, every wave done with chunk ch-1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!W4ABL(16) || ch == 0) __syncthreads();          // (tuning builds, bit 16: no chunk barrier - wrong results, timing only)
             W4STAMP(0)
             W4TRACE(ch, 0)
             const float *tsrc = lds + t_src + (st ^ 1) * L::PCAP;
