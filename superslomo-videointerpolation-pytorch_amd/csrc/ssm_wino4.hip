@@ -116,7 +116,8 @@ struct W4Lds {
     static constexpr int UOFF = 0;                              // two filter stages
     static constexpr int DOFF = 2 * C::USZ;                     // the DMA'd patch (plain: lands SHIFT floats in; UPS: the low-res raw patch)
     static constexpr int DCAP = NGP * 256 + 256;
-    static constexpr int HOFF = DOFF + NBUF * DCAP;             // UPS: the expanded hi-res patch
+    static constexpr int NBD = 2;                               // the DMA'd (raw) patch is double-buffered in both forms: it runs two chunks ahead
+    static constexpr int HOFF = DOFF + NBD * DCAP;              // UPS: the expanded hi-res patch
     static constexpr int HCAP = C::PSZ + 4;
     static constexpr int POFF = UPS ? HOFF : DOFF;              // the patch the transform reads (its floats start at + SHIFT in the plain form)
     static constexpr int PCAP = UPS ? HCAP : DCAP;              // ... and the distance between its two buffers
@@ -368,6 +369,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
         }
     }
     const int uoff = lane * 16;
+    int uoffk[L::NIU];          // 256-thread form: filter piece k of this wave = one scalar base per chunk + this lane offset
+#pragma unroll
+    for (int k = 0; k < L::NIU; ++k) uoffk[k] = lane * 16 + k * (L::NW * 1024);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
 
     // k-th DMA instruction of this wave for chunk `ch`: k < NIU filter group 4k + wave into filter stage `stage`, else the patch
@@ -413,7 +417,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     const bool u_full = wid < L::NGU - NW * (L::NIU - 1);          // this wave brings NIU filter pieces per chunk (else NIU - 1)
     if constexpr (NCB == 1) {
 #pragma unroll
-        for (int n = 0; n < L::NI; ++n) issue_n(0, 0, n);
+        for (int n = 0; n < L::NI; ++n) issue_n(0, 0, n);          // patch (buffer 0) and filter (stage 0) of chunk 0
+        if (p.Cin / CK > 1) {
+#pragma unroll
+            for (int k = L::NIU; k < L::NI; ++k) issue_k(1, 0, k, 1);  // patch of chunk 1 (buffer 1)
+        }
     }
     // bias of this lane's four couts (cb*16 + 4q + r): added after the output transform
     float bv[4];
@@ -624,27 +632,62 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
         // Two barriers per chunk: [patch of chunk ch landed | V free] expand, transform [filter of chunk ch landed | V complete] matrix
         // loop, which carries the DMA of chunk ch+1: the patch into the buffer the transform has finished with, the filter into the stage
         // the matrix loop of chunk ch-1 has released.
-        for (int ch = 0; ch < nchunks; ++ch) {
+        // NEXT (compile-time): a chunk follows - its DMA rides in this chunk's matrix loop.  The scalar operands of those DMA instructions
+        // are formed HERE, once per chunk: with the test "is there a next chunk" in every slot, each piece sat behind its own scalar
+        // branch with its own copy of the address arithmetic (7 scalar instructions per filter piece, 18 per patch piece) - and a
+        // scalar instruction costs a wave's issue slot like any other (tuning build, bit 32: every piece from one address: conv11b
+        // 0.558 -> 0.467 ms, fuse_conv 0.935 -> 0.779 at batch 7, as much as having no DMA at all).
+        // N1 / N2 (compile-time): chunks ch+1 / ch+2 exist.  Order of a wave's DMA inside matrix(ch): the filter pieces of chunk ch+1, then
+        // the patch pieces of chunk ch+2 (into the patch buffer chunk ch has just been transformed from).  The patch - every
+        // workgroup's own rows, an HBM-latency read - so has two chunks to arrive, the filter (L2-resident, shared by all
+        // workgroups) one; the counted waits: at the top the patch of chunk ch (younger: filter(ch), patch(ch+1)), before the
+        // matrix loop the filter of chunk ch (younger: patch(ch+1)).
+        static_assert(L::NGP % L::NW == 0, "every wave brings NIP patch pieces per chunk");
+        auto chunk1 = [&](int ch, auto N1, auto N2) __attribute__((always_inline)) {
+            constexpr bool n1 = decltype(N1)::value, n2 = decltype(N2)::value;
             const int stage = ch & 1;
-            if (u_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU - 1) : "memory");
+            if (u_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU + (n1 ? L::NIP : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NIU - 1 + (n1 ? L::NIP : 0)) : "memory");
             __syncthreads();
             W4STAMP(0)
-            const bool dma_next = ch + 1 < nchunks && !(W4ABL(1) && ch >= 1);
             if constexpr (UPS) {
-                expand(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, CK>{});
+                expand(stage, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, CK>{});
                 __syncthreads();
             }
-            if (!W4ABL(4) || ch == 0) transform();
+            if (!W4ABL(4) || ch == 0) transform(UPS ? 0 : stage, 0);
             W4STAMP(1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the filter of chunk ch
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n1 ? L::NIP : 0) : "memory");          // the filter of chunk ch
             __syncthreads();
             W4STAMP(2)
-            matrix(stage, 0, [&](int g) {
-                if (dma_next) issue_n(ch + 1, stage ^ 1, g);
+            const int (&uk)[L::NIU] = uoffk;          // (named here: the nested lambda of a generic lambda does not capture it implicitly)
+            const int (&pk)[L::NIP] = poff;
+            const int c1 = (ch + 1) * CK, c2 = (ch + 2) * CK;
+            const float *fb = wbase + wid * 256 + (long long)c1 * (9 * 32 * 4);                           // filter piece k of this wave: + k * 4 KiB
+            const float *pb = (c2 < p.C1) ? pbase1 + (long long)c2 * p.sc : pbase2 + (long long)(c2 - p.C1) * p.sc;
+            const unsigned mu = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(L::UOFF + (stage ^ 1) * C::USZ) * 4u + (unsigned)wid * 1024u);
+            const unsigned mp = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(L::DOFF + stage * L::DCAP) * 4u + (unsigned)wid * 1024u + (UPS ? 0u : 4u * C::SHIFT));
+            matrix(stage, 0, [&](int n) {
+                if (W4ABL(1) && ch >= 1) return;
+                constexpr int NW = L::NW;
+                if (n < L::NIU) {
+                    if constexpr (n1) {
+                        if (NW * n + NW - 1 < L::NGU || NW * n + wid < L::NGU)
+                            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uk[n]), "s"(fb), "s"(mu + (unsigned)(n * NW * 1024)) : "memory", "m0");
+                    }
+                } else if constexpr (n2) {
+                    const int k = n - L::NIU;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(pk[k]), "s"(pb), "s"(mp + (unsigned)(k * NW * 1024)) : "memory", "m0");
+                }
             }, [](int) {});
             W4STAMP(3)
-        }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        int ch = 0;
+        for (; ch + 2 < nchunks; ++ch) chunk1(ch, T{}, T{});
+        if (ch + 1 < nchunks) chunk1(ch++, T{}, F{});
+        chunk1(ch, F{}, F{});
+
     } else {
         // One barrier per chunk (patch, hi-res patch and V double-buffered): behind its MFMAs of chunk ch a wave transforms chunk ch+1
         // (and, fused upsample, expands chunk ch+2) while the other wave of its SIMD is still feeding the matrix pipe - the two waves
