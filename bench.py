@@ -72,7 +72,7 @@ ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(4x4,3x3) (
                      "(csrc/ssm_elem.hip); the t-independent input channels of stage 2's conv1a / conv7a convolved once per pair",
              "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output; the t-independent input channels of "
                     "stage 2's conv1a / conv7a summed once per pair and added - SSM_HOIST=0 keeps one chain)"}
-PMC_FILES = {"f32w": ("r9_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel")),
+PMC_FILES = {"f32w": ("r10_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel")),
              "f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "final_conv_kernel")),
              "f16x3": ("r1k_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel")),
              "f16f8": ("r1q_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel"))}
