@@ -160,7 +160,7 @@ def layer_kernel_size(lname):
 
 def issued_factor(lname, precision, B=14, H=736, W=1280):
     """Multiply-adds the matrix cores issue per direct-form multiply-add of this layer in this precision mode: the plan's algorithm
-    for the layer (ssm_amd.engine.choose_algo: F(4x4,3x3) x 1/4, F(2x2,3x3) x 16/36, 7x7 as blocked F(4x4,4x4) x 1/4, F(4,5) x 8/20, direct x 1).
+    for the layer (ssm_amd.engine.choose_algo: F(4x4,3x3) x 1/4, F(2x2,3x3) x 16/36, 7x7 as blocked F(4x4,4x4) x 1/4, 5x5 as F(4x4,5x5) x 64/400 (F(4,5) along x, the fallback: x 8/20), direct x 1).
     B, H, W: batch and full-resolution size of the plan the layer belongs to."""
     if precision != "f32w" or lname.startswith("final"):
         return 1.0
@@ -672,7 +672,7 @@ def infer_bench(args):
             issued_note = ("the multiply-adds the matrix cores execute: the t-independent input channels of stage 2's conv1a (6 of 16) and "
                            "conv7a (512 of 1024) are convolved once per pair instead of once per t" +
                            ("; Winograd layers: direct-form FLOP x 1/4 (F(4x4,3x3)) or x 16/36 (F(2x2,3x3)), x 1/4 (7x7 as 2x2 blocks of F(4x4,4x4)), "
-                            "x 8/20 (5x5 as F(4,5) along x), per layer as the plan picks the form" if precision == "f32w" else ""))
+                            "x 64/400 (5x5 as F(4x4,5x5)), per layer as the plan picks the form" if precision == "f32w" else ""))
         else:
             issued_note = "direct-form FLOP (each product costs %s narrow MFMA operations in this mode)" % \
                           {"f16x3": "3 fp16", "f16f8": "1 fp16 + 2 fp8"}.get(precision, "1")

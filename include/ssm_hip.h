@@ -28,8 +28,15 @@
  *  aligned, and sh/sc/sb are multiples of 4.  The zero frame implements the
  *  convolution's zero padding (scripts/models/layers.py:22-31) with no bounds
  *  test in the kernel.  Kernels only ever write interiors, so a buffer zeroed
- *  once stays valid.  Conv inputs must be readable for SSM_TAIL_SLACK_FLOATS
- *  past their last element (tile overshoot reads, never used).
+ *  once stays valid.  The DIRECT-form kernels (ssm_conv2d_*, ssm_conv2d_hl8_*)
+ *  read a tile's overshoot past the map unpredicated: their inputs must be
+ *  readable for SSM_TAIL_SLACK_FLOATS past the last element; what is read
+ *  there only feeds outputs that are not stored.  The Winograd-form kernels
+ *  (ssm_wino_*, ssm_wino1d_*, ssm_wino4_*, ssm_wino5_*, ssm_wino7_*) never read
+ *  outside the padded plane: a tile's transform mixes its whole input patch
+ *  into every output, so overshoot rows / 16-byte pieces are fetched from the
+ *  zero frame instead (tests/test_hip_overshoot.py poisons the memory behind
+ *  the last plane with NaN).
  */
 #ifndef SSM_HIP_H
 #define SSM_HIP_H
@@ -174,8 +181,7 @@ int ssm_wino_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const fl
  * 736x1280 is unchanged within its fp32 noise (tests/emulate_winograd_f44_precision.py; profiles/DESIGN_history_r1-r3.md 3.2f).
  * Cin and the first cat source multiples of 4, Cout a multiple of 32; any H, W (fused upsample: even).
  * ssm_wino4_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/32][Cin][9][32][4] (+ bias).
- * Inputs must be padded planes with SSM_TAIL_SLACK_FLOATS readable floats behind them: a 16-row tile that overshoots the map reads 14
- * rows past the frame, so row strides beyond (SSM_TAIL_SLACK_FLOATS - 72) / 14 floats (~4.6 K pixels) are refused (SSM_E_UNSUPPORTED). */
+ * Inputs must be padded planes; nothing outside them is read (tile overshoot is fetched from the zero frame), any row stride.          */
 int ssm_wino4_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK);
 int ssm_wino4_preferred(int Cin, int Cout, int B, int H, int W, int ups);   /* 1: modelled faster than F(2x2,3x3) for this problem */
 double ssm_wino_estimate(int Cin, int Cout, int B, int H, int W, int ups);     /* modelled cycles of ssm_wino_conv2d_*_fwd (-1: unsupported) */
@@ -212,12 +218,12 @@ int ssm_wino1d_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const 
  * Same operator and operand layout as ssm_wino1d_conv2d_add_fwd for k = 7 (layers.conv, scripts/models/layers.py:21-33; conv1a /
  * conv1b of both U-Nets, scripts/models/flow_computation.py:36-45 and flow_interpolation.py:36-45; fused 2x2 mean, layers.py:60-63;
  * pre-activation addend for the hoisted part of stage 2's conv1a).  The 7x7 filter (zero-padded to 8x8) is 2x2 blocks of 4x4 taps;
- * each block is a F(4x4,4x4) Winograd filter over the seven points {0, +-1, +-1/2, +-2}, and because the blocks of a 4x4 output tile
+ * each block is a F(4x4,4x4) Winograd filter over the seven points {0, +-1, +-2, 1/2, inf}, and because the blocks of a 4x4 output tile
  * read input windows that are whole tiles apart, one input transform per window position serves all four: 4 x 49 multiplies per 16
  * outputs and (cin, cout) = 12.25 per output against 28 for F(2,7) and 49 for the direct form (csrc/ssm_wino7.hip).
  * In fp32 the result differs from the direct form by rounding only (a 32-channel layer: 2e-6 rms / 3e-5 max at unit output scale).
  * One input source, any Cin >= 1 (a k-step is the four blocks of one channel: no channel padding); Cout a multiple of 32.
- * Inputs are padded planes with SSM_TAIL_SLACK_FLOATS readable floats behind them (tile overshoot; refused if it would outrun them).
+ * Inputs are padded planes; nothing outside them is read (tile overshoot and the bottom window's row H + 3 come from the zero frame).
  * ssm_wino7_pack_weights: OIHW fp32 7x7 filter -> U_b = G g_b G^T as [Cout/32][Cin][14 quads][4 blocks][32][4] (+ bias).            */
 int ssm_wino7_plan(int Cin, int Cout, int B, int H, int W, int *kind);
 int ssm_wino7_force_kind(int kind);      /* tests / tuning only (-1 = automatic); returns the number of configurations */
@@ -232,8 +238,8 @@ int ssm_wino7_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const f
  * {0, +-1, +-2, +-1/2, inf} of the 1-D F(4,5) form on BOTH axes - 64 multiplies per 16 outputs and (cin, cout) = 4 per output
  * against 10 for F(4,5) along x and 25 for the direct form (csrc/ssm_wino5.hip).  In fp32 the result differs from the
  * direct form by rounding only (a 64-channel layer: 3e-6 rms / 3e-5 max at unit output scale).
- * One input source; Cin a multiple of 4 (pad the view; pack with CinP), Cout a multiple of 32.  Inputs are padded planes with
- * SSM_TAIL_SLACK_FLOATS readable floats behind them.
+ * One input source; Cin a multiple of 4 (pad the view; pack with CinP), Cout a multiple of 32.  Inputs are padded planes; nothing
+ * outside them is read (tile overshoot comes from the zero frame).
  * ssm_wino5_pack_weights: OIHW fp32 5x5 filter -> U = G g G^T as [Cout/32][CinP/4][16 quads][4 channels][32][4] (+ bias).          */
 int ssm_wino5_plan(int Cin, int Cout, int B, int H, int W, int *kind);
 int ssm_wino5_force_kind(int kind);      /* tests / tuning only (-1 = automatic); returns the number of configurations */

@@ -6,6 +6,8 @@ the global_load_lds / global_store instructions of this library's asm statements
 (memory access fault) when a register-allocation change moved a store base into vector registers.  The asm statements whose base may
 come from a readfirstlane carry their own s_nop; this script fails the build if any vector-memory instruction still reads a scalar
 register within 5 wait states of the v_readfirstlane that wrote it.
+Second rule (gfx940+): a vector-memory store of more than 64 bits (dwordx3 / dwordx4) followed by a VALU write of its data registers needs
+2 wait states; the epilogues' stores are opaque asm statements, so the compiler does not see the pair either.
 usage: llvm-objdump -d dev.co | check_hazard.py <name>"""
 import re
 import sys
@@ -39,4 +41,40 @@ for idx, text in enumerate(ins):
             break
         nm = re.match(r"s_nop (\d+)", p)
         ws += int(nm.group(1)) + 1 if nm else 1
+
+def vrange(tok):
+    """'v5' -> (5, 5); 'v[4:7]' -> (4, 7); anything else -> None"""
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return int(m.group(1)), int(m.group(2))
+    m = re.match(r"v(\d+)$", tok)
+    return (int(m.group(1)),) * 2 if m else None
+
+
+WIDE_STORE = re.compile(r"\b(?:global|flat|scratch|buffer)_store_dwordx[34]\s+(.*)")
+for idx, text in enumerate(ins):
+    m = WIDE_STORE.search(text)
+    if not m:
+        continue
+    ops = [o.strip() for o in m.group(1).split(",")]
+    data = None
+    for o in ops[1:2] if text.lstrip().startswith(("global", "flat", "scratch")) else ops[0:1]:
+        data = vrange(o)
+    if data is None:
+        continue
+    ws = 0
+    for j in range(idx + 1, min(idx + 4, len(ins))):
+        p = ins[j]
+        nm = re.match(r"s_nop (\d+)", p)
+        if nm:
+            ws += int(nm.group(1)) + 1
+        else:
+            if ws < 2 and p.startswith("v_"):
+                dst = vrange(p.split(None, 1)[1].split(",")[0].strip()) if len(p.split(None, 1)) > 1 else None
+                if dst and dst[0] <= data[1] and data[0] <= dst[1]:
+                    bad += 1
+                    print("check_hazard: %s: `%s` overwrites the data of `%s` %d wait state(s) after it" % (sys.argv[1], p, text, ws), file=sys.stderr)
+            ws += 1
+        if ws >= 2:
+            break
 sys.exit(1 if bad else 0)

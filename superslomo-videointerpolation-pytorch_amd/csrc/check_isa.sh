@@ -17,7 +17,7 @@ for o in "$@"; do
     python3 "$(dirname "$0")/check_hazard.py" "$o" < $tmp/dev.s || bad=1          # VALU-written SGPR -> vector-memory base (see the script)
     # scratch fence: the accumulator arrays of these kernels must live in registers (a loop that stays rolled - e.g. ssm_wino7.hip below its
     # -pragma-unroll-threshold - indexes them at run time and the compiler moves them to scratch memory: correct, and several times slower)
-    case "$(basename "$o")" in ssm_conv.o|ssm_wino.o|ssm_wino1d.o|ssm_wino5.o|ssm_wino7.o|ssm_elem.o|ssm_rnn.o)
+    case "$(basename "$o")" in ssm_conv.o|ssm_wino.o|ssm_wino1d.o|ssm_wino4.o|ssm_wino5.o|ssm_wino7.o|ssm_elem.o|ssm_rnn.o)
         ns=$(grep -c 'scratch_' $tmp/dev.s || true)
         if [ "$ns" != "0" ]; then
             echo "check_isa: $o contains $ns scratch-memory instructions (an array left the registers)" >&2

@@ -155,7 +155,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int rem = qq - c * (L::DH * L::DW4);
             const int r = rem / L::DW4;
             const int j = rem - r * L::DW4;
-            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+            // overshoot rows / pieces are read from the source's zero frame, never from behind the padded plane (see ssm_wino4.hip)
+            const int sH = UPS ? p.hs : p.H, sW = UPS ? p.ws : p.W, sy = UPS ? y0 / 2 - 1 : y0 - 1, sx = UPS ? x0 / 2 : x0;
+            const int re = min(r, sH + (SSM_PADY - 1) - sy), fe = min(4 * j, ((sW + 2 * SSM_PADX + 3) & ~3) - 4 - sx);
+            poff[i] = ((int)(c * p.sc) + re * p.sh + fe) * 4;
         } else {
             poff[i] = 0;          // tail of the last 1-KiB piece: lands in the stage's padding
         }
@@ -511,7 +514,10 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
             const int rem = qq - c * (L::DH * L::DW4);
             const int r = rem / L::DW4;
             const int j = rem - r * L::DW4;
-            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+            // overshoot rows / pieces are read from the source's zero frame, never from behind the padded plane (see ssm_wino4.hip)
+            const int sH = UPS ? p.hs : p.H, sW = UPS ? p.ws : p.W, sy = UPS ? y0 / 2 - 1 : y0 - 1, sx = UPS ? x0 / 2 : x0;
+            const int re = min(r, sH + (SSM_PADY - 1) - sy), fe = min(4 * j, ((sW + 2 * SSM_PADX + 3) & ~3) - 4 - sx);
+            poff[i] = ((int)(c * p.sc) + re * p.sh + fe) * 4;
         } else {
             poff[i] = 0;
         }

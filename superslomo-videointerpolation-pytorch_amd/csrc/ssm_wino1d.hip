@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256, 2) void wino1d_kernel(const W1Params p) {
             const int rem = qq - c * (PH * C::PW4);
             const int r = rem / C::PW4;
             const int j = rem - r * C::PW4;
-            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+            // overshoot rows / pieces are read from the zero frame, never from behind the padded plane (see ssm_wino4.hip)
+            const int re = min(r, p.H + (SSM_PADY - 1) - (y0 - C::PAD)), fe = min(4 * j, ((p.W + 2 * SSM_PADX + 3) & ~3) - 4 - x0);
+            poff[i] = ((int)(c * p.sc) + re * p.sh + fe) * 4;
         } else {
             poff[i] = 0;          // tail of the last 1-KiB piece: lands in the stage's padding
         }

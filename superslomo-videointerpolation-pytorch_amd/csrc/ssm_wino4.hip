@@ -124,7 +124,7 @@ struct W4Lds {
     static constexpr int VOFF = HOFF + (UPS ? NBUF * HCAP : 0); // transformed patch
     static constexpr int BYTES = (VOFF + NBUF * C::VSZ) * 4;
     static_assert(VOFF % 4 == 0 && DOFF % 4 == 0 && HOFF % 4 == 0 && HCAP % 4 == 0 && DCAP % 4 == 0, "16-byte aligned regions");
-    static_assert(BYTES <= (C::NCB == 1 ? 80 : 160) * 1024, "LDS budget (two workgroups of 256 or one of 512 per CU)");
+    static_assert(BYTES + (C::NCB == 2 ? 256 : 0) <= (C::NCB == 1 ? 80 : 160) * 1024, "LDS budget (two workgroups of 256 or one of 512 per CU; 64-cout form: + its biases)");
 };
 
 // interpolation points 0, +-PA, +-PB, inf (PA * PB = 1); the transform matrices in the monic form:
@@ -363,7 +363,12 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             const int rem = qq - c * (L::DH * L::DW4);
             const int r = rem / L::DW4;
             const int j = rem - r * L::DW4;
-            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+            // rows below the source's bottom zero frame / 16-byte pieces right of its padded row: read from the frame's last row / piece
+            // (zeros) - a tile that overshoots the map never brings in another plane's pixels or the memory behind the last plane, whose
+            // values B^T d B would mix into the tile's valid outputs (times a zero, up to rounding - or NaN).  Per-lane constants: free.
+            const int sH = UPS ? p.hs : p.H, sW = UPS ? p.ws : p.W, sy = UPS ? y0 / 2 - 1 : y0 - 1, sx = UPS ? x0 / 2 : x0;
+            const int re = min(r, sH + (SSM_PADY - 1) - sy), fe = min(4 * j, ((sW + 2 * SSM_PADX + 3) & ~3) - 4 - sx);
+            poff[i] = ((int)(c * p.sc) + re * p.sh + fe) * 4;
         } else {
             poff[i] = 0;          // tail of the last 1-KiB piece: lands in the region's padding
         }
@@ -423,10 +428,15 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
             for (int k = L::NIU; k < L::NI; ++k) issue_k(1, 0, k, 1);  // patch of chunk 1 (buffer 1)
         }
     }
-    // bias of this lane's four couts (cb*16 + 4q + r): added after the output transform
+    // bias of this lane's four couts (cb*16 + 4q + r): added after the output transform.  64-cout form: parked in LDS across the chunk
+    // loop (the loop runs at the 256-register cap; four registers held for the epilogue were spilled to scratch memory)
     float bv[4];
+    if constexpr (NCB == 2) {
+        if (tid < BN) lds[L::BYTES / 4 + tid] = p.bias[nb * BN + tid];          // (visible after the first barrier below)
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * BN + blk * 32 + cb * 16 + 4 * q + r];
+        for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * BN + blk * 32 + cb * 16 + 4 * q + r];
+    }
 
     // ---- per-thread constants of the transform phase: unit = (cin, tile), two threads per unit (frequency rows 0..2 | 3..5) -------
     const int thh = (wid >> 1) & 1;                  // wave-uniform: which three column-frequencies this thread computes
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     // tuning build (-DW4_TRACE): the same timeline without run-time switches in the loop - the stamps of workgroup 0 go to 4 KiB of
     // LDS behind the kernel's regions (no vector-memory traffic that the loop's vmcnt waits would see) and to dbg[16 ..] at the end
 #define W4STAMP(i)
-    unsigned long long *ltrace = (unsigned long long *)(lds + L::BYTES / 4);
+    unsigned long long *ltrace = (unsigned long long *)(lds + L::BYTES / 4 + 64);
     const bool trace = p.dbg && blockIdx.x == 0;
 #define W4TRACE(chv, pt) \
     if (trace && (chv) < 16 && lane == 0) ltrace[(wid * 16 + (chv)) * 4 + (pt)] = __builtin_amdgcn_s_memtime();
@@ -840,6 +850,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     if (W4ABL(2) && acc[0][0] != 12345.678f) return;
 #endif
     {
+        if constexpr (NCB == 2) {
+            const f32x4 b4 = *(const f32x4 *)(lds + L::BYTES / 4 + blk * 32 + cb * 16 + 4 * q);
+            bv[0] = b4[0], bv[1] = b4[1], bv[2] = b4[2], bv[3] = b4[3];
+        }
         const int gx = l15 % C::GTX, gy = l15 / C::GTX;
         const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
         w4_epilogue(p, acc, bv, b, nb * BN + blk * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
@@ -868,8 +882,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
 using X4A = W4Cfg<8, 2, 1>;      //          8 x 4                16   32
 using X4B = W4Cfg<16, 2, 1>;     //         16 x 2                 8   64
 using X4C = W4Cfg<4, 1, 2>;      //          8 x 4 (4x4 groups)   16   32
-// (row tiles stay <= 16: a tile that overshoots the map reads TH - 2 rows past the plane's frame, which the 64 Ki floats of slack behind
-// every tensor cover up to 4K-wide planes)
 
 // 64 couts x 32 tiles per workgroup of 8 waves (same tile shapes as X4*)
 using Y4A = W4Cfg<8, 2, 1, 2>;
@@ -949,24 +961,14 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
         return SSM_E_UNSUPPORTED;
     }
     p.NB = p.Cout / C::BN;
-    // The patch DMA is not predicated in y: a tile that overshoots the map reads up to TH - 2 rows (fused upsample: TH / 2 - 1 low-res
-    // rows) past the plane's frame, into the SSM_TAIL_SLACK_FLOATS every conv input carries (include/ssm_hip.h).  Rows wider than ~4K
-    // floats outgrow that slack: refuse them here instead of reading out of bounds (the plan then keeps the layer on F(2x2,3x3)).
-    {
-        const long long over = (long long)(UPS ? C::TH / 2 - 1 : C::TH - 2) * p.sh + (UPS ? C::TW / 2 : C::TW) + 8;
-        if (over > SSM_TAIL_SLACK_FLOATS) {
-            ssm::set_error("wino4 conv: row stride %d: a %d-row tile overshoot reads %lld floats past the plane (slack %d)", p.sh, C::TH, over,
-                           SSM_TAIL_SLACK_FLOATS);
-            return SSM_E_UNSUPPORTED;
-        }
-    }
+    // (no read outside the padded plane: the per-lane DMA offsets clamp overshoot rows / pieces to the zero frame, see wino4_kernel)
     const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("wino4 conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
     void (*kern)(const W4Params) = wino4_kernel<C, UPS>;
-    int lds_bytes = W4Lds<C, UPS>::BYTES;
+    int lds_bytes = W4Lds<C, UPS>::BYTES + (C::NCB == 2 ? C::BN * 4 : 0);          // (64-cout form: + the workgroup's biases)
     const int threads = C::THREADS;
 #ifdef W4_TRACE
     lds_bytes += 4096;
@@ -1015,21 +1017,32 @@ __global__ void wino4_pack_kernel(const float *__restrict__ w, const float *__re
         const int co = nb * 32 + n, f = 4 * fq + e, i = (f % 18) / 3, j = 3 * (f / 18) + f % 3;          // f = w4_freq(i, j)
         double val = 0.0;
         if (co < Cout) {
-            const double pt[5] = {0.0, W4_PA, -W4_PA, W4_PB, -W4_PB};
-            double G[6][3];
-            for (int f5 = 0; f5 < 5; ++f5) {
+            // row f of G (fixed-index locals only: a [6][3] table indexed at run time lived in scratch memory)
+            auto grow = [](int f, double (&g)[3]) {
+                const double p = f == 0 ? 0.0 : f == 1 ? W4_PA : f == 2 ? -W4_PA : f == 3 ? W4_PB : -W4_PB;
+                if (f == 5) {
+                    g[0] = g[1] = 0.0;
+                    g[2] = 1.0;
+                    return;
+                }
                 double nrm = 1.0;
-                for (int o = 0; o < 5; ++o)
-                    if (o != f5) nrm *= pt[f5] - pt[o];
-                G[f5][0] = 1.0 / nrm;
-                G[f5][1] = pt[f5] / nrm;
-                G[f5][2] = pt[f5] * pt[f5] / nrm;
-            }
-            G[5][0] = G[5][1] = 0.0;
-            G[5][2] = 1.0;
+#pragma unroll
+                for (int o = 0; o < 5; ++o) {
+                    const double po = o == 0 ? 0.0 : o == 1 ? W4_PA : o == 2 ? -W4_PA : o == 3 ? W4_PB : -W4_PB;
+                    if (o != f) nrm *= p - po;
+                }
+                g[0] = 1.0 / nrm;
+                g[1] = p / nrm;
+                g[2] = p * p / nrm;
+            };
+            double gi[3], gj[3];
+            grow(i, gi);
+            grow(j, gj);
             const float *g = w + ((long long)co * Cin + cin) * 9;
+#pragma unroll
             for (int a = 0; a < 3; ++a)
-                for (int c = 0; c < 3; ++c) val += G[i][a] * (double)g[3 * a + c] * G[j][c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) val += gi[a] * (double)g[3 * a + c] * gj[c];
         }
         wp[idx] = (float)val;
     }
@@ -1144,7 +1157,6 @@ extern "C" int ssm_wino4_debug_buffer(unsigned long long *dev_counters) {
 extern "C" int ssm_wino4_preferred(int Cin, int Cout, int B, int H, int W, int ups) {
     if (Cin % 4 || Cout % 32 || Cin <= 0 || Cout <= 0) return 0;
     if ((long long)H * W < 2048) return 0;
-    if (14LL * ((ups ? W / 2 : W) + 2 * SSM_PADX + 4) + 72 > SSM_TAIL_SLACK_FLOATS) return 0;      // tile overshoot would outrun the input's tail slack (w4launch refuses it)
     return 1;
 }
 

@@ -254,8 +254,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int qq = (i * 4 + wid) * 64 + lane;
         if (qq < C::NDQ) {
             const int c = qq / (PH * (PW / 4)), rem = qq - c * (PH * (PW / 4));
+            // rows below the bottom zero frame / pieces right of the padded row: read from the frame's last row / piece (zeros) - a tile
+            // overshoot never brings in another plane's pixels or the memory behind the last plane (see ssm_wino7.hip)
             const int r = rem / (PW / 4), j = rem - r * (PW / 4);
-            poff[i] = ((int)(c * p.sc) + r * p.sh + 4 * j) * 4;
+            const int re = min(r, p.H + (SSM_PADY - 1) - (y0 - 2)), fe = min(4 * j, ((p.W + 2 * SSM_PADX + 3) & ~3) - 4 - x0);
+            poff[i] = ((int)(c * p.sc) + re * p.sh + fe) * 4;
         } else {
             poff[i] = 0;          // tail of the last 1-KiB piece: lands in the buffer's padding
         }
@@ -458,15 +461,7 @@ int w5launch(W5Params &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
     p.NB = p.Cout / 32;
-    // (the patch DMA is not predicated: tile overshoot reads must stay inside the input's SSM_TAIL_SLACK_FLOATS, include/ssm_hip.h)
-    {
-        const long long over = (long long)(p.tilesY * C::TH - p.H) * p.sh + C::TW + 8;
-        if (over > SSM_TAIL_SLACK_FLOATS) {
-            ssm::set_error("wino5 conv: row stride %d: the tile overshoot of a %dx%d map reads %lld floats past the plane (slack %d)", p.sh, p.H,
-                           p.W, over, SSM_TAIL_SLACK_FLOATS);
-            return SSM_E_UNSUPPORTED;
-        }
-    }
+    // (no read outside the padded plane: the per-lane DMA offsets clamp overshoot rows / pieces to the zero frame, see wino5_kernel)
     const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("wino5 conv: grid of %lld workgroups out of range", blocks);

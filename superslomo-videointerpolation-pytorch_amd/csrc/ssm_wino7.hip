@@ -302,8 +302,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
         const int qq = wid * 64 + lane;
         if (qq < C::NDQ) {
+            // Rows below the bottom zero frame and 16-byte pieces right of the padded row are read from the frame's last row / last piece
+            // instead (zeros): a tile that overshoots the map, and the bottom window's row H + 3 (the zero tap ky = 7, which B^T d B still
+            // mixes into every frequency), never bring in what lies behind the plane - another plane's pixels, or the caller's unzeroed
+            // memory behind the last one (NaN there would reach valid outputs).  Costs nothing in the loop: the offsets are per-lane constants.
             const int r = qq / (PW / 4), j = qq - r * (PW / 4);
-            poff = (r * p.sh + 4 * j) * 4;
+            const int re = min(r, p.H + (SSM_PADY - 1) - (y0 - 3)), fe = min(4 * j, ((p.W + 2 * SSM_PADX + 3) & ~3) - 4 - x0);
+            poff = (re * p.sh + fe) * 4;
         } else {
             poff = 0;          // tail of the last 1-KiB piece: lands in the buffer's padding
         }
@@ -643,16 +648,7 @@ int w7launch(W7Params &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
     p.NB = p.Cout / 32;
-    // The patch DMA is not predicated: the rows / columns of a tile that overshoots the map are read from whatever follows (never used).
-    // They must stay inside the input's allocation: SSM_TAIL_SLACK_FLOATS behind the last element (include/ssm_hip.h).
-    {
-        const long long over = (long long)(p.tilesY * C::TH - p.H) * p.sh + C::TW + 8;
-        if (over > SSM_TAIL_SLACK_FLOATS) {
-            ssm::set_error("wino7 conv: row stride %d: the tile overshoot of a %dx%d map reads %lld floats past the plane (slack %d)", p.sh, p.H,
-                           p.W, over, SSM_TAIL_SLACK_FLOATS);
-            return SSM_E_UNSUPPORTED;
-        }
-    }
+    // (no read outside the padded plane: the per-lane DMA offsets clamp overshoot rows / pieces to the zero frame, see wino7_kernel)
     const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("wino7 conv: grid of %lld workgroups out of range", blocks);

@@ -16,6 +16,39 @@ def test_sliding_window_matches_reference_semantics():
     assert t_values(8) == [i / 8.0 for i in range(1, 8)]
 
 
+def test_evaluation_windows_known_answers():
+    """pad_clip_edges / generate_sliding_windows (default_reader.py:209-248), answers worked out by hand from that code."""
+    from ssm_amd.evaluation import generate_sliding_windows as gsw, inference_item_indexes, pad_clip_edges
+    # N_FRAMES = 2: no edge padding; a clip that ends on an input has a full last window
+    assert pad_clip_edges(9, 2) == (list(range(9)), 7)
+    assert list(gsw(9, 2)) == [(list(range(9)), 7)]
+    assert pad_clip_edges(17, 2) == (list(range(17)), 7)
+    assert list(gsw(17, 2)) == [(list(range(0, 9)), 7), (list(range(8, 17)), 7)]
+    # 20 images: last_idx 19 = 2 * 8 + 3 -> three real targets in the last window, five copies of the last input (16) complete it
+    idx, n_last = pad_clip_edges(20, 2)
+    assert n_last == 3 and idx == list(range(20)) + [16] * 5
+    assert list(gsw(20, 2)) == [(list(range(0, 9)), 7), (list(range(8, 17)), 7), ([16, 17, 18, 19, 16, 16, 16, 16, 16], 3)]
+    # N_FRAMES = 4: 8 copies of image 0 in front; behind 8 (+ 5) copies of indexes[last_input] of the FRONT-PADDED list = image 8
+    idx, n_last = pad_clip_edges(20, 4)
+    assert n_last == 3 and idx == [0] * 8 + list(range(20)) + [8] * 13 and len(idx) == 41
+    w = list(gsw(20, 4))
+    assert [n for _, n in w] == [7, 7, 3] and all(len(win) == 25 for win, _ in w)
+    assert w[0][0] == [0] * 8 + list(range(17)) and w[1][0] == list(range(20)) + [8] * 5 and w[2][0] == list(range(8, 20)) + [8] * 13
+    idx, n_last = pad_clip_edges(17, 4)           # ends on an input: full last window, 8 copies of indexes[16] = image 8
+    assert n_last == 7 and idx == [0] * 8 + list(range(17)) + [8] * 8
+    assert [win for win, _ in gsw(17, 4)] == [[0] * 8 + list(range(17)), list(range(17)) + [8] * 8]
+    idx, n_last = pad_clip_edges(9, 4)            # last_input 8 -> indexes[8] of the padded list = image 0
+    assert idx == [0] * 8 + list(range(9)) + [0] * 8 and [n for _, n in gsw(9, 4)] == [7]
+    # positions inside a window: inputs every 8 images, targets strictly between the two middle inputs
+    assert inference_item_indexes(2) == ([0, 8], list(range(1, 8)))
+    assert inference_item_indexes(4) == ([0, 8, 16, 24], list(range(9, 16)))
+    win = w[2][0]                                 # the last window of the 20-image clip, N_FRAMES = 4
+    assert [win[i] for i in inference_item_indexes(4)[0]] == [8, 16, 8, 8]
+    assert [win[i] for i in inference_item_indexes(4)[1]][:3] == [17, 18, 19]
+    with pytest.raises(AssertionError):
+        list(gsw(5, 4, interp_factor=8, reqd_images=60))      # a window longer than the padded clip is filled with None upstream
+
+
 def test_metrics_known_answers():
     from ssm_amd.evaluation import eval_single_image, interpolation_error, psnr, ssim
     rng = np.random.RandomState(0)
@@ -120,3 +153,38 @@ def test_visualize_cli_writes_interleaved_pngs(tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / "out" / "t" / "images" / "img_00004.png")), clip[1])
     mid = np.asarray(Image.open(tmp_path / "out" / "t" / "images" / "img_00002.png"))
     assert mid.shape == (60, 90, 3) and mid.std() > 1.0
+
+
+@pytest.mark.gpu
+def test_evaluator_loop_on_a_synthetic_clip():
+    """Evaluator (evaluate_interpolation_results.py:35-278) over a 20-image clip, N_FRAMES = 2: three windows, 7 + 7 + 3 scored
+    frames; PSNR / IE / SSIM means against the same loop on the CPU oracle (uint8 frames may differ by one grey level)."""
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.evaluation import Evaluator, clip_samples, eval_single_image, generate_sliding_windows, inference_item_indexes
+    from ssm_amd.weights import synthetic_frames_u8, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = load_config("superslomo_original.ini", synthetic_weight_overrides())
+    m = FullModel(cfg)
+    sd1, sd2 = synthetic_state_dict(1), synthetic_state_dict(2)
+    m.stage1_model.load_state_dict(sd1)
+    m.stage2_model.load_state_dict(sd2)
+    m = m.to(dev).eval()
+    h, w = 60, 90
+    clip = synthetic_frames_u8(20, h, w, seed=11).permute(0, 2, 3, 1).contiguous()
+    ev = Evaluator(cfg, m, h, w, dataset="ADOBE")
+    assert (ev.H_REF, ev.W_REF, ev.H_START, ev.W_START) == (64, 96, 2, 3)
+    got = ev.run_evaluation(clip_samples(clip.to(dev), cfg, n_frames=2))
+    assert got["frames"] == 17
+    x = O.frames_from_u8(clip, IMAGENET_MEAN, IMAGENET_STD, pad_before_norm=False)
+    ins, tg = inference_item_indexes(2)
+    P, S, E = [], [], []
+    for win, n in generate_sliding_windows(20, 2):
+        pair = torch.cat([x[win[ins[0]]], x[win[ins[1]]]])[None]
+        outs = O.interpolate_pair(sd1, sd2, pair, [i / 8.0 for i in range(1, 8)])
+        for k in range(n):
+            o = O.frames_to_u8(outs[k], h, w, IMAGENET_MEAN, IMAGENET_STD)[0].numpy()
+            t = O.frames_to_u8(x[win[tg[k]]][None], h, w, IMAGENET_MEAN, IMAGENET_STD)[0].numpy()
+            p, s, e = eval_single_image(t, o)
+            P.append(p), S.append(s), E.append(e)
+    assert abs(got["PSNR"] - np.mean(P)) < 0.02 and abs(got["IE"] - np.mean(E)) < 0.02 and abs(got["SSIM"] - np.mean(S)) < 1e-3

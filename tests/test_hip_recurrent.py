@@ -265,17 +265,16 @@ def test_recurrent_config4_at_720p(dev, precision, oracle_config4_720p):
     b = m.interpolate_windows(xd, ts)
     assert torch.isfinite(a).all() and torch.equal(a, b), "same clip must give bit-identical frames"
     # (b) hoisted vs per-t: two fp32 evaluations of the same function at different batch sizes (7 vs 1: other tile kinds, other
-    # summation order; the network amplifies fp32 rounding ~1000x).  Neither is "the" answer, so the bar is not a measured spread
-    # (r3 set 3e-4 from F(2x2)-era numbers and F(4x4) measured 3.09e-4: a red round for a self-comparison) but what the contract
-    # implies: both sit within the north-star tolerance of the reference, so they sit within 1e-3 of each other; each evaluation is
-    # ALSO held to the CPU oracle below (5e-4), which is the parity statement.  Measured spreads: profiles/README.md (r8).
+    # summation order; the network amplifies fp32 rounding ~1000x).  Neither is "the" answer; each is held to the CPU oracle below at
+    # 5e-4 (the parity statement), and the spread between them to the same 5e-4 (measured 3.1e-4 with the F(4x4) forms, r4; 1e-3 -
+    # the sum of the two oracle bars - would let a real regression of one evaluation through).
     per_t = {}
     for j in (0, 3, 6):
         one, _ = m(xd, torch.full((1, 3, 1, 1, 1), ts[j], device=dev), inference_mode=True)
         per_t[j] = one[0].clone()
         spread = float((one[0] - a[j]).abs().max())
         print("recurrent 720p [%s]: max|hoisted - per-t| at t=%.3f = %.3e" % (precision, ts[j], spread))
-        assert spread < 1e-3, "hoisted != per-t at t=%.3f" % ts[j]
+        assert spread < 5e-4, "hoisted != per-t at t=%.3f" % ts[j]
     bar = 6e-4 if precision == "f16f8" else 5e-4          # north-star tolerance 1e-3; measured 1.2e-4 in f32w (r3)
     err = float((a[3:4].cpu() - want).abs().max())
     err1 = float((per_t[3].cpu() - want[0]).abs().max())

@@ -12,8 +12,15 @@
 //   9  waves 0..3 MFMA only, waves 4..7 LDS reads only (36 ds_read_b128 per iteration)
 //  10  waves 0..3: 36 MFMAs with 4 v_fma_f32 behind each, waves 4..7: 36 MFMAs only   (all the vector work on the favoured wave)
 //  11  waves 0..3: 36 MFMAs only, waves 4..7: 36 MFMAs with 4 v_fma_f32 behind each
+//  12  all 8 waves: 36 MFMAs with 1 v_pk_fma_f32 behind each (36 per iteration = the arithmetic of mode 2)
+//  13  all 8 waves: 36 MFMAs with 2 v_pk_fma_f32 behind each (72 per iteration = the arithmetic of mode 5)
+//  14  all 8 waves: 36 MFMAs with 4 v_pk_fma_f32 behind each (144 per iteration)
+//  15  waves 0..3 MFMA only, waves 4..7 vector only (144 v_pk_fma_f32 per iteration)
+//  16  waves 4..7 v_pk_fma_f32 only, waves 0..3 idle
+//  17  all 8 waves: 36 MFMAs with 1 v_fma_f32 behind each (36 per iteration)
 // Each wave reports its shader cycles per iteration (s_memtime) into out[block][wave].
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -22,6 +29,12 @@ __global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (mode == 10) mode = wid < 4 ? 5 : 0;
     if (mode == 11) mode = wid < 4 ? 0 : 5;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int npk = mode == 12 ? 1 : mode == 13 ? 2 : mode == 14 ? 4 : 0;
+    const bool pkonly = (mode == 15 || mode == 16) && wid >= 4;
+    const bool mfpk = npk > 0;
+    const bool mf1 = mode == 17;
+    if (mode == 15 && wid < 4) mode = 4;
     const bool mf = mode == 0 || mode == 2 || mode == 5 || mode == 8 || ((mode == 1 || mode == 4 || mode == 6 || mode == 9) && wid < 4);
     const bool dm = (mode == 6 || mode == 7) && wid >= 4;
     const bool lr = mode == 9 && wid >= 4;
@@ -104,6 +117,52 @@ __global__ __launch_bounds__(512, 2) void mfma_valu_kernel(int mode, int iters, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    } else if (mfpk) {
+        f2 cp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cp[i] = f2{(float)i, (float)i + 0.5f};
+        f2 k1 = {1.0001f, 1.0002f}, k2 = {0.5f, 0.25f};
+        asm volatile("" : "+v"(k1), "+v"(k2));
+        auto body = [&](auto NPK) __attribute__((always_inline)) {
+            constexpr int n = decltype(NPK)::value;
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int i = 0; i < 36; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < n; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(cp[(n * i + k) & 7]) : "v"(k1), "v"(k2));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if (npk == 1) body(std::integral_constant<int, 1>{});
+        else if (npk == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 4>{});
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] += cp[i][0] + cp[i][1];
+    } else if (mf1) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                c[i & 7] = __builtin_fmaf(c[i & 7], 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (pkonly) {
+        f2 cp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cp[i] = f2{(float)i, (float)i + 0.5f};
+        f2 k1 = {1.0001f, 1.0002f}, k2 = {0.5f, 0.25f};
+        asm volatile("" : "+v"(k1), "+v"(k2));
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 144; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(cp[i & 7]) : "v"(k1), "v"(k2));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] += cp[i][0] + cp[i][1];
     } else if (va) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll

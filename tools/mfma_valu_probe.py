@@ -17,8 +17,11 @@ names = {0: "8 waves MFMA only (36 / iteration)", 1: "waves 0-3 MFMA, waves 4-7 
          3: "waves 4-7 vector only", 4: "waves 0-3 MFMA only", 5: "8 waves: 36 MFMA + 144 fma interleaved",
          6: "waves 0-3 MFMA, waves 4-7 LDS-DMA (12 x 1 KiB / iteration)", 7: "waves 4-7 LDS-DMA only", 8: "8 waves: 36 MFMA + 6 LDS-DMA interleaved",
          9: "waves 0-3 MFMA, waves 4-7 36 ds_read_b128 / iteration", 10: "waves 0-3: 36 MFMA + 144 fma, waves 4-7: 36 MFMA",
-         11: "waves 0-3: 36 MFMA, waves 4-7: 36 MFMA + 144 fma"}
-for mode in (4, 3, 0, 1, 2, 5, 7, 6, 8, 9, 10, 11):
+         11: "waves 0-3: 36 MFMA, waves 4-7: 36 MFMA + 144 fma", 12: "8 waves: 36 MFMA + 36 pk_fma interleaved",
+         13: "8 waves: 36 MFMA + 72 pk_fma interleaved", 14: "8 waves: 36 MFMA + 144 pk_fma interleaved",
+         15: "waves 0-3 MFMA, waves 4-7 vector (144 pk_fma / iteration)", 16: "waves 4-7 pk_fma only (144 / iteration)",
+         17: "8 waves: 36 MFMA + 36 fma interleaved"}
+for mode in (4, 3, 16, 0, 1, 15, 17, 2, 5, 12, 13, 14, 7, 6, 8, 9, 10, 11):
     for _ in range(2):
         out.zero_()
         lib.mfma_valu_launch(mode, iters, blocks, out.data_ptr(), sink.data_ptr(), None)
