@@ -98,7 +98,19 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # a rank that dies before the rendezvous would leave the others waiting for it until the store times out: poll, and end the launch
+    # as soon as any rank has failed
+    out = b""
+    while True:
+        rcs = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in rcs) or all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.05)
+    if any(rc not in (None, 0) for rc in rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out = procs[0].stdout.read() if procs[0].stdout else b""
     rcs = [p.wait() for p in procs]
     sys.stdout.write(out.decode())
     sys.stdout.flush()
@@ -109,11 +121,70 @@ def spawn_ranks(n):
     sys.exit(0)
 
 
+CONFIG_RUNS = (
+    # key, BASELINE.json configs[] index, arguments of the child bench.py, needs a one-rank process group
+    ("config3_train", 2, ["--mode", "train", "--precision", "f32w", "--steps", "20", "--warmup", "3", "--force-allreduce"], True),
+    ("config4_recurrent", 3, ["--mode", "recurrent", "--precision", "f32w", "--steps", "10", "--warmup", "2"], False),
+    ("config5_4k", 4, ["--size", "4k", "--precision", "f32w", "--streams", "1", "--pairs-per-batch", "1", "--pairs-per-step", "1", "--steps", "4",
+                       "--warmup", "1", "--no-kernel-timers", "--no-clock-probes", "--parity-4k"], False),
+)
+
+
+def collect_configs(timeout_s=240):
+    """BASELINE configs[2..4] beside the headline: short runs of `--mode train` (with the RCCL gradient buckets
+    forced at world 1), `--mode recurrent` and `--size 4k`, each a fresh child process of THIS script, one after the other, started
+    before this process has touched the GPU (no exec from a process that holds the device).  Returns {key: summary}."""
+    out = {}
+    for key, idx, argv, group in CONFIG_RUNS:
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if group:
+            env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-configs"] + argv, env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, timeout=timeout_s)
+            line = [ln for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+            if pr.returncode != 0 or not line:
+                out[key] = {"error": "rc %d: %s" % (pr.returncode, pr.stderr.decode()[-400:])}
+                continue
+            d = json.loads(line[-1])
+        except subprocess.TimeoutExpired:
+            out[key] = {"error": "timed out after %d s" % timeout_s}
+            continue
+        rf = d.get("roofline", {})
+        rec = {"baseline_config": idx, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+               "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "workload": d["config"].get("workload"),
+               "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac") if k in rf},
+               "parity": d.get("parity"), "argv": " ".join(argv), "child_wall_s": round(time.perf_counter() - t0, 1)}
+        for k in ("allreduce", "host_enqueue_ms_per_step"):
+            if k in d:
+                rec[k] = d[k]
+        out[key] = rec
+    return out
+
+
+def pin_rank_cpus(local_rank, local_world):
+    """One process per GPU, N of them on one host: every rank keeps to its own contiguous 1/N of the CPUs this job may use, so that the
+    launch threads of the ranks (each needs host_enqueue_ms_per_step of a core per step) and their HIP helper threads do not migrate over
+    one another.  $SSM_RANK_AFFINITY=0 leaves the affinity alone.  Returns the CPU list, or None when nothing was changed."""
+    if local_world <= 1 or os.environ.get("SSM_RANK_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    n = len(cpus) // local_world
+    if n < 1:
+        return None
+    mine = cpus[local_rank * n:(local_rank + 1) * n]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def setup_ranks(args):
     """(rank, local_rank, world, device).  --stub: CPU + gloo (launcher / timing-protocol test, no GPU work)."""
     from ssm_amd import dist as sdist
     rank, local_rank, world = sdist.env_world()
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    args.rank_cpus = pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if args.stub:
         sdist.init("gloo")
         return rank, local_rank, world, torch.device("cpu")
@@ -302,6 +373,23 @@ def train_bench(args):
     def sync():
         torch.cuda.synchronize(dev)
 
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the step's forward (losses [B,4] and predicted frame) on the initial weights beside the CPU oracle's training_loss
+        # (losses.py:196-249 restated); the gradients are held to the oracle's autograd and to the reference's own gradient fixture in
+        # tests/test_hip_backward.py (minutes of CPU autograd: not repeated here)
+        from oracle import ssm_oracle as O
+        lr_, lp_, lw_ = model.loss.loss_weights
+        vsd = None if args.no_perceptual else synthetic_vgg_state_dict()
+        with torch.no_grad():
+            pred_h, loss_h = model(xin, t, target_images=tgt, inference_mode=False)
+            loss_o, pred_o = O.training_loss(synthetic_state_dict(1), synthetic_state_dict(2), torch.cat([xin[:, 0], xin[:, 1]], 1).cpu(),
+                                             t.view(B, 1, 1, 1).cpu(), tgt[:, 0].cpu(), lr_, lw_, vsd, lp_ if vsd is not None else 0.0)
+        parity = {"frame_max_abs_vs_oracle": float((pred_h.cpu() - pred_o).abs().max()), "tolerance": 1e-3,
+                  "loss_rel_err_vs_oracle": float(((loss_h.cpu() - loss_o).abs() / loss_o.abs().clamp_min(1e-12))[:, 0].max()),
+                  "what": "forward of one step (predicted frame, total loss per sample) on the initial weights vs the CPU oracle; gradients: "
+                          "tests/test_hip_backward.py (oracle autograd + the reference's gradient fixture)"}
+        model._drop_plans()
     for _ in range(args.warmup):
         step()
     sync()
@@ -330,6 +418,8 @@ def train_bench(args):
                          "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                          "note": "ms_per_step = exposed wait of the bucketed exchange (overlapped with the backward)"},
            "host_enqueue_ms_per_step": round(1e3 * sdist.timed_steps.last_enqueue_s / args.steps, 3)}
+    if parity is not None:
+        out["parity"] = parity
     if rank == 0:
         summ = timer.summary()
         out["time_split_ms_per_step"] = {fam: round(d["ms"] / 3, 3) for fam, d in summ.items()}
@@ -470,6 +560,9 @@ def stub_bench(args):
     rank, local_rank, world, dev = setup_ranks(args)
     mine = sdist.assign_pairs(args.pairs_per_step * world, world, rank)
 
+    if args.stub_fail_rank is not None and rank == args.stub_fail_rank:
+        sys.exit(3)          # (launcher test: a rank that dies before the rendezvous completes must fail the whole launch)
+
     def step():
         for _ in mine:
             time.sleep(0.001 * (rank + 1))
@@ -480,7 +573,8 @@ def stub_bench(args):
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "stub (no GPU work: launcher / timing-protocol test only)",
-                          "config": {"workload": "stub", "pairs_per_step": len(mine)}}))
+                          "config": {"workload": "stub", "pairs_per_step": len(mine)},
+                          "host": {"usable_cpus": usable_cpus(), "cpus_of_this_rank": args.rank_cpus}}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
@@ -537,11 +631,12 @@ def usable_cpus():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(sd1, sd2, pair, budget_s=120.0):
+def cpu_baseline(sd1, sd2, pair):
     """The CPU oracle timed on this host (kind "port": torch CPU fp32 restatement pinned to the reference by fixtures).
-    Thread sweep on C1 (warm), then C2 = 1 pair x 7 t at the best thread count: the hoisted loop is timed directly; the
-    reference-style loop (stage 1 recomputed per t, evaluate_interpolation_results.py:234-242) differs from it by exactly
-    6 more stage-1 passes, which are timed directly too.  Returns (dict, frames of the 7 t)."""
+    Thread count: a sweep over a C2-sized stage-1 pass (736x1280, ~2 s each; r4 swept on the 256x256 case, which stops scaling at 16
+    threads and says nothing about 720p).  At the best count: the hoisted loop (stage 1 once, 7 t; its frames are the parity
+    reference) and the reference-style loop (stage 1 recomputed per t, evaluate_interpolation_results.py:234-242) timed FOR REAL on
+    a bounded sample of 3 of the pair's 7 t values.  C1 (256x256, one t) at the same count.  Returns (dict, frames of the 7 t, C1)."""
     from oracle import ssm_oracle as O
     from ssm_amd.weights import synthetic_frames
     logical, phys = usable_cpus(), physical_cores()
@@ -549,37 +644,78 @@ def cpu_baseline(sd1, sd2, pair, budget_s=120.0):
     x1 = synthetic_frames(2, 256, 256, seed=42)
     pair1 = torch.cat([x1[:, 0], x1[:, 1]], 1)
     sweep = {}
+    ts = [i / 8.0 for i in range(1, N_T + 1)]
     with torch.no_grad():
+        torch.set_num_threads(cand[0])
+        t0 = time.perf_counter()
+        O.stage1(sd1, pair)                                               # first call at these shapes (allocator, oneDNN primitives)
+        s1_cold = time.perf_counter() - t0
         for n in cand:
             torch.set_num_threads(n)
-            O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)      # warm-up at this thread count
+            O.stage1(sd1, pair1)                                           # spin the thread pool up at this count
             t0 = time.perf_counter()
-            want1 = O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)
+            O.stage1(sd1, pair)
             sweep[n] = time.perf_counter() - t0
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
-        ts = [i / 8.0 for i in range(1, N_T + 1)]
-        t0 = time.perf_counter()
-        s1 = O.stage1(sd1, pair)                                           # doubles as the warm-up of the 736x1280 shapes
-        s1_cold = time.perf_counter() - t0
         t0 = time.perf_counter()
         want = O.interpolate_pair(sd1, sd2, pair, ts, hoist=True)
         hoisted_s = time.perf_counter() - t0
+        sample_ts = [ts[0], ts[3], ts[6]]
         t0 = time.perf_counter()
-        O.stage1(sd1, pair)
-        s1_s = time.perf_counter() - t0
-    recompute_s = hoisted_s + (N_T - 1) * s1_s
-    out = {"value": round(N_T / recompute_s, 4), "unit": "frames/s", "cores": best, "kind": "port",
-           "sample": "1 pair 736x1280 x 7 intermediates, torch CPU fp32 oracle, warm, %d threads (best of the sweep); "
-                     "reference-style loop (stage 1 per t) = hoisted loop %.1f s + 6 x stage-1 pass %.2f s = %.1f s"
-                     % (best, hoisted_s, s1_s, recompute_s),
-           "hoisted": {"value": round(N_T / hoisted_s, 4), "seconds": round(hoisted_s, 2)},
-           "recompute": {"value": round(N_T / recompute_s, 4), "seconds": round(recompute_s, 2),
-                         "stage1_pass_seconds": round(s1_s, 2), "stage1_first_call_seconds": round(s1_cold, 2)},
-           "c1_256x256": {"value": round(1.0 / sweep[best], 3), "unit": "frames/s", "seconds": round(sweep[best], 3)},
-           "thread_sweep_c1_seconds": {str(k): round(v, 3) for k, v in sweep.items()},
+        O.interpolate_pair(sd1, sd2, pair, sample_ts, hoist=False)
+        recompute_s = time.perf_counter() - t0
+        O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)
+        t0 = time.perf_counter()
+        want1 = O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)
+        c1_s = time.perf_counter() - t0
+    out = {"value": round(len(sample_ts) / recompute_s, 4), "unit": "frames/s", "cores": best, "kind": "port",
+           "sample": "reference-style loop (stage 1 + stage 2 per t) over 3 of the 7 t of one 736x1280 pair, torch CPU fp32 oracle, warm, "
+                     "%d threads (best of a sweep over a 736x1280 stage-1 pass): %.1f s" % (best, recompute_s),
+           "hoisted": {"value": round(N_T / hoisted_s, 4), "seconds": round(hoisted_s, 2), "sample": "1 pair x 7 t, stage 1 once"},
+           "recompute": {"value": round(len(sample_ts) / recompute_s, 4), "seconds": round(recompute_s, 2), "frames": len(sample_ts),
+                         "stage1_first_call_seconds": round(s1_cold, 2)},
+           "c1_256x256": {"value": round(1.0 / c1_s, 3), "unit": "frames/s", "seconds": round(c1_s, 3)},
+           "thread_sweep_c2_stage1_seconds": {str(k): round(v, 3) for k, v in sweep.items()},
            "host": {"logical_cpus_usable": logical, "physical_cores": phys}}
     return out, want, (x1, want1[0])
+
+
+def family_parity(cfg, dev, weights, frames, modes, want32=None, x=None):
+    """max|HIP - oracle| at 736x1280, t = 0.5, for one (weight family, frame family) in the given fp32 modes, beside the oracle's OWN
+    rounding d = max|oracle fp32 - oracle float64| (VERDICT r4 item 1; tests/test_hip_model.py::test_720p_parity_families_both_fp32_forms
+    asserts the same relations).  want32: the fp32 oracle frame at t = 0.5 when the caller already has it."""
+    from models.superslomo_r import FullModel
+    from oracle import ssm_oracle as O
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+    sdA, sdB = synthetic_state_dict(1, family=weights), synthetic_state_dict(2, family=weights)
+    if x is None:
+        x = synthetic_frames(2, H_IN, W_IN, seed=42 if frames == "texture" else 7, family=frames)
+    pair = torch.cat([x[:, 0], x[:, 1]], 1)
+    with torch.no_grad():
+        if want32 is None:
+            want32 = O.interpolate_pair(sdA, sdB, pair, [0.5])[0]
+        w64 = O.interpolate_pair({k: v.double() for k, v in sdA.items()}, {k: v.double() for k, v in sdB.items()}, pair.double(), [0.5])[0]
+
+    def st(e):
+        e = e.abs().flatten()
+        return {"max_abs": float(e.max()), "p9999": float(e.kthvalue(int(e.numel() * 0.9999)).values)}
+    d = st(want32.double() - w64)
+    rec = {"weights": weights, "frames": frames, "t": 0.5, "oracle_fp32_vs_f64": d, "modes": {}}
+    m2 = FullModel(cfg)
+    m2.stage1_model.load_state_dict(sdA)
+    m2.stage2_model.load_state_dict(sdB)
+    m2 = m2.to(dev).eval()
+    for mode in modes:
+        m2.precision = mode
+        got = m2.interpolate(x.to(dev), [0.5]).cpu()
+        a, b = st(got - want32), st(got.double() - w64)
+        rec["modes"][mode] = {"max_abs_vs_oracle": a["max_abs"], "p9999_vs_oracle": a["p9999"], "max_abs_vs_f64": b["max_abs"],
+                              "vs_oracle_in_units_of_d": round(a["max_abs"] / d["max_abs"], 3)}
+    m2._drop_plans()
+    del m2
+    torch.cuda.empty_cache()
+    return rec
 
 
 def io_legs(dev, h, w, reps=10):
@@ -654,6 +790,15 @@ def infer_bench(args):
         elapsed = sdist.timed_steps(step, steps, 0, sync)
         ms_step = 1e3 * elapsed / steps
         res = {"value": N_T * P * world * steps / elapsed, "ms_per_step": ms_step, "ms_per_pair": ms_step / P, "elapsed_s": elapsed}
+        # host time to ISSUE a step's launches (outside the timed region; the queues are empty when it starts, so nothing blocks the host)
+        enq = 0.0
+        for _ in range(3):
+            sync()
+            t0 = time.perf_counter()
+            step()
+            enq += time.perf_counter() - t0
+        sync()
+        res["host_enqueue_ms_per_step"] = 1e3 * enq / 3
         peak = PEAK_F32_MFMA_TFLOPS if precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
         kname = {"f32w": "wino4_kernel<*, ups 0|1> (3x3 layers, F(4x4,3x3), v_mfma_f32_16x16x4_f32) + wino2_kernel<*> (3x3 layers on the 1/32 maps, "
@@ -772,6 +917,12 @@ def infer_bench(args):
     for k in ("roofline", "roofline_warp", "time_split_ms_per_pair"):
         if k in main_res:
             out[k] = main_res[k]
+    he = main_res["host_enqueue_ms_per_step"]
+    out["host_enqueue_ms_per_step"] = round(he, 3)
+    out["host"] = {"enqueue_ms_per_step": round(he, 3), "enqueue_share_of_step": round(he / main_res["ms_per_step"], 3),
+                   "usable_cpus": usable_cpus(), "cpus_of_this_rank": args.rank_cpus,
+                   "note": "one host thread per rank issues the launches; at N ranks per host the ranks need N x this share of a core each "
+                           "(DESIGN 6): the step is GPU-bound as long as the share stays below 1"}
     if torch.distributed.is_initialized():          # rendezvous, timing barrier and max-over-ranks reduction ran on this backend
         out["dist"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size()}
 
@@ -812,34 +963,43 @@ def infer_bench(args):
             par[m] = {"max_abs_vs_oracle": max(per_t), "per_t": [round(e, 7) for e in per_t]}
             if m != headline:
                 out["modes"][m]["parity"] = par[m]
-        # a second deterministic weight family through the same pair (the margin must not be a property of one weight
-        # distribution): He-normal values, Gaussian-windowed 7x7 / 5x5 filters, decoder at gain 1.25; `max_abs_vs_oracle` = the WORST family
-        fams = [{"weights": "uniform (index-hash He-uniform: the fixtures' and the timed family)", "frames": "low-pass texture, 3-px motion",
-                 "max_abs_vs_oracle": par[headline]["max_abs_vs_oracle"]}]
+        # Families: two weight families x two frame families, BOTH fp32 modes, at t = 0.5, each beside the
+        # oracle's own fp32-vs-float64 distance d on that input.  `max_abs_vs_oracle` of the line = the worst LOW-GRADIENT family (the
+        # imagery the 1e-3 contract is about); the hard-edge families are reported in units of d, which is itself > 1e-3 there.
+        fams = []
         if not args.no_second_family:
-            sdA, sdB = synthetic_state_dict(1, family="smooth"), synthetic_state_dict(2, family="smooth")
-            model2 = FullModel(cfg)
-            model2.stage1_model.load_state_dict(sdA)
-            model2.stage2_model.load_state_dict(sdB)
-            model2 = model2.to(dev).eval()
-            model2.precision = headline
-            ts2 = [0.125, 0.5, 0.875]
-            from oracle import ssm_oracle as O
-            with torch.no_grad():
-                want2 = torch.cat(O.interpolate_pair(sdA, sdB, pair, ts2), 0)
-            got2 = model2.interpolate(xs[0].to(dev), ts2).cpu()
-            fams.append({"weights": "smooth (He-normal, windowed 7x7 / 5x5 filters, decoder gain 1.25)", "frames": "low-pass texture, 3-px motion",
-                         "max_abs_vs_oracle": float((got2 - want2).abs().max()), "t": ts2})
-            del model2
-        out["parity"] = {"max_abs_vs_oracle": max(f["max_abs_vs_oracle"] for f in fams), "per_t": par[headline]["per_t"], "tolerance": 1e-3,
+            model._drop_plans()
+            torch.cuda.empty_cache()
+            for fw, ff in (("uniform", "texture"), ("smooth", "texture"), ("uniform", "edges"), ("smooth", "edges")):
+                first = (fw, ff) == ("uniform", "texture")
+                fams.append(family_parity(cfg, dev, fw, ff, ("f32w", "f32"), want32=want[3] if first else None, x=xs[0] if first else None))
+        low = [f["modes"][headline]["max_abs_vs_oracle"] for f in fams if f["frames"] == "texture" and headline in f["modes"]]
+        out["parity"] = {"max_abs_vs_oracle": max([par[headline]["max_abs_vs_oracle"]] + low), "per_t": par[headline]["per_t"], "tolerance": 1e-3,
                          "frames": N_T, "size": "%dx%d" % (Hp, Wp), "mode": headline, "families": fams,
-                         "note": "hard-edged frames with 28-px motion put the reference's own CPU fp32 path 1.4e-3 from a float64 evaluation of "
-                                 "itself (profiles/r8h_parity_families_720p.txt): per-pixel max-abs between two fp32 evaluations is set by the "
-                                 "image gradient there, not by the arithmetic; the HIP path tracks the oracle's own rounding "
-                                 "(tests/test_hip_model.py::test_hard_edge_frames_track_the_oracles_own_rounding)"}
+                         "families_note": "weights: uniform = index-hash He-uniform (the fixtures' and the timed family), smooth = He-normal, "
+                                          "Gaussian-windowed 7x7 / 5x5 filters, decoder gain 1.25; frames: texture = low-pass texture, 3-px motion, "
+                                          "edges = full-contrast rectangles / bars / checkerboards, 28 x 20 px motion.  d = max|oracle fp32 - "
+                                          "oracle float64|: what the reference's own fp32 arithmetic loses on that input.  On hard edges d is "
+                                          "1.4-1.7e-3 (a step edge of height dI turns a flow rounding difference of e px into dI * e), so no fp32 "
+                                          "evaluation - the reference's CPU path included - meets 1e-3 per pixel there; the direct form (f32) sits "
+                                          "as far from the oracle as the multiply-saving forms (f32w) do, and stage 1 direct + stage 2 Winograd "
+                                          "changes nothing (profiles/r11a_parity_families_720p.txt): f32w stays the default; the test asserts "
+                                          "max|HIP - oracle| < 2 d and f32w < 1.25 x max(f32, d) for every family"}
     if rank == 0 and world == 1 and not args.no_io and args.size == "720p":
         out["io"] = io_legs(dev, h_in, w_in)
 
+    if rank == 0 and getattr(args, "configs", None):
+        out["configs"] = args.configs
+    if rank == 0 and world == 1 and args.size == "4k" and args.parity_4k:
+        from oracle import ssm_oracle as O
+        torch.set_num_threads(min(usable_cpus(), physical_cores(), 32))
+        pair = torch.cat([xs[0][:, 0], xs[0][:, 1]], 1)
+        with torch.no_grad():
+            want4 = O.interpolate_pair(sd1, sd2, pair, [0.5])[0]
+        model.precision = headline
+        got4 = model.interpolate(xs[0].to(dev), [0.5]).cpu()
+        out["parity"] = {"max_abs_vs_oracle": float((got4 - want4).abs().max()), "tolerance": 1e-3, "frames": 1, "t": 0.5,
+                         "size": "%dx%d" % (Hp, Wp), "mode": headline}
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():
@@ -877,10 +1037,16 @@ def main():
     ap.add_argument("--graphs", type=int, default=0, help="1: replay each pair's launch sequence from a captured HIP graph")
     ap.add_argument("--detail", default=None, help="write the per-launch event-timer table (JSON) to this path")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo stand-in for the per-pair work (launcher test; no GPU)")
+    ap.add_argument("--stub-fail-rank", type=int, default=None, help="--stub: this rank exits with an error before the rendezvous (launcher test)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of BASELINE configs 3, 4, 5 reported under `configs` (N = 1, 720p)")
+    ap.add_argument("--parity-4k", action="store_true", help="--size 4k: one t of one pair against the CPU oracle (about a minute of host time)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(args.gpus)          # before anything touches the GPU; does not return
+    args.configs = None
+    if (args.gpus == 1 and "RANK" not in os.environ and args.mode == "infer" and args.size == "720p" and not args.stub and not args.no_configs):
+        args.configs = collect_configs()          # children first: this process has not initialised the GPU yet
     if args.stub:
         return stub_bench(args)
     if args.mode == "recurrent":

@@ -71,6 +71,7 @@ struct W4Params {
     int vec;             // 1: outputs / addend / pooled outputs may be moved as aligned 16- / 8-byte pieces (checked on the host)
     int abl;             // diagnostics build only: 1 no LDS-DMA in the loop, 2 no stores, 4 no transform
     unsigned long long *dbg;   // diagnostics build only ($SSM_WINO4_ABL & 32): per-phase shader-cycle sums of wave 0 of every workgroup
+    int trace_block;     // tuning build (-DW4_TRACE): the workgroup whose waves stamp their timeline ($SSM_W4_TRACE_BLOCK)
     int stagger;         // s_sleep units (64 cycles) by which the second workgroup of every CU starts late (first round; $SSM_WINO4_STAGGER)
     const float *add;    // optional pre-activation addend [B / adiv][Cout][H][W] (ssm_conv2d_add_fwd)
     long long asb, asc;
@@ -588,9 +589,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     // LDS behind the kernel's regions (no vector-memory traffic that the loop's vmcnt waits would see) and to dbg[16 ..] at the end
 #define W4STAMP(i)
     unsigned long long *ltrace = (unsigned long long *)(lds + L::BYTES / 4 + 64);
-    const bool trace = p.dbg && blockIdx.x == 0;
+    const bool trace = p.dbg && blockIdx.x == (unsigned)p.trace_block;
 #define W4TRACE(chv, pt) \
     if (trace && (chv) < 16 && lane == 0) ltrace[(wid * 16 + (chv)) * 4 + (pt)] = __builtin_amdgcn_s_memtime();
+    if (trace && lane == 0) ltrace[(wid * 16 + 0) * 4 + 1] = __builtin_amdgcn_s_memtime();          // kernel entry (slot 1 of chunk 0)
 #else
 #define W4STAMP(i)
 #define W4TRACE(chv, pt)
@@ -860,6 +862,9 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     }
 #if defined(W4_TRACE) && !defined(SSM_WINO_ABLATE)
     if (trace) {
+        if (lane == 0) ltrace[(wid * 16 + 1) * 4 + 1] = __builtin_amdgcn_s_memtime();          // epilogue issued (slot 1 of chunk 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) ltrace[(wid * 16 + 2) * 4 + 1] = __builtin_amdgcn_s_memtime();          // ... and its stores complete (slot 1 of chunk 2)
         __syncthreads();
         for (int i = tid; i < NW * 64; i += C::THREADS) p.dbg[16 + i] = ltrace[i];
     }
@@ -1106,6 +1111,10 @@ int w4fill(W4Params &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w
         return e ? atoi(e) : 0;
     }();
     p.stagger = stagger;
+    p.trace_block = 0;
+#ifdef W4_TRACE
+    if (const char *e = getenv("SSM_W4_TRACE_BLOCK")) p.trace_block = atoi(e);
+#endif
     bool vec = W % 4 == 0 && ssm::aligned16(y.ptr) && y.sh % 4 == 0 && y.sc % 4 == 0 && y.sb % 4 == 0;
     if (add.ptr) {
         SSM_REQUIRE(add_div >= 1 && B % add_div == 0, "wino4 conv: the addend serves %d batch entries each, batch %d is no multiple", add_div, B);

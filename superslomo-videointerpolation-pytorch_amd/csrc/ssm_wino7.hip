@@ -45,6 +45,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef W7_VPAD
+#define W7_VPAD 1            // position rows of V padded against the operand reads' bank conflict (0: tuning builds, the r4 layout)
+#endif
+
 namespace {
 
 struct W7Params {
@@ -82,7 +86,12 @@ struct W7Cfg {
     static constexpr int SHIFT = 3;                                            // floats: window P starts at patch column 4 P + 1 + SHIFT (16-byte aligned)
     static constexpr int NFQ = SSM_W7_NFQ;                                     // quads of frequencies (7 row-frequencies x 2)
     static constexpr int USZ = NFQ * 4 * 32 * 4;                               // filter floats per input channel
-    static constexpr int VSZ = NFQ * NP * 4;                                   // transformed windows
+    // V [quad][position][4]: the 16 tiles of a lane group read GTY rows of GTX consecutive positions (+ the block's shift); with the rows
+    // NPX = 9 units apart the 16th lane's 16 bytes fall on the first lane's banks (a 2-way conflict on every operand read of the matrix
+    // loop: LDS bank-conflict share 0.39, profiles/r10e_wino_sq_counters.txt) - position rows are stored NPV units apart, NPV = GTX mod 16
+    static constexpr int NPV = !W7_VPAD ? NPX : GTX == 8 ? 24 : GTX == 4 ? 20 : NPX;
+    static constexpr int NPT = (NPY - 1) * NPV + NPX;                          // units per quad
+    static constexpr int VSZ = NFQ * NPT * 4;                                  // transformed windows
     static constexpr int XSZ = 2 * PH * NPX * 4;                               // row-pass results, [h][row][px][4]
     static constexpr int NDQ = PH * PW / 4, NGP = (NDQ + 63) / 64;             // 16-byte pieces / 1-KiB DMA groups of the patch
     static constexpr int PCAP = NGP * 256 + 256;                               // floats per patch buffer (tail of the last group + shift)
@@ -354,14 +363,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int c_pos = min(lane, NP - 1);
     const int c_py = c_pos / NPX, c_px = c_pos - c_py * NPX;
     const int c_src = C::XOFF + ((wid >> 1) * PH * NPX + (4 * c_py) * NPX + c_px) * 4 + (wid & 1) * 2;
-    const int c_dst = C::VOFF + ((wid >> 1) * NP + c_pos) * 4 + (wid & 1) * 2;    // + rf * 2 * NP * 4 per row-frequency
+    const int c_dst = C::VOFF + ((wid >> 1) * C::NPT + c_py * C::NPV + c_px) * 4 + (wid & 1) * 2;    // + rf * 2 * NPT * 4 per row-frequency
 
     // ---- operand bases of the matrix loop (f32x4 units): U of (quad, block q, cout cb*16 + l15), V of (quad, position of the tile + block q)
     const f32x4 *lds4 = (const f32x4 *)lds;
     const int gx = l15 % C::GTX, gy = l15 / C::GTX;
     const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
     const int aBase = C::UOFF / 4 + q * 32 + cb * 16 + l15;
-    const int bBase = C::VOFF / 4 + (Ty + (q >> 1)) * NPX + Tx + (q & 1);
+    const int bBase = C::VOFF / 4 + (Ty + (q >> 1)) * C::NPV + Tx + (q & 1);
 
     const int n = p.Cin;
     f32x4 ra[2];                       // row pass: the window row
@@ -415,8 +424,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float *dst = lds + c_dst + vbuf * C::VSZ;
 #pragma unroll
             for (int rf = (k == 13 ? 0 : 4); rf < (k == 13 ? 4 : 7); ++rf) {
-                if (j < 3) *(f32x2 *)(dst + rf * 2 * NP * 4) = f32x2{cv0[rf], cv1[rf]};
-                else dst[rf * 2 * NP * 4] = cv0[rf];
+                if (j < 3) *(f32x2 *)(dst + rf * 2 * C::NPT * 4) = f32x2{cv0[rf], cv1[rf]};
+                else dst[rf * 2 * C::NPT * 4] = cv0[rf];
             }
         }
     };
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         a[0] = lds4[ai];
         bq[0] = lds4[bi];
         a[1] = lds4[ai + 128];
-        bq[1] = lds4[bi + NP];
+        bq[1] = lds4[bi + C::NPT];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
@@ -478,10 +487,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     __builtin_amdgcn_sched_barrier(0);
                     if (g + 2 < NFQ - 2) {
                         a[nxt] = lds4[ai + (g + 2) * 128];
-                        bq[nxt] = lds4[bi + (g + 2) * NP];
+                        bq[nxt] = lds4[bi + (g + 2) * C::NPT];
                     } else {          // g = 10, 11: the operands of quads 12, 13
                         ha[g - (NFQ - 4)] = lds4[ai + (g + 2) * 128];
-                        hb[g - (NFQ - 4)] = lds4[bi + (g + 2) * NP];
+                        hb[g - (NFQ - 4)] = lds4[bi + (g + 2) * C::NPT];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

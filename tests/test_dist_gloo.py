@@ -140,6 +140,34 @@ def test_bench_bare_command_starts_its_own_ranks():
     assert "stub" in out["data"]
 
 
+def test_bench_eight_ranks_stub_launch():
+    """The real `python bench.py --gpus 8` argument path at world 8 (--stub: gloo, a sleep as the per-pair work): one
+    JSON line, n_gpus 8, the max over ranks (rank 7 sleeps 8 ms per pair), and every rank pinned to its own 1/8 of the usable CPUs."""
+    import json
+    r = _run_bench("--gpus", "8", "--stub", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["ms_per_step"] >= 8 * 8.0                     # 8 pairs x 8 ms on the slowest rank
+    n = len(os.sched_getaffinity(0))
+    if n >= 8:
+        assert len(out["host"]["cpus_of_this_rank"]) == n // 8 and out["host"]["usable_cpus"] == n // 8
+    # weak scaling: every rank ran 8 pairs -> 8 x 8 x 7 frames per step
+    assert abs(out["value"] - 7 * 8 * 8 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]
+
+
+def test_bench_eight_ranks_one_failing_rank_fails_the_launch():
+    """A rank that exits with an error (here before the rendezvous) ends the launch promptly: non-zero exit, no JSON line."""
+    import time as _t
+    t0 = _t.time()
+    r = _run_bench("--gpus", "8", "--stub", "--stub-fail-rank", "5", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and "rank(s) failed" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert _t.time() - t0 < 120
+
+
 def test_bench_launcher_fails_loudly_when_a_rank_fails():
     """Without a GPU the real ranks assert; the parent must exit non-zero and print no JSON line."""
     if torch.cuda.is_available():

@@ -17,7 +17,7 @@ from ssm_amd import hipbind as hb  # noqa: E402
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "conv5b"
-    shapes = {"conv5b": (512, 512, 46, 80), "conv3b": (128, 128, 184, 320), "conv10b": (64, 64, 368, 640)}
+    shapes = {"conv5b": (512, 512, 46, 80), "conv3b": (128, 128, 184, 320), "conv10b": (64, 64, 368, 640), "conv3a": (64, 128, 184, 320)}
     cin, cout, h, w = shapes[name]
     B = 7
     dev = torch.device("cuda:0")
@@ -40,6 +40,14 @@ def main():
     t0 = int(t[t > 0].min())
     print("%s kind %s: cycles since the first stamp; per wave and chunk: barrier passed | matrix start | matrix end | transform end" % (
         name, os.environ.get("W4KIND", "auto")))
+    nch = cin // 4
+    # kernel entry (slot 1 of chunk 0) -> first barrier passed | last stamped chunk's work done -> epilogue issued -> its stores complete
+    for wv in range(8):
+        ent, ep1, ep2 = int(t[wv, 0, 1]), int(t[wv, 1, 1]), int(t[wv, 2, 1])
+        last = min(nch, 16) - 1
+        print("wave %d: entry -> first barrier %6d | chunk %d done -> epilogue issued %6d -> stores complete %6d | entry -> end %7d (%d chunks%s)" % (
+            wv, int(t[wv, 0, 0]) - ent, last, ep1 - int(t[wv, last, 3]), ep2 - ep1, ep2 - ent, nch, "" if nch <= 16 else ", only the first 16 stamped"))
+    print()
     for ch in range(2, 8):
         for wv in range(8):
             r = [int(v) - t0 if int(v) else -1 for v in t[wv, ch]]
