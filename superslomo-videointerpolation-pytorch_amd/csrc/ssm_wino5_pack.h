@@ -2,9 +2,14 @@
 // one-launch batch repack (csrc/ssm_pack.hip): one thread = one quad of four frequencies.
 //      U = G g G^T,   G[f][k] = c_f p_f^k over the points p = {0, 1, -1, 2, -2, 1/2, -1/2}, c = {1, -2/9, -2/9, 1/90, 1/90, 32/45, 32/45}
 // (the scaling that goes with B^T in the kernel), G[7][k] = [k == 4] (the point at infinity).  Evaluated in float64, rounded once.
-// Packed layout [Cout/32][CinP/4][16 quads][4 channels][32 couts][4]: quad fq = 2 rf + h holds the column-frequencies 4 h .. 4 h + 3 of
-// row-frequency rf; channels beyond Cin are zero.
+// Packed layout [Cout/32][CinP/4][16 quads][4 channels][32 couts][4]: quad fq = 2 rf + h holds four column-frequencies of row-frequency
+// rf; channels beyond Cin are zero.  W5_SPLIT (the frequency-split kernel, default): half h = 0 holds the column-frequencies {0, 1, 2, 7},
+// h = 1 {3, 4, 5, 6} - the two halves of the 8-point transform that share no sub-expression (ssm_wino5.hip: w5_bt_lo / w5_bt_hi), so the
+// two waves of a SIMD each transform and multiply their own half.  W5_SPLIT = 0 (tuning builds: the r4 kernel): cf = 4 h + e.
 #pragma once
+#ifndef W5_SPLIT
+#define W5_SPLIT 1
+#endif
 
 template <class At>
 __device__ inline void ssm_w5_pack_quad(const At &at, int Cout, int Cin, int CinP, long long idx, float out[4]) {
@@ -32,7 +37,11 @@ __device__ inline void ssm_w5_pack_quad(const At &at, int Cout, int Cin, int Cin
         row[c] = v;
     }
     for (int e = 0; e < 4; ++e) {
+#if W5_SPLIT
+        const int cf = h == 0 ? (e == 3 ? 7 : e) : 3 + e;
+#else
         const int cf = 4 * h + e;
+#endif
         double v = 0.0, pw = 1.0;
         for (int k = 0; k < 5; ++k) {
             v += row[k] * (cf == 7 ? (k == 4 ? 1.0 : 0.0) : cs[cf] * pw);

@@ -46,7 +46,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef W7_VPAD
-#define W7_VPAD 1            // position rows of V padded against the operand reads' bank conflict (0: tuning builds, the r4 layout)
+#define W7_VPAD 0            // 1: position rows of V padded against the operand reads' bank conflict - measured 1 % SLOWER (profiles/r11d_wino7_vpad_ab.txt): off
 #endif
 
 namespace {

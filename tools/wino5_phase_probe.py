@@ -21,7 +21,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = hb.load()
     lib.ssm_wino5_debug_buffer.argtypes = [ctypes.c_void_p]
-    cnt = torch.zeros(32, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(64, dtype=torch.int64, device=dev)
     wt = torch.randn(cout, cin, 5, 5, device=dev) / (cin * 25) ** 0.5
     bs = torch.randn(cout, device=dev) * 0.1
     pk = hb.PackedWino5(wt, bs, B, H, W)
@@ -37,8 +37,17 @@ def main():
     hb.conv2d_wino5(x.view(), cin, None, 0, pk, y.view(), None, B, H, W)
     e1.record()
     torch.cuda.synchronize()
-    c = cnt.cpu().view(4, 8)
     ns = cin // 4
+    if int(cnt[32:].abs().sum()) > 0:          # the frequency-split kernel (8 waves): matrix | transform | barrier behind each | epilogue | prologue
+        c = cnt.cpu().view(8, 8)
+        print("cin %d cout %d batch %d: %.3f ms; %d k-steps per workgroup (split kernel)" % (cin, cout, B, e0.elapsed_time(e1), ns))
+        for w in range(8):
+            n = max(int(c[w, 7]), 1)
+            v = [float(c[w, i]) / n for i in range(6)]
+            print("wave %d (half %d; %d samples), cycles per k-step: matrix %5.0f + wait/barrier %5.0f | transform %5.0f + wait/barrier %5.0f || prologue %6.0f, "
+                  "epilogue %6.0f per workgroup" % (w, w >> 2, n, v[0] / ns, v[2] / ns, v[1] / ns, v[3] / ns, v[5], v[4]))
+        return
+    c = cnt[:32].cpu().view(4, 8)
     print("cin %d cout %d batch %d: %.3f ms; %d k-steps per workgroup" % (cin, cout, B, e0.elapsed_time(e1), ns))
     for w in range(4):
         n = max(int(c[w, 7]), 1)
