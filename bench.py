@@ -90,6 +90,10 @@ def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* set as torch.distributed.run would) and relay rank 0's JSON line.  This parent never touches the GPU: it is
     called before any HIP / torch.cuda call, and it does not exec."""
+    if under_profiler():
+        sys.stderr.write("bench.py --gpus %d: a profiler is attached to this process; start the ranks with torch.distributed.run instead "
+                         "(one profiler per rank), or profile `--gpus 1`\n" % n)
+        sys.exit(2)
     port = free_port()
     procs = []
     for r in range(n):
@@ -130,11 +134,21 @@ CONFIG_RUNS = (
 )
 
 
+def under_profiler():
+    """rocprofv3 (and the older rocprof tools) preload a tool library that initialises HSA / HIP before Python starts: a process in that
+    state must not start other programs (the GPU boxes refuse such an exec)."""
+    env = os.environ
+    return (any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCTRACER")) for k in env) or bool(env.get("HSA_TOOLS_LIB"))
+            or "rocprof" in env.get("LD_PRELOAD", "").lower())
+
+
 def collect_configs(timeout_s=240):
     """BASELINE configs[2..4] beside the headline: short runs of `--mode train` (with the RCCL gradient buckets
     forced at world 1), `--mode recurrent` and `--size 4k`, each a fresh child process of THIS script, one after the other, started
     before this process has touched the GPU (no exec from a process that holds the device).  Returns {key: summary}."""
     out = {}
+    if under_profiler():
+        return {"skipped": "a profiler is attached to this process (its preloaded tool library initialises the GPU before main): no child processes are started"}
     for key, idx, argv, group in CONFIG_RUNS:
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -151,6 +165,9 @@ def collect_configs(timeout_s=240):
             d = json.loads(line[-1])
         except subprocess.TimeoutExpired:
             out[key] = {"error": "timed out after %d s" % timeout_s}
+            continue
+        except OSError as e:          # the child could not be started (e.g. exec refused on this host)
+            out[key] = {"error": "could not start the child: %s" % e}
             continue
         rf = d.get("roofline", {})
         rec = {"baseline_config": idx, "metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
