@@ -882,272 +882,6 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
 #endif
 }
 
-// =====================================================================================================================================
-// wino4t_kernel (r5): 32 couts x 64 tiles per workgroup of 8 waves - the form for the 32-cout full-resolution layers (conv11b, fuse_conv),
-// which the 256-thread form runs as two co-resident workgroups of 32 couts x 32 tiles: each with its own copy of the filter slab, two
-// barriers per chunk and its transform as a block in front of the matrix loop (4.4-4.6 vector instructions per MFMA, 0.36-0.46 of the
-// pipe).  Here ONE filter slab and ONE barrier per chunk serve the 64 tiles, V and the DMA'd patch are double-buffered, and every wave
-// carries the next chunk's transform of its own half unit in the slots behind its MFMAs - the pipeline of the 64-cout form with the
-// second 32-cout block replaced by a second half of the tiles: a wave = (cout half cb, tile group g4 of four), all 36 frequencies.
-// Transform: 256 units (cin, tile) per chunk, two threads per unit (column-frequency halves), 512 threads: wave w transforms channel
-// w >> 1, half w & 1, tile = lane.  Plain convolution only (one or two sources, fused pool, addend); the fused-upsample layers keep the
-// other forms.
-template <int GTX_, int WTY_, int WTX_>
-struct W4TCfg {
-    static constexpr int GTX = GTX_, GTY = 16 / GTX_, WTY = WTY_, WTX = WTX_;
-    static constexpr int THREADS = 512, CK = 4, BN = 32, NT = 64;
-    static constexpr int NTX = GTX * WTX, NTY = GTY * WTY;
-    static constexpr int TH = 4 * NTY, TW = 4 * NTX;
-    static constexpr int PH = TH + 2, PW = TW + 8, PW4 = PW / 4;
-    static constexpr int SHIFT = 1;
-    static constexpr int USZ = CK * 9 * 32 * 4;                                // filter floats per chunk
-    static constexpr int PSZ = CK * PH * PW;
-    static constexpr int VSZ = CK * 9 * NT * 4;
-    static constexpr int NGU = USZ / 256, NDQ = PSZ / 4, NGP = (NDQ + 63) / 64;
-    static constexpr int NIU = (NGU + 7) / 8, NIP = (NGP + 7) / 8, NI = NIU + NIP;      // DMA instructions per wave and chunk (8 issuing waves)
-    static constexpr int DCAP = NGP * 256 + 256;
-    static constexpr int UOFF = 0, DOFF = 2 * USZ, VOFF = DOFF + 2 * DCAP, BOFF = VOFF + 2 * VSZ;      // BOFF: the workgroup's 32 biases
-    static constexpr int BYTES = (BOFF + 32) * 4;
-    static_assert(WTY * WTX == 4 && (GTX == 4 || GTX == 8 || GTX == 16), "four tile groups of 16 tiles");
-    static_assert(NI <= 9 && BYTES <= 160 * 1024 && VOFF % 4 == 0 && DOFF % 4 == 0 && DCAP % 4 == 0, "one DMA slot per frequency group; LDS budget");
-};
-
-template <class C>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4t_kernel(const W4Params p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int PH = C::PH, PW = C::PW, CK = C::CK, NT = C::NT;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, l15 = lane & 15, q = lane >> 4;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cb = wid & 1, g4 = wid >> 1;          // cout half, tile group of this wave
-
-    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
-    const int nb = id % p.NB;
-    id /= p.NB;
-    const int tx = id % p.tilesX;
-    id /= p.tilesX;
-    const int ty = id % p.tilesY;
-    const int b = id / p.tilesY;
-    const int x0 = tx * C::TW, y0 = ty * C::TH;
-
-    const long long porg = (long long)(y0 - 1) * p.sh + (x0 - 4);
-    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
-    const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
-    const float *wbase = p.wpk + (long long)nb * p.Cin * (9 * 32 * 4);
-
-    // per-lane source offsets (bytes) of the patch pieces this wave brings per chunk (overshoot rows / pieces clamped to the zero frame)
-    int poff[C::NIP];
-#pragma unroll
-    for (int i = 0; i < C::NIP; ++i) {
-        const int qq = (i * 8 + wid) * 64 + lane;
-        if (qq < C::NDQ) {
-            const int c = qq / (PH * C::PW4);
-            const int rem = qq - c * (PH * C::PW4);
-            const int r = rem / C::PW4;
-            const int j = rem - r * C::PW4;
-            const int re = min(r, p.H + (SSM_PADY - 1) - (y0 - 1)), fe = min(4 * j, ((p.W + 2 * SSM_PADX + 3) & ~3) - 4 - x0);
-            poff[i] = ((int)(c * p.sc) + re * p.sh + fe) * 4;
-        } else {
-            poff[i] = 0;          // tail of the last 1-KiB piece: lands in the region's padding
-        }
-    }
-    const int uoff = lane * 16;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
-    auto dma = [](const float *base, int voff_bytes, unsigned m0v) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(m0v) : "memory", "m0");
-    };
-    // n-th DMA instruction of this wave for a chunk: n < NIU filter piece 8 n + wid of chunk `ch` into stage `st`; else patch piece of chunk
-    // `ch` into patch buffer `pb`
-    auto issue_u = [&](int ch, int st, int n) {
-        const int g = 8 * n + wid;
-        if (8 * n + 7 < C::NGU || g < C::NGU) {
-            const float *base = wbase + (long long)(ch * CK) * (9 * 32 * 4) + g * 256;
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::UOFF + st * C::USZ) * 4u + (unsigned)g * 1024u);
-            dma(base, uoff, m0v);
-        }
-    };
-    auto issue_p = [&](int ch, int pb, int n) {
-        const int g = 8 * n + wid;
-        if (8 * n + 7 < C::NGP || g < C::NGP) {
-            const int c0 = ch * CK;
-            const float *base = (c0 < p.C1) ? pbase1 + (long long)c0 * p.sc : pbase2 + (long long)(c0 - p.C1) * p.sc;
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::DOFF + pb * C::DCAP) * 4u + (unsigned)g * 1024u + 4u * C::SHIFT);
-            dma(base, poff[n], m0v);
-        }
-    };
-
-    f32x4 acc[36];
-#pragma unroll
-    for (int f = 0; f < 36; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (tid < 32) lds[C::BOFF + tid] = p.bias[nb * 32 + tid];          // (visible after the first barrier)
-
-    // ---- transform: unit (cin = wave >> 1, tile = lane), this thread's half hh = wave & 1 of the column-frequencies ---------------------
-    const int thh = wid & 1, tcin = wid >> 1, ttile = lane;
-    const int tgx = (ttile & 15) % C::GTX, tgy = (ttile & 15) / C::GTX, tg2 = ttile >> 4;
-    const int tTx = (tg2 % C::WTX) * C::GTX + tgx, tTy = (tg2 / C::WTX) * C::GTY + tgy;
-    const int t_src = C::DOFF + C::SHIFT + (tcin * PH + 4 * tTy) * PW + 4 * tTx + 3;          // floats; 16-byte aligned
-    const int t_dst = C::VOFF / 4 + (tcin * 9) * NT + ttile;                                 // f32x4 units
-
-    const f32x4 *lds4 = (const f32x4 *)lds;
-    const int aBase = C::UOFF / 4 + q * (9 * 32) + cb * 16 + l15;
-    const int bBase = C::VOFF / 4 + q * (9 * NT) + g4 * 16 + l15;
-
-    // the whole transform of this thread's half unit as a block (prologue): patch buffer sbuf -> V buffer vbuf
-    auto transform_block = [&](auto HH, int sbuf, int vbuf) __attribute__((always_inline)) {
-        constexpr int hh = decltype(HH)::value;
-        const float *rp = lds + t_src + sbuf * C::DCAP;
-        f32x4 *vo = (f32x4 *)lds + t_dst + vbuf * (C::VSZ / 4);
-        f32x4 a4[6];
-        f32x2 a2[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            a4[i] = *(const f32x4 *)(rp + i * PW);
-            a2[i] = *(const f32x2 *)(rp + i * PW + 4);
-        }
-        float X[6][3];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float d[6] = {a4[i][0], a4[i][1], a4[i][2], a4[i][3], a2[i][0], a2[i][1]};
-            w4_row_pass(hh, d, X[i]);
-        }
-        float v[18];
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) w4_col_pass(X[0][jj], X[1][jj], X[2][jj], X[3][jj], X[4][jj], X[5][jj], v + jj, 3);
-        w4_store_v<NT>(hh, v, vo);
-    };
-
-    // the same transform cut into the pieces that ride behind the MFMAs of the matrix loop (the schedule of the 64-cout form):
-    //   slots 0..5 window row i | slots 3..8 row pass of row i - 3 | slots 9..17 the three column passes | slots 18..22 the V stores
-    f32x4 r4[6];
-    f32x2 r2[6];
-    float tX[6][3];
-    float tv18[18];
-    auto tstep = [&](auto HH, int m, const float *src, f32x4 *vo) __attribute__((always_inline)) {
-        constexpr int hh = decltype(HH)::value;
-        if (m < 6) {
-            r4[m] = *(const f32x4 *)(src + m * PW);
-            r2[m] = *(const f32x2 *)(src + m * PW + 4);
-        }
-        if (m >= 3 && m < 9) {
-            const int i = m - 3;
-            const float d[6] = {r4[i][0], r4[i][1], r4[i][2], r4[i][3], r2[i][0], r2[i][1]};
-            w4_row_pass(hh, d, tX[i]);
-        }
-        if (m >= 9 && m < 18) {
-            const int jj = (m - 9) / 3, st3 = (m - 9) % 3;
-            const float x0v = tX[0][jj], x1v = tX[1][jj], x2v = tX[2][jj], x3v = tX[3][jj], x4v = tX[4][jj], x5v = tX[5][jj];
-            if (st3 == 0) {          // (the expressions of w4_col_pass)
-                tv18[jj] = (kP0 * x0v - kS2 * x2v) + x4v;
-                tv18[15 + jj] = (kP0 * x1v - kS2 * x3v) + x5v;
-            }
-            if (st3 == 1) {
-                const float te = x4v - kB2 * x2v, to = x3v - kB2 * x1v;
-                tv18[3 + jj] = te + kA * to;
-                tv18[6 + jj] = te - kA * to;
-            }
-            if (st3 == 2) {
-                const float ue = x4v - kA2 * x2v, uo = x3v - kA2 * x1v;
-                tv18[9 + jj] = ue + kB * uo;
-                tv18[12 + jj] = ue - kB * uo;
-            }
-        }
-        if (m >= 18 && m < 23) {          // the five stores of w4_store_v, one per slot
-            const int k = m - 18;
-            if (hh == 0) {
-                if (k < 4) vo[k * NT] = f32x4{tv18[4 * k], tv18[4 * k + 1], tv18[4 * k + 2], tv18[4 * k + 3]};
-                else *(f32x2 *)(vo + 4 * NT) = f32x2{tv18[16], tv18[17]};
-            } else {
-                if (k == 0) *((f32x2 *)(vo + 4 * NT) + 1) = f32x2{tv18[0], tv18[1]};
-                else vo[(4 + k) * NT] = f32x4{tv18[4 * k - 2], tv18[4 * k - 1], tv18[4 * k], tv18[4 * k + 1]};
-            }
-        }
-    };
-
-    f32x4 a[3], bq[3];
-    auto matrix = [&](int stage, int vbuf, auto dmaf, auto slot) __attribute__((always_inline)) {
-        const int ai = aBase + stage * (C::USZ / 4), bi = bBase + vbuf * (C::VSZ / 4);
-        a[0] = lds4[ai];
-        bq[0] = lds4[bi];
-        a[1] = lds4[ai + 32];
-        bq[1] = lds4[bi + NT];
-#pragma unroll
-        for (int g = 0; g < 9; ++g) {
-            const int cur = g % 3, nxt = (g + 2) % 3;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[4 * g + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[4 * g + e], 0, 0, 0);
-                if (e == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (g + 2 < 9) {
-                        a[nxt] = lds4[ai + (g + 2) * 32];
-                        bq[nxt] = lds4[bi + (g + 2) * NT];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                slot(4 * g + e);
-                __builtin_amdgcn_sched_barrier(0);
-                if (e == 1 && g < C::NI) {
-                    dmaf(g);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    const int nchunks = p.Cin / CK;
-    // ---- prologue: filter and patch of chunk 0, patch of chunk 1; V(0) as a block --------------------------------------------------------
-#pragma unroll
-    for (int n = 0; n < C::NIU; ++n) issue_u(0, 0, n);
-#pragma unroll
-    for (int n = 0; n < C::NIP; ++n) issue_p(0, 0, n);
-    if (nchunks > 1) {
-#pragma unroll
-        for (int n = 0; n < C::NIP; ++n) issue_p(1, 1, n);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    if (thh == 0) transform_block(I0{}, 0, 0);
-    else transform_block(I1{}, 0, 0);
-
-    // one chunk: [V(ch), filter(ch), patch(ch+1) landed | every wave done with chunk ch-1] matrix(ch) carrying transform(ch+1) and the DMA of
-    // filter(ch+1) -> the other stage, patch(ch+2) -> the buffer transform(ch) read
-    auto chunks = [&](auto HH) __attribute__((always_inline)) {
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const bool m1 = ch + 1 < nchunks, m2 = ch + 2 < nchunks;
-            const int st = ch & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const float *tsrc = lds + t_src + (st ^ 1) * C::DCAP;
-            f32x4 *tdst = (f32x4 *)lds + t_dst + (st ^ 1) * (C::VSZ / 4);
-            matrix(st, st, [&](int n) {
-                if (n < C::NIU) {
-                    if (m1) issue_u(ch + 1, st ^ 1, n);
-                } else if (m2) {
-                    issue_p(ch + 2, st, n - C::NIU);
-                }
-            }, [&](int m) {
-                if (m1) tstep(HH, m, tsrc, tdst);
-            });
-        }
-    };
-    if (thh == 0) chunks(I0{});
-    else chunks(I1{});
-
-    // ---- epilogue ---------------------------------------------------------------------------------------------------------------------
-    {
-        float bv[4];
-        const f32x4 b4 = *(const f32x4 *)(lds + C::BOFF + cb * 16 + 4 * q);
-        bv[0] = b4[0], bv[1] = b4[1], bv[2] = b4[2], bv[3] = b4[3];
-        const int gx = l15 % C::GTX, gy = l15 / C::GTX;
-        const int Tx = (g4 % C::WTX) * C::GTX + gx, Ty = (g4 / C::WTX) * C::GTY + gy;
-        w4_epilogue(p, acc, bv, b, nb * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
-    }
-}
-
 // ---- tile configurations ---------------------------------------------------------------------------------------------------------
 //                     GTX WTY WTX          tiles of 4x4 px     TH   TW
 using X4A = W4Cfg<8, 2, 1>;      //          8 x 4                16   32
@@ -1159,27 +893,26 @@ using Y4A = W4Cfg<8, 2, 1, 2>;
 using Y4B = W4Cfg<16, 2, 1, 2>;
 using Y4C = W4Cfg<4, 1, 2, 2>;
 
-// 32 couts x 64 tiles per workgroup of 8 waves (wino4t_kernel; plain convolutions only)
-using T4A = W4TCfg<8, 2, 2>;     //         16 x 4 (2 x 2 groups)  16   64
-using T4C = W4TCfg<8, 4, 1>;     //          8 x 8 (4 x 1 groups)  32   32
+// (r5: a third form, 32 couts x 64 tiles per workgroup of 8 waves - one filter slab and one barrier per chunk for twice the tiles, every
+// wave carrying a half-unit transform behind its MFMAs - was built, passed the suite and measured 10 % SLOWER than two co-resident
+// 256-thread workgroups on conv11b / fuse_conv (profiles/r11j_wino4t_layers.txt): removed)
 
 #define SSM_W4_KINDS(X) X(X4A_, X4A) X(X4B_, X4B) X(X4C_, X4C) X(Y4A_, Y4A) X(Y4B_, Y4B) X(Y4C_, Y4C)
-#define SSM_W4T_KINDS(X) X(T4A_, T4A) X(T4C_, T4C)
 
 enum W4Kind {
 #define X(name, cfg) name,
-    SSM_W4_KINDS(X) SSM_W4T_KINDS(X)
+    SSM_W4_KINDS(X)
 #undef X
         NW4KIND
 };
 
 struct W4KindInfo {
-    int th, tw, bn, nt;          // pixels, couts and tiles per workgroup (nt = 64: wino4t_kernel)
+    int th, tw, bn;
 };
 
 constexpr W4KindInfo kW4Info[NW4KIND] = {
-#define X(name, cfg) W4KindInfo{cfg::TH, cfg::TW, cfg::BN, cfg::NT},
-    SSM_W4_KINDS(X) SSM_W4T_KINDS(X)
+#define X(name, cfg) W4KindInfo{cfg::TH, cfg::TW, cfg::BN},
+    SSM_W4_KINDS(X)
 #undef X
 };
 
@@ -1193,18 +926,10 @@ std::atomic<unsigned long long *> g_w4dbg{nullptr};      // diagnostics builds o
 // channels (2 x 36 MFMAs of 32 cycles are 2304 of them), e = 11 k of prologue + epilogue (the other workgroup of the CU covers most of
 // it); whole rounds of 512 workgroups.  64-cout form: one workgroup per CU, c = 3600 for twice the couts, e = 26 k (nothing covers its
 // first loads and its stores), rounds of 256 - the better form from ~16 chunks on.
-#ifndef W4T_C
-#define W4T_C 3800.0
-#define W4T_E 17000.0
-#endif
 double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W, int ups) {
     const long long tiles = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th);
     const long long nwg = tiles * (Cout / ki.bn);
     const double chunks = (double)Cin / 4.0;
-    if (ki.nt == 64) {          // 32 couts x 64 tiles, one workgroup per CU: c, e fitted like the others (profiles/r11j_wino4t_layers.txt)
-        const double per = chunks * W4T_C + W4T_E;
-        return (double)((nwg + 255) / 256) * per;
-    }
     if (ki.bn == 64) {          // (with the DMA issue on waves 0..3: c = 3500, e = 24 k; ahead of the 256-thread form from 16 chunks on)
         const double per = chunks * 3500.0 + 24000.0;
         return (double)((nwg + 255) / 256) * per;
@@ -1218,20 +943,15 @@ double estimate_w4(const W4KindInfo &ki, int Cin, int Cout, int B, int H, int W,
 
 int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     const int forced = g_force_w4kind.load();
-    if (forced >= 0 && forced < NW4KIND) return (ups && kW4Info[forced].nt == 64) ? 0 : forced;          // (the 64-tile form has no fused upsample)
+    if (forced >= 0 && forced < NW4KIND) return forced;
     int best = -1;
     double bt = 0.0;
     static const int allow_wide = [] {
         const char *e = getenv("SSM_WINO4_WIDE");
         return e ? atoi(e) : 1;
     }();
-    static const int allow_t = [] {
-        const char *e = getenv("SSM_WINO4_T");
-        return e ? atoi(e) : 1;
-    }();
     for (int i = 0; i < NW4KIND; ++i) {
         if (kW4Info[i].bn == 64 && (!allow_wide || Cout % 64)) continue;
-        if (kW4Info[i].nt == 64 && (ups || !allow_t)) continue;
         const double t = estimate_w4(kW4Info[i], Cin, Cout, B, H, W, ups);
         if (best < 0 || t < bt * 0.999) {
             best = i;
@@ -1277,39 +997,12 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
     return ssm::check_launch(UPS ? "ssm_wino4_conv2d_ups_fwd" : "ssm_wino4_conv2d_fwd");
 }
 
-template <class C>
-int w4tlaunch(W4Params &p, int B, hipStream_t st) {
-    p.tilesX = (p.W + C::TW - 1) / C::TW;
-    p.tilesY = (p.H + C::TH - 1) / C::TH;
-    p.NB = p.Cout / 32;
-    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) {
-        ssm::set_error("wino4 conv: grid of %lld workgroups out of range", blocks);
-        return SSM_E_ARG;
-    }
-    void (*kern)(const W4Params) = wino4t_kernel<C>;
-    constexpr int lds_bytes = C::BYTES;
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
-    if (attr_rc != hipSuccess) {
-        ssm::set_error("wino4 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
-        return SSM_E_LAUNCH;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), lds_bytes, st, p);
-    return ssm::check_launch("ssm_wino4_conv2d_fwd");
-}
-
 template <bool UPS>
 int w4dispatch(int kind, W4Params &p, int B, hipStream_t st) {
     switch (kind) {
 #define X(name, cfg) \
     case name: return w4launch<cfg, UPS>(p, B, st);
         SSM_W4_KINDS(X)
-#undef X
-#define X(name, cfg) \
-    case name: if (UPS) break; return w4tlaunch<cfg>(p, B, st);
-        SSM_W4T_KINDS(X)
 #undef X
     }
     ssm::set_error("wino4 conv: tile configuration %d is not available for this problem", kind);

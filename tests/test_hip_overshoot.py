@@ -37,7 +37,6 @@ CASES = [  # (form, k, cin, cout, shapes)
     ("wino1d", 5, 8, 32, ((1, 16, 32), (1, 23, 41))),
     ("wino4", 3, 8, 32, ((1, 16, 32), (1, 23, 40), (1, 9, 131), (1, 50, 66))),
     ("wino4:Y4A", 3, 64, 64, ((1, 16, 32), (1, 23, 40))),      # the 64-cout form, forced (kind 3 of csrc/ssm_wino4.hip SSM_W4_KINDS)
-    ("wino4:T4A", 3, 16, 32, ((1, 16, 64), (1, 23, 40), (1, 50, 66))),      # 32 couts x 64 tiles, forced (kind 6)
     ("wino", 3, 8, 32, ((1, 16, 32), (1, 23, 42), (1, 9, 130))),          # F(2x2,3x3): even W
 ]
 
@@ -51,9 +50,7 @@ def test_outputs_do_not_depend_on_memory_behind_the_last_plane(dev, form, k, cin
                "wino4": (hb.PackedWino4, hb.conv2d_wino4), "wino": (hb.PackedWino, hb.conv2d_wino)}
     Packed, conv = packers[form.split(":")[0]]
     if form.endswith(":Y4A"):
-        assert hb.load().ssm_wino4_force_kind(3) == 8
-    if form.endswith(":T4A"):
-        assert hb.load().ssm_wino4_force_kind(6) == 8
+        assert hb.load().ssm_wino4_force_kind(3) == 6
     g = torch.Generator().manual_seed(k * 100 + cin)
     for B, H, W in shapes:
         x = torch.randn(B, cin, H, W, generator=g)
@@ -79,7 +76,7 @@ def test_fused_upsample_sources_poisoned_behind_the_last_plane(dev, form, poison
     g = torch.Generator().manual_seed(77)
     for (h, w), (c1, c2, cout) in (((8, 16), (8, 8, 32)), ((11, 21), (8, 8, 32)), ((8, 16), (32, 32, 64))):
         if cout == 64 and form == "wino4":
-            assert hb.load().ssm_wino4_force_kind(3) == 8          # the 64-cout form
+            assert hb.load().ssm_wino4_force_kind(3) == 6          # the 64-cout form
         a, b = torch.randn(1, c1, h, w, generator=g), torch.randn(1, c2, h, w, generator=g)
         wt = torch.randn(cout, c1 + c2, 3, 3, generator=g) / ((c1 + c2) * 9) ** 0.5
         bias = torch.randn(cout, generator=g) * 0.1

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["X4A", "X4B", "X4C", "Y4A", "Y4B", "Y4C", "T4A", "T4C"]      # X4*: 32 couts x 32 tiles per workgroup (256 threads); Y4*: 64 couts x 32 tiles (512 threads); T4*: 32 couts x 64 tiles (512 threads, plain convolutions: a fused-upsample launch falls back to X4A)
+KINDS = ["X4A", "X4B", "X4C", "Y4A", "Y4B", "Y4C"]      # X4*: 32 couts per workgroup (256 threads); Y4*: 64 couts per workgroup (512 threads)
 
 
 @pytest.fixture(scope="module")
