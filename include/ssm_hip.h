@@ -193,6 +193,23 @@ int ssm_wino4_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const flo
                              void *stream);
 int ssm_wino4_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
                                  ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+/* conv3x3(upsample2x(cat[a, b])) (scripts/models/flow_computation.py:244-247; layers.conv, scripts/models/layers.py:21-33) in its SUB-PIXEL form
+ * away from the map's border (r5).  The operator is linear in the low-res input: output parity (pa, pb) of real channel c is a plain 3x3
+ * convolution of the LOW-res map with the effective filter M_pa W_c M_pb^T (bilinear weights 1/4, 3/4 folded into the taps), so the layer is
+ *   ssm_wino4_conv2d_shuffle_fwd: a 3x3 convolution with 4 Cout effective output channels, channel 4 c + 2 pa + pb, whose 4x4 low-res tiles are
+ *     stored as 8x8 blocks of the 2H x 2W output (pixel-shuffle store).  x1 / x2: low-res padded-plane views AT THE REGION'S ORIGIN (the region's
+ *     neighbours must be the real neighbouring pixels: it is the map's interior), y: the full-resolution output view at twice that origin,
+ *     H x W: the low-res region, w_packed / bias_packed: ssm_wino4_pack_weights of the effective filter (bias repeated per parity).
+ * where the bilinear rule does not clamp and the convolution does not zero-pad, i.e. everywhere but on the border ring, which
+ *   ssm_wino4_conv2d_ups_border_fwd: the fused-upsample kernel (arguments of ssm_wino4_conv2d_ups_add_fwd) restricted to the workgroup tiles
+ *     of SSM_WINO4_BORDER_TH x SSM_WINO4_BORDER_TW output pixels on the map's border ring
+ * computes.  Together they equal ssm_wino4_conv2d_ups_add_fwd (no addend) when the shuffle launch covers exactly the interior tiles. */
+#define SSM_WINO4_BORDER_TH 16
+#define SSM_WINO4_BORDER_TW 32
+int ssm_wino4_conv2d_shuffle_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y, int B,
+                                 int H, int W, int Cout4, float slope, int flags, void *stream);
+int ssm_wino4_conv2d_ups_border_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y, int B,
+                                    int H, int W, int Cout, float slope, int flags, void *stream);
 
 /* ---- the 7x7 / 5x5 convolutions as one-dimensional Winograd along x, all arithmetic fp32 (v_mfma_f32_32x32x2_f32) ----------
  * Same operator and operand layout as ssm_conv2d_add_fwd for k = 7 / 5 (layers.conv, scripts/models/layers.py:21-33; the layers

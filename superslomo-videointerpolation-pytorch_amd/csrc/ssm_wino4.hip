@@ -73,6 +73,7 @@ struct W4Params {
     unsigned long long *dbg;   // diagnostics build only ($SSM_WINO4_ABL & 32): per-phase shader-cycle sums of wave 0 of every workgroup
     int trace_block;     // tuning build (-DW4_TRACE): the workgroup whose waves stamp their timeline ($SSM_W4_TRACE_BLOCK)
     int stagger;         // s_sleep units (64 cycles) by which the second workgroup of every CU starts late (first round; $SSM_WINO4_STAGGER)
+    int border;          // fused-upsample launches: 1 = only the workgroup tiles on the map's border ring (ssm_wino4_conv2d_ups_border_fwd)
     const float *add;    // optional pre-activation addend [B / adiv][Cout][H][W] (ssm_conv2d_add_fwd)
     long long asb, asc;
     int ash, adiv;
@@ -238,6 +239,13 @@ __device__ __forceinline__ void w4_store_v(int hh, const float *v, f32x4 *vo) {
 // ---- epilogue of both kernel forms: Y = A^T M A per accumulator register (4 couts per lane), + bias, addend, LeakyReLU, stores, fused
 // 2x2 mean.  A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1].  cu0: first cout of the wave's 16-cout
 // block (this lane holds couts cu0 + 4 q + r), (px, py): the lane's 4x4 output tile.
+// SHUF (the sub-pixel form of conv3x3(upsample2x(x)), ssm_wino4_conv2d_shuffle_fwd): the launch is a plain convolution of the LOW-res
+// map with 4 Cout effective output channels, channel 4 c + 2 a + b = the filter of output parity (a, b) of real channel c - so the four
+// accumulator elements r of a lane are the four parities of ONE real channel, and its 4x4 low-res tile becomes an 8x8 block of the 2H x 2W
+// output: pixel (2 (py + i) + a, 2 (px + e) + b).  dst / dsc / dsh describe that output (real channels).
+template <bool SHUF>
+__device__ __forceinline__ void w4_epilogue_shuffle(const W4Params &p, const f32x4 (&acc)[36], const float (&bv)[4], int b, int cu0, int q, int px, int py);
+
 __device__ __forceinline__ void w4_epilogue(const W4Params &p, const f32x4 (&acc)[36], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
         const float sl = p.lrelu ? p.slope : 1.f;
         float *dstb = p.dst + (long long)b * p.dsb;
@@ -329,7 +337,73 @@ __device__ __forceinline__ void w4_epilogue(const W4Params &p, const f32x4 (&acc
         }
 }
 
-template <class C, bool UPS>
+// one cout register r of a lane: y = A^T M A + bias, LeakyReLU (the arithmetic of w4_epilogue)
+__device__ __forceinline__ void w4_output_tile(const f32x4 (&acc)[36], int r, float bias, float sl, float (&y)[4][4]) {
+    float t[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float m0 = acc[w4_freq(0, j)][r], m1 = acc[w4_freq(1, j)][r], m2 = acc[w4_freq(2, j)][r], m3 = acc[w4_freq(3, j)][r],
+                    m4 = acc[w4_freq(4, j)][r], m5 = acc[w4_freq(5, j)][r];
+        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        t[0][j] = (m0 + s1) + s2;
+        t[1][j] = kA * d1 + kB * d2;
+        t[2][j] = kA2 * s1 + kB2 * s2;
+        t[3][j] = (kA3 * d1 + m5) + kB3 * d2;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s1 = t[i][1] + t[i][2], d1 = t[i][1] - t[i][2], s2 = t[i][3] + t[i][4], d2 = t[i][3] - t[i][4];
+        y[i][0] = ((t[i][0] + s1) + s2) + bias;
+        y[i][1] = (kA * d1 + kB * d2) + bias;
+        y[i][2] = (kA2 * s1 + kB2 * s2) + bias;
+        y[i][3] = ((kA3 * d1 + t[i][5]) + kB3 * d2) + bias;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[i][e] = fmaxf(y[i][e], y[i][e] * sl);
+}
+
+template <>
+__device__ __forceinline__ void w4_epilogue_shuffle<true>(const W4Params &p, const f32x4 (&acc)[36], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
+    const float sl = p.lrelu ? p.slope : 1.f;
+    float *dstb = p.dst + (long long)b * p.dsb + (long long)(cu0 >> 2) * p.dsc;          // real channel cu0 / 4 (+ q per lane)
+    const unsigned pb = 4u * ((unsigned)q * (unsigned)p.dsc + (unsigned)(2 * py) * (unsigned)p.dsh + (unsigned)(2 * px));
+    const bool vok = py + 4 <= p.H && px + 4 <= p.W && p.vec;          // whole low-res tile inside the region, output rows as aligned 16-byte pieces
+    auto st4 = [](const float *base, unsigned off_bytes, f32x4 val) {
+        // (s_nop 1: a store of more than 64 bits followed by a vector write of its data registers needs 2 wait states on gfx940+, and the
+        // compiler does not see inside the asm - csrc/check_hazard.py caught exactly that here)
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+    };
+    auto st1 = [](const float *base, unsigned off_bytes, float val) {
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
+    };
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {          // output rows 2 (py + i) + a: the parities (a, 0) and (a, 1) interleave along x
+        float y0[4][4], y1[4][4];
+        w4_output_tile(acc, 2 * a, bv[2 * a], sl, y0);
+        w4_output_tile(acc, 2 * a + 1, bv[2 * a + 1], sl, y1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *rowp = dstb + (long long)(2 * i + a) * p.dsh;
+            if (vok) {
+                st4(rowp, pb, f32x4{y0[i][0], y1[i][0], y0[i][1], y1[i][1]});
+                st4(rowp + 4, pb, f32x4{y0[i][2], y1[i][2], y0[i][3], y1[i][3]});
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (py + i < p.H && px + e < p.W) {
+                        st1(rowp + 2 * e, pb, y0[i][e]);
+                        st1(rowp + 2 * e + 1, pb, y1[i][e]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class C, bool UPS, bool SHUF = false>
 __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = W4Lds<C, UPS>;
@@ -343,10 +417,25 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
     int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
     const int nb = id % p.NB;
     id /= p.NB;
-    const int tx = id % p.tilesX;
-    id /= p.tilesX;
-    const int ty = id % p.tilesY;
-    const int b = id / p.tilesY;
+    int tx, ty, b;
+    if (UPS && C::NCB == 1 && p.border) {          // (256-thread fused-upsample form) only the tiles of the border ring: top row, bottom row, then (left, right) per row between (host: >= 2 x 2 tiles)
+        const int nbt = 2 * p.tilesX + 2 * (p.tilesY - 2);
+        const int k = id % nbt;
+        b = id / nbt;
+        if (k < 2 * p.tilesX) {
+            ty = k < p.tilesX ? 0 : p.tilesY - 1;
+            tx = k < p.tilesX ? k : k - p.tilesX;
+        } else {
+            const int kk = k - 2 * p.tilesX;
+            ty = 1 + (kk >> 1);
+            tx = (kk & 1) ? p.tilesX - 1 : 0;
+        }
+    } else {
+        tx = id % p.tilesX;
+        id /= p.tilesX;
+        ty = id % p.tilesY;
+        b = id / p.tilesY;
+    }
     const int x0 = tx * C::TW, y0 = ty * C::TH;
 
     const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - 1) * p.sh + (x0 - 4);
@@ -858,7 +947,8 @@ __global__ __launch_bounds__(C::THREADS, 2) void wino4_kernel(const W4Params p) 
         }
         const int gx = l15 % C::GTX, gy = l15 / C::GTX;
         const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
-        w4_epilogue(p, acc, bv, b, nb * BN + blk * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
+        if constexpr (SHUF) w4_epilogue_shuffle<true>(p, acc, bv, b, nb * BN + blk * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
+        else w4_epilogue(p, acc, bv, b, nb * BN + blk * 32 + cb * 16, q, x0 + 4 * Tx, y0 + 4 * Ty);
     }
 #if defined(W4_TRACE) && !defined(SSM_WINO_ABLATE)
     if (trace) {
@@ -961,7 +1051,7 @@ int pick_w4kind(int Cin, int Cout, int B, int H, int W, int ups) {
     return best;
 }
 
-template <class C, bool UPS>
+template <class C, bool UPS, bool SHUF = false>
 int w4launch(W4Params &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
@@ -971,12 +1061,17 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
     }
     p.NB = p.Cout / C::BN;
     // (no read outside the padded plane: the per-lane DMA offsets clamp overshoot rows / pieces to the zero frame, see wino4_kernel)
-    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    if (p.border && (!UPS || p.tilesX < 2 || p.tilesY < 2)) {
+        ssm::set_error("wino4 conv: a border-ring launch needs the fused-upsample form and at least 2 x 2 workgroup tiles (%d x %d)", p.tilesX, p.tilesY);
+        return SSM_E_UNSUPPORTED;
+    }
+    const long long ntiles = p.border ? 2LL * p.tilesX + 2LL * (p.tilesY - 2) : (long long)p.tilesX * p.tilesY;
+    const long long blocks = ntiles * p.NB * B;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("wino4 conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
-    void (*kern)(const W4Params) = wino4_kernel<C, UPS>;
+    void (*kern)(const W4Params) = wino4_kernel<C, UPS, SHUF>;
     int lds_bytes = W4Lds<C, UPS>::BYTES + (C::NCB == 2 ? C::BN * 4 : 0);          // (64-cout form: + the workgroup's biases)
     const int threads = C::THREADS;
 #ifdef W4_TRACE
@@ -1099,6 +1194,7 @@ int w4fill(W4Params &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w
     p.slope = slope;
     p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
     p.abl = 0;
+    p.border = 0;
     p.add = nullptr;
     p.asb = p.asc = 0;
     p.ash = 0;
@@ -1202,6 +1298,42 @@ extern "C" int ssm_wino4_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2
     const int rf = w4fill(p, x1, C1, x2, C2, w_packed, bias_packed, y, pool, add, add_div, B, H, W, Cout, slope, flags, W);
     if (rf != SSM_OK) return rf;
     return w4dispatch<false>(kind, p, B, (hipStream_t)stream);
+}
+
+// ---- the sub-pixel form of conv3x3(upsample2x(cat[a, b])) for the INTERIOR of the map + the ordinary fused-upsample kernel for its border ring
+// (scripts/models/flow_computation.py:244-247; r5).  conv3x3(upsample2x(x)) is linear in x: output parity (a, b) is a 3x3 convolution of the
+// LOW-res map with the effective filter M_a W M_b^T (ssm_amd/subpixel.py), so away from the border the layer is a plain 3x3 convolution with
+// 4 Cout outputs and a pixel-shuffle store - no upsampled patch to expand in LDS, and a 32-cout full-resolution layer (conv11a) becomes a 128-cout
+// half-resolution one that runs in the 64-cout form.  At the border the bilinear rule clamps while the convolution zero-pads: those workgroup
+// tiles (16 x 32 output pixels) stay with the fused-upsample kernel.
+extern "C" int ssm_wino4_conv2d_shuffle_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                            int B, int H, int W, int Cout4, float slope, int flags, void *stream) {
+    SSM_REQUIRE(Cout4 > 0 && Cout4 % 64 == 0, "wino4 conv_shuffle: 4 Cout (%d) must be a multiple of 64", Cout4);
+    int kind = 0;
+    const int rc = ssm_wino4_plan(C1 + C2, Cout4, B, H, W, 0, &kind, nullptr, nullptr);
+    if (rc != SSM_OK) return rc;
+    if (kW4Info[kind].bn != 64) kind = Y4A_;
+    W4Params p;
+    const ssm_view none = {nullptr, 0, 0, 0};
+    const int rf = w4fill(p, x1, C1, x2, C2, w_packed, bias_packed, y, none, none, 1, B, H, W, Cout4, slope, flags, W);
+    if (rf != SSM_OK) return rf;
+    switch (kind) {
+        case Y4A_: return w4launch<Y4A, false, true>(p, B, (hipStream_t)stream);
+        case Y4B_: return w4launch<Y4B, false, true>(p, B, (hipStream_t)stream);
+        default: return w4launch<Y4C, false, true>(p, B, (hipStream_t)stream);
+    }
+}
+
+extern "C" int ssm_wino4_conv2d_ups_border_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
+                                               int B, int H, int W, int Cout, float slope, int flags, void *stream) {
+    SSM_REQUIRE(H % 2 == 0 && W % 2 == 0, "wino4 conv_ups_border: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
+    SSM_REQUIRE(C1 + C2 > 0 && (C1 + C2) % 4 == 0 && Cout % 32 == 0, "wino4 conv_ups_border: Cin a multiple of 4, Cout of 32");
+    W4Params p;
+    const ssm_view none = {nullptr, 0, 0, 0};
+    const int rf = w4fill(p, a, C1, b, C2, w_packed, bias_packed, y, none, none, 1, B, H, W, Cout, slope, flags, W / 2);
+    if (rf != SSM_OK) return rf;
+    p.border = 1;
+    return w4launch<X4A, true>(p, B, (hipStream_t)stream);          // (the 16 x 32-pixel tile: SSM_WINO4_BORDER_TH / _TW of include/ssm_hip.h)
 }
 
 extern "C" int ssm_wino4_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed, ssm_view y,

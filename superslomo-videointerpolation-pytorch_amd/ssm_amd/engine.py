@@ -99,6 +99,12 @@ WINO4 = os.environ.get("SSM_WINO4", "1")
 TRAIN_WINO4 = os.environ.get("SSM_TRAIN_WINO4", "0")
 
 
+# fused-upsample 3x3 layers of an f32w INFERENCE plan in the sub-pixel form (interior: a plain F(4x4,3x3) convolution of the low-res sources with 4 Cout
+# effective channels in the 64-cout kernel form; border ring: the fused-upsample kernel; hb.PackedSubpixelWino4): conv11a, the one 32-cout
+# fused-upsample layer (1.67 -> ms at batch 7, profiles/r11l_*); $SSM_WINO4_SUBPIXEL=0 keeps the fused-upsample kernel everywhere
+WINO4_SUBPIXEL = tuple(n for n in os.environ.get("SSM_WINO4_SUBPIXEL", "conv11a").split(",") if n not in ("", "0"))
+
+
 def wino4_enabled(name):
     return WINO4 not in ("0", "") and (WINO4 == "1" or name in WINO4.split(","))
 
@@ -333,6 +339,10 @@ class UNetPlan:
                     zb = torch.zeros_like(b)
                     self.pk[name] = cls(w[:, :512].contiguous(), b, nb, self.H // s, self.W // s, ups=ups)
                     self.pk_pair[name] = cls(w[:, 512:].contiguous(), zb, self.hoist[0], self.H // s, self.W // s, ups=ups)
+                elif (ups and cls is hb.PackedWino4 and name in WINO4_SUBPIXEL and not self.twins
+                      and hb.subpixel_wino4_supported(ci, co, self.H // s, self.W // s)):
+                    self.pk[name] = hb.PackedSubpixelWino4(w, b, nb, self.H // s, self.W // s)
+                    batch32 = False          # (its effective filters are not part of the one-launch repack)
                 else:
                     self.pk[name] = cls(w, b, nb, self.H // s, self.W // s, pool=name in POOLED, ups=ups)
         self._pack32 = None
@@ -430,6 +440,9 @@ class UNetPlan:
             hb.conv2d_ups_hl8(self._v(a), A.G * 8, bview, Bp.G * 8 if Bp else 0, pk,
                               d.view(), self.f32[dst].view() if self.twins else None, self._Bcur, d.H, d.W, lrelu=True,
                               fast=self.mode == "f16" or ("s%d.%s" % (self.stage, name)) in UNetPlan.fast_layers)
+        elif isinstance(pk, hb.PackedSubpixelWino4) and b_planes is None:
+            hb.conv2d_ups_subpixel_wino4(lambda y0, x0: self._v(a, y0=y0, x0=x0), A.C, (lambda y0, x0: self._v(b, y0=y0, x0=x0)) if b else None,
+                                         Bp.C if Bp else 0, pk, lambda y0, x0: d.view(y0=y0, x0=x0), self._Bcur, d.H, d.W, lrelu=True)
         elif self.hoist and name == "conv7a" and self.cross:
             assert self._pair_parts_ready, "hoisted stage-2 plan: run_pair_parts() must run before the per-t launches of a pass"
             conv_fn(pk, True)(self._v(a), A.C, None, 0, pk, d.view(), self._Bcur, d.H, d.W, lrelu=True, add=self.t["pair7a"].view(), add_div=self.hoist[1])

@@ -73,6 +73,9 @@ SIGNATURES = {
                                           _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_wino4_conv2d_ups_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int,
                                               _c_int, _c_float, _c_int, _vp]),
+    "ssm_wino4_conv2d_shuffle_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
+    "ssm_wino4_conv2d_ups_border_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int,
+                                                 _vp]),
     "ssm_wino1d_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino1d_force_kind": (_c_int, [_c_int]),
     "ssm_wino1d_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int, _c_int]),
@@ -236,10 +239,10 @@ class Planes:
         """torch view of the logical tensor (non-contiguous)."""
         return self.full[:, :, SSM_PADY:SSM_PADY + self.H, SSM_PADX:SSM_PADX + self.W]
 
-    def view(self, c0=0, broadcast=False, b0=0):
-        """ssm_view of channels c0.. of batch entries b0.. (broadcast: every batch index reads entry b0)."""
+    def view(self, c0=0, broadcast=False, b0=0, y0=0, x0=0):
+        """ssm_view of channels c0.. of batch entries b0.. (broadcast: every batch index reads entry b0), its origin at pixel (y0, x0)."""
         sc = self.Hp * self.Wp
-        base = self.buf.data_ptr() + 4 * (((b0 * self.C + c0) * self.Hp + SSM_PADY) * self.Wp + SSM_PADX)
+        base = self.buf.data_ptr() + 4 * (((b0 * self.C + c0) * self.Hp + SSM_PADY + y0) * self.Wp + SSM_PADX + x0)
         return SsmView(base, 0 if broadcast else self.C * sc, sc, self.Wp)
 
     def slice(self, c0, c):
@@ -449,6 +452,49 @@ def conv2d_ups_wino4(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=No
     check(lib.ssm_wino4_conv2d_ups_add_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                            add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
                                            SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+
+
+WINO4_BORDER_TH, WINO4_BORDER_TW = 16, 32          # SSM_WINO4_BORDER_TH / _TW of include/ssm_hip.h
+
+
+def subpixel_wino4_supported(cin, cout, H, W):
+    """Can conv3x3(upsample2x(.)) with a H x W OUTPUT run as sub-pixel interior + fused-upsample border ring?  (whole 16 x 32-pixel border
+    tiles, an interior of whole 16 x 32 low-res tiles of the 64-cout form, cout a multiple of 32)"""
+    ty, tx = H // WINO4_BORDER_TH, W // WINO4_BORDER_TW
+    return (cin % 4 == 0 and cout % 32 == 0 and H % WINO4_BORDER_TH == 0 and W % WINO4_BORDER_TW == 0 and ty >= 4 and tx >= 4
+            and ((ty - 2) * WINO4_BORDER_TH // 2) % 16 == 0 and ((tx - 2) * WINO4_BORDER_TW // 2) % 32 == 0)
+
+
+class PackedSubpixelWino4:
+    """conv3x3(upsample2x(cat[a, b])) with a H x W output as F(4x4,3x3) in the sub-pixel form (include/ssm_hip.h, ssm_wino4_conv2d_shuffle_fwd):
+    the effective filters E[4 c + 2 pa + pb] = M_pa W_c M_pb^T of the interior (ssm_amd.subpixel.effective_filter, float64 then fp32) packed
+    like any F(4x4,3x3) filter, beside the layer's ordinary fused-upsample filter for the border ring."""
+
+    algo = "wino4"
+
+    def __init__(self, weight, bias, B, H, W):
+        from .subpixel import effective_filter
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], 3
+        assert subpixel_wino4_supported(self.cin, self.cout, H, W), "sub-pixel F(4x4,3x3): unsupported shape"
+        self.border = PackedWino4(weight, bias, B, H, W, ups=True)
+        e = effective_filter(weight.detach().to(torch.float32), "int", "int")                    # [(2 pa + pb) Co + c]
+        e = e.view(4, self.cout, self.cin, 3, 3).permute(1, 0, 2, 3, 4).reshape(4 * self.cout, self.cin, 3, 3).contiguous()
+        self.inner = PackedWino4(e, bias.detach().to(torch.float32).repeat_interleave(4).contiguous(), B, H // 2, W // 2)
+        self.w, self.b = self.border.w, self.border.b          # (the handles the plan's bookkeeping looks at)
+        self.ups, self.cin_p, self.bn, self.ck = True, self.cin, self.border.bn, self.border.ck
+
+
+def conv2d_ups_subpixel_wino4(a_view, c1, b_view, c2, pk, y_view, B, H, W, lrelu=True, slope=0.1):
+    """a_view / b_view / y_view: callables (y0, x0) -> ssm_view of the LOW-res sources / the output at that pixel (views at two origins are
+    needed: the interior's and the map's); b_view None: one source."""
+    lib = load()
+    flags = SSM_FLAG_LRELU if lrelu else 0
+    y0, x0 = WINO4_BORDER_TH // 2, WINO4_BORDER_TW // 2                       # low-res origin of the interior
+    h, w = H // 2 - 2 * y0, W // 2 - 2 * x0
+    check(lib.ssm_wino4_conv2d_shuffle_fwd(a_view(y0, x0), c1, b_view(y0, x0) if b_view is not None else NULL_VIEW, c2, pk.inner.w.data_ptr(),
+                                           pk.inner.b.data_ptr(), y_view(2 * y0, 2 * x0), B, h, w, 4 * pk.cout, slope, flags, stream_ptr()))
+    check(lib.ssm_wino4_conv2d_ups_border_fwd(a_view(0, 0), c1, b_view(0, 0) if b_view is not None else NULL_VIEW, c2, pk.border.w.data_ptr(),
+                                              pk.border.b.data_ptr(), y_view(0, 0), B, H, W, pk.cout, slope, flags, stream_ptr()))
 
 
 # ---- 7x7 / 5x5 convolutions as 1-D Winograd along x, F(2,7) / F(4,5), in fp32 (csrc/ssm_wino1d.hip) -----------------

@@ -175,3 +175,39 @@ def test_wino4_pre_activation_addend(dev, kind):
         else:
             hb.conv2d_wino4(px.view(), cin, None, 0, pk, y.view(), None, B, H, W, add=pa.view(), add_div=div)
         assert _err(y.to_nchw().cpu(), want) < 5e-5, "%s ups=%d %dx%d: %.3e" % (kind, ups, H, W, _err(y.to_nchw().cpu(), want))
+
+
+def test_wino4_subpixel_interior_plus_border_ring(dev):
+    """conv3x3(upsample2x(cat[a, b])) (scripts/models/flow_computation.py:244-247) as the sub-pixel F(4x4,3x3) form on the map's interior
+    (ssm_wino4_conv2d_shuffle_fwd: effective filters M_pa W M_pb^T, 4 Cout channels, pixel-shuffle store) + the fused-upsample kernel on the
+    border ring of 16 x 32-pixel tiles (ssm_wino4_conv2d_ups_border_fwd): every output pixel written exactly once, 5e-5 from the oracle's
+    upsample-then-convolve - two sources, one source, the smallest supported map, several batch entries, a 64-channel case."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(77)
+    for B, h, w, c1, c2, cout in ((2, 32, 64, 8, 8, 32), (1, 48, 96, 16, 0, 32), (3, 32, 96, 4, 12, 64), (1, 64, 64, 32, 32, 32)):
+        H, W = 2 * h, 2 * w
+        assert hb.subpixel_wino4_supported(c1 + c2, cout, H, W)
+        a = torch.randn(B, c1, h, w, generator=g)
+        b = torch.randn(B, max(c2, 1), h, w, generator=g)
+        x = torch.cat([a, b], 1) if c2 else a
+        wt = torch.randn(cout, c1 + c2, 3, 3, generator=g) / ((c1 + c2) * 9) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        want = O.conv2d_lrelu(O.upsample2x_bilinear(x), wt, bias)
+        pk = hb.PackedSubpixelWino4(wt.to(dev), bias.to(dev), B, H, W)
+        pa = hb.Planes(B, c1, h, w, dev).load(a.to(dev))
+        pb = hb.Planes(B, c2, h, w, dev).load(b.to(dev)) if c2 else None
+        y = hb.Planes(B, cout, H, W, dev)
+        y.interior.fill_(float("nan"))                       # every output pixel must be written by one of the two launches
+        hb.conv2d_ups_subpixel_wino4(lambda y0, x0: pa.view(y0=y0, x0=x0), c1, (lambda y0, x0: pb.view(y0=y0, x0=x0)) if c2 else None, c2, pk,
+                                     lambda y0, x0: y.view(y0=y0, x0=x0), B, H, W)
+        got = y.to_nchw().cpu()
+        assert bool(torch.isfinite(got).all()), "%dx%d: pixels left unwritten" % (H, W)
+        e = _err(got, want)
+        ring = got.clone()
+        ring[:, :, 16:H - 16, 32:W - 32] = want[:, :, 16:H - 16, 32:W - 32]
+        assert e < 5e-5, "%dx%dx%d c %d+%d -> %d: %.3e (border ring alone %.3e)" % (B, H, W, c1, c2, cout, e, _err(ring, want))
+        full = y.full.cpu().clone()
+        full[:, :, hb.SSM_PADY:hb.SSM_PADY + H, hb.SSM_PADX:hb.SSM_PADX + W] = 0
+        assert float(full.abs().max()) == 0.0, "wrote outside the interior"
+    assert not hb.subpixel_wino4_supported(256, 64, 368, 640) and hb.subpixel_wino4_supported(128, 32, 736, 1280)

@@ -71,7 +71,14 @@ def main():
             print("%-10s skipped: %s" % (name, str(e)[:80]), flush=True)
             continue
         bv = xb.view() if xb is not None else None
-        if ups:
+        from ssm_amd.engine import WINO4_SUBPIXEL
+        subpix = w4 and ups and name in WINO4_SUBPIXEL and hb.subpixel_wino4_supported(cin, cout, h, w)          # the plan's form of this layer
+        if subpix:
+            psp = hb.PackedSubpixelWino4(wt, bs, B, h, w)
+            f0 = lambda: hb.conv2d_ups(xa.view(), c1, bv, c2, pk, y0.view(), B, h, w)  # noqa: E731
+            f1 = lambda: hb.conv2d_ups_subpixel_wino4(lambda yy, xx: xa.view(y0=yy, x0=xx), c1, (lambda yy, xx: xb.view(y0=yy, x0=xx)) if xb is not None else None,  # noqa: E731
+                                                      c2, psp, lambda yy, xx: y1.view(y0=yy, x0=xx), B, h, w)
+        elif ups:
             f0 = lambda: hb.conv2d_ups(xa.view(), c1, bv, c2, pk, y0.view(), B, h, w)  # noqa: E731
             f1 = lambda: (hb.conv2d_ups_wino4 if w4 else hb.conv2d_ups_wino)(xa.view(), c1, bv, c2, pw, y1.view(), B, h, w)  # noqa: E731
         else:
@@ -89,7 +96,7 @@ def main():
         tot[1] += t0
         tot[2] += t1
         print("%-10s %5d %5d %4dx%-4d %4d %9.2f | %8.3f %7.1f | %8.3f %7.1f %5d | %6.2f %9.2e" % (
-            name, cin, cout, h, w, ups, gf, t0, gf / t0, t1, gf / t1, (hb.wino4_plan if w4 else hb.wino_plan)(cin, cout, B, h, w, ups)[0], t0 / t1, diff), flush=True)
+            name, cin, cout, h, w, ups, gf, t0, gf / t0, t1, gf / t1, -4 if subpix else (hb.wino4_plan if w4 else hb.wino_plan)(cin, cout, B, h, w, ups)[0], t0 / t1, diff), flush=True)          # (kind -4: sub-pixel interior + border ring)
         del xa, xb, y0, y1, pk, pw
     print("TOTAL 3x3 layers: %.1f GFLOP; direct %.2f ms = %.1f TFLOP/s; winograd %.2f ms = %.1f TFLOP/s algorithmic (fp32 MFMA peak 157.3)" % (
         tot[0], tot[1], tot[0] / tot[1], tot[2], tot[0] / tot[2]))
