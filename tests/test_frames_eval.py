@@ -185,9 +185,13 @@ def test_evaluator_loop_on_a_synthetic_clip():
     for win, n in generate_sliding_windows(12, 2):
         outs = m.interpolate(torch.stack([x[win[ins[0]]], x[win[ins[1]]]])[None], t_values(8))
         o8 = F.frames_to_u8(outs[:n], h, w, cfg).cpu().numpy()
+        # the targets take the reference's round trip too (normalise -> denormalise -> truncating cast: evaluate_interpolation_results.py:
+        # 143-163 applies convert_tensor_to_numpy_image to the target batch as well; it can cost a grey level)
+        t8 = F.frames_to_u8(x[[win[tg[k]] for k in range(n)]], h, w, cfg).cpu().numpy()
         for k in range(n):
             assert win[tg[k]] < 12                                   # a scored target is a real image of the clip, never a pad copy
-            p, s, e = eval_single_image(clip[win[tg[k]]].numpy(), o8[k])
+            assert int(np.abs(t8[k].astype(int) - clip[win[tg[k]]].numpy().astype(int)).max()) <= 1
+            p, s, e = eval_single_image(t8[k], o8[k])
             P.append(p), S.append(s), E.append(e)
     assert abs(got["PSNR"] - np.mean(P)) < 1e-9 and abs(got["IE"] - np.mean(E)) < 1e-9 and abs(got["SSIM"] - np.mean(S)) < 1e-9
     # one window against the CPU oracle: uint8 frames may differ by one grey level
