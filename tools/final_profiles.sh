@@ -1,7 +1,7 @@
 #!/bin/bash
 # Artefacts behind the numbers of a round (run on the MI355X box from the repo root): default bench line + per-launch table, rocprofv3
 # kernel stats of the same command (3 streams, and 1 stream for attribution), PMC traffic of the conv kernels (separate passes),
-# per-layer tables of the Winograd kernels, train / recurrent / 4K lines.      tools/final_profiles.sh <tag>
+# per-layer tables of the Winograd kernels, SQ counters.      tools/final_profiles.sh <tag>
 set -x
 T=${1:-r6}
 mkdir -p gpurun_out/$T
@@ -18,9 +18,6 @@ timeout -k 10 200 python tools/bench_layers_wino7.py 14 > gpurun_out/$T/wino7_la
 timeout -k 10 200 python tools/bench_layers_wino5.py 14 > gpurun_out/$T/wino5_layers_b14.txt 2>&1; tail -2 gpurun_out/$T/wino5_layers_b14.txt
 bash tools/pmc_wino7.sh gpurun_out/$T/pmc_wino7 14 > gpurun_out/$T/pmc_wino7.log 2>&1; tail -6 gpurun_out/$T/pmc_wino7.log
 bash tools/pmc_wino4.sh gpurun_out/$T/pmc_wino4 7 > gpurun_out/$T/pmc_wino4.log 2>&1; tail -24 gpurun_out/$T/pmc_wino4.log
-python bench.py --mode train --precision f32w > gpurun_out/$T/train_f32w_line.json 2>> gpurun_out/$T/bench_err.log
-python bench.py --mode train > gpurun_out/$T/train_f32_line.json 2>> gpurun_out/$T/bench_err.log
-python bench.py --mode recurrent > gpurun_out/$T/recurrent_f32w_line.json 2>> gpurun_out/$T/bench_err.log
-python bench.py --size 4k --precision f32w --streams 1 --pairs-per-batch 1 --pairs-per-step 1 --steps 4 --warmup 1 --no-kernel-timers > gpurun_out/$T/4k_f32w_line.json 2>> gpurun_out/$T/bench_err.log
-python bench.py --size 4k --precision f16 --streams 1 --pairs-per-batch 1 --pairs-per-step 1 --steps 4 --warmup 1 --no-kernel-timers > gpurun_out/$T/4k_f16_line.json 2>> gpurun_out/$T/bench_err.log
+# (r5: the train / recurrent / 4K f32w lines are part of the default bench line: `configs`)
+python bench.py --mode train --no-cpu-baseline > gpurun_out/$T/train_f32_line.json 2>> gpurun_out/$T/bench_err.log
 ls gpurun_out/$T
