@@ -11,13 +11,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/prof -o
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/prof_s1 -o f32w_s1 -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-io --no-clock-probes --modes '' > $R/gpurun_out/$T/prof_s1_bench.json 2> $R/gpurun_out/$T/prof_s1_err.log
 cd $R
 bash tools/pmc_traffic.sh gpurun_out/$T/pmc f32w > gpurun_out/$T/pmc.log 2>&1; tail -8 gpurun_out/$T/pmc.log
-W4=1 timeout -k 10 200 python tools/bench_layers_wino.py 7 > gpurun_out/$T/wino4_layers_b7.txt 2>&1; tail -2 gpurun_out/$T/wino4_layers_b7.txt
-timeout -k 10 200 python tools/bench_layers_wino.py 7 > gpurun_out/$T/wino2_layers_b7.txt 2>&1; tail -2 gpurun_out/$T/wino2_layers_b7.txt
-timeout -k 10 200 python tools/bench_layers_wino1d.py 14 > gpurun_out/$T/wino1d_layers_b14.txt 2>&1; tail -3 gpurun_out/$T/wino1d_layers_b14.txt
-timeout -k 10 200 python tools/bench_layers_wino7.py 14 > gpurun_out/$T/wino7_layers_b14.txt 2>&1; tail -2 gpurun_out/$T/wino7_layers_b14.txt
-timeout -k 10 200 python tools/bench_layers_wino5.py 14 > gpurun_out/$T/wino5_layers_b14.txt 2>&1; tail -2 gpurun_out/$T/wino5_layers_b14.txt
-bash tools/pmc_wino7.sh gpurun_out/$T/pmc_wino7 14 > gpurun_out/$T/pmc_wino7.log 2>&1; tail -6 gpurun_out/$T/pmc_wino7.log
-bash tools/pmc_wino4.sh gpurun_out/$T/pmc_wino4 7 > gpurun_out/$T/pmc_wino4.log 2>&1; tail -24 gpurun_out/$T/pmc_wino4.log
-# (r5: the train / recurrent / 4K f32w lines are part of the default bench line: `configs`)
-python bench.py --mode train --no-cpu-baseline > gpurun_out/$T/train_f32_line.json 2>> gpurun_out/$T/bench_err.log
+# (per-layer tables, SQ counters, the direct-form training line: tools/final_profiles_b.sh <tag>, a GPU call of its own)
 ls gpurun_out/$T

@@ -18,8 +18,8 @@ for sub in ("sq", "sq2"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "wino4" not in k or "pack" in k: continue
-            m = re.search(r"(wino4p?_kernel)<.*?(W[48]Cfg<[^>]*>), (true|false)>", k.replace("(anonymous namespace)::", ""))
-            cfg = "%s %s%s" % (m.group(1), m.group(2), " ups" if m.group(3) == "true" else "") if m else k[:60]
+            m = re.search(r"(wino4p?_kernel)<.*?(W[48]Cfg<[^>]*>), (true|false)(?:, (true|false))?>", k.replace("(anonymous namespace)::", ""))
+            cfg = "%s %s%s%s" % (m.group(1), m.group(2), " ups" if m.group(3) == "true" else "", " shuffle (sub-pixel interior)" if m.group(4) == "true" else "") if m else k[:60]
             agg[cfg][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(os.path.join(out, "summary.txt"), "w") as fo:
     for cfg, d in sorted(agg.items()):
