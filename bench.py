@@ -67,15 +67,14 @@ DTYPE_NOTE = {"f32": "f32",
               "f16f8": "split f16+e4m3: 1x f16 MFMA + 2x block-scaled e4m3 MFMA for the compensation products (~15-bit products, "
                        "activations stored as f16 hi + e4m3 lo, f32 accumulate) - narrower than f32"}
 # rocprofv3 --pmc traffic summaries (tools/pmc_traffic.sh) per mode: (file under profiles/, conv kernel family keys)
-ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(4x4,3x3) (csrc/ssm_wino4.hip) or F(2x2,3x3) (csrc/ssm_wino.hip), 7x7 / 5x5 "
+ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(4x4,3x3) (csrc/ssm_wino4.hip; conv11a in the sub-pixel form) or F(2x2,3x3) (csrc/ssm_wino.hip), 7x7 / 5x5 "
                      "convolutions as 2x2 blocks of F(4x4,4x4) (csrc/ssm_wino7.hip) / F(4x4,5x5) (csrc/ssm_wino5.hip), final convolutions in the direct form "
                      "(csrc/ssm_elem.hip); the t-independent input channels of stage 2's conv1a / conv7a convolved once per pair",
              "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output; the t-independent input channels of "
                     "stage 2's conv1a / conv7a summed once per pair and added - SSM_HOIST=0 keeps one chain)"}
-PMC_FILES = {"f32w": ("r10_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel")),
-             "f32": ("r2_pmc_traffic_f32_summary.json", ("conv_mfma_kernel", "final_conv_kernel")),
-             "f16x3": ("r1k_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel")),
-             "f16f8": ("r1q_pmc_traffic_summary.json", ("conv16_kernel", "conv16_ups_kernel", "conv16_multi_kernel"))}
+PMC_FILES = {"f32w": ("r11_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel"))}
+# (the side modes report no `traffic`: their counter passes date from rounds 1-2 - profiles/r2_pmc_traffic_f32_summary.json, r1k / r1q - and the
+# kernels have changed since; only the headline mode's summary is regenerated every round by tools/final_profiles.sh)
 
 
 def free_port():
@@ -819,8 +818,8 @@ def infer_bench(args):
         peak = PEAK_F32_MFMA_TFLOPS if precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
         kname = {"f32w": "wino4_kernel<*, ups 0|1> (3x3 layers, F(4x4,3x3), v_mfma_f32_16x16x4_f32) + wino2_kernel<*> (3x3 layers on the 1/32 maps, "
-                         "F(2x2,3x3)) + wino7_kernel<*> (7x7 layers, 2x2 blocks of F(4x4,4x4), v_mfma_f32_16x16x4_f32) + wino5_kernel<*> (5x5 layers, "
-                         "F(4x4,5x5), v_mfma_f32_16x16x4_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
+                         "F(2x2,3x3)) + wino7_kernel<*> (7x7 layers, 2x2 blocks of F(4x4,4x4), v_mfma_f32_16x16x4_f32) + wino5s_kernel<*> (5x5 layers, "
+                         "F(4x4,5x5), frequency-split, v_mfma_f32_16x16x4_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "
                           "v_mfma_scale_f32_32x32x64_f8f6f4)"}.get(precision, "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)")
