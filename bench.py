@@ -72,7 +72,7 @@ ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(4x4,3x3) (
                      "(csrc/ssm_elem.hip); the t-independent input channels of stage 2's conv1a / conv7a convolved once per pair",
              "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output; the t-independent input channels of "
                     "stage 2's conv1a / conv7a summed once per pair and added - SSM_HOIST=0 keeps one chain)"}
-PMC_FILES = {"f32w": ("r11_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_kernel"))}
+PMC_FILES = {"f32w": ("r11_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_valu_kernel", "final_conv_kernel"))}
 # (the side modes report no `traffic`: their counter passes date from rounds 1-2 - profiles/r2_pmc_traffic_f32_summary.json, r1k / r1q - and the
 # kernels have changed since; only the headline mode's summary is regenerated every round by tools/final_profiles.sh)
 
@@ -268,7 +268,7 @@ def family_rooflines(by_name, n_pairs, precision, peak, batch=14, H=736, W=1280)
     fams = {}
     for n, (ms, fl, cnt) in by_name.items():
         lname = n.split(".", 1)[1]
-        key = "final_conv (4x4x1 MFMA)" if lname.startswith("final") else "%dx%d layers" % ((layer_kernel_size(lname),) * 2)
+        key = "final_conv (vector ALU)" if lname.startswith("final") else "%dx%d layers" % ((layer_kernel_size(lname),) * 2)
         d = fams.setdefault(key, {"ms": 0.0, "alg": 0.0, "iss": 0.0})
         d["ms"] += ms
         d["alg"] += fl
@@ -819,8 +819,8 @@ def infer_bench(args):
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
         kname = {"f32w": "wino4_kernel<*, ups 0|1> (3x3 layers, F(4x4,3x3), v_mfma_f32_16x16x4_f32) + wino2_kernel<*> (3x3 layers on the 1/32 maps, "
                          "F(2x2,3x3)) + wino7_kernel<*> (7x7 layers, 2x2 blocks of F(4x4,4x4), v_mfma_f32_16x16x4_f32) + wino5s_kernel<*> (5x5 layers, "
-                         "F(4x4,5x5), frequency-split, v_mfma_f32_16x16x4_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
-                 "f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_kernel<*> (v_mfma_f32_4x4x1_16B_f32)",
+                         "F(4x4,5x5), frequency-split, v_mfma_f32_16x16x4_f32) + final_conv_valu_kernel<*> (v_fma_f32)",
+                 "f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_valu_kernel<*> (v_fma_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "
                           "v_mfma_scale_f32_32x32x64_f8f6f4)"}.get(precision, "conv16_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16)")
         pmc_file, pmc_keys = PMC_FILES.get(precision, (None, ()))

@@ -422,9 +422,9 @@ int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, const float 
                        ssm_view aux, int B, int H, int W, void *stream);
 
 /* final_conv [+ synthesis]: Conv2d(32 -> NC, k3, pad 1, bias), no activation (scripts/models/flow_computation.py:145-153,
- * flow_interpolation.py:149-157) on v_mfma_f32_4x4x1_16B_f32 (4 couts x 64 pixels per instruction: nothing padded for the
- * 4 flow channels of stage 1, 8 for the 5 of stage 2), exact fp32.  x [B,32,H,W] padded-plane view; w_oihw / bias the
- * reference's state-dict tensors as they are (device fp32), NC <= 8.
+ * flow_interpolation.py:149-157), exact fp32: NC = 4 / 5 (the model's two filters) as v_fma_f32 chains in (cin, ky, kx) order,
+ * every other NC (and $SSM_FINAL_VALU=0) on v_mfma_f32_4x4x1_16B_f32 (4 couts x 64 pixels per instruction).  x [B,32,H,W]
+ * padded-plane view; w_oihw / bias the reference's state-dict tensors as they are (device fp32), NC <= 8.
  *   out (ptr NULL = off): [B,NC,H,W].
  *   y3 (ptr NULL = plain convolution): with NC = 5, extract_outputs + compute_output_image (flow_interpolation.py:374-429)
  *   run on the five sums in registers - arguments as ssm_synthesize_fwd, the 5-channel map is never written unless `out`

@@ -6,6 +6,8 @@
 // coordinate arithmetic rounds exactly like the reference's unfused fp32 CPU ops.
 #include "ssm_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ float *vp(const ssm_view &v, int b, int c, int y) {
@@ -273,6 +275,110 @@ __global__ __launch_bounds__(256, 2) void final_conv_kernel(const FinalParams p)
 #pragma unroll
             for (int c = 0; c < NG4 * 4; ++c)
                 if (c < p.NC) vp(p.out, b, c, y)[x] = o[c];
+        }
+    }
+}
+
+// ---- final_conv on the vector ALUs (r5) ----------------------------------------------------------------------------------------------
+// 32 -> NC <= 5 channels is too narrow for any MFMA shape to pay: the 4x4x1 form above issues one LDS read per MFMA (12 reads per 12
+// MFMAs of 8 cycles) and runs at 0.26 of the pipe, a third of it on padding couts.  Here a lane owns two vertically adjacent pixels and
+// every product is one v_fma_f32 with the filter value broadcast from LDS: per input channel 12 + 18 LDS reads feed 18 NC FMAs, the
+// kernel is bound by vector issue (4 cycles per instruction, 6 waves per SIMD).  Same tile (8 x 64 pixels, 4 waves x 2 rows), the same
+// LDS-DMA patch stages and the same summation order (cin, ky, kx: an fmaf chain per output) as final_conv_kernel: bit-identical sums.
+template <int NC, bool SYNTH, int RPT>
+__global__ __launch_bounds__(256, 4) void final_conv_valu_kernel(const FinalParams p) {
+    // RPT rows per lane (4 waves x RPT rows = the tile's height): the filter values read for a tap serve RPT pixels
+    constexpr int CIN = 32, CK = 4, TH = 4 * RPT, TW = 64, PH = TH + 2, PW = TW + 8, PSZ = CK * PH * PW;
+    constexpr int NPQ = PSZ / 4, NG = (NPQ + 63) / 64, STAGE = NG * 256, NI = (NG + 3) / 4;
+    constexpr int WFL = CIN * 9 * 8;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + WFL];
+    float *wl = lds + 2 * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    // filter -> LDS as [cin][tap][8 couts], zero beyond NC
+    for (int i = tid; i < WFL; i += 256) {
+        const int co = i & 7, ct = i >> 3;       // ct = cin*9 + tap
+        wl[i] = co < NC ? p.w[(long long)co * (CIN * 9) + ct] : 0.f;
+    }
+    const float *pbase = p.x.ptr + (long long)b * p.x.sb + (long long)(y0 - 1) * p.x.sh + (x0 - 4);
+    int off[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = (i * 4 + wid) * 64 + lane;
+        if (q < NPQ) {
+            const int c = q / (PH * (PW / 4)), rem = q - c * (PH * (PW / 4));
+            const int r = rem / (PW / 4), j = rem - r * (PW / 4);
+            off[i] = (int)(c * p.x.sc) + r * p.x.sh + 4 * j;
+        } else {
+            off[i] = 0;       // tail of the last 1-KiB piece: lands in the stage's padding
+        }
+    }
+    auto issue = [&](int ch, int stage) {
+        const float *pb = pbase + (long long)(ch * CK) * p.x.sc;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int g = i * 4 + wid;
+            if (g < NG) SSM_GLDS16(pb + off[i], lds + stage * STAGE + g * 256);
+        }
+    };
+    float acc[RPT][NC];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[r][c] = 0.f;
+
+    issue(0, 0);
+    for (int ch = 0; ch < CIN / CK; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // chunk ch (and, first time, the filter) is in LDS; chunk ch-1 is consumed
+        if (ch + 1 < CIN / CK) issue(ch + 1, (ch + 1) & 1);
+        const float *sb = lds + (ch & 1) * STAGE + (RPT * wid) * PW + lane + 3;
+#pragma unroll 1
+        for (int c = 0; c < CK; ++c) {          // (one channel at a time: unrolled, the compiler hoists all 120 LDS reads of a chunk and spills)
+            float xr[RPT + 2][3];          // rows RPT wid - 1 .. RPT wid + RPT of this channel at columns x - 1 .. x + 1
+#pragma unroll
+            for (int r = 0; r < RPT + 2; ++r)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) xr[r][kx] = sb[(c * PH + r) * PW + kx];
+            const float *wc = wl + ((ch * CK + c) * 9) * 8;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 w4 = *(const f32x4 *)(wc + (ky * 3 + kx) * 8);          // (one address for the whole wave: a broadcast read)
+                    const float w5 = NC > 4 ? wc[(ky * 3 + kx) * 8 + 4] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const float xv = xr[r + ky][kx];
+#pragma unroll
+                        for (int co = 0; co < NC; ++co) acc[r][co] = __builtin_fmaf(co < 4 ? w4[co] : w5, xv, acc[r][co]);
+                    }
+                }
+        }
+    }
+    const int x = x0 + lane;
+    if (x >= p.W) return;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int y = y0 + RPT * wid + r;
+        if (y >= p.H) continue;
+        float o[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = acc[r][c] + p.bias[c];
+        if constexpr (SYNTH) {
+            const float o5[5] = {o[0], o[1], o[2], o[3], o[NC > 4 ? 4 : 0]};
+            synth_pixel(p.img6, p.in16, o5, p.t[b], p.y3, p.aux, b, y, x, p.H, p.W);
+        }
+        if (p.out.ptr) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) vp(p.out, b, c, y)[x] = o[c];
         }
     }
 }
@@ -632,12 +738,21 @@ extern "C" int ssm_final_conv_fwd(ssm_view x, const float *w_oihw, const float *
     }
     FinalParams p;
     p.x = x; p.w = w_oihw; p.bias = bias; p.NC = NC; p.out = out; p.img6 = img6; p.in16 = in16; p.y3 = y3; p.aux = aux; p.t = t;
+    // the vector-ALU form for the two filters of the model (4 and 5 channels; $SSM_FINAL_VALU=0: the 4x4x1-MFMA form, which also serves other NC).
+    // Both forms sit on the read of the 32 input planes (profiles/r11s_final_conv_valu_ab.txt: four rows per lane instead of two changes nothing)
+    const char *env = getenv("SSM_FINAL_VALU");          // read per call: the parity tests run both forms in one process
+    const bool valu = !(env && atoi(env) == 0);
+    const bool use_valu = valu && (NC == 4 || NC == 5);
     p.H = H; p.W = W; p.tilesX = (W + 63) / 64; p.tilesY = (H + 7) / 8;
     const long long blocks = (long long)p.tilesX * p.tilesY * B;
     SSM_REQUIRE(blocks > 0 && blocks <= 0x7fffffffLL, "final_conv: grid out of range");
     const dim3 grid((unsigned)blocks), blk(256);
     hipStream_t st = (hipStream_t)stream;
-    if (synth) hipLaunchKernelGGL((final_conv_kernel<2, true>), grid, blk, 0, st, p);
+    if (use_valu) {
+        if (synth) hipLaunchKernelGGL((final_conv_valu_kernel<5, true, 2>), grid, blk, 0, st, p);
+        else if (NC == 4) hipLaunchKernelGGL((final_conv_valu_kernel<4, false, 2>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((final_conv_valu_kernel<5, false, 2>), grid, blk, 0, st, p);
+    } else if (synth) hipLaunchKernelGGL((final_conv_kernel<2, true>), grid, blk, 0, st, p);
     else if (NC <= 4) hipLaunchKernelGGL((final_conv_kernel<1, false>), grid, blk, 0, st, p);
     else hipLaunchKernelGGL((final_conv_kernel<2, false>), grid, blk, 0, st, p);
     return ssm::check_launch("ssm_final_conv_fwd");

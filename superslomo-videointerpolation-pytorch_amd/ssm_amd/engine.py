@@ -225,7 +225,7 @@ class UNetPlan:
         if hoist is not None and stage == 2 and mode == "f32" and self.fuse_up and not twins and hoist[1] > 1 and bottleneck == "CONV":
             assert B == hoist[0] * hoist[1] and dec is None
             self.hoist = (int(hoist[0]), int(hoist[1]))
-        # final_conv (32 -> 4 / 5 channels) on the 4x4x1-MFMA kernel instead of a 32-cout tile (mode f32, inference plans);
+        # final_conv (32 -> 4 / 5 channels) on its own kernel (ssm_final_conv_fwd) instead of a 32-cout tile (mode f32, inference plans);
         # stage 2 can then run the synthesis in its epilogue (run_decoder(synth=...))
         self.final4 = (mode == "f32" and self.fuse_up) if final4 is None else (bool(final4) and mode == "f32")
         if self.q8:

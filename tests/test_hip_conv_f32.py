@@ -121,12 +121,15 @@ def test_automatic_plan_matches_oracle_on_the_unet_shapes(dev):
         assert _err(yu.to_nchw().cpu(), wantu) < 5e-5
 
 
+@pytest.mark.parametrize("form", ["1", "0"], ids=["valu", "mfma4x4"])
 @pytest.mark.parametrize("nc", [4, 5, 8, 1])
-def test_final_conv_mfma4x4_vs_oracle(dev, nc):
-    """final_conv (32 -> 4 / 5 channels, no activation) on v_mfma_f32_4x4x1_16B_f32 against the oracle's conv2d, ragged
-    and tiny maps included (tile = 8 x 64)."""
+def test_final_conv_both_forms_vs_oracle(dev, nc, form, monkeypatch):
+    """final_conv (32 -> 4 / 5 channels, no activation) against the oracle's conv2d, ragged and tiny maps included (tile = 8 x 64):
+    the vector-ALU form (the default for the model's 4 / 5 channels) and the v_mfma_f32_4x4x1_16B_f32 form ($SSM_FINAL_VALU=0 and
+    every other channel count)."""
     from oracle import ssm_oracle as O
     from ssm_amd import hipbind as hb
+    monkeypatch.setenv("SSM_FINAL_VALU", form)
     g = torch.Generator().manual_seed(40 + nc)
     w = torch.randn(nc, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
     bias = torch.randn(nc, generator=g) * 0.1
@@ -142,11 +145,13 @@ def test_final_conv_mfma4x4_vs_oracle(dev, nc):
         assert _err(y.to_nchw().cpu(), want) < 5e-5, "final_conv NC=%d %dx%dx%d: %.3e" % (nc, B, H, W, _err(y.to_nchw().cpu(), want))
 
 
-def test_final_conv_fused_synthesis_vs_oracle(dev):
+@pytest.mark.parametrize("form", ["1", "0"], ids=["valu", "mfma4x4"])
+def test_final_conv_fused_synthesis_vs_oracle(dev, form, monkeypatch):
     """final_conv + extract_outputs + compute_output_image (flow_interpolation.py:374-429) in one kernel == the oracle's
-    synthesize(conv2d(.)) and == the two-kernel HIP path; the 5-channel map is optional."""
+    synthesize(conv2d(.)) and == the two-kernel HIP path; the 5-channel map is optional.  Both forms of the convolution."""
     from oracle import ssm_oracle as O
     from ssm_amd import hipbind as hb
+    monkeypatch.setenv("SSM_FINAL_VALU", form)
     g = torch.Generator().manual_seed(77)
     B, H, W = 3, 21, 75
     x = torch.randn(B, 32, H, W, generator=g)
