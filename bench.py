@@ -72,7 +72,7 @@ ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(4x4,3x3) (
                      "(csrc/ssm_elem.hip); the t-independent input channels of stage 2's conv1a / conv7a convolved once per pair",
              "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output; the t-independent input channels of "
                     "stage 2's conv1a / conv7a summed once per pair and added - SSM_HOIST=0 keeps one chain)"}
-PMC_FILES = {"f32w": ("r11_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_valu_kernel", "final_conv_kernel"))}
+PMC_FILES = {"f32w": ("r11_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7s_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_valu_kernel", "final_conv_kernel"))}
 # (the side modes report no `traffic`: their counter passes date from rounds 1-2 - profiles/r2_pmc_traffic_f32_summary.json, r1k / r1q - and the
 # kernels have changed since; only the headline mode's summary is regenerated every round by tools/final_profiles.sh)
 
@@ -818,7 +818,7 @@ def infer_bench(args):
         peak = PEAK_F32_MFMA_TFLOPS if precision in ("f32", "f32w") else PEAK_F16_MFMA_TFLOPS
         ach = flops_pair * P / (ms_step * 1e-3) / 1e12
         kname = {"f32w": "wino4_kernel<*, ups 0|1> (3x3 layers, F(4x4,3x3), v_mfma_f32_16x16x4_f32) + wino2_kernel<*> (3x3 layers on the 1/32 maps, "
-                         "F(2x2,3x3)) + wino7_kernel<*> (7x7 layers, 2x2 blocks of F(4x4,4x4), v_mfma_f32_16x16x4_f32) + wino5s_kernel<*> (5x5 layers, "
+                         "F(2x2,3x3)) + wino7s_kernel<*> (7x7 layers, 2x2 blocks of F(4x4,4x4), frequency-split, v_mfma_f32_16x16x4_f32) + wino5s_kernel<*> (5x5 layers, "
                          "F(4x4,5x5), frequency-split, v_mfma_f32_16x16x4_f32) + final_conv_valu_kernel<*> (v_fma_f32)",
                  "f32": "conv_mfma_kernel<*, ups 0|1> (v_mfma_f32_32x32x2_f32) + final_conv_valu_kernel<*> (v_fma_f32)",
                  "f16f8": "conv16_kernel<*> + conv16_multi_kernel<*> + conv16_ups_kernel<*> (v_mfma_f32_32x32x16_f16 + "

@@ -149,8 +149,10 @@ __device__ __forceinline__ void w7_at(float m0, float m1, float m2, float m3, fl
 // registers and are stored after the last addend row has been used.  The stores are inline assembly (scalar base + 32-bit lane offset),
 // invisible to the compiler's wait-count pass: a compiler-placed wait for an addend load also waits for every store issued before it, so
 // stores between the loads cost store round trips (tools/bench_layers_wino7.py, conv1a with the addend: 2.11 -> 2.01 ms at batch 14).
-template <bool FAST, bool HOLD>
-__device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc)[49], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
+// NR couts of the lane starting at accumulator element r0 (the 4-wave kernel: all four; a wave of the frequency-split kernel finishes two);
+// tile(r, y): the 4x4 tile of element r before the bias.
+template <bool FAST, bool HOLD, int NR, class Tile>
+__device__ __forceinline__ void w7_epilogue(const W7Params &p, Tile tile, const float (&bv)[4], int b, int cu0, int r0, int q, int px, int py) {
     const float sl = p.lrelu ? p.slope : 1.f;
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
@@ -169,7 +171,7 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
     const float *addb = p.add ? p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * q) * p.asc + (long long)py * p.ash + px : nullptr;
     // the addend rows of cout r + 1 are requested while cout r is transformed (four independent 16-byte loads, one cout ahead): their
     // latency runs beside the output transform instead of in front of each cout's stores
-    constexpr int ZN = HOLD ? 4 : 2;          // HOLD: all 16 addend rows are requested up front (no store stands between them and their use)
+    constexpr int ZN = HOLD ? NR : 2;          // HOLD: all addend rows are requested up front (no store stands between them and their use)
     f32x4 zadd[ZN][4];
     const bool hasadd = p.add != nullptr;          // uniform (addb is a per-lane pointer: a test of it compiles to a divergent branch)
     const bool zvec = hasadd && vok;
@@ -179,13 +181,12 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
             for (int i = 0; i < 4; ++i) zadd[r % ZN][i] = *(const f32x4 *)(addb + (long long)(cu0 + r) * p.asc + (long long)i * p.ash);
         }
     };
-    zload(0);
+    zload(r0);
     if (HOLD) {
-        zload(1);
-        zload(2);
-        zload(3);
+#pragma unroll
+        for (int rr = 1; rr < NR; ++rr) zload(r0 + rr);
     }
-    f32x4 yk[HOLD ? 4 : 1][4];
+    f32x4 yk[HOLD ? NR : 1][4];
     auto emit = [&](int r, const float (&y)[4][4]) {
         const int cu = cu0 + r;
         float *bp = dstb + (long long)cu * p.dsc;
@@ -216,25 +217,15 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
         }
     };
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = r0; r < r0 + NR; ++r) {
         const int cu = cu0 + r;          // uniform; this lane's cout = cu + 4 * q
-        if (!HOLD && r + 1 < 4) zload(r + 1);
-        float t[4][7];                   // A^T M: over the row-frequencies, for every column-frequency
-#pragma unroll
-        for (int cf = 0; cf < 7; ++cf) {
-            float y4[4];
-            w7_at(acc[cf][r], acc[7 + cf][r], acc[14 + cf][r], acc[21 + cf][r], acc[28 + cf][r], acc[35 + cf][r], acc[42 + cf][r], y4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t[i][cf] = y4[i];
-        }
+        if (!HOLD && r + 1 < r0 + NR) zload(r + 1);
         float y[4][4];
+        tile(r, y);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float y4[4];
-            w7_at(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], t[i][6], y4);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[i][e] = y4[e] + bv[r];
-        }
+            for (int e = 0; e < 4; ++e) y[i][e] += bv[r];
         if (hasadd) {
             const float *ap = addb + (long long)cu * p.asc;
 #pragma unroll
@@ -258,7 +249,7 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
             for (int e = 0; e < 4; ++e) y[i][e] = fmaxf(y[i][e], y[i][e] * sl);
         if (HOLD) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) yk[r][i] = f32x4{y[i][0], y[i][1], y[i][2], y[i][3]};
+            for (int i = 0; i < 4; ++i) yk[r - r0][i] = f32x4{y[i][0], y[i][1], y[i][2], y[i][3]};
         } else {
             emit(r, y);
         }
@@ -266,12 +257,26 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, const f32x4 (&acc
     }
     if (HOLD) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float y[4][4] = {{yk[r][0][0], yk[r][0][1], yk[r][0][2], yk[r][0][3]}, {yk[r][1][0], yk[r][1][1], yk[r][1][2], yk[r][1][3]},
-                                   {yk[r][2][0], yk[r][2][1], yk[r][2][2], yk[r][2][3]}, {yk[r][3][0], yk[r][3][1], yk[r][3][2], yk[r][3][3]}};
-            emit(r, y);
+        for (int k = 0; k < NR; ++k) {
+            const float y[4][4] = {{yk[k][0][0], yk[k][0][1], yk[k][0][2], yk[k][0][3]}, {yk[k][1][0], yk[k][1][1], yk[k][1][2], yk[k][1][3]},
+                                   {yk[k][2][0], yk[k][2][1], yk[k][2][2], yk[k][2][3]}, {yk[k][3][0], yk[k][3][1], yk[k][3][2], yk[k][3][3]}};
+            emit(r0 + k, y);
         }
     }
+}
+
+// Y = A^T M A of accumulator element r, all 49 frequencies in one wave (the 4-wave kernel)
+__device__ __forceinline__ void w7_tile_full(const f32x4 (&acc)[49], int r, float (&y)[4][4]) {
+    float t[4][7];                   // A^T M: over the row-frequencies, for every column-frequency
+#pragma unroll
+    for (int cf = 0; cf < 7; ++cf) {
+        float y4[4];
+        w7_at(acc[cf][r], acc[7 + cf][r], acc[14 + cf][r], acc[21 + cf][r], acc[28 + cf][r], acc[35 + cf][r], acc[42 + cf][r], y4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i][cf] = y4[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w7_at(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], t[i][6], y[i]);
 }
 
 #ifndef W7_ABL
@@ -591,9 +596,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
         const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
         const bool edge = !(py + 4 <= p.H && px + 4 <= p.W && p.vec);
-        if (__builtin_amdgcn_ballot_w64(edge) != 0) w7_epilogue<false, false>(p, acc, bv, b, nb * 32 + cb * 16, q, px, py);
-        else if (p.add) w7_epilogue<true, true>(p, acc, bv, b, nb * 32 + cb * 16, q, px, py);
-        else w7_epilogue<true, false>(p, acc, bv, b, nb * 32 + cb * 16, q, px, py);
+        auto tile = [&](int r, float (&y)[4][4]) __attribute__((always_inline)) { w7_tile_full(acc, r, y); };
+        if (__builtin_amdgcn_ballot_w64(edge) != 0) w7_epilogue<false, false, 4>(p, tile, bv, b, nb * 32 + cb * 16, 0, q, px, py);
+        else if (p.add) w7_epilogue<true, true, 4>(p, tile, bv, b, nb * 32 + cb * 16, 0, q, px, py);
+        else w7_epilogue<true, false, 4>(p, tile, bv, b, nb * 32 + cb * 16, 0, q, px, py);
     }
 #ifdef W7_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -606,26 +612,380 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
+// ---- the frequency-split form (r5): EIGHT waves, two per SIMD -----------------------------------------------------------------------
+// The pair of waves on a SIMD (w4 and w4 + 4) shares the 16 couts x 16 tiles of one wave of wino7_kernel and splits its 49 frequencies by
+// column-frequency: half 0 owns cf 0..3 (the even quads of U / V: 28 accumulators), half 1 cf 4..6 (the odd quads: 21).  Same workgroup
+// tile, same LDS layout and the same pipeline as above; what changes is who issues what:
+//      half 0:  28 MFMAs + the chunk's LDS-DMA (filter + patch) + the ROW pass (one unit per thread, 256 threads)
+//      half 1:  21 MFMAs + the COLUMN pass (wave w4 = pair w4 of column-frequencies, one position per lane)
+// (half 1 is the longer role, 2200 against 1575 cycles of work per channel - but dealing the column pass over seven waves, one
+// column-frequency each, raised the instruction count and measured 2 % slower: profiles/r11v_wino7_split.txt)
+// so each wave carries about half of the vector / LDS instructions the lone wave carried, and the two instruction streams of a SIMD
+// interleave: one wave's vector work issues while the other's MFMA occupies the matrix pipe (tools/mfma_valu_probe.py: two mixed waves
+// reach 0.85 of the pipe where a lone mixed wave reaches 0.65).  112 / 84 accumulator registers: two waves fit a SIMD's 512.
+// Output transform: t = A^T M over the row-frequencies is local to the half that owns the column-frequency; each half then forms its
+// PARTIAL 4x4 tile over its own column-frequencies, the pair exchanges partial tiles through LDS and each wave finishes two of the lane's
+// four couts:  y = (partial_0 + partial_1) + bias.
+template <int FH>
+__device__ __forceinline__ void w7s_partial(const f32x4 (&acc)[28], int r, float (&y)[4][4]) {
+    constexpr int NE = FH ? 3 : 4;
+    float t[4][NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        float y4[4];
+        w7_at(acc[e][r], acc[NE + e][r], acc[2 * NE + e][r], acc[3 * NE + e][r], acc[4 * NE + e][r], acc[5 * NE + e][r], acc[6 * NE + e][r], y4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i][e] = y4[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (FH == 0) {          // column-frequencies 0, +1, -1, +2 of A^T
+            const float m0 = t[i][0], s1 = t[i][1] + t[i][2], t1 = t[i][1] - t[i][2], m3 = t[i][3];
+            y[i][0] = (m0 + s1) + m3;
+            y[i][1] = t1 + 2.f * m3;
+            y[i][2] = s1 + 4.f * m3;
+            y[i][3] = t1 + 8.f * m3;
+        } else {                // -2, 1/2, inf
+            const float m4 = t[i][0], m5 = t[i][1], m6 = t[i][NE - 1];
+            y[i][0] = m4 + m5;
+            y[i][1] = 0.5f * m5 - 2.f * m4;
+            y[i][2] = 4.f * m4 + 0.25f * m5;
+            y[i][3] = (0.125f * m5 - 8.f * m4) + m6;
+        }
+    }
+}
+
+#ifndef W7S_ABL
+#define W7S_ABL 0            // tuning builds (make w7alt W7FLAGS=-DW7S_ABL=n), steady-state loop only: 1 no LDS-DMA, 2 no transform pieces, 8 no operand re-reads
+#endif
+template <class C>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino7s_kernel(const W7Params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PH = C::PH, PW = C::PW, NPX = C::NPX, NP = C::NP;
+    static_assert(C::BYTES >= 8 * 2 * 4 * 64 * 16, "the partial-tile exchange of the epilogue fits the loop's LDS");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fh = wid >> 2, w4 = wid & 3;          // frequency half; waves w4 and w4 + 4 sit on SIMD w4
+    const int cb = w4 & 1, tg = w4 >> 1;            // cout half, tile group of the pair
+
+    int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int nb = id % p.NB;
+    id /= p.NB;
+    const int tx = id % p.tilesX;
+    id /= p.tilesX;
+    const int ty = id % p.tilesY;
+    const int b = id / p.tilesY;
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    const float *pbase = p.src + (long long)b * p.sb + (long long)(y0 - 3) * p.sh + (x0 - 4);
+    const float *wbase = p.wpk + (long long)nb * p.Cin * C::USZ;
+
+    int poff;          // (half 0) per-lane source offset of the wave's patch piece, overshoot clamped to the zero frame as in wino7_kernel
+    {
+        const int qq = w4 * 64 + lane;
+        if (qq < C::NDQ) {
+            const int r = qq / (PW / 4), j = qq - r * (PW / 4);
+            const int re = min(r, p.H + (SSM_PADY - 1) - (y0 - 3)), fe = min(4 * j, ((p.W + 2 * SSM_PADX + 3) & ~3) - 4 - x0);
+            poff = (re * p.sh + fe) * 4;
+        } else {
+            poff = 0;
+        }
+    }
+    const int uoff = lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+
+    auto dma = [](const float *base, int voff_bytes, unsigned m0v) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(base), "s"(m0v) : "memory", "m0");
+    };
+    auto dma_u = [&](int c, int k, int buf) {
+        const int g = 4 * k + w4;
+        const float *base = wbase + (long long)c * C::USZ + g * 256;
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::UOFF + buf * C::USZ) * 4u + (unsigned)g * 1024u);
+        dma(base, uoff, m0v);
+    };
+    auto dma_p = [&](int c, int buf) {
+        if (w4 < C::NGP) {
+            const float *base = pbase + (long long)c * p.sc;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(C::POFF + buf * C::PCAP + C::SHIFT) * 4u + (unsigned)w4 * 1024u);
+            dma(base, poff, m0v);
+        }
+    };
+
+    f32x4 acc[28];          // [row-frequency][this half's column-frequency]: 7 x 4 (half 0) / 7 x 3 (half 1)
+#pragma unroll
+    for (int f = 0; f < 28; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = p.bias[nb * 32 + cb * 16 + 4 * q + r];
+
+    // row pass (half 0): unit = (patch row, position column), one per thread of the half; column pass (half 1): unit = (position, pair w4)
+    const int r_unit = min(w4 * 64 + lane, C::NRU - 1);
+    const int r_row = r_unit / NPX, r_px = r_unit - r_row * NPX;
+    const int r_src = C::POFF + C::SHIFT + r_row * PW + 4 * r_px + 1;
+    const int r_dst = C::XOFF + (r_row * NPX + r_px) * 4;
+    const int c_pos = min(lane, NP - 1);
+    const int c_py = c_pos / NPX, c_px = c_pos - c_py * NPX;
+    const int c_src = C::XOFF + ((w4 >> 1) * PH * NPX + (4 * c_py) * NPX + c_px) * 4 + (w4 & 1) * 2;
+    const int c_dst = C::VOFF + ((w4 >> 1) * C::NPT + c_py * C::NPV + c_px) * 4 + (w4 & 1) * 2;
+
+    const f32x4 *lds4 = (const f32x4 *)lds;
+    const int gx = l15 % C::GTX, gy = l15 / C::GTX;
+    const int Tx = (tg % C::WTX) * C::GTX + gx, Ty = (tg / C::WTX) * C::GTY + gy;
+    const int aBase = C::UOFF / 4 + q * 32 + cb * 16 + l15 + fh * 128;                            // this half's quads: 2 rf + fh
+    const int bBase = C::VOFF / 4 + (Ty + (q >> 1)) * C::NPV + Tx + (q & 1) + fh * C::NPT;
+
+    const int n = p.Cin;
+    f32x4 ra[2];
+    float rc[7], re[6];
+    f32x2 cx[7];
+    float cv0[7], cv1[7], ce0[6], ce1[6];
+    f32x4 a[3], bq[3];
+
+    // transform pieces (as in wino7_kernel): 0 .. 4 the row pass, 5 .. 14 the column pass of pair J
+    auto tpiece = [&](auto J, int k, bool doR, bool doC, int rbuf, int xrbuf, int xcbuf, int vbuf) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        if (k == 0 && doR) {
+            const float *src = lds + r_src + rbuf * C::PCAP;
+            ra[0] = *(const f32x4 *)src;
+            ra[1] = *(const f32x4 *)(src + 4);
+        }
+        if (k >= 1 && k <= 3 && doR) {
+            const float d[7] = {ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[1][0], ra[1][1], ra[1][2]};
+            if (k == 1) w7_bt_e(d, re);
+            if (k == 2) w7_bt_a(re, rc);
+            if (k == 3) w7_bt_b(d, re, rc);
+        }
+        if (k == 4 && doR) {
+            float *dst = lds + r_dst + xrbuf * C::XSZ;
+            *(f32x4 *)dst = f32x4{rc[0], rc[1], rc[2], rc[3]};
+            *(f32x4 *)(dst + PH * NPX * 4) = f32x4{rc[4], rc[5], rc[6], 0.f};
+        }
+        if ((k == 5 || k == 6) && doC) {
+            const float *src = lds + c_src + xcbuf * C::XSZ;
+#pragma unroll
+            for (int i = (k == 5 ? 0 : 4); i < (k == 5 ? 4 : 7); ++i) cx[i] = *(const f32x2 *)(src + i * NPX * 4);
+        }
+        if (k >= 7 && k <= 12 && doC) {
+            const int which = (k - 7) / 3, part = (k - 7) % 3;
+            if (which == 0 || j < 3) {
+                const float d[7] = {cx[0][which], cx[1][which], cx[2][which], cx[3][which], cx[4][which], cx[5][which], cx[6][which]};
+                if (which == 0) {
+                    if (part == 0) w7_bt_e(d, ce0);
+                    if (part == 1) w7_bt_a(ce0, cv0);
+                    if (part == 2) w7_bt_b(d, ce0, cv0);
+                } else {
+                    if (part == 0) w7_bt_e(d, ce1);
+                    if (part == 1) w7_bt_a(ce1, cv1);
+                    if (part == 2) w7_bt_b(d, ce1, cv1);
+                }
+            }
+        }
+        if ((k == 13 || k == 14) && doC) {
+            float *dst = lds + c_dst + vbuf * C::VSZ;
+#pragma unroll
+            for (int rf = (k == 13 ? 0 : 4); rf < (k == 13 ? 4 : 7); ++rf) {
+                if (j < 3) *(f32x2 *)(dst + rf * 2 * C::NPT * 4) = f32x2{cv0[rf], cv1[rf]};
+                else dst[rf * 2 * C::NPT * 4] = cv0[rf];
+            }
+        }
+    };
+    // half 0, slot m of 28: DMA instructions (NIU filter pieces, then the patch piece) in the odd slots, the row pass in the even ones;
+    // half 1, slot m of 21: the column pass
+    auto dma_of_slot = [](int m) constexpr -> int { return (m % 2 == 1 && m / 2 < C::NIU + 1) ? m / 2 : -1; };
+    auto rpiece_of_slot = [](int m) constexpr -> int { return m == 0 ? 0 : m == 4 ? 1 : m == 6 ? 2 : m == 8 ? 3 : m == 10 ? 4 : -1; };
+    auto cpiece_of_slot = [](int m) constexpr -> int {
+        switch (m) {
+            case 0: return 5;
+            case 1: return 6;
+            case 4: return 7;
+            case 5: return 8;
+            case 7: return 9;
+            case 8: return 10;
+            case 10: return 11;
+            case 11: return 12;
+            case 14: return 13;
+            case 16: return 14;
+            default: return -1;
+        }
+    };
+
+    // 7 quads of this half per input channel (4 / 3 MFMAs each), operands of quad rf + 2 fetched behind the first MFMA of quad rf
+    auto matrix = [&](auto FHc, int st, bool steady, auto slot) __attribute__((always_inline)) {
+        constexpr int FH = decltype(FHc)::value, NE = FH ? 3 : 4;
+        const int ai = aBase + st * (C::USZ / 4), bi = bBase + st * (C::VSZ / 4);
+        a[0] = lds4[ai];
+        bq[0] = lds4[bi];
+        a[1] = lds4[ai + 256];
+        bq[1] = lds4[bi + 2 * C::NPT];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rf = 0; rf < 7; ++rf) {
+            const int cur = rf % 3, nxt = (rf + 2) % 3;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                acc[rf * NE + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][e], bq[cur][e], acc[rf * NE + e], 0, 0, 0);
+                if (e == 0 && rf + 2 < 7 && !(steady && (W7S_ABL & 8))) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    a[nxt] = lds4[ai + (rf + 2) * 256];
+                    bq[nxt] = lds4[bi + (rf + 2) * 2 * C::NPT];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                slot(rf * NE + e);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+#ifdef W7_TRACE
+    unsigned long long tph[4] = {0, 0, 0, 0};
+    unsigned long long tk = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tk;
+#endif
+    // one iteration of the pipeline (c from -2): DMA U(c+1), patch(c+3) | row pass (c+2) | column pass (c+1) | matrix (c)
+    auto iter = [&](auto FHc, auto J, int c, auto STEADY) __attribute__((always_inline)) {
+        constexpr int FH = decltype(FHc)::value, NS = FH ? 21 : 28;
+        constexpr bool steady = decltype(STEADY)::value;
+        const int par = c & 1;
+        const bool doM = steady || c >= 0;
+        const bool doC = steady || (c + 1 >= 0 && c + 1 < n);
+        const bool doR = steady || c + 2 < n;
+        const bool doP = steady || c + 3 < n;
+        W7STAMP(0)
+        if (FH == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W7STAMP(1)
+        __syncthreads();
+        W7STAMP(2)
+        const int rbuf = par, xrbuf = par, xcbuf = par ^ 1, vbuf = par ^ 1;
+        auto slot = [&](int m) __attribute__((always_inline)) {
+            if (steady && (W7S_ABL & 2) && !(FH == 0 && dma_of_slot(m) >= 0)) return;
+            if (FH == 0) {
+                const int d = dma_of_slot(m);
+                if (d >= 0 && !(steady && (W7S_ABL & 1))) {
+                    if (d < C::NIU) {
+                        if (doC) dma_u(c + 1, d, par ^ 1);
+                    } else if (doP) {
+                        dma_p(c + 3, par ^ 1);
+                    }
+                }
+                const int k = rpiece_of_slot(m);
+                if (k >= 0) tpiece(J, k, doR, false, rbuf, xrbuf, xcbuf, vbuf);
+            } else {
+                const int k = cpiece_of_slot(m);
+                if (k >= 0) tpiece(J, k, false, doC, rbuf, xrbuf, xcbuf, vbuf);
+            }
+        };
+        if (doM) {
+            matrix(FHc, par, steady, slot);
+        } else {
+#pragma unroll
+            for (int m = 0; m < NS; ++m) {
+                slot(m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    auto run = [&](auto FHc, auto J) __attribute__((always_inline)) {
+        using T = std::true_type;
+        using F = std::false_type;
+        iter(FHc, J, -2, F{});
+        iter(FHc, J, -1, F{});
+        int c = 0;
+        for (; c + 3 < n; ++c) iter(FHc, J, c, T{});
+        for (; c < n; ++c) iter(FHc, J, c, F{});
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    if (fh == 0) {
+        dma_p(0, 0);
+        run(H0{}, std::integral_constant<int, 0>{});
+    } else if (w4 == 0) run(H1{}, std::integral_constant<int, 0>{});
+    else if (w4 == 1) run(H1{}, std::integral_constant<int, 1>{});
+    else if (w4 == 2) run(H1{}, std::integral_constant<int, 2>{});
+    else run(H1{}, std::integral_constant<int, 3>{});
+
+    W7STAMP(0)
+    // ---- epilogue: partial tiles of the four couts, exchange, this wave's two couts (elements 2 fh, 2 fh + 1) finished
+    __syncthreads();          // every wave is out of the matrix loop: LDS is free
+    f32x4 *ex = (f32x4 *)lds;          // [wave][k][row][lane]
+    float yo[2][4][4];
+    auto halves = [&](auto FHc) __attribute__((always_inline)) {
+        constexpr int FH = decltype(FHc)::value;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float y[4][4];
+            w7s_partial<FH>(acc, 2 * (1 - FH) + k, y);          // the partner's couts
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[((wid * 2 + k) * 4 + i) * 64 + lane] = f32x4{y[i][0], y[i][1], y[i][2], y[i][3]};
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) w7s_partial<FH>(acc, 2 * FH + k, yo[k]);
+    };
+    if (fh == 0) halves(H0{});
+    else halves(H1{});
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 z = ex[(((wid ^ 4) * 2 + k) * 4 + i) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yo[k][i][e] += z[e];
+        }
+    {
+        const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
+        const bool edge = !(py + 4 <= p.H && px + 4 <= p.W && p.vec);
+        const int r0 = 2 * fh;
+        auto tile = [&](int r, float (&y)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[i][e] = yo[r & 1][i][e];
+        };
+        auto fin = [&](auto R0) __attribute__((always_inline)) {
+            constexpr int r0c = decltype(R0)::value;
+            if (__builtin_amdgcn_ballot_w64(edge) != 0) w7_epilogue<false, false, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py);
+            else if (p.add) w7_epilogue<true, true, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py);
+            else w7_epilogue<true, false, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py);
+        };
+        if (r0 == 0) fin(std::integral_constant<int, 0>{});
+        else fin(std::integral_constant<int, 2>{});
+    }
+#ifdef W7_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W7STAMP(3)
+    if (p.dbg && lane == 0 && (blockIdx.x % 64) == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(p.dbg + wid * 8 + i, tph[i]);
+        atomicAdd(p.dbg + wid * 8 + 4, tk - tstart);
+        atomicAdd(p.dbg + wid * 8 + 5, 1ULL);
+    }
+#endif
+}
+
 // ---- tile configurations ---------------------------------------------------------------------------------------------------------
 //                     GTX WTY WTX          tiles of 4x4 px     TH   TW
 using Z7A = W7Cfg<8, 2, 1>;      //          8 x 4                16   32
 using Z7B = W7Cfg<4, 1, 2>;      //          8 x 4 (4x4 groups)   16   32
 
-#define SSM_W7_KINDS(X) X(Z7A_, Z7A) X(Z7B_, Z7B)
+// (name, configuration, 1 = the frequency-split kernel of eight waves)
+#define SSM_W7_KINDS(X) X(Z7A_, Z7A, 0) X(Z7B_, Z7B, 0) X(Z7AS_, Z7A, 1) X(Z7BS_, Z7B, 1)
 
 enum W7Kind {
-#define X(name, cfg) name,
+#define X(name, cfg, split) name,
     SSM_W7_KINDS(X)
 #undef X
         NW7KIND
 };
 
 struct W7KindInfo {
-    int th, tw;
+    int th, tw, split;
 };
 
 constexpr W7KindInfo kW7Info[NW7KIND] = {
-#define X(name, cfg) W7KindInfo{cfg::TH, cfg::TW},
+#define X(name, cfg, split) W7KindInfo{cfg::TH, cfg::TW, split},
     SSM_W7_KINDS(X)
 #undef X
 };
@@ -639,9 +999,13 @@ std::atomic<unsigned long long *> g_w7dbg{nullptr};
 int pick_w7kind(int Cout, int B, int H, int W) {
     const int forced = g_force_w7kind.load();
     if (forced >= 0 && forced < NW7KIND) return forced;
-    int best = 0;
+    // $SSM_WINO7_SPLIT=0: the 4-wave kernel (read per call: A/B runs and the parity tests use both in one process)
+    const char *env = getenv("SSM_WINO7_SPLIT");
+    const int split = !(env && atoi(env) == 0);
+    int best = -1;
     long long bt = -1;
     for (int i = 0; i < NW7KIND; ++i) {
+        if (kW7Info[i].split != split) continue;
         const long long nwg = (long long)B * ((W + kW7Info[i].tw - 1) / kW7Info[i].tw) * ((H + kW7Info[i].th - 1) / kW7Info[i].th) * (Cout / 32);
         const long long rounds = (nwg + 255) / 256;
         if (bt < 0 || rounds < bt) {
@@ -652,7 +1016,7 @@ int pick_w7kind(int Cout, int B, int H, int W) {
     return best;
 }
 
-template <class C>
+template <class C, int SPLIT>
 int w7launch(W7Params &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
@@ -663,7 +1027,7 @@ int w7launch(W7Params &p, int B, hipStream_t st) {
         ssm::set_error("wino7 conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
     }
-    void (*kern)(const W7Params) = wino7_kernel<C>;
+    void (*kern)(const W7Params) = SPLIT ? wino7s_kernel<C> : wino7_kernel<C>;
     constexpr int lds_bytes = C::BYTES;
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
@@ -672,14 +1036,14 @@ int w7launch(W7Params &p, int B, hipStream_t st) {
         ssm::set_error("wino7 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SPLIT ? 512 : 256), lds_bytes, st, p);
     return ssm::check_launch("ssm_wino7_conv2d_add_fwd");
 }
 
 int w7dispatch(int kind, W7Params &p, int B, hipStream_t st) {
     switch (kind) {
-#define X(name, cfg) \
-    case name: return w7launch<cfg>(p, B, st);
+#define X(name, cfg, split) \
+    case name: return w7launch<cfg, split>(p, B, st);
         SSM_W7_KINDS(X)
 #undef X
     }

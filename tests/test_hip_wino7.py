@@ -10,7 +10,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["Z7A", "Z7B"]      # 16x32-pixel workgroup tiles: tile groups of 8x2 tiles stacked / of 4x4 tiles side by side
+# 16x32-pixel workgroup tiles: tile groups of 8x2 tiles stacked / of 4x4 tiles side by side; ..S: the frequency-split kernel of eight waves (r5)
+KINDS = ["Z7A", "Z7B", "Z7AS", "Z7BS"]
 BAR = 5e-5
 
 

@@ -2,7 +2,7 @@
 """Per-layer A/B of the 7x7 layers at the 736x1280 shapes of SURVEY Appendix A: the 1-D Winograd kernel (csrc/ssm_wino1d.hip, F(2,7) along
 x) vs the blocked two-dimensional form (csrc/ssm_wino7.hip, 2x2 blocks of F(4x4,4x4)), with the fused 2x2 mean where the plan has it.
 TFLOP/s are ALGORITHMIC (direct-form FLOPs); "issued" = the multiply-adds the matrix cores execute (x 8/14 | x 196/784).
-usage: python tools/bench_layers_wino7.py [B] [H] [W] [kind|-1]      (kinds: 0 Z7A, 1 Z7B)"""
+usage: python tools/bench_layers_wino7.py [B] [H] [W] [kind|-1]      (kinds: 0 Z7A, 1 Z7B, 2 / 3 the same tiles in the frequency-split kernel of eight waves; -1: the plan's choice, $SSM_WINO7_SPLIT)"""
 import os
 import sys
 

@@ -21,7 +21,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             name = row.get("Kernel_Name", "")
             if row.get("Counter_Name") != ctr:
                 continue
-            fam = next((k for k in ("wino_pack_kernel", "wino4_pack_kernel", "wino1d_pack_kernel", "pack32_batch_kernel", "wino7_pack_kernel", "wino5_pack_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino4_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "final_conv_valu_kernel", "final_conv_kernel", "conv16_ups_kernel", "conv16_multi_kernel", "conv16_kernel", "conv_mfma_kernel", "upsample2x_cat_hl8_kernel", "upsample2x_cat_kernel",
+            fam = next((k for k in ("wino_pack_kernel", "wino4_pack_kernel", "wino1d_pack_kernel", "pack32_batch_kernel", "wino7_pack_kernel", "wino5_pack_kernel", "wino7s_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino4_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "final_conv_valu_kernel", "final_conv_kernel", "conv16_ups_kernel", "conv16_multi_kernel", "conv16_kernel", "conv_mfma_kernel", "upsample2x_cat_hl8_kernel", "upsample2x_cat_kernel",
                                     "flowinterp_inputs_hl8_kernel", "flowinterp_inputs_kernel", "to_hl8_kernel", "to_hq8_kernel", "gather_cols_kernel", "pack16_kernel",
                                     "synthesize_kernel", "copy_view_kernel", "pack_weights_kernel", "FillFunctor",
                                     "copyBuffer") if k in name), "other")

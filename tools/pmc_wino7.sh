@@ -17,8 +17,8 @@ for sub in ("sq", "sq2"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "wino7_kernel" not in k: continue
-            m = re.search(r"(wino7_kernel)<.*?(W7Cfg<[^>]*>)", k.replace("(anonymous namespace)::", ""))
+            if "wino7_kernel" not in k and "wino7s_kernel" not in k: continue
+            m = re.search(r"(wino7s?_kernel)<.*?(W7Cfg<[^>]*>)", k.replace("(anonymous namespace)::", ""))
             cfg = "%s %s" % (m.group(1), m.group(2)) if m else k[:60]
             agg[cfg][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(os.path.join(out, "summary.txt"), "w") as fo:

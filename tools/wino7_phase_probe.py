@@ -20,7 +20,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = hb.load()
     lib.ssm_wino7_debug_buffer.argtypes = [ctypes.c_void_p]
-    cnt = torch.zeros(32, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(64, dtype=torch.int64, device=dev)          # 8 waves x 8 counters (the 4-wave kernel uses the first 4 rows)
     wt = torch.randn(cout, cin, 7, 7, device=dev) / (cin * 49) ** 0.5
     bs = torch.randn(cout, device=dev) * 0.1
     pk = hb.PackedWino7(wt, bs, B, H, W)
@@ -41,9 +41,11 @@ def main():
     hb.conv2d_wino7(x.view(), cin, None, 0, pk, y.view(), None, B, H, W, **akw)
     e1.record()
     torch.cuda.synchronize()
-    c = cnt.cpu().view(4, 8)
+    c = cnt.cpu().view(8, 8)
     print("cin %d batch %d: %.3f ms; iterations per workgroup %d (+2 without MFMAs)" % (cin, B, e0.elapsed_time(e1), cin))
-    for w in range(4):
+    for w in range(8):
+        if int(c[w, 5]) == 0:
+            continue
         n = max(int(c[w, 5]), 1)
         work, dma, bar, epi, life = (float(c[w, i]) / n for i in range(5))
         print("wave %d (%d samples): lifetime %8.0f cycles = work %8.0f (%.0f per iteration) + DMA wait %6.0f (%.0f) + barrier wait %6.0f (%.0f) + "
