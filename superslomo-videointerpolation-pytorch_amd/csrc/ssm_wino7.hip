@@ -151,8 +151,11 @@ __device__ __forceinline__ void w7_at(float m0, float m1, float m2, float m3, fl
 // stores between the loads cost store round trips (tools/bench_layers_wino7.py, conv1a with the addend: 2.11 -> 2.01 ms at batch 14).
 // NR couts of the lane starting at accumulator element r0 (the 4-wave kernel: all four; a wave of the frequency-split kernel finishes two);
 // tile(r, y): the 4x4 tile of element r before the bias.
+// zin (HOLD only): the NR x 4 addend rows already requested by the caller (the split kernel asks for them behind the barrier of its last
+// channel: their latency runs under that channel's MFMAs), or nullptr.
 template <bool FAST, bool HOLD, int NR, class Tile>
-__device__ __forceinline__ void w7_epilogue(const W7Params &p, Tile tile, const float (&bv)[4], int b, int cu0, int r0, int q, int px, int py) {
+__device__ __forceinline__ void w7_epilogue(const W7Params &p, Tile tile, const float (&bv)[4], int b, int cu0, int r0, int q, int px, int py,
+                                            const f32x4 *zin = nullptr) {
     const float sl = p.lrelu ? p.slope : 1.f;
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
@@ -181,10 +184,17 @@ __device__ __forceinline__ void w7_epilogue(const W7Params &p, Tile tile, const 
             for (int i = 0; i < 4; ++i) zadd[r % ZN][i] = *(const f32x4 *)(addb + (long long)(cu0 + r) * p.asc + (long long)i * p.ash);
         }
     };
-    zload(r0);
-    if (HOLD) {
+    if (HOLD && zin) {
 #pragma unroll
-        for (int rr = 1; rr < NR; ++rr) zload(r0 + rr);
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zadd[(r0 + rr) % ZN][i] = zin[rr * 4 + i];
+    } else {
+        zload(r0);
+        if (HOLD) {
+#pragma unroll
+            for (int rr = 1; rr < NR; ++rr) zload(r0 + rr);
+        }
     }
     f32x4 yk[HOLD ? NR : 1][4];
     auto emit = [&](int r, const float (&y)[4][4]) {
@@ -744,6 +754,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float cv0[7], cv1[7], ce0[6], ce1[6];
     f32x4 a[3], bq[3];
 
+    // the wave's epilogue variant is known up front; with an addend and no edge tile in the wave, the 2 x 4 addend rows of the wave's couts
+    // are requested behind the barrier of the LAST channel (no LDS-DMA is issued after it: nothing else waits on the vector-memory counter)
+    const int opx = x0 + 4 * Tx, opy = y0 + 4 * Ty;
+    const bool edge_any = __builtin_amdgcn_ballot_w64(!(opy + 4 <= p.H && opx + 4 <= p.W && p.vec)) != 0;
+    const bool zpre_on = p.add != nullptr && !edge_any;
+    f32x4 zpre[8];
+    auto addend_prefetch = [&]() __attribute__((always_inline)) {
+        if (zpre_on) {
+            const float *addb = p.add + (long long)(b / p.adiv) * p.asb + (long long)(4 * q + nb * 32 + cb * 16 + 2 * fh) * p.asc + (long long)opy * p.ash + opx;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zpre[k * 4 + i] = *(const f32x4 *)(addb + (long long)k * p.asc + (long long)i * p.ash);
+        }
+    };
+
     // transform pieces (as in wino7_kernel): 0 .. 4 the row pass, 5 .. 14 the column pass of pair J
     auto tpiece = [&](auto J, int k, bool doR, bool doC, int rbuf, int xrbuf, int xcbuf, int vbuf) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value;
@@ -852,12 +878,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool doM = steady || c >= 0;
         const bool doC = steady || (c + 1 >= 0 && c + 1 < n);
         const bool doR = steady || c + 2 < n;
-        const bool doP = steady || c + 3 < n;
+        const bool doP = steady || (c + 3 < n && c > -2);          // (the patch of channel 1 is requested up front, with channel 0's)
         W7STAMP(0)
         if (FH == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W7STAMP(1)
         __syncthreads();
         W7STAMP(2)
+        if (!steady && c == n - 1) addend_prefetch();
         const int rbuf = par, xrbuf = par, xcbuf = par ^ 1, vbuf = par ^ 1;
         auto slot = [&](int m) __attribute__((always_inline)) {
             if (steady && (W7S_ABL & 2) && !(FH == 0 && dma_of_slot(m) >= 0)) return;
@@ -901,6 +928,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     using H1 = std::integral_constant<int, 1>;
     if (fh == 0) {
         dma_p(0, 0);
+        if (n > 1) dma_p(1, 1);          // both patch buffers at once: one memory latency in front of the first row pass instead of two
         run(H0{}, std::integral_constant<int, 0>{});
     } else if (w4 == 0) run(H1{}, std::integral_constant<int, 0>{});
     else if (w4 == 1) run(H1{}, std::integral_constant<int, 1>{});
@@ -936,8 +964,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = 0; e < 4; ++e) yo[k][i][e] += z[e];
         }
     {
-        const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
-        const bool edge = !(py + 4 <= p.H && px + 4 <= p.W && p.vec);
+        const int px = opx, py = opy;
         const int r0 = 2 * fh;
         auto tile = [&](int r, float (&y)[4][4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -947,8 +974,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         auto fin = [&](auto R0) __attribute__((always_inline)) {
             constexpr int r0c = decltype(R0)::value;
-            if (__builtin_amdgcn_ballot_w64(edge) != 0) w7_epilogue<false, false, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py);
-            else if (p.add) w7_epilogue<true, true, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py);
+            if (edge_any) w7_epilogue<false, false, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py);
+            else if (p.add) w7_epilogue<true, true, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py, zpre);
             else w7_epilogue<true, false, 2>(p, tile, bv, b, nb * 32 + cb * 16, r0c, q, px, py);
         };
         if (r0 == 0) fin(std::integral_constant<int, 0>{});
