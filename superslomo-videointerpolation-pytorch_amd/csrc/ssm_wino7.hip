@@ -878,7 +878,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool doM = steady || c >= 0;
         const bool doC = steady || (c + 1 >= 0 && c + 1 < n);
         const bool doR = steady || c + 2 < n;
-        const bool doP = steady || (c + 3 < n && c > -2);          // (the patch of channel 1 is requested up front, with channel 0's)
+        const bool doP = steady || (c + 3 < n && c > -2);          // (the patch of channel 1 and the filter of channel 0 are requested up
+        const bool doU = steady || (c + 1 < n && c >= 0);          //  front, with channel 0's patch)
         W7STAMP(0)
         if (FH == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W7STAMP(1)
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int d = dma_of_slot(m);
                 if (d >= 0 && !(steady && (W7S_ABL & 1))) {
                     if (d < C::NIU) {
-                        if (doC) dma_u(c + 1, d, par ^ 1);
+                        if (doU) dma_u(c + 1, d, par ^ 1);
                     } else if (doP) {
                         dma_p(c + 3, par ^ 1);
                     }
@@ -928,7 +929,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     using H1 = std::integral_constant<int, 1>;
     if (fh == 0) {
         dma_p(0, 0);
-        if (n > 1) dma_p(1, 1);          // both patch buffers at once: one memory latency in front of the first row pass instead of two
+        if (n > 1) dma_p(1, 1);          // both patch buffers and the first filter at once: one memory latency in front of the first row
+#pragma unroll
+        for (int k = 0; k < C::NIU; ++k) dma_u(0, k, 0);          // pass instead of one per prologue iteration
         run(H0{}, std::integral_constant<int, 0>{});
     } else if (w4 == 0) run(H1{}, std::integral_constant<int, 0>{});
     else if (w4 == 1) run(H1{}, std::integral_constant<int, 1>{});
