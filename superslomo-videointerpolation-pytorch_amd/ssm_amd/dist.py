@@ -113,6 +113,7 @@ class GradientAllReduce:
         self.bytes = 4 * n
         self.last_runs = None
         self._works, self._bucket_bytes, self.last_buckets = [], 0, 0
+        self._exposed_events, self._exposed_host_s = [], 0.0
 
     # ---- bucketed, overlapped form ----------------------------------------------------------------------
     def attach(self, pair_grad):
@@ -134,18 +135,40 @@ class GradientAllReduce:
         self._bucket_bytes += 4 * view.numel()
 
     def _finish_buckets(self):
-        """Wait for the bucket all-reduces of this step; returns the seconds the caller was blocked (the exposed part)."""
+        """Order the compute stream behind the bucket all-reduces of this step.  On the GPU nothing here blocks the HOST (r5: a stream
+        synchronise at this point - there only to put a number on the wait - stopped the host's run-ahead once per step and made the
+        exchange cost 2 ms of a 20 ms step even in a world of one): `Work.wait()` of the RCCL backend makes the current stream wait,
+        and the exposed part - the time the compute stream sat behind the collectives - is bracketed by two events, read later through
+        exposed_seconds().  Returns the seconds the caller was blocked (CPU / gloo: the whole wait; GPU: none)."""
         cuda = self.flat.is_cuda
         t0 = time.perf_counter()
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
         if cuda:
-            torch.cuda.current_stream().synchronize()
-        el = time.perf_counter() - t0
+            e1.record()
+            self._exposed_events.append((e0, e1))
+            if len(self._exposed_events) > 4096:          # a long run that never reads the figure
+                del self._exposed_events[:2048]
+        el = 0.0 if cuda else time.perf_counter() - t0
+        self._exposed_host_s += el
         self.last_buckets, self._works = len(self._works), []
         covered, self._bucket_bytes = self._bucket_bytes, 0
         assert covered == self.bytes, "bucketed all-reduce covered %d of %d gradient bytes" % (covered, self.bytes)
         return el
+
+    def exposed_seconds(self, reset=True):
+        """Seconds the compute stream (GPU: event brackets, synchronised here) or the caller (CPU) waited for the bucketed exchange
+        since the last call."""
+        total = self._exposed_host_s
+        for e0, e1 in self._exposed_events:
+            e1.synchronize()
+            total += 1e-3 * e0.elapsed_time(e1)
+        if reset:
+            self._exposed_events, self._exposed_host_s = [], 0.0
+        return total
 
     MAX_RUNS = 8     # in-place path: the gradients form at most this many contiguous memory runs
 
