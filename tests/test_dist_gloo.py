@@ -210,6 +210,10 @@ def _ar_bucket_worker(rank, world, port, ret):
         v.mul_(pg.sync_scale)
         pg.sync.reduce(v)
     ar()
+    # the exposed wait of the step is accumulated until it is read (CPU / gloo: the host seconds of Work.wait(); GPU: event brackets,
+    # nothing blocks the host) and reset by the read
+    waited = ar.exposed_seconds()
+    assert waited >= 0.0 and ar.exposed_seconds() == 0.0
     ret[rank] = (flat.clone(), flat2.clone(), ar.last_buckets, params2[4].grad.data_ptr() == flat2[186:].data_ptr())
     dist.destroy_process_group()
 
