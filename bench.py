@@ -464,8 +464,9 @@ def train_bench(args):
                                "algorithmic_in_kernel": round(d["flops"] / d["ms"] / 1e9, 2)}
                          for fam, d in summ.items() if d["flops"] > 0},
             "traffic": None,
-            "note": ("3x3 forward / data-gradient / VGG layers run as Winograd F(2x2,3x3): 16/36 of their direct-form FLOP are issued; weight "
-                     "gradients, 7x7 / 5x5 / final layers run in the direct form" if train_mode == "f32w" else
+            "note": ("3x3 forward / data-gradient / VGG layers run as Winograd F(2x2,3x3): 16/36 of their direct-form FLOP are issued; the data gradients of "
+                     "conv1b / conv2a / conv2b in the blocked 7x7 / F(4x4,5x5) forms (1/4, 64/400); weight gradients, 7x7 / 5x5 forward and final "
+                     "layers run in the direct form" if train_mode == "f32w" else
                      "every product issued in the direct form: FLOP counted = FLOP issued")}
         if args.detail:
             det = {fam: {n: {"ms_per_step": v[0] / 3, "tflops": (v[1] / v[0] / 1e9 if v[0] > 0 else 0.0)}

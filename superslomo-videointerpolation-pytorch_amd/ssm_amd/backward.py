@@ -18,6 +18,10 @@ import torch
 from . import hipbind as hb
 
 
+DGRAD_BLOCKED = os.environ.get("SSM_TRAIN_DGRAD_BLOCKED", "1") != "0"
+DGRAD_WINO4 = os.environ.get("SSM_TRAIN_DGRAD_WINO4", "0") != "0"          # 3x3 data gradients as F(4x4,3x3) where the cost model prefers it
+
+
 def transposed_filter(w):
     """OIHW filter of the data-gradient convolution: W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx]."""
     return w.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous()
@@ -247,12 +251,22 @@ class UNetGrad:
                 # runs in the Winograd form like the forward (its "input channels" are the layer's output channels)
                 use_w = getattr(self.plan, "wino", False) and hb.wino_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
                 cls = hb.PackedWino if use_w else hb.PackedConv
-                if (use_w and getattr(self.plan, "wino4", False) and hb.wino4_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
+                if (use_w and (getattr(self.plan, "wino4", False) or DGRAD_WINO4) and hb.wino4_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
                         and hb.wino4_preferred(co, ci, self.B, self.plan.H // s, self.plan.W // s, False)):
                     cls = hb.PackedWino4
                 from .engine import wino1d_enabled
                 if getattr(self.plan, "wino1d", False) and wino1d_enabled(k) and hb.wino1d_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
                     cls = hb.PackedWino1d          # data gradient of a 7x7 / 5x5 layer: the same convolution on the transposed filter
+                # r5: the data gradient of a 7x7 / 5x5 layer in the blocked two-dimensional forms of the inference plans (csrc/ssm_wino7.hip,
+                # ssm_wino5.hip) where the transposed layer has whole 32-channel output blocks (conv1b, conv2a, conv2b).  The forward of a
+                # training plan stays in the direct form - a coarser forward rounding moves pre-activations across the loss's kinks
+                # (engine.UNetPlan) - but a data gradient is linear in dZ and the masks come from that forward: nothing moves, the
+                # gradient carries the form's own 3e-5 and the bars of tests/test_hip_backward.py hold.  $SSM_TRAIN_DGRAD_BLOCKED=0: off
+                if getattr(self.plan, "wino", False) and DGRAD_BLOCKED:
+                    if hb.wino7_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
+                        cls = hb.PackedWino7
+                    elif hb.wino5_supported(co, ci, self.plan.H // s, self.plan.W // s, k) and co % 4 == 0:
+                        cls = hb.PackedWino5
                 self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
         if batch32:
             self._pack32 = (key32, hb.PackBatch32([(self.pk_t[n], w, None, True) for n, w in zip(names, ws)], self.dev))

@@ -11,6 +11,8 @@ import numpy as np
 import torch
 
 from . import hipbind as hb
+import os
+
 from .engine import conv_fn
 from .backward import transposed_filter
 from .weights import _hash_uniform
@@ -33,6 +35,9 @@ def synthetic_vgg_state_dict(gain=1.0):
         sd["features.%d.weight" % idx] = torch.from_numpy(w.astype(np.float32).reshape(cout, cin, 3, 3).copy())
         sd["features.%d.bias" % idx] = torch.from_numpy(b.astype(np.float32).copy())
     return sd
+
+
+VGG_WINO4 = os.environ.get("SSM_VGG_WINO4", "1") != "0"          # measured + 1.3 % of a training step, gradient bars unchanged (profiles/r12c_*)
 
 
 class VGGFeatures:
@@ -82,6 +87,9 @@ class VGGFeatures:
         self.g, self.pk_t = {}, {}
 
     def _cls(self, cin, cout, h, w):
+        # mode f32w ($SSM_VGG_WINO4=0: off): F(4x4,3x3) where the library's cost model prefers it over F(2x2,3x3) at this batch
+        if (self.wino and VGG_WINO4 and hb.wino4_supported(cin, cout, h, w) and hb.wino4_preferred(cin, cout, max(1, self.B // 2), h, w, False)):
+            return hb.PackedWino4
         return hb.PackedWino if (self.wino and hb.wino_supported(cin, cout, h, w)) else hb.PackedConv
 
     def _pk(self, idx, nb, src):
@@ -90,7 +98,8 @@ class VGGFeatures:
         if self.q8:
             return self.pk[idx]
         pk = self.pk[idx]
-        plan = hb.wino_plan(pk.cin, pk.cout, nb, src.H, src.W) if pk.algo == "wino" else hb.conv_plan(3, pk.cin_p, pk.cout, nb, src.H, src.W)
+        plan = (hb.wino_plan(pk.cin, pk.cout, nb, src.H, src.W) if pk.algo == "wino" else
+                hb.wino4_plan(pk.cin, pk.cout, nb, src.H, src.W) if pk.algo == "wino4" else hb.conv_plan(3, pk.cin_p, pk.cout, nb, src.H, src.W))
         if plan[1:] == (pk.bn, pk.ck):
             return pk
         key = (idx, nb)
@@ -102,7 +111,8 @@ class VGGFeatures:
         tm = VGGFeatures.timer
         if tm is None:
             return None
-        issued = flops * (16.0 / 36.0 if pk is not None and getattr(pk, "algo", "") == "wino" else 1.0)      # F(2x2,3x3) layers
+        algo = getattr(pk, "algo", "") if pk is not None else ""
+        issued = flops * (16.0 / 36.0 if algo == "wino" else 0.25 if algo == "wino4" else 1.0)      # F(2x2,3x3) / F(4x4,3x3) layers
         e0, e1 = tm.span(fam, name, flops, issued=issued)
         e0.record()
         return e1
