@@ -241,7 +241,9 @@ int ssm_wino1d_conv2d_add_fwd(ssm_view x, int Cin, const float *w_packed, const 
  * In fp32 the result differs from the direct form by rounding only (a 32-channel layer: 2e-6 rms / 3e-5 max at unit output scale).
  * One input source, any Cin >= 1 (a k-step is the four blocks of one channel: no channel padding); Cout a multiple of 32.
  * Inputs are padded planes; nothing outside them is read (tile overshoot and the bottom window's row H + 3 come from the zero frame).
- * ssm_wino7_pack_weights: OIHW fp32 7x7 filter -> U_b = G g_b G^T as [Cout/32][Cin][14 quads][4 blocks][32][4] (+ bias).            */
+ * ssm_wino7_pack_weights: OIHW fp32 7x7 filter -> U_b = G g_b G^T as [ceil(Cout/32)][Cin][14 quads][4 blocks][32][4] (+ bias, whole
+ * 32-channel blocks).  Cout may be any positive count there: the channels up to the next multiple of 32 are packed as zeros, and the
+ * convolution is then launched with that padded count on an output view that holds them (the data gradient of stage 2's conv1a).     */
 int ssm_wino7_plan(int Cin, int Cout, int B, int H, int W, int *kind);
 int ssm_wino7_force_kind(int kind);      /* tests / tuning only (-1 = automatic); returns the number of configurations */
 size_t ssm_wino7_packed_weight_floats(int Cout, int Cin);

@@ -1119,14 +1119,16 @@ extern "C" int ssm_wino7_force_kind(int kind) {
     return NW7KIND;
 }
 
-extern "C" size_t ssm_wino7_packed_weight_floats(int Cout, int Cin) { return (size_t)(Cout / 32) * (size_t)Cin * SSM_W7_NFQ * 4 * 32 * 4; }
+// (Cout rounded up to whole 32-channel blocks: the pack fills the channels beyond Cout with zeros - a caller that convolves with a
+// narrower filter, e.g. the data gradient of a layer with fewer than 32 inputs, launches the convolution with the padded count)
+extern "C" size_t ssm_wino7_packed_weight_floats(int Cout, int Cin) { return (size_t)((Cout + 31) / 32) * (size_t)Cin * SSM_W7_NFQ * 4 * 32 * 4; }
 
 extern "C" int ssm_wino7_pack_weights(const float *w, const float *bias, float *wp, float *bp, int Cout, int Cin, void *stream) {
     SSM_REQUIRE(w && bias && wp && bp, "wino7 pack_weights: null pointer");
-    SSM_REQUIRE(Cout > 0 && Cin > 0 && Cout % 32 == 0, "wino7 pack_weights: bad sizes (Cout a multiple of 32)");
+    SSM_REQUIRE(Cout > 0 && Cin > 0, "wino7 pack_weights: bad sizes");
     SSM_REQUIRE(ssm::aligned16(wp), "wino7 pack_weights: the packed filter must be 16-byte aligned");
     const long long total = (long long)ssm_wino7_packed_weight_floats(Cout, Cin);
-    const int nbias = Cout;
+    const int nbias = (Cout + 31) / 32 * 32;          // (bias_packed holds whole blocks too)
     const long long n = (total > nbias ? total : nbias) / 4 + 1;
     hipLaunchKernelGGL(wino7_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin, total,
                        nbias);

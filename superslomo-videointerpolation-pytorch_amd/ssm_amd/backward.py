@@ -263,8 +263,8 @@ class UNetGrad:
                 # (engine.UNetPlan) - but a data gradient is linear in dZ and the masks come from that forward: nothing moves, the
                 # gradient carries the form's own 3e-5 and the bars of tests/test_hip_backward.py hold.  $SSM_TRAIN_DGRAD_BLOCKED=0: off
                 if getattr(self.plan, "wino", False) and DGRAD_BLOCKED:
-                    if hb.wino7_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
-                        cls = hb.PackedWino7
+                    if hb.wino7_supported(co, ci, self.plan.H // s, self.plan.W // s, k) or (k == 7 and 8 <= ci < 32):
+                        cls = hb.PackedWino7          # (stage 2's conv1a, 16 inputs: the transposed layer padded to one 32-channel block, see backward())
                     elif hb.wino5_supported(co, ci, self.plan.H // s, self.plan.W // s, k) and co % 4 == 0:
                         cls = hb.PackedWino5
                 self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
@@ -381,7 +381,8 @@ class UNetGrad:
         L("conv2b", G("c2"), G("p3"), G("t2a"), need_wgrad)
         L("conv2a", G("t2a"), None, G("p2"), need_wgrad)
         L("conv1b", d_c1, G("p2"), G("t1a"), need_wgrad)
-        d_in = G("in") if need_input_grad else None
+        # (a data gradient in the blocked 7x7 form writes whole 32-channel blocks: zeros beyond the layer's inputs)
+        d_in = G("in", C=getattr(self.pk_t.get("conv1a"), "cout_p", None)) if need_input_grad else None
         L("conv1a", G("t1a"), None, d_in, need_wgrad)
         return d_in
 

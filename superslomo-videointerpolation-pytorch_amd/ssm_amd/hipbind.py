@@ -603,12 +603,14 @@ class PackedWino7:
         require_device(bias, "conv bias")
         assert not ups, "the 7x7 layers have no fused-upsample form"
         self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
-        assert self.k == 7 and weight.shape[3] == 7 and self.cout % 32 == 0, "the blocked Winograd form is for 7x7 filters, Cout a multiple of 32"
+        assert self.k == 7 and weight.shape[3] == 7, "the blocked Winograd form is for 7x7 filters"
+        # cout_p: the channels the convolution writes (whole 32-channel blocks; zeros beyond cout - the output view must hold them)
+        self.cout_p = (self.cout + 31) // 32 * 32
         self.ups = False
         self.bn, self.ck, self.cin_p = 32, 1, self.cin
         lib = load()
         self.w = torch.empty(lib.ssm_wino7_packed_weight_floats(self.cout, self.cin), dtype=torch.float32, device=weight.device)
-        self.b = torch.empty(self.cout, dtype=torch.float32, device=weight.device)
+        self.b = torch.empty(self.cout_p, dtype=torch.float32, device=weight.device)
         wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
         check(lib.ssm_wino7_pack_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout, self.cin, stream_ptr()))
 
@@ -619,7 +621,7 @@ def conv2d_wino7(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, ad
     assert x2 is None and c2 == 0, "the 7x7 layers have no concatenated source"
     assert pk.cin == c1, "packed filter expects %d input channels, got %d" % (pk.cin, c1)
     check(lib.ssm_wino7_conv2d_add_fwd(x1, c1, pk.w.data_ptr(), pk.b.data_ptr(), y, pool if pool is not None else NULL_VIEW,
-                                       add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
+                                       add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout_p, slope,
                                        SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
 
 
