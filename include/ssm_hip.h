@@ -166,6 +166,20 @@ int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w
                         ssm_view y, ssm_view pool, int B, int H, int W, int Cout, float slope, int flags, void *stream);
 int ssm_wino_conv2d_ups_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *w_packed, const float *bias_packed,
                             ssm_view y, int B, int H, int W, int Cout, float slope, int flags, void *stream);
+
+/* Split-K form of the two convolutions above for launches that leave most of the chip idle (config 3's bottleneck layers: 512 -> 512
+ * channels on 22x22 / 11x11 maps at batch 2 are 96-192 workgroups, each walking every input channel).  ssm_wino_splitk_plan proposes
+ * KS in {1, 2, 4, 8} (1: do not split; $SSM_WINO_SPLITK=0: always 1) for a filter packed with BN couts per block;
+ * ssm_wino_conv2d_splitk_fwd (ups = 1: conv3x3(upsample2x(cat[a, b])), H x W the output) runs KS workgroups per output tile, workgroup
+ * ks summing input channels [ks, ks + 1) * Cin / KS, and stores the raw sums (the bias with ks = 0, no activation) as batch entry
+ * ks * B + b of `part` ([KS * B, Cout, H, W] padded planes owned by the caller); ssm_splitk_finish_fwd (csrc/ssm_elem.hip) adds the KS
+ * partial maps in the order ks = 0, 1, ... (deterministic), then the optional addend [B / add_div, C, H, W], LeakyReLU (flags) and the
+ * optional fused 2x2 mean - layers.conv / avg_pool of scripts/models/layers.py:21-33,60-63 as before, in two launches.              */
+int ssm_wino_splitk_plan(int Cin, int Cout, int B, int H, int W, int ups, int BN, int *KS);
+int ssm_wino_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view part,
+                               int KS, int ups, int B, int H, int W, int Cout, int BN, void *stream);
+int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view pool, ssm_view add, int add_div, int B, int C, int H, int W,
+                          float slope, int flags, void *stream);
 /* ... with the pre-activation addend of ssm_conv2d_add_fwd (8-byte aligned view). */
 int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
                             ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags,

@@ -70,6 +70,9 @@ struct WinoParams {
     const float *add;
     long long asb, asc;
     int ash, adiv;
+    // split-K launches (wino2_kernel only; ssm_wino_conv2d_splitk_fwd): KS workgroups share an output tile, workgroup ks sums input
+    // channels [ks, ks + 1) * Cin / KS and stores its raw sums (the bias rides with ks = 0; no activation) as batch entry ks * ksB + b of dst
+    int KS, ksB;
 };
 
 // WN cout blocks x (WTY x WTX) tile groups = 4 waves; a tile group = GTW x (32/GTW) Winograd tiles of 2x2 pixels
@@ -489,6 +492,8 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     const int tyl = l31 / C::GTW, txl = l31 % C::GTW;
 
     int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int ks = id % p.KS;          // (split-K partners are neighbours in the grid: they read the same patches)
+    id /= p.KS;
     const int nb = id % p.NB;
     id /= p.NB;
     const int tx = id % p.tilesX;
@@ -524,8 +529,10 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     }
     const int uoff = lane * 16;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+    const int nchunks = p.Cin / CK / p.KS;
+    const int cbeg = ks * nchunks * CK;          // first input channel of this workgroup
     auto issue_k = [&](int ch, int stage, int k) {
-        const int c0 = ch * CK;
+        const int c0 = cbeg + ch * CK;
         const unsigned lsb = lds0 + (unsigned)(stage * L::STAGE) * 4u;
         if (k < L::NIU) {
             const int g = 4 * k + wid;
@@ -559,7 +566,6 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     const int bBase = (half * (PH * PW) + ((wty * C::GTH + tyl) * 2 + FH) * PW + (wtx * C::GTW + txl) * 2 + 3 + WS_B64) / 2;   // f32x2 units; patch rows FH .. FH+2
 
     constexpr int S = CK / 2;
-    const int nchunks = p.Cin / CK;
     const f32x4 *lds4 = (const f32x4 *)lds;
     f32x4 a[2][2];
     float d[12], t[8], v[2][8];
@@ -666,7 +672,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
 #pragma unroll
     for (int c = 0; c < L::NST; ++c)
         if (c < nchunks) issue(c, c);
-    if constexpr (FH == 0) {        // bias: accumulator of frequency (1,1) = local 5 of the first half
+    if (FH == 0 && ks == 0) {        // bias: accumulator of frequency (1,1) = local 5 of the first half
         const float bv0 = p.bias[nb * BN + wn * 32 + l31];
         const float ab = half ? 0.f : bv0, ones = half ? 0.f : 1.f;
         acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab, ones, acc[5], 0, 0, 0);
@@ -808,7 +814,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     {
         const int px = x0 + (wtx * C::GTW + txl) * 2, py = y0 + (wty * C::GTH + tyl) * 2;
         const float sl = p.lrelu ? p.slope : 1.f;
-        float *dstb = p.dst + (long long)b * p.dsb;
+        float *dstb = p.dst + (long long)(b + ks * p.ksB) * p.dsb;
         float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
         const int cu0 = nb * BN + wn * 32;
         const bool full = cu0 + 32 <= p.Cout;
@@ -957,7 +963,7 @@ int wlaunch(WinoParams &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
     p.tilesY = (p.H + C::TH - 1) / C::TH;
     p.NB = (p.Cout + C::BN - 1) / C::BN;
-    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B * p.KS;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("wino conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
@@ -1065,6 +1071,8 @@ int wfill(WinoParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *
     p.asb = p.asc = 0;
     p.ash = 0;
     p.adiv = 1;
+    p.KS = 1;
+    p.ksB = 0;
 #ifdef SSM_WINO_ABLATE
     if (const char *e = getenv("SSM_WINO_ABL")) p.abl = atoi(e);
 #endif
@@ -1144,6 +1152,67 @@ extern "C" int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2,
         p.psh = pool.sh;
     }
     return wdispatch<false>(kind, p, B, (hipStream_t)stream);
+}
+
+// ---- split-K for launches that leave most of the chip idle (r5) -------------------------------------------------------------------
+// A 512 -> 512 layer on a 22x22 map at batch 2 (config 3's bottleneck layers) is 96-192 workgroups that each walk all 512 input channels:
+// one partial round, as long as ONE workgroup's channel loop (0.10 ms for 4.6 GFLOP).  KS workgroups per output tile, each over Cin / KS
+// channels, fill the idle CUs; their raw sums land as KS x B batch entries of a scratch tensor and ssm_splitk_finish_fwd (csrc/ssm_elem.hip)
+// adds them in a fixed order (deterministic), then applies the addend, the activation and the fused 2x2 mean.
+namespace {
+// the two-workgroups-per-CU configuration (wino2_kernel) with BN couts per block that the cost model puts first for Cin / KS channels
+int pick_wkind_split(int CinPart, int Cout, int B, int H, int W, int ups, int BN) {
+    int best = -1;
+    double bt = 0.0;
+    for (int i = 0; i < NWKIND; ++i) {
+        const WKindInfo &ki = kWInfo[i];
+        if (ki.nblk != 2 || ki.bn != BN || CinPart % ki.ck) continue;
+        const double t = estimate_wino(ki, CinPart, Cout, B, H, W, ups);
+        if (best < 0 || t < bt * 0.999) {
+            best = i;
+            bt = t;
+        }
+    }
+    return best;
+}
+}  // namespace
+
+extern "C" int ssm_wino_splitk_plan(int Cin, int Cout, int B, int H, int W, int ups, int BN, int *KS) {
+    SSM_REQUIRE(KS, "wino splitk_plan: null pointer");
+    *KS = 1;
+    static const int enabled = [] {
+        const char *e = getenv("SSM_WINO_SPLITK");
+        return e ? atoi(e) : 1;
+    }();
+    if (!enabled || W % 2 || BN % 32 || Cin < 128) return SSM_OK;
+    const int kd = pick_wkind_split(Cin, Cout, B, H, W, ups, BN);
+    if (kd < 0) return SSM_OK;
+    const WKindInfo &ki = kWInfo[kd];
+    const long long nwg = (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th) * ((Cout + ki.bn - 1) / ki.bn);
+    // double the split while all workgroups stay co-resident (2 per CU) and a workgroup keeps at least 64 channels
+    int ks = 1;
+    while (ks < 8 && nwg * ks * 2 <= 512 && Cin % (ks * 2 * 8) == 0 && Cin / (ks * 2) >= 64) ks *= 2;
+    *KS = ks;
+    return SSM_OK;
+}
+
+extern "C" int ssm_wino_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view part,
+                                          int KS, int ups, int B, int H, int W, int Cout, int BN, void *stream) {
+    SSM_REQUIRE(B > 0 && KS >= 1 && KS <= 8 && (C1 + C2) % KS == 0, "wino conv_splitk: bad batch / split (KS = %d, Cin = %d)", KS, C1 + C2);
+    SSM_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0), "wino conv_splitk: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
+    const int kind = (W % 2 == 0) ? pick_wkind_split((C1 + C2) / KS, Cout, B, H, W, ups, BN) : -1;
+    if (kind < 0) {
+        ssm::set_error("wino conv_splitk: no two-workgroup configuration of %d couts for Cin/KS = %d on a %dx%d map", BN, (C1 + C2) / KS, H, W);
+        return SSM_E_UNSUPPORTED;
+    }
+    const int CK = kWInfo[kind].ck;
+    SSM_REQUIRE(((C1 + C2) / KS) % CK == 0, "wino conv_splitk: Cin / KS = %d is no multiple of the chunk (%d)", (C1 + C2) / KS, CK);
+    WinoParams p;
+    const int rf = wfill(p, x1, C1, x2, C2, w_packed, bias_packed, part, H, W, Cout, 0.f, 0, CK, ups ? W / 2 : W);
+    if (rf != SSM_OK) return rf;
+    p.KS = KS;
+    p.ksB = B;
+    return ups ? wdispatch<true>(kind, p, B, (hipStream_t)stream) : wdispatch<false>(kind, p, B, (hipStream_t)stream);
 }
 
 extern "C" int ssm_wino_conv2d_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,

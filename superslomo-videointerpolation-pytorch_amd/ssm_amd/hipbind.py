@@ -59,6 +59,10 @@ SIGNATURES = {
     "ssm_wino_conv2d_ups_add_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int,
                                              _c_int, _c_float, _c_int, _vp]),
     "ssm_wino_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
+    "ssm_wino_splitk_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip]),
+    "ssm_wino_conv2d_splitk_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                            _c_int, _vp]),
+    "ssm_splitk_finish_fwd": (_c_int, [SsmView, _c_int, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
     "ssm_wino_force_kind": (_c_int, [_c_int]),
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
@@ -379,10 +383,39 @@ class PackedWino:
                                         self.bn, stream_ptr()))
 
 
+def wino_splitk(pk, B, H, W, ups=False):
+    """Split factor the library proposes for this launch (1: none): launches that leave most of the chip idle - a 512 -> 512 layer on a
+    22x22 map at batch 2 is 96-192 workgroups walking all 512 channels each - run KS workgroups per output tile over Cin / KS channels
+    each and a second, element-wise launch adds the partial sums (csrc/ssm_wino.hip: ssm_wino_conv2d_splitk_fwd)."""
+    key = (B, H, W, bool(ups))
+    cache = pk.__dict__.setdefault("_splitk", {})
+    if key not in cache:
+        ks = ctypes.c_int(1)
+        check(load().ssm_wino_splitk_plan(pk.cin, pk.cout, B, H, W, 1 if ups else 0, pk.bn, ctypes.byref(ks)))
+        cache[key] = ks.value
+    return cache[key]
+
+
+def _splitk_launch(x1, c1, x2, c2, pk, y, pool, add, add_div, ks, ups, B, H, W, lrelu, slope):
+    lib, st = load(), stream_ptr()
+    scratch = pk.__dict__.setdefault("_splitk_part", {})          # the partial sums: one tensor per (stream, problem) - plans on other streams run beside this one
+    key = (getattr(st, "value", st), ks, B, H, W)
+    if key not in scratch:
+        scratch[key] = Planes(ks * B, pk.cout, H, W, pk.w.device)
+    part = scratch[key]
+    check(lib.ssm_wino_conv2d_splitk_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), part.view(), ks,
+                                         1 if ups else 0, B, H, W, pk.cout, pk.bn, st))
+    check(lib.ssm_splitk_finish_fwd(part.view(), ks, y, pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div,
+                                    B, pk.cout, H, W, slope, SSM_FLAG_LRELU if lrelu else 0, st))
+
+
 def conv2d_wino(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
     assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W, False)[1:], "filter was packed for another tile configuration"
+    ks = wino_splitk(pk, B, H, W, False)
+    if ks > 1:
+        return _splitk_launch(x1, c1, x2, c2, pk, y, pool, add, add_div, ks, False, B, H, W, lrelu, slope)
     check(lib.ssm_wino_conv2d_add_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                       pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, H, W,
                                       pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
@@ -393,6 +426,9 @@ def conv2d_ups_wino(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=Non
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
     assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W, True)[1:], "filter was packed for another tile configuration"
+    ks = wino_splitk(pk, B, H, W, True)
+    if ks > 1:
+        return _splitk_launch(a, c1, b, c2, pk, y, None, add, add_div, ks, True, B, H, W, lrelu, slope)
     check(lib.ssm_wino_conv2d_ups_add_fwd(a, c1, b if b is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                           add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
                                           SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))

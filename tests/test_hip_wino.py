@@ -140,3 +140,55 @@ def test_wino_pre_activation_addend(dev, kind):
         else:
             hb.conv2d_wino(px.view(), cin, None, 0, pk, y.view(), None, B, H, W, add=pa.view(), add_div=div)
         assert _err(y.to_nchw().cpu(), want) < 5e-5, "%s ups=%d: %.3e" % (kind, ups, _err(y.to_nchw().cpu(), want))
+
+
+def test_wino_split_k_bottleneck_layers(dev):
+    """Launches that leave most of the chip idle run split over the input channels (ssm_wino_conv2d_splitk_fwd + ssm_splitk_finish_fwd,
+    chosen by ssm_wino_splitk_plan inside hb.conv2d_wino / conv2d_ups_wino): config 3's bottleneck shapes - plain, two sources, fused
+    2x2 mean, pre-activation addend, fused upsample, an odd height - against the oracle, and bit-identical from run to run (the partial
+    sums are added in a fixed order)."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(77)
+    seen = set()
+    #            B  cin (c1)      cout  H   W   ups    pool   add
+    for B, cin, c1, cout, H, W, ups, pool, addend in ((2, 512, 512, 512, 22, 22, False, True, False),
+                                                     (2, 256, 128, 512, 22, 22, False, False, True),
+                                                     (2, 1024, 512, 512, 22, 22, True, False, False),
+                                                     (1, 512, 512, 64, 21, 26, False, False, False),
+                                                     (2, 256, 256, 256, 44, 44, False, True, False)):
+        c2 = cin - c1
+        h, wd = (H // 2, W // 2) if ups else (H, W)
+        xa, xb = torch.randn(B, c1, h, wd, generator=g), (torch.randn(B, c2, h, wd, generator=g) if c2 else None)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        add = torch.randn(B, cout, H, W, generator=g) if addend else None
+        xin = torch.cat([xa, xb], 1) if c2 else xa
+        z = O.conv2d(O.upsample2x_bilinear(xin) if ups else xin, w, bias)
+        if add is not None:
+            z = z + add
+        want = torch.where(z >= 0, z, z * 0.1)
+        pk = hb.PackedWino(w.to(dev), bias.to(dev), B, H, W, ups=ups)
+        ks = hb.wino_splitk(pk, B, H, W, ups)
+        seen.add(ks)
+        assert ks > 1, "%d -> %d at %dx%d, batch %d: the plan does not split (KS = %d)" % (cin, cout, H, W, B, ks)
+        pa, pb = hb.Planes(B, c1, h, wd, dev).load(xa.to(dev)), (hb.Planes(B, c2, h, wd, dev).load(xb.to(dev)) if c2 else None)
+        pz = hb.Planes(B, cout, H, W, dev).load(add.to(dev)) if add is not None else None
+        outs = []
+        for _ in range(2):
+            y, yp = hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, max(H // 2, 1), max(W // 2, 1), dev)
+            if ups:
+                hb.conv2d_ups_wino(pa.view(), c1, pb.view() if pb is not None else None, c2, pk, y.view(), B, H, W,
+                                   add=pz.view() if pz is not None else None)
+            else:
+                hb.conv2d_wino(pa.view(), c1, pb.view() if pb is not None else None, c2, pk, y.view(), yp.view() if pool else None, B, H, W,
+                               add=pz.view() if pz is not None else None)
+            outs.append((y.to_nchw().cpu(), yp.to_nchw().cpu()))
+        assert _err(outs[0][0], want) < 5e-5, "KS %d, %d -> %d at %dx%d ups=%d: %.3e" % (ks, cin, cout, H, W, ups, _err(outs[0][0], want))
+        if pool:
+            assert _err(outs[0][1], O.avg_pool2(want)) < 5e-5
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "split-K result differs between two runs"
+        full = y.full.cpu().clone()
+        full[:, :, hb.SSM_PADY:hb.SSM_PADY + H, hb.SSM_PADX:hb.SSM_PADX + W] = 0
+        assert float(full.abs().max()) == 0.0, "split-K wrote outside the interior"
+    assert len(seen) > 1, "the shapes of this test exercise one split factor only: %s" % seen
