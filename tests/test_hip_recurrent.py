@@ -162,7 +162,9 @@ def test_full_model_recurrent_vs_oracle(dev, kind, precision):
     # the loss path (all windows decoded) returns the same middle-window frame
     tgt = torch.zeros(2, 3, 3, 64, 96, device=dev)
     img2, losses = m(x.to(dev), t.to(dev), target_images=tgt, inference_mode=False)
-    assert float((img2 - img).abs().max()) < 1e-5 and tuple(losses.shape) == (2, 4) and bool(torch.isfinite(losses).all())
+    # (two launch plans of the same arithmetic: the loss path decodes every window, so its batch - and with it tile configurations and
+    # the split-K factors of the bottleneck layers, i.e. the order of the fp32 sums - differs from the inference plan's)
+    assert float((img2 - img).abs().max()) < 5e-5 and tuple(losses.shape) == (2, 4) and bool(torch.isfinite(losses).all())
 
 
 def test_interpolate_windows_hoisted(dev):
