@@ -65,6 +65,8 @@ for idx, text in enumerate(ins):
     ws = 0
     for j in range(idx + 1, min(idx + 4, len(ins))):
         p = ins[j]
+        if p.startswith(("s_endpgm", "s_branch", "s_setpc_b64")):          # the listing's next line is another block: nothing follows the store here
+            break
         nm = re.match(r"s_nop (\d+)", p)
         if nm:
             ws += int(nm.group(1)) + 1

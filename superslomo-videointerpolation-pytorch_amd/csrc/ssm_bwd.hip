@@ -32,19 +32,45 @@ inline dim3 pix_grid(int B, int H, int W) { return dim3((W + 63) / 64, (H + 3) /
 
 // channels are spread over blockIdx.z in groups of BWD_CPT so small maps with many channels still fill the chip
 #define BWD_CPT 4
-__global__ __launch_bounds__(256) void lrelu_bwd_kernel(ssm_view dy, ssm_view dpool, ssm_view yv, ssm_view dz, int C, int H, int W,
-                                                        float slope, int has_act, int cgroups) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    const int b = blockIdx.z / cgroups, cg = blockIdx.z - b * cgroups;
-    if (x >= W || y >= H) return;
-#pragma unroll
-    for (int i = 0; i < BWD_CPT; ++i) {
-        const int c = cg * BWD_CPT + i;
-        if (c >= C) break;
-        float g = dy.ptr ? vp(dy, b, c, y)[x] : 0.f;
-        if (dpool.ptr) g += 0.25f * vp(dpool, b, c, y >> 1)[x >> 1];
-        if (has_act) g *= (vp(yv, b, c, y)[x] > 0.f) ? 1.0f : slope;
-        vp(dz, b, c, y)[x] = g;
+// dZ = (dY + 0.25 * dPool[y / 2][x / 2]) * LeakyReLU'(Y): the adjoint of layers.conv's activation and of the fused 2x2 mean, over ONE flat
+// index (r5): a thread owns VW consecutive pixels of one row of one channel.  A grid shaped after the map
+// leaves most lanes of a wave idle on the 11-46 pixel wide maps of a training step (58 launches per step), and on the wide maps four
+// pixels per thread move as 16-byte pieces (VW = 4: W a multiple of 4 and 16-byte aligned views; VW = 1 otherwise).
+template <int VW>
+__global__ __launch_bounds__(256) void lrelu_bwd_flat_kernel(ssm_view dy, ssm_view dpool, ssm_view yv, ssm_view dz, int C, int H, int W,
+                                                             float slope, int has_act, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int wq = W / VW;
+    const int x = (int)(idx % wq) * VW;
+    long long r = idx / wq;
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    float g[VW];
+    if constexpr (VW == 4) {
+        float4 v = dy.ptr ? *reinterpret_cast<const float4 *>(vp(dy, b, c, y) + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[0] = v.x, g[1] = v.y, g[2] = v.z, g[3] = v.w;
+        if (dpool.ptr) {
+            const float2 q = *reinterpret_cast<const float2 *>(vp(dpool, b, c, y >> 1) + (x >> 1));
+            g[0] += 0.25f * q.x;
+            g[1] += 0.25f * q.x;
+            g[2] += 0.25f * q.y;
+            g[3] += 0.25f * q.y;
+        }
+        if (has_act) {
+            const float4 a = *reinterpret_cast<const float4 *>(vp(yv, b, c, y) + x);
+            g[0] *= a.x > 0.f ? 1.0f : slope;
+            g[1] *= a.y > 0.f ? 1.0f : slope;
+            g[2] *= a.z > 0.f ? 1.0f : slope;
+            g[3] *= a.w > 0.f ? 1.0f : slope;
+        }
+        *reinterpret_cast<float4 *>(vp(dz, b, c, y) + x) = make_float4(g[0], g[1], g[2], g[3]);
+    } else {
+        g[0] = dy.ptr ? vp(dy, b, c, y)[x] : 0.f;
+        if (dpool.ptr) g[0] += 0.25f * vp(dpool, b, c, y >> 1)[x >> 1];
+        if (has_act) g[0] *= (vp(yv, b, c, y)[x] > 0.f) ? 1.0f : slope;
+        vp(dz, b, c, y)[x] = g[0];
     }
 }
 
@@ -594,6 +620,54 @@ __global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(ssm_view du, ssm_
     }
 }
 
+// The same adjoint for even W and 16-byte aligned hi-res rows (r5): a thread owns TWO neighbouring low-res pixels of one channel - the six
+// hi-res columns 2x-1 .. 2x+4 of a row arrive as one 16-byte piece + two scalars (12 loads for two outputs instead of 32) - over one flat
+// index (the maps are 22-176 pixels wide: a grid shaped after the map leaves lanes idle).
+__global__ __launch_bounds__(256) void upsample_cat_bwd2_kernel(ssm_view du, ssm_view da, int Ca, ssm_view dbv, int Cb, int H, int W, int acc_a,
+                                                                int acc_b, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int C = Ca + Cb, wp = W / 2;
+    const int x = 2 * (int)(idx % wp);          // H, W = LOW-res dims
+    long long r = idx / wp;
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    const float wy[4] = {y > 0 ? 0.25f : 0.f, y > 0 ? 0.75f : 1.0f, y < H - 1 ? 0.75f : 1.0f, y < H - 1 ? 0.25f : 0.f};
+    // 1-D weights of the six columns for the two outputs x (columns 0..3) and x + 1 (columns 2..5)
+    const float a0 = x > 0 ? 0.25f : 0.f, a1 = x > 0 ? 0.75f : 1.0f, a2 = 0.75f, a3 = 0.25f;                       // x < W - 1 always (W even)
+    const float b2 = 0.25f, b3 = 0.75f, b4 = x + 1 < W - 1 ? 0.75f : 1.0f, b5 = x + 1 < W - 1 ? 0.25f : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (wy[j] == 0.f) continue;
+        const float *row = vp(du, b, c, 2 * y - 1 + j) + 2 * x;
+        const float4 m = *reinterpret_cast<const float4 *>(row);          // columns 2x .. 2x+3
+        const float l = a0 != 0.f ? row[-1] : 0.f, rr = b5 != 0.f ? row[4] : 0.f;
+        // (same association as the one-pixel kernel: left to right within a row, rows top to bottom)
+        float t0 = 0.f, t1 = 0.f;
+        if (a0 != 0.f) t0 += a0 * l;
+        t0 += a1 * m.x;
+        t0 += a2 * m.y;
+        t0 += a3 * m.z;
+        t1 += b2 * m.y;
+        t1 += b3 * m.z;
+        t1 += b4 * m.w;
+        if (b5 != 0.f) t1 += b5 * rr;
+        s0 += wy[j] * t0;
+        s1 += wy[j] * t1;
+    }
+    float2 *d = reinterpret_cast<float2 *>((c < Ca ? vp(da, b, c, y) : vp(dbv, b, c - Ca, y)) + x);
+    const bool acc = c < Ca ? acc_a : acc_b;
+    float2 o = make_float2(s0, s1);
+    if (acc) {
+        const float2 p = *d;
+        o.x += p.x;
+        o.y += p.y;
+    }
+    *d = o;
+}
+
 // ---- bilinear sampler with derivatives --------------------------------------------------------------------
 struct TapsD {
     int o00, o01, o10, o11;
@@ -818,10 +892,14 @@ extern "C" int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view d
                              int has_act, void *stream) {
     SSM_CHECK_DIMS("lrelu_bwd");
     SSM_REQUIRE(dz.ptr && (dy.ptr || dpool.ptr) && (!has_act || y.ptr) && C > 0, "lrelu_bwd: null pointer / C");
-    const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
-    SSM_REQUIRE((long long)B * cgroups <= 65535, "lrelu_bwd: B*C too large for one launch");
-    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y,
-                       dz, C, H, W, slope, has_act, cgroups);
+    auto al16 = [](const ssm_view &v) { return !v.ptr || (ssm::aligned16(v.ptr) && v.sh % 4 == 0 && v.sc % 4 == 0 && v.sb % 4 == 0); };
+    auto al8 = [](const ssm_view &v) { return !v.ptr || ((reinterpret_cast<size_t>(v.ptr) & 7) == 0 && v.sh % 2 == 0 && v.sc % 2 == 0 && v.sb % 2 == 0); };
+    const bool vec = W % 4 == 0 && al16(dy) && al16(y) && al16(dz) && al8(dpool);
+    const long long total = (long long)B * C * H * (vec ? W / 4 : W);
+    SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "lrelu_bwd: problem too large for one launch");
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (vec) hipLaunchKernelGGL(lrelu_bwd_flat_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act, total);
+    else hipLaunchKernelGGL(lrelu_bwd_flat_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act, total);
     return ssm::check_launch("ssm_lrelu_bwd");
 }
 
@@ -988,6 +1066,15 @@ extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view
                                       void *stream) {
     SSM_CHECK_DIMS("upsample2x_cat_bwd");
     SSM_REQUIRE(du.ptr && da.ptr && Ca > 0 && Cb >= 0 && (Cb == 0 || db.ptr), "upsample2x_cat_bwd: null pointer / channels");
+    auto al16 = [](const ssm_view &v) { return ssm::aligned16(v.ptr) && v.sh % 4 == 0 && v.sc % 4 == 0 && v.sb % 4 == 0; };
+    auto al8 = [](const ssm_view &v) { return (reinterpret_cast<size_t>(v.ptr) & 7) == 0 && v.sh % 2 == 0 && v.sc % 2 == 0 && v.sb % 2 == 0; };
+    if (W % 2 == 0 && al16(du) && al8(da) && (Cb == 0 || al8(db))) {
+        const long long total = (long long)B * (Ca + Cb) * H * (W / 2);
+        SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "upsample2x_cat_bwd: problem too large for one launch");
+        hipLaunchKernelGGL(upsample_cat_bwd2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, du, da, Ca,
+                           Cb ? db : da, Cb, H, W, acc_a, acc_b, total);
+        return ssm::check_launch("ssm_upsample2x_cat_bwd");
+    }
     const int cgroups = (Ca + Cb + BWD_CPT - 1) / BWD_CPT;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "upsample2x_cat_bwd: B*C too large for one launch");
     hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, du, da,

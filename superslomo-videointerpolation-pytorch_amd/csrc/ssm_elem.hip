@@ -404,43 +404,47 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(ssm_view xin, ssm_view yo
 
 // Second half of a split-K convolution (csrc/ssm_wino.hip, ssm_wino_conv2d_splitk_fwd): y = act(sum_ks part[ks * B + b] + addend), the
 // partial sums added in the order ks = 0, 1, ... (deterministic), + the fused 2x2 mean (vertical pairs first, like the convolution
-// kernels' epilogues).  One thread = a 2x2 block of one channel (W even, H any); channels in groups of 4 over blockIdx.z.
+// kernels' epilogues).  One thread = a 2x2 block of one channel (W even, H any), the blocks of the whole batch in one flat index: the
+// maps this runs on are 22-46 pixels wide - a grid shaped after the map would leave most lanes of a wave without a block.
 __global__ __launch_bounds__(256) void splitk_finish_kernel(ssm_view part, int KS, ssm_view yout, ssm_view pool, ssm_view add, int adiv, int B,
-                                                            int C, int H, int W, float sl, int cgroups) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;          // block coordinates
-    const int b = blockIdx.z / cgroups, c0 = (blockIdx.z - b * cgroups) * 4;
-    if (2 * x >= W || 2 * y >= H) return;
+                                                            int C, int H, int W, float sl, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int bw = W / 2, bh = (H + 1) / 2;
+    const int x = (int)(idx % bw);
+    long long r = idx / bw;
+    const int y = (int)(r % bh);
+    r /= bh;
+    const int c = (int)(r % C), b = (int)(r / C);
     const bool two = 2 * y + 1 < H;
-    for (int c = c0; c < c0 + 4 && c < C; ++c) {
-        float2 r0 = make_float2(0.f, 0.f), r1 = make_float2(0.f, 0.f);
-        for (int k = 0; k < KS; ++k) {
-            const float2 a0 = *reinterpret_cast<const float2 *>(vp(part, k * B + b, c, 2 * y) + 2 * x);
-            r0.x += a0.x;
-            r0.y += a0.y;
-            if (two) {
-                const float2 a1 = *reinterpret_cast<const float2 *>(vp(part, k * B + b, c, 2 * y + 1) + 2 * x);
-                r1.x += a1.x;
-                r1.y += a1.y;
-            }
+    float2 r0 = make_float2(0.f, 0.f), r1 = make_float2(0.f, 0.f);
+    for (int k = 0; k < KS; ++k) {
+        const float2 a0 = *reinterpret_cast<const float2 *>(vp(part, k * B + b, c, 2 * y) + 2 * x);
+        r0.x += a0.x;
+        r0.y += a0.y;
+        if (two) {
+            const float2 a1 = *reinterpret_cast<const float2 *>(vp(part, k * B + b, c, 2 * y + 1) + 2 * x);
+            r1.x += a1.x;
+            r1.y += a1.y;
         }
-        if (add.ptr) {
-            const float2 z0 = *reinterpret_cast<const float2 *>(vp(add, b / adiv, c, 2 * y) + 2 * x);
-            r0.x += z0.x;
-            r0.y += z0.y;
-            if (two) {
-                const float2 z1 = *reinterpret_cast<const float2 *>(vp(add, b / adiv, c, 2 * y + 1) + 2 * x);
-                r1.x += z1.x;
-                r1.y += z1.y;
-            }
-        }
-        r0.x = fmaxf(r0.x, r0.x * sl);
-        r0.y = fmaxf(r0.y, r0.y * sl);
-        r1.x = fmaxf(r1.x, r1.x * sl);
-        r1.y = fmaxf(r1.y, r1.y * sl);
-        *reinterpret_cast<float2 *>(vp(yout, b, c, 2 * y) + 2 * x) = r0;
-        if (two) *reinterpret_cast<float2 *>(vp(yout, b, c, 2 * y + 1) + 2 * x) = r1;
-        if (pool.ptr && two) vp(pool, b, c, y)[x] = ((r0.x + r1.x) + (r0.y + r1.y)) * 0.25f;
     }
+    if (add.ptr) {
+        const float2 z0 = *reinterpret_cast<const float2 *>(vp(add, b / adiv, c, 2 * y) + 2 * x);
+        r0.x += z0.x;
+        r0.y += z0.y;
+        if (two) {
+            const float2 z1 = *reinterpret_cast<const float2 *>(vp(add, b / adiv, c, 2 * y + 1) + 2 * x);
+            r1.x += z1.x;
+            r1.y += z1.y;
+        }
+    }
+    r0.x = fmaxf(r0.x, r0.x * sl);
+    r0.y = fmaxf(r0.y, r0.y * sl);
+    r1.x = fmaxf(r1.x, r1.x * sl);
+    r1.y = fmaxf(r1.y, r1.y * sl);
+    *reinterpret_cast<float2 *>(vp(yout, b, c, 2 * y) + 2 * x) = r0;
+    if (two) *reinterpret_cast<float2 *>(vp(yout, b, c, 2 * y + 1) + 2 * x) = r1;
+    if (pool.ptr && two) vp(pool, b, c, y)[x] = ((r0.x + r1.x) + (r0.y + r1.y)) * 0.25f;
 }
 
 // F.upsample(cat[a,b], size=(2h,2w), mode="bilinear"), align_corners=False:
@@ -725,11 +729,11 @@ extern "C" int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view
     SSM_REQUIRE(even_view(part) && even_view(y), "splitk_finish: partial sums and output must be 8-byte aligned views with even strides");
     SSM_REQUIRE(!add.ptr || (even_view(add) && add_div >= 1 && B % add_div == 0), "splitk_finish: addend view / divisor");
     SSM_REQUIRE(!pool.ptr || (H % 2 == 0), "splitk_finish: the fused 2x2 mean needs even H, W");
-    const int cgroups = (C + 3) / 4;
-    SSM_REQUIRE((long long)B * cgroups <= 65535, "splitk_finish: B*C too large for one launch");
+    const long long total = (long long)B * C * ((H + 1) / 2) * (W / 2);
+    SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "splitk_finish: problem too large for one launch");
     const float sl = (flags & SSM_FLAG_LRELU) ? slope : 1.f;
-    hipLaunchKernelGGL(splitk_finish_kernel, pix_grid(B * cgroups, (H + 1) / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, part, KS, y, pool, add,
-                       add_div < 1 ? 1 : add_div, B, C, H, W, sl, cgroups);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, pool, add,
+                       add_div < 1 ? 1 : add_div, B, C, H, W, sl, total);
     return ssm::check_launch("ssm_splitk_finish_fwd");
 }
 
