@@ -1,6 +1,2 @@
-set -e
-timeout -k 10 900 python -m pytest tests/test_hip_backward.py -x -q -m gpu 2>&1 | tail -2
-for i in 1 2; do
-timeout -k 10 300 python bench.py --no-configs --mode train --precision f32w --steps 20 --warmup 3 --no-cpu-baseline 2>>gpurun_out/_e.txt | python -c "
-import json,sys; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('+ two-pixel upsample_cat_bwd:', d['value'], d['ms_per_step'], d['time_split_ms_per_step'])"
-done
+R=$(pwd); cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r13t2/prof -o train -- python3 $R/bench.py --no-configs --mode train --precision f32w --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timers > $R/gpurun_out/r13t2_train_line.json 2> $R/gpurun_out/r13t2_err.log
