@@ -344,7 +344,7 @@ def family_clocks(eng, dev, peak, fams):
 TRAIN_DTYPE_NOTE = {
     "f16f8": "f32 parameters/activations/gradients; products via 1x f16 + 2x block-scaled e4m3 MFMA (forward, data gradients) and 3x bf16 "
              "MFMA on hi/lo-split operands (weight gradients), f32 accumulate - narrower than f32",
-    "f32": "f32 (fp32 MFMA)", "f32w": "f32 (fp32 MFMA; forward and data-gradient 3x3 convolutions as Winograd F(2x2,3x3))"}
+    "f32": "f32 (fp32 MFMA)", "f32w": "f32 (fp32 MFMA; forward and data-gradient convolutions in the Winograd forms: 3x3 F(2x2,3x3), 7x7 / 5x5 blocked; weight gradients direct)"}
 
 
 def train_bench(args):
@@ -464,8 +464,8 @@ def train_bench(args):
                                "algorithmic_in_kernel": round(d["flops"] / d["ms"] / 1e9, 2)}
                          for fam, d in summ.items() if d["flops"] > 0},
             "traffic": None,
-            "note": ("3x3 forward / data-gradient / VGG layers run as Winograd F(2x2,3x3): 16/36 of their direct-form FLOP are issued; the data gradients of "
-                     "conv1b / conv2a / conv2b in the blocked 7x7 / F(4x4,5x5) forms (1/4, 64/400); weight gradients, 7x7 / 5x5 forward and final "
+            "note": ("3x3 forward / data-gradient / VGG layers run as Winograd F(2x2,3x3) / F(4x4,3x3): 16/36 / 1/4 of their direct-form FLOP are issued; the "
+                     "7x7 / 5x5 layers (forward and data gradients) in the blocked 7x7 / F(4x4,5x5) forms (1/4, 64/400); weight gradients and final "
                      "layers run in the direct form" if train_mode == "f32w" else
                      "every product issued in the direct form: FLOP counted = FLOP issued")}
         if args.detail:

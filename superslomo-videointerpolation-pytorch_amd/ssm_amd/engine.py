@@ -97,6 +97,12 @@ WINO4 = os.environ.get("SSM_WINO4", "1")
 # but the step is not faster at 2 samples of 352x352: forward 4.97 -> 4.88 ms and data gradients 7.87 -> 7.26 ms in kernel, wall 20.8 ->
 # 21.3 ms per step (the 64-cout form holds a whole CU's LDS, and the weight-gradient stream runs beside it) - off by default.
 TRAIN_WINO4 = os.environ.get("SSM_TRAIN_WINO4", "0")
+# The 7x7 / 5x5 layers of a TRAINING plan's forward in the two-dimensional blocked forms of the inference plans (csrc/ssm_wino7.hip,
+# ssm_wino5.hip).  r3 kept them direct after measuring the 1-D forms F(2,7) / F(4,5) in the forward: parameter gradients at 64x64 4e-4 from
+# CPU autograd (bar 3e-4).  Measured in r5 with the 2-D forms (profiles/r14d_grad_matrix.txt): 5.9e-5 at 64x64 (direct forward: 2e-6;
+# the data gradients' form makes no difference), 6.5e-4 at 2x352x352 like the direct forward - inside both bars, every test of
+# tests/test_hip_backward.py green - and the step is 4 % faster (16.6 -> 15.95 ms).  $SSM_TRAIN_FWD_BLOCKED=0: direct forward
+TRAIN_FWD_BLOCKED = os.environ.get("SSM_TRAIN_FWD_BLOCKED", "1")
 
 
 # fused-upsample 3x3 layers of an f32w INFERENCE plan in the sub-pixel form (interior: a plain F(4x4,3x3) convolution of the low-res sources with 4 Cout
@@ -210,11 +216,11 @@ class UNetPlan:
         self._Bcur = B
         self.mode, self.hl8, self.q8 = mode, mode != "f32", mode == "f16f8"
         self.fuse_up = bool(fuse_upsample)      # concat+upsample fused into the consumer conv's loader (every mode)
-        # 7x7 / 5x5 layers in the 1-D Winograd form: inference plans only.  The training plans (materialised upsample tensors) keep them
-        # direct: the 8-point transforms round ~5x coarser than an fmaf chain, which moves more pre-activations across the LeakyReLU /
-        # |.| kinks of the loss - the parameter gradients at 64x64 then sit 4e-4 from CPU autograd instead of 6e-5 (bar 3e-4)
-        self.wino1d = self.wino and self.fuse_up and not twins
-        self.wino4 = self.wino and (self.wino1d or TRAIN_WINO4 == "1")          # F(4x4,3x3) for the 3x3 layers
+        # 7x7 / 5x5 layers in a Winograd form (choose_algo: the blocked 2-D forms, else the 1-D ones): inference plans, and since r5 the
+        # training plans too (TRAIN_FWD_BLOCKED above: the gradient bars hold with the 2-D forms)
+        infer_plan = self.fuse_up and not twins
+        self.wino1d = self.wino and (infer_plan or TRAIN_FWD_BLOCKED == "1")
+        self.wino4 = self.wino and (infer_plan or TRAIN_WINO4 == "1")          # F(4x4,3x3) for the 3x3 layers
         # hoist = (B1, G): stage-2 inference plan whose batch holds G interpolation times for each of B1 pairs (entry p*G + i).  The
         # parts of two convolutions' inputs that do not depend on t - the image channels 0:3 / 13:16 of conv1a's 16-channel input
         # (flow_interpolation.py:364-367) and the stage-1 half of the cross-skip concat in front of conv7a (:98-101,224-231) - are
