@@ -517,10 +517,13 @@ int ssm_flowinterp_inputs_bwd(ssm_view img6, ssm_view flow4, ssm_view din16, ssm
  * same kernel on the transposed filters, ReLU' is ssm_lrelu_bwd with slope 0.  fp32 planes.
  *  ssm_maxpool2_fwd   y[B,C,H/2,W/2] = nn.MaxPool2d(2, 2)(x)                       (H, W = input size, even)
  *  ssm_maxpool2_bwd   dx = dy routed to the first maximum of each 2x2 window (row-major scan, as torch's backward)
- *  ssm_sqdiff_grad    out = coef[b] * (a - b): gradient of the per-sample mean squared feature difference         */
+ *  ssm_sqdiff_grad    out = coef[b] * (a - b): gradient of the per-sample mean squared feature difference
+ *  ssm_sqdiff_mean    out[b] = mean over C x H x W of (a - b)^2, the per-sample MSELoss(reduce=False).mean of losses.py:218,227
+ *                     (two deterministic launches; scratch: 64 * B device floats owned by the caller)                    */
 int ssm_maxpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int W, void *stream);
 int ssm_maxpool2_bwd(ssm_view x, ssm_view dy, ssm_view dx, int B, int C, int H, int W, void *stream);
 int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_view out, int B, int C, int H, int W, void *stream);
+int ssm_sqdiff_mean(ssm_view a, ssm_view b, float *scratch, float *out, int B, int C, int H, int W, void *stream);
 
 /* ---- recurrent bottleneck (BOTTLENECK=CLSTM|CGRU; BASELINE config 4) -----------------------------------------
  * Replaces ConvBLSTM / ConvBGRU(in_channels=512, hidden_channels=512, kernel_size=(3,3), num_layers=2,

@@ -883,6 +883,40 @@ __global__ __launch_bounds__(256) void sqdiff_grad_kernel(ssm_view a, ssm_view b
     for (int c = c0; c < c1; ++c) vp(out, b, c, y)[x] = k * (vp(a, b, c, y)[x] - vp(bb, b, c, y)[x]);
 }
 
+// per-sample mean of (a - b)^2 over C x H x W in two deterministic launches: SQD_CHUNKS blocks per sample each reduce a contiguous slice
+// (in-thread sums, then a fixed tree through LDS), then one thread per sample adds the slices in order (r5: replaces four strided torch
+// kernels - subtract, square, copy to contiguous, reduce - of the perceptual term's forward)
+#define SQD_CHUNKS 64
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(ssm_view a, ssm_view bb, float *__restrict__ partial, int C, int H, int W) {
+    __shared__ float red[256];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const long long n = (long long)C * H * W, per = (n + SQD_CHUNKS - 1) / SQD_CHUNKS;
+    const long long e0 = chunk * per, e1 = e0 + per < n ? e0 + per : n;
+    float s = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int x = (int)(e % W);
+        const long long r = e / W;
+        const int y = (int)(r % H), c = (int)(r / H);
+        const float d = vp(a, b, c, y)[x] - vp(bb, b, c, y)[x];
+        s += d * d;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[b * SQD_CHUNKS + chunk] = red[0];
+}
+
+__global__ void sqdiff_finish_kernel(const float *__restrict__ partial, float *__restrict__ out, int B, float inv_n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int k = 0; k < SQD_CHUNKS; ++k) s += partial[b * SQD_CHUNKS + k];
+    out[b] = s * inv_n;
+}
+
 }  // namespace
 
 #define SSM_CHECK_DIMS(name)                                                                         \
@@ -1127,6 +1161,15 @@ extern "C" int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_vi
     SSM_REQUIRE((long long)B * cgroups <= 65535, "sqdiff_grad: B*C too large for one launch");
     hipLaunchKernelGGL(sqdiff_grad_kernel, pix_grid(B * cgroups, H, W), dim3(64, 4), 0, (hipStream_t)stream, a, b, coef, out, C, H, W, cgroups);
     return ssm::check_launch("ssm_sqdiff_grad");
+}
+
+extern "C" int ssm_sqdiff_mean(ssm_view a, ssm_view b, float *scratch, float *out, int B, int C, int H, int W, void *stream) {
+    SSM_CHECK_DIMS("sqdiff_mean");
+    SSM_REQUIRE(a.ptr && b.ptr && scratch && out && C > 0, "sqdiff_mean: null pointer");
+    hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(SQD_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, a, b, scratch, C, H, W);
+    hipLaunchKernelGGL(sqdiff_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, out, B,
+                       1.0f / ((float)C * (float)H * (float)W));
+    return ssm::check_launch("ssm_sqdiff_mean");
 }
 
 extern "C" int ssm_warp_bilinear_bwd(ssm_view img, ssm_view flow, ssm_view dy, ssm_view dflow, ssm_view dimg, int B, int C, int H, int W,

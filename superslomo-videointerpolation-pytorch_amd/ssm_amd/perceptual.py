@@ -207,6 +207,7 @@ class PerceptualTerm:
         self.coef = torch.empty(B, dtype=torch.float32, device=device)
         self.both = torch.empty(2 * B, 3, H, W, dtype=torch.float32, device=device)
         self._side, self._pending = None, None
+        self._sq_scratch = torch.empty(64 * B, dtype=torch.float32, device=device)          # slice sums of ssm_sqdiff_mean
 
     def begin_target(self, target):
         """Start the target's half of the VGG pass on a second stream (the training step calls this before the U-Net forward: the
@@ -223,14 +224,18 @@ class PerceptualTerm:
         """-> [B] unweighted per-sample feature MSE."""
         B = self.B
         if self._pending is not None and self._pending is target:
-            f = self.vgg.forward(pred, b0=0).interior
+            self.vgg.forward(pred, b0=0)
             torch.cuda.current_stream().wait_stream(self._side)
         else:
             self.both[:B].copy_(pred)
             self.both[B:].copy_(target)
-            f = self.vgg.forward(self.both).interior
+            self.vgg.forward(self.both)
         self._pending = None
-        return ((f[:B] - f[B:]) ** 2).reshape(B, -1).mean(dim=1)
+        phi = self.vgg.t[self.vgg.out]
+        out = torch.empty(B, dtype=torch.float32, device=phi.full.device)
+        hb.check(hb.load().ssm_sqdiff_mean(phi.view(), phi.view(b0=B), self._sq_scratch.data_ptr(), out.data_ptr(), B, phi.C, phi.H, phi.W,
+                                           hb.stream_ptr()))
+        return out
 
     def grad_pred(self, weight):
         """weight [B] = (upstream gradient x lambda_p) per sample -> Planes [2B,3,H,W] whose first B entries hold
