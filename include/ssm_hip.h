@@ -180,6 +180,13 @@ int ssm_wino_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const f
                                int KS, int ups, int B, int H, int W, int Cout, int BN, void *stream);
 int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view pool, ssm_view add, int add_div, int B, int C, int H, int W,
                           float slope, int flags, void *stream);
+/* The direct-form twin (csrc/ssm_conv.hip) for the maps no Winograd form takes (odd widths: config 3's 11x11 bottleneck): the same
+ * convolution as ssm_conv2d_fwd - one or two sources, no fused pool - with KS workgroups per output tile; `part` and the finishing
+ * launch as above (ssm_splitk_finish_fwd takes odd widths too).  ssm_conv_splitk_plan: KS for the tile configuration the filter was
+ * packed for (1: do not split; $SSM_CONV_SPLITK=0: always 1).                                                                    */
+int ssm_conv_splitk_plan(int k, int Cin, int Cout, int B, int H, int W, int *KS);
+int ssm_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view part,
+                          int KS, int B, int H, int W, int Cout, int k, void *stream);
 /* ... with the pre-activation addend of ssm_conv2d_add_fwd (8-byte aligned view). */
 int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y,
                             ssm_view pool, ssm_view add, int add_div, int B, int H, int W, int Cout, float slope, int flags,

@@ -69,6 +69,9 @@ struct ConvParams {
     const float *add;
     long long asb, asc;
     int ash, adiv;
+    // split-K launches (ssm_conv2d_splitk_fwd): NSPLIT workgroups share an output tile, workgroup ks sums input channels
+    // [ks, ks + 1) * Cin / NSPLIT and stores its raw sums (the bias with ks = 0; no activation) as batch entry ks * ksB + b of dst
+    int NSPLIT, ksB;
 };
 
 template <int KS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int CK_, int GW_ = 32>
@@ -118,7 +121,9 @@ struct Lds {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),      \
                                      (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
 
-template <class C, bool UPS>
+// SPLIT: the split-K instantiation (ssm_conv2d_splitk_fwd; compiled for the tile configurations of CONV_SPLIT_OK only - the large-tile
+// configurations sit at the register cap, and the split's three extra scalars tip them into scratch)
+template <class C, bool UPS, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<C, UPS>;
@@ -132,6 +137,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int wn = wid % C::WN, wy = (wid / C::WN) % C::WY, wx = wid / (C::WN * C::WY);
 
     int id = ssm_xcd_tile(blockIdx.x, gridDim.x);
+    const int ks = SPLIT ? id % p.NSPLIT : 0;          // (split-K partners are neighbours in the grid: they read the same patches)
+    if (SPLIT) id /= p.NSPLIT;
     const int nb = id % p.NB;
     id /= p.NB;
     const int tx = id % p.tilesX;
@@ -139,12 +146,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int ty = id % p.tilesY;
     const int b = id / p.tilesY;
     const int x0 = tx * C::TW, y0 = ty * C::TH;
+    const int nchunks = SPLIT ? p.Cin / C::CK / p.NSPLIT : p.Cin / C::CK;          // (split launches are single-source: the offsets below cover them)
 
     // DMA origin: element (c, y0-PAD, x0-4) of the padded planes, or (c, y0/2-1, x0/2-4) of the low-res source
     const long long porg = UPS ? (long long)(y0 / 2 - 1) * p.sh + (x0 / 2 - 4) : (long long)(y0 - C::PAD) * p.sh + (x0 - 4);
-    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg;
+    const long long cbeg = SPLIT ? (long long)ks * nchunks * C::CK : 0;          // first input channel of this workgroup
+    const float *pbase1 = p.src1 + (long long)b * p.sb1 + porg + cbeg * p.sc;
     const float *pbase2 = p.src2 + (long long)b * p.sb2 + porg;
-    const float *wbase = p.wpk + (long long)nb * p.Cin * (KS2 * BN);
+    const float *wbase = p.wpk + ((long long)nb * p.Cin + cbeg) * (KS2 * BN);
 
     // per-lane source offset of each LDS-DMA piece this wave issues (same for every chunk)
     int off[L::NI];
@@ -240,7 +249,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     const int aBase = half * (KS2 * BN) + wn * (NT * 32) + l31;
     const int bBase = half * (PH * PW) + (wy * C::MTY * GH + gy) * PW + wx * (C::MTX * GW) + gx + (4 - C::PAD);
 
-    const int nchunks = p.Cin / C::CK;
     issue(0, 0);
     for (int ch = 0; ch < nchunks; ++ch) {
         // chunk ch has landed for every wave; every wave is done reading chunk ch-1
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const float bv0 = p.bias[nb * BN + (wn * NT + n) * 32 + l31];       // every lane loads (no divergent branch), half 1 drops it
-            abias[n] = half ? 0.f : bv0;
+            abias[n] = (half || (SPLIT && ks != 0)) ? 0.f : bv0;
         }
         const float ones = half ? 0.f : 1.f;
 #pragma unroll
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p) {
     // The first version recomputed a 64-bit address and three predicates per store: ~16 vector instructions per store, 1600 per
     // wave and tile - a fifth of the MFMA time of a 32->32 3x3 tile.
     const float sl = p.lrelu ? p.slope : 1.f;
-    float *dstb = p.dst + (long long)b * p.dsb;
+    float *dstb = p.dst + (long long)(SPLIT ? b + ks * p.ksB : b) * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
     const int cu0 = nb * BN + wn * (NT * 32);                    // first cout of this wave's block (uniform)
     const bool full = cu0 + NT * 32 <= p.Cout;                   // uniform: no cout padding in this wave's block
@@ -579,6 +587,10 @@ int pick_kind(int k, int Cin, int Cout, int B, int H, int W, int pool, int ups) 
     return best;
 }
 
+// tile configurations that have a split-K instantiation: the 32-cout 3x3 one the small maps run on (ssm_conv_plan's pick for 11x11 .. 22x22)
+template <class C>
+constexpr bool conv_split_ok() { return std::is_same<C, CfgK3N32T>::value; }
+
 template <class C, bool UPS>
 int launch(ConvParams &p, int B, hipStream_t st) {
     p.tilesX = (p.W + C::TW - 1) / C::TW;
@@ -588,7 +600,7 @@ int launch(ConvParams &p, int B, hipStream_t st) {
         ssm::set_error("conv: fused pool needs an even row tile");
         return SSM_E_UNSUPPORTED;
     }
-    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.NB * B * p.NSPLIT;
     if (blocks <= 0 || blocks > 0x7fffffffLL) {
         ssm::set_error("conv: grid of %lld workgroups out of range", blocks);
         return SSM_E_ARG;
@@ -598,6 +610,15 @@ int launch(ConvParams &p, int B, hipStream_t st) {
         return SSM_E_UNSUPPORTED;
     } else {
         constexpr int lds_bytes = Lds<C, UPS>::BYTES;
+        if (p.NSPLIT > 1) {
+            if constexpr (!UPS && conv_split_ok<C>()) {
+                hipLaunchKernelGGL((conv_mfma_kernel<C, false, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+                return ssm::check_launch("ssm_conv2d_splitk_fwd");
+            } else {
+                ssm::set_error("conv_splitk: this tile configuration has no split-K form");
+                return SSM_E_UNSUPPORTED;
+            }
+        }
         auto kern = conv_mfma_kernel<C, UPS>;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
         return ssm::check_launch(UPS ? "ssm_conv2d_ups_fwd" : "ssm_conv2d_fwd");
@@ -679,6 +700,8 @@ int fill_common(ConvParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const f
     p.asb = p.asc = 0;
     p.ash = 0;
     p.adiv = 1;
+    p.NSPLIT = 1;
+    p.ksB = 0;
 #ifdef SSM_CONV_ABLATE
     if (const char *e = getenv("SSM_CONV_ABL")) p.abl = atoi(e);
 #endif
@@ -763,6 +786,44 @@ extern "C" int ssm_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, cons
         p.psc = pool.sc;
         p.psh = pool.sh;
     }
+    return dispatch<false>(kind, p, B, (hipStream_t)stream);
+}
+
+// ---- split-K for launches that leave most of the chip idle (r5; the direct-form twin of ssm_wino_conv2d_splitk_fwd, csrc/ssm_wino.hip) ----
+// The bottleneck convolutions of config 3 on the 11x11 maps (odd width: no Winograd form) are a few dozen workgroups that each walk all
+// 512 input channels.  ssm_conv_splitk_plan proposes KS for the tile configuration the filter was packed for; the partial maps are
+// finished by ssm_splitk_finish_fwd (csrc/ssm_elem.hip) like the Winograd form's.
+extern "C" int ssm_conv_splitk_plan(int k, int Cin, int Cout, int B, int H, int W, int *KS) {
+    SSM_REQUIRE(KS, "conv splitk_plan: null pointer");
+    *KS = 1;
+    static const int enabled = [] {
+        const char *e = getenv("SSM_CONV_SPLITK");
+        return e ? atoi(e) : 1;
+    }();
+    if (!enabled || Cin < 128) return SSM_OK;
+    const int kd = pick_kind(k, Cin, Cout, B, H, W, 0, 0);
+    if (kd != K3N32T) return SSM_OK;          // (the one configuration with a split-K instantiation, see conv_split_ok)
+    const long long nwg = (long long)B * ((W + kInfo[kd].tw - 1) / kInfo[kd].tw) * ((H + kInfo[kd].th - 1) / kInfo[kd].th) *
+                          ((Cout + kInfo[kd].bn - 1) / kInfo[kd].bn);
+    int ks = 1;
+    while (ks < 8 && nwg * ks * 2 <= 256 && Cin % (ks * 2 * kInfo[kd].ck) == 0 && Cin / (ks * 2) >= 64) ks *= 2;
+    *KS = ks;
+    return SSM_OK;
+}
+
+extern "C" int ssm_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view part,
+                                     int KS, int B, int H, int W, int Cout, int k, void *stream) {
+    int kind = 0, BN = 0, CK = 0;
+    SSM_REQUIRE(B > 0 && KS >= 1 && KS <= 8, "conv_splitk: bad batch / split (KS = %d)", KS);
+    const int rc = ssm_conv_plan(k, C1 + C2, Cout, B, H, W, 0, 0, &kind, &BN, &CK);          // the configuration the filter was packed for
+    if (rc != SSM_OK) return rc;
+    SSM_REQUIRE((C1 + C2) % (KS * CK) == 0, "conv_splitk: Cin = %d is no multiple of KS x chunk = %d x %d", C1 + C2, KS, CK);
+    SSM_REQUIRE(C2 == 0 || KS == 1, "conv_splitk: one source only (the kernel offsets its first source by the split's channel range)");
+    ConvParams p;
+    const int rf = fill_common(p, x1, C1, x2, C2, w_packed, bias_packed, part, H, W, Cout, 0.f, 0, CK, W);
+    if (rf != SSM_OK) return rf;
+    p.NSPLIT = KS;
+    p.ksB = B;
     return dispatch<false>(kind, p, B, (hipStream_t)stream);
 }
 

@@ -447,6 +447,22 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ssm_view part, int K
     if (pool.ptr && two) vp(pool, b, c, y)[x] = ((r0.x + r1.x) + (r0.y + r1.y)) * 0.25f;
 }
 
+// the same for odd map widths (the 11x11 bottleneck maps of config 3: direct-form split-K, no fused mean): one thread = one pixel
+__global__ __launch_bounds__(256) void splitk_finish1_kernel(ssm_view part, int KS, ssm_view yout, ssm_view add, int adiv, int B, int C, int H,
+                                                             int W, float sl, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W);
+    long long r = idx / W;
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    float v = 0.f;
+    for (int k = 0; k < KS; ++k) v += vp(part, k * B + b, c, y)[x];
+    if (add.ptr) v += vp(add, b / adiv, c, y)[x];
+    vp(yout, b, c, y)[x] = fmaxf(v, v * sl);
+}
+
 // F.upsample(cat[a,b], size=(2h,2w), mode="bilinear"), align_corners=False:
 // scripts/models/flow_computation.py:92-94,:244-245.  One thread owns TWO adjacent source
 // pixels of one row and writes their 2x4 output block as two 16-byte stores per channel
@@ -725,7 +741,15 @@ extern "C" int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view
                                      float slope, int flags, void *stream) {
     SSM_CHECK_DIMS("splitk_finish");
     SSM_REQUIRE(part.ptr && y.ptr && C > 0 && KS >= 1 && KS <= 8, "splitk_finish: null pointer / C / KS");
-    SSM_REQUIRE(W % 2 == 0, "splitk_finish: the map width must be even (got %d)", W);
+    if (W % 2) {          // odd width: one pixel per thread, no fused mean
+        SSM_REQUIRE(!pool.ptr, "splitk_finish: the fused 2x2 mean needs even H, W");
+        SSM_REQUIRE(!add.ptr || (add_div >= 1 && B % add_div == 0), "splitk_finish: addend divisor");
+        const long long tot1 = (long long)B * C * H * W;
+        SSM_REQUIRE(tot1 <= 0x7fffffffLL * 256LL, "splitk_finish: problem too large for one launch");
+        hipLaunchKernelGGL(splitk_finish1_kernel, dim3((unsigned)((tot1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, add,
+                           add_div < 1 ? 1 : add_div, B, C, H, W, (flags & SSM_FLAG_LRELU) ? slope : 1.f, tot1);
+        return ssm::check_launch("ssm_splitk_finish_fwd");
+    }
     SSM_REQUIRE(even_view(part) && even_view(y), "splitk_finish: partial sums and output must be 8-byte aligned views with even strides");
     SSM_REQUIRE(!add.ptr || (even_view(add) && add_div >= 1 && B % add_div == 0), "splitk_finish: addend view / divisor");
     SSM_REQUIRE(!pool.ptr || (H % 2 == 0), "splitk_finish: the fused 2x2 mean needs even H, W");

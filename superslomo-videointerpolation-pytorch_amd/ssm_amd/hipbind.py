@@ -60,6 +60,8 @@ SIGNATURES = {
                                              _c_int, _c_float, _c_int, _vp]),
     "ssm_wino_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino_splitk_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip]),
+    "ssm_conv_splitk_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip]),
+    "ssm_conv2d_splitk_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_wino_conv2d_splitk_fwd": (_c_int, [SsmView, _c_int, SsmView, _c_int, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                             _c_int, _vp]),
     "ssm_splitk_finish_fwd": (_c_int, [SsmView, _c_int, SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _vp]),
@@ -329,6 +331,26 @@ def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None
     assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
     assert (pk.bn, pk.ck) == conv_plan(pk.k, c1 + c2, pk.cout, B, H, W, pool is not None)[1:], \
         "filter was packed for another tile configuration (batch/size/pool changed)"
+    if pool is None:          # launches that leave most of the chip idle run split over the input channels (see wino_splitk)
+        key = (B, H, W)
+        cache = pk.__dict__.setdefault("_splitk", {})
+        if key not in cache:
+            ks = ctypes.c_int(1)
+            check(lib.ssm_conv_splitk_plan(pk.k, c1 + c2, pk.cout, B, H, W, ctypes.byref(ks)))
+            cache[key] = ks.value
+        ks = cache[key]
+        if ks > 1:
+            st = stream_ptr()
+            scratch = pk.__dict__.setdefault("_splitk_part", {})
+            skey = (getattr(st, "value", st), ks, B, H, W)
+            if skey not in scratch:
+                scratch[skey] = Planes(ks * B, pk.cout, H, W, pk.w.device)
+            part = scratch[skey]
+            check(lib.ssm_conv2d_splitk_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), part.view(), ks,
+                                            B, H, W, pk.cout, pk.k, st))
+            check(lib.ssm_splitk_finish_fwd(part.view(), ks, y, NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, pk.cout, H, W,
+                                            slope, SSM_FLAG_LRELU if lrelu else 0, st))
+            return
     check(lib.ssm_conv2d_add_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                  pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, H, W,
                                  pk.cout, pk.k, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))

@@ -213,3 +213,36 @@ def test_direct_conv_pre_activation_addend(dev, kind, k):
         else:
             hb.conv2d(px.view(c0=3), cin, None, 0, pk, y.view(), None, B, H, W, add=pa.view(), add_div=div)
         assert _err(y.to_nchw().cpu(), want) < 5e-5, "%s ups=%d: %.3e" % (kind, ups, _err(y.to_nchw().cpu(), want))
+
+
+def test_direct_conv_split_k_on_the_bottleneck_maps(dev):
+    """The direct-form convolutions of config 3's bottleneck (512 -> 512 on 11x11 maps - odd width, no Winograd form - at batch 2) run split
+    over the input channels inside hb.conv2d (ssm_conv2d_splitk_fwd + ssm_splitk_finish_fwd, KS from ssm_conv_splitk_plan): against the
+    oracle, with and without a pre-activation addend, and bit-identical from run to run."""
+    import ctypes
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(91)
+    for B, cin, cout, H, W, addend in ((2, 512, 512, 11, 11, False), (2, 512, 512, 11, 11, True), (2, 256, 256, 11, 11, False), (1, 512, 64, 7, 9, False)):
+        ks = ctypes.c_int(1)
+        hb.check(hb.load().ssm_conv_splitk_plan(3, cin, cout, B, H, W, ctypes.byref(ks)))
+        assert ks.value > 1, "%d -> %d at %dx%d, batch %d: the plan does not split" % (cin, cout, H, W, B)
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        add = torch.randn(B, cout, H, W, generator=g) if addend else None
+        z = O.conv2d(x, w, bias) + (add if add is not None else 0.0)
+        want = torch.where(z >= 0, z, z * 0.1)
+        px = hb.Planes(B, cin, H, W, dev).load(x.to(dev))
+        pz = hb.Planes(B, cout, H, W, dev).load(add.to(dev)) if add is not None else None
+        pk = hb.PackedConv(w.to(dev), bias.to(dev), B, H, W)
+        outs = []
+        for _ in range(2):
+            y = hb.Planes(B, cout, H, W, dev)
+            hb.conv2d(px.view(), cin, None, 0, pk, y.view(), None, B, H, W, add=pz.view() if pz is not None else None)
+            outs.append(y.to_nchw().cpu())
+        assert _err(outs[0], want) < 5e-5, "KS %d, %d -> %d at %dx%d: %.3e" % (ks.value, cin, cout, H, W, _err(outs[0], want))
+        assert torch.equal(outs[0], outs[1]), "split-K result differs between two runs"
+        full = y.full.cpu().clone()
+        full[:, :, hb.SSM_PADY:hb.SSM_PADY + H, hb.SSM_PADX:hb.SSM_PADX + W] = 0
+        assert float(full.abs().max()) == 0.0, "split-K wrote outside the interior"
