@@ -806,7 +806,7 @@ extern "C" int ssm_conv_splitk_plan(int k, int Cin, int Cout, int B, int H, int 
     const long long nwg = (long long)B * ((W + kInfo[kd].tw - 1) / kInfo[kd].tw) * ((H + kInfo[kd].th - 1) / kInfo[kd].th) *
                           ((Cout + kInfo[kd].bn - 1) / kInfo[kd].bn);
     int ks = 1;
-    while (ks < 8 && nwg * ks * 2 <= 256 && Cin % (ks * 2 * kInfo[kd].ck) == 0 && Cin / (ks * 2) >= 64) ks *= 2;
+    while (ks < 8 && nwg * ks * 2 <= 512 && Cin % (ks * 2 * kInfo[kd].ck) == 0 && Cin / (ks * 2) >= 64) ks *= 2;
     *KS = ks;
     return SSM_OK;
 }

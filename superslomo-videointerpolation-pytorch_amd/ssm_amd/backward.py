@@ -19,7 +19,7 @@ from . import hipbind as hb
 
 
 DGRAD_BLOCKED = os.environ.get("SSM_TRAIN_DGRAD_BLOCKED", "1") != "0"
-DGRAD_WINO4 = os.environ.get("SSM_TRAIN_DGRAD_WINO4", "0") != "0"          # 3x3 data gradients as F(4x4,3x3) where the cost model prefers it
+DGRAD_WINO4 = os.environ.get("SSM_TRAIN_DGRAD_WINO4", "1") != "0"          # 3x3 data gradients as F(4x4,3x3) where the cost model prefers it
 
 
 def transposed_filter(w):
@@ -268,6 +268,8 @@ class UNetGrad:
                     elif hb.wino5_supported(co, ci, self.plan.H // s, self.plan.W // s, k) and co % 4 == 0:
                         cls = hb.PackedWino5
                 self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
+                if getattr(self.plan, "wino", False) and cls is hb.PackedConv:
+                    self.pk_t[name].split_ok = True          # (mode f32w: see engine.UNetPlan.refresh_weights)
         if batch32:
             self._pack32 = (key32, hb.PackBatch32([(self.pk_t[n], w, None, True) for n, w in zip(names, ws)], self.dev))
 

@@ -92,11 +92,12 @@ WINO5 = os.environ.get("SSM_WINO5", "1")
 WINO4 = os.environ.get("SSM_WINO4", "1")
 
 
-# ... and in the TRAINING plans (forward and data-gradient convolutions on the 46x46+ maps): $SSM_TRAIN_WINO4=1.  Gradient parity holds
-# (tests/test_hip_backward.py green with it: 1.8e-6 from the reference's gradient fixture, 6.8e-4 worst at 2x352x352 like mode f32),
-# but the step is not faster at 2 samples of 352x352: forward 4.97 -> 4.88 ms and data gradients 7.87 -> 7.26 ms in kernel, wall 20.8 ->
-# 21.3 ms per step (the 64-cout form holds a whole CU's LDS, and the weight-gradient stream runs beside it) - off by default.
-TRAIN_WINO4 = os.environ.get("SSM_TRAIN_WINO4", "0")
+# ... and in the TRAINING plans (forward and data-gradient convolutions, where the cost model prefers it over F(2x2,3x3)): on since r5
+# ($SSM_TRAIN_WINO4=0: off).  Gradient parity holds (tests/test_hip_backward.py green with it: 5.9e-5 at 64x64 like every other form
+# that reorders a sum, 3.3e-4 at 2x352x352).  It did not pay while the step had other floors (r4: wall 20.8 -> 21.3 ms; r5 before the
+# blocked forward, split-K and the flat element-wise kernels: + 0.3 %); with those gone: 15.46 -> 15.27 ms per step together with
+# $SSM_TRAIN_DGRAD_WINO4 (profiles/r14i_more.txt).
+TRAIN_WINO4 = os.environ.get("SSM_TRAIN_WINO4", "1")
 # The 7x7 / 5x5 layers of a TRAINING plan's forward in the two-dimensional blocked forms of the inference plans (csrc/ssm_wino7.hip,
 # ssm_wino5.hip).  r3 kept them direct after measuring the 1-D forms F(2,7) / F(4,5) in the forward: parameter gradients at 64x64 4e-4 from
 # CPU autograd (bar 3e-4).  Measured in r5 with the 2-D forms (profiles/r14d_grad_matrix.txt): 5.9e-5 at 64x64 (direct forward: 2e-6;
@@ -351,6 +352,11 @@ class UNetPlan:
                     batch32 = False          # (its effective filters are not part of the one-launch repack)
                 else:
                     self.pk[name] = cls(w, b, nb, self.H // s, self.W // s, pool=name in POOLED, ups=ups)
+        # mode f32w only: direct-form launches that leave most of the chip idle may run split over the input channels (hb.conv2d) - the
+        # sums of this mode are reordered by its Winograd forms anyway; mode f32 keeps one fmaf chain per output, like the reference
+        for pkk in list(self.pk.values()) + list(getattr(self, "pk_pair", {}).values()):
+            if self.wino and isinstance(pkk, hb.PackedConv):
+                pkk.split_ok = True
         self._pack32 = None
         if batch32:
             entries = [(self.pk[name], state_dict[param_key(name, "weight")], state_dict[param_key(name, "bias")], False)

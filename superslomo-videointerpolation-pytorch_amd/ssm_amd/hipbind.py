@@ -331,7 +331,9 @@ def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None
     assert pk.cin_p == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1 + c2)
     assert (pk.bn, pk.ck) == conv_plan(pk.k, c1 + c2, pk.cout, B, H, W, pool is not None)[1:], \
         "filter was packed for another tile configuration (batch/size/pool changed)"
-    if pool is None:          # launches that leave most of the chip idle run split over the input channels (see wino_splitk)
+    # launches that leave most of the chip idle run split over the input channels (see wino_splitk) - only where the plan allows it
+    # (pk.split_ok: mode f32w; mode f32 and torch.ops.ssm.conv2d keep the reference's one fmaf chain per output)
+    if pool is None and getattr(pk, "split_ok", False):
         key = (B, H, W)
         cache = pk.__dict__.setdefault("_splitk", {})
         if key not in cache:

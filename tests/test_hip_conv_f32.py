@@ -236,11 +236,16 @@ def test_direct_conv_split_k_on_the_bottleneck_maps(dev):
         px = hb.Planes(B, cin, H, W, dev).load(x.to(dev))
         pz = hb.Planes(B, cout, H, W, dev).load(add.to(dev)) if add is not None else None
         pk = hb.PackedConv(w.to(dev), bias.to(dev), B, H, W)
+        y1 = hb.Planes(B, cout, H, W, dev)
+        hb.conv2d(px.view(), cin, None, 0, pk, y1.view(), None, B, H, W, add=pz.view() if pz is not None else None)      # not split: mode f32
+        pk.split_ok = True          # what an f32w plan sets on its direct-form filters
         outs = []
         for _ in range(2):
             y = hb.Planes(B, cout, H, W, dev)
             hb.conv2d(px.view(), cin, None, 0, pk, y.view(), None, B, H, W, add=pz.view() if pz is not None else None)
             outs.append(y.to_nchw().cpu())
+        assert "_splitk_part" in pk.__dict__, "the split path was not taken"
+        assert _err(y1.to_nchw().cpu(), want) < 5e-5 and _err(outs[0], y1.to_nchw().cpu()) < 5e-5          # (4608-term fp32 sums in two orders)
         assert _err(outs[0], want) < 5e-5, "KS %d, %d -> %d at %dx%d: %.3e" % (ks.value, cin, cout, H, W, _err(outs[0], want))
         assert torch.equal(outs[0], outs[1]), "split-K result differs between two runs"
         full = y.full.cpu().clone()
