@@ -305,6 +305,11 @@ typedef struct {
 } ssm_pack32_job;
 /* (a thread stores four packed elements: every job's `first` and `total` are multiples of 4 - BN is - and `wp` is 16-byte aligned) */
 int ssm_pack32_weights_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_elements, void *stream);
+/* The F(2x2,3x3) jobs (algo 1) with k = 3, Cout % BN == 0, Cin % 16 == 0, BN <= 64 - most of a U-Net's bytes - by TILES of BN couts x 16
+ * input channels: a workgroup reads its tile as contiguous rows and writes one contiguous run of the packed filter (the element-wise
+ * kernel above fetches nine weights per thread from addresses Cin x 36 bytes apart).  Same job struct: `first` = the job's first tile,
+ * `total` = its tiles = (Cout / BN) x (Cin / 16); max_bn = the largest BN of the table (LDS).  Bit-identical to the element-wise form. */
+int ssm_pack32_wino_tiles_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_tiles, int max_bn, void *stream);
 
 /* ---- fp16-MFMA convolution on HL8 activations (v_mfma_f32_32x32x16_f16) ---------------
  * Same operator as ssm_conv2d_fwd.  Default mode evaluates a*b as a_hi*b_hi + a_hi*b_lo +

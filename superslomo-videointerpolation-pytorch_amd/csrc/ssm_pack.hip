@@ -182,7 +182,59 @@ __global__ void pack32_batch_kernel(const ssm_pack32_job *__restrict__ jobs, int
         if (e + q < j.nbias) j.bp[e + q] = (j.bias && e + q < j.Cout) ? j.bias[e + q] : 0.f;
 }
 
+// ---- F(2x2,3x3) filters by TILES (r5): the jobs that carry most of a U-Net's bytes -------------------------------------------------
+// pack32_batch_kernel gives neighbouring threads neighbouring couts: their nine weights sit Cin x 36 bytes apart, every thread fetches its
+// own 36 bytes (0.9 TB/s; 1.15 ms of a 15 ms training step for the four repacks).  Here a workgroup owns a tile of BN couts x 16 input
+// channels: it reads the tile as rows of 144 (transposed: BN x 9) CONTIGUOUS floats into LDS and writes the 16 x 4 x BN quads of the tile,
+// which are one contiguous 1024 x BN byte run of the packed filter.  Same expressions as pack_wino_4: bit-identical.
+// jobs: `first` = first tile of the job, `total` = its tiles = (Cout / BN) x (Cin / 16); Cout % BN == 0, Cin % 16 == 0, k == 3, BN <= 64.
+__global__ __launch_bounds__(256) void pack32_wino_tiles_kernel(const ssm_pack32_job *__restrict__ jobs, int njobs, long long total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const long long t = blockIdx.x;
+    if (t >= total) return;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    const ssm_pack32_job j = jobs[lo];
+    const int tl = (int)(t - j.first), nct = j.Cin / 16, nb = tl / nct, cin0 = (tl - nb * nct) * 16, BN = j.BN;
+    const int tid = threadIdx.x;
+    // the parameter is [Cout][Cin][3][3], or for a transposed job [Cin][Cout][3][3] (Cout, Cin: the PACKED filter's)
+    const int rowlen = j.transposed ? BN * 9 : 16 * 9, nrows = j.transposed ? 16 : BN;
+    for (int idx = tid; idx < nrows * rowlen; idx += 256) {
+        const int r = idx / rowlen, c = idx - r * rowlen;
+        const float *src = j.transposed ? j.w + ((long long)(cin0 + r) * j.Cout + (long long)nb * BN) * 9
+                                        : j.w + ((long long)(nb * BN + r) * j.Cin + cin0) * 9;
+        wl[idx] = src[c];
+    }
+    __syncthreads();
+    float *out = j.wp + ((long long)nb * j.Cin + cin0) * 4 * BN * 4;
+    for (int qd = tid; qd < 64 * BN; qd += 256) {
+        const int n = qd % BN, q = (qd / BN) & 3, cl = qd / (4 * BN);
+        const float *g = j.transposed ? wl + (cl * BN + n) * 9 : wl + (n * 16 + cl) * 9;
+        float row[3];      // row q of G g
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g0 = j.transposed ? g[8 - c] : g[c], g1 = j.transposed ? g[5 - c] : g[3 + c], g2 = j.transposed ? g[2 - c] : g[6 + c];
+            row[c] = q == 0 ? g0 : (q == 1 ? 0.5f * (g0 + g1 + g2) : (q == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+        }
+        *reinterpret_cast<pk_f4 *>(out + (long long)qd * 4) = pk_f4{row[0], 0.5f * (row[0] + row[1] + row[2]), 0.5f * (row[0] - row[1] + row[2]), row[2]};
+    }
+    if (tl == 0)
+        for (int i = tid; i < j.nbias; i += 256) j.bp[i] = (j.bias && i < j.Cout) ? j.bias[i] : 0.f;
+}
+
 }  // namespace
+
+extern "C" int ssm_pack32_wino_tiles_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_tiles, int max_bn, void *stream) {
+    SSM_REQUIRE(jobs_device && n_jobs > 0 && total_tiles > 0 && total_tiles <= 0x7fffffffLL, "pack32 wino tiles: empty / oversized job table");
+    SSM_REQUIRE(max_bn == 32 || max_bn == 64, "pack32 wino tiles: cout blocks of 32 or 64 (got %d)", max_bn);
+    hipLaunchKernelGGL(pack32_wino_tiles_kernel, dim3((unsigned)total_tiles), dim3(256), (size_t)max_bn * 144 * sizeof(float), (hipStream_t)stream,
+                       jobs_device, n_jobs, total_tiles);
+    return ssm::check_launch("ssm_pack32_wino_tiles_batch");
+}
 
 extern "C" int ssm_pack32_weights_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_elements, void *stream) {
     SSM_REQUIRE(jobs_device && n_jobs > 0 && total_elements > 0, "pack32 batch: empty job table");

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ssm_wino_packed_weight_floats": (_sz, [_c_int, _c_int, _c_int]),
     "ssm_wino_pack_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "ssm_pack32_weights_batch": (_c_int, [_vp, _c_int, ctypes.c_longlong, _vp]),
+    "ssm_pack32_wino_tiles_batch": (_c_int, [_vp, _c_int, ctypes.c_longlong, _c_int, _vp]),
     "ssm_wino4_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ip, _ip, _ip]),
     "ssm_wino4_force_kind": (_c_int, [_c_int]),
     "ssm_wino4_preferred": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
@@ -832,7 +833,25 @@ class PackBatch32:
     ALGO = {"direct": 0, "wino": 1, "wino1d": 2, "wino4": 3, "wino7": 4, "wino5": 5}
 
     def __init__(self, entries, device):
-        jobs = (SsmPack32Job * len(entries))()
+        # F(2x2,3x3) jobs with whole tiles go to the tiled kernel (ssm_pack32_wino_tiles_batch: contiguous reads and writes), the rest to
+        # the element-wise one; $SSM_PACK_TILES=0: everything element-wise
+        tiled = [e for e in entries if self._tiled(e[0])] if os.environ.get("SSM_PACK_TILES", "1") != "0" else []
+        entries = [e for e in entries if not any(e is t for t in tiled)]
+        self.tiles = None
+        if tiled:
+            tj = (SsmPack32Job * len(tiled))()
+            toff = 0
+            for j, (pk, w, b, transposed) in zip(tj, tiled):
+                assert w.is_contiguous() and w.dtype == torch.float32 and w.device == pk.w.device
+                assert tuple(w.shape) == ((pk.cin, pk.cout, 3, 3) if transposed else (pk.cout, pk.cin, 3, 3))
+                j.w, j.bias, j.wp, j.bp = w.data_ptr(), (b.data_ptr() if b is not None else None), pk.w.data_ptr(), pk.b.data_ptr()
+                j.Cout, j.Cin, j.CinP, j.k, j.BN = pk.cout, pk.cin, pk.cin_p, 3, pk.bn
+                j.algo, j.transposed, j.nbias = self.ALGO["wino"], 1 if transposed else 0, pk.b.numel()
+                j.first, j.total = toff, (pk.cout // pk.bn) * (pk.cin // 16)
+                toff += j.total
+            self.tiles = (torch.frombuffer(bytearray(bytes(tj)), dtype=torch.uint8).to(device), len(tiled), toff, max(e[0].bn for e in tiled))
+            self.keep_tiled = list(tiled)
+        jobs = (SsmPack32Job * max(len(entries), 1))()
         off = 0
         self.keep = []
         for j, (pk, w, b, transposed) in zip(jobs, entries):
@@ -850,8 +869,17 @@ class PackBatch32:
         self.n, self.total = len(entries), off
         self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
 
+    @staticmethod
+    def _tiled(pk):
+        return (pk.algo == "wino" and pk.k == 3 and pk.bn in (32, 64) and pk.cout % pk.bn == 0 and pk.cin % 16 == 0 and pk.cin_p == pk.cin
+                and pk.w.numel() == (pk.cout // pk.bn) * pk.cin * 16 * pk.bn)
+
     def run(self):
-        check(load().ssm_pack32_weights_batch(self.table.data_ptr(), self.n, self.total, stream_ptr()))
+        lib, st = load(), stream_ptr()
+        if self.n:
+            check(lib.ssm_pack32_weights_batch(self.table.data_ptr(), self.n, self.total, st))
+        if self.tiles is not None:
+            check(lib.ssm_pack32_wino_tiles_batch(self.tiles[0].data_ptr(), self.tiles[1], self.tiles[2], self.tiles[3], st))
 
 
 def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slope=0.1, fast=False):
