@@ -536,6 +536,13 @@ int ssm_maxpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int W, void *s
 int ssm_maxpool2_bwd(ssm_view x, ssm_view dy, ssm_view dx, int B, int C, int H, int W, void *stream);
 int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_view out, int B, int C, int H, int W, void *stream);
 int ssm_sqdiff_mean(ssm_view a, ssm_view b, float *scratch, float *out, int B, int C, int H, int W, void *stream);
+/* The L1 terms of SSMLosses.forward (scripts/models/losses.py:113-170 warp terms with the FREEZE gating of :159-167, :218-233
+ * reconstruction) of one window as per-sample sums, out[b][0] = sum |pred - target|, out[b][1] = sum of the (up to four) warp maps -
+ * the caller divides by 3 H W and applies lambda_r / lambda_w.  img6 = [I0 | I1], flow4 = stage 1's [F01 | F10], est4 = the approximated
+ * flows [Ft1 | Ft0] (channels 6:10 of the stage-2 input), out5 = stage 2's output, pred = the synthesised frame.  Two deterministic
+ * launches; scratch: 128 * B device floats owned by the caller.                                                                     */
+int ssm_train_loss_sums(ssm_view img6, ssm_view flow4, ssm_view est4, ssm_view out5, ssm_view pred, ssm_view target, float *scratch,
+                        float *out, int B, int H, int W, int stage1_terms, int stage2_terms, void *stream);
 
 /* ---- recurrent bottleneck (BOTTLENECK=CLSTM|CGRU; BASELINE config 4) -----------------------------------------
  * Replaces ConvBLSTM / ConvBGRU(in_channels=512, hidden_channels=512, kernel_size=(3,3), num_layers=2,

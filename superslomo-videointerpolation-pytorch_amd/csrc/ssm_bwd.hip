@@ -917,6 +917,78 @@ __global__ void sqdiff_finish_kernel(const float *__restrict__ partial, float *_
     out[b] = s * inv_n;
 }
 
+// The L1 terms of the training loss (losses.py:113-170,196-233) of the planned step as per-sample SUMS in two deterministic launches
+// (r5: the step's forward spent ~25 small strided torch kernels on them, back to back on an otherwise idle GPU):
+//   out[b][0] = sum_{c,y,x} |pred - target|
+//   out[b][1] = sum_{c,y,x} ( [stage 1 trains] (|g(I1,F01) - I0| + |g(I0,F10) - I1|) + [stage 2 trains] (|g(I0,Ft0) - I_t| + |g(I1,Ft1) - I_t|) )
+// with the refined flows Ft1 = est[0:2] + out5[1:3], Ft0 = est[2:4] + out5[3:5] and the bilinear sampler of the adjoint kernels above.
+__global__ __launch_bounds__(256) void loss_terms_partial_kernel(ssm_view img6, ssm_view flow4, ssm_view est, ssm_view out5, ssm_view pred,
+                                                                 ssm_view target, float *__restrict__ partial, int H, int W, int s1terms,
+                                                                 int s2terms) {
+    __shared__ float red[2][256];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int n = H * W, per = (n + SQD_CHUNKS - 1) / SQD_CHUNKS;
+    const int e0 = chunk * per, e1 = e0 + per < n ? e0 + per : n;
+    float srec = 0.f, swrp = 0.f;
+    for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
+        const int y = e / W, x = e - y * W;
+        float tg[3], i0[3], i1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            tg[c] = vp(target, b, c, y)[x];
+            srec += fabsf(vp(pred, b, c, y)[x] - tg[c]);
+            i0[c] = vp(img6, b, c, y)[x];
+            i1[c] = vp(img6, b, 3 + c, y)[x];
+        }
+        if (s2terms) {
+            const float ft1u = vp(est, b, 0, y)[x] + vp(out5, b, 1, y)[x], ft1v = vp(est, b, 1, y)[x] + vp(out5, b, 2, y)[x];
+            const float ft0u = vp(est, b, 2, y)[x] + vp(out5, b, 3, y)[x], ft0v = vp(est, b, 3, y)[x] + vp(out5, b, 4, y)[x];
+            const TapsD t0 = make_taps_d(x, y, ft0u, ft0v, H, W, img6.sh), t1 = make_taps_d(x, y, ft1u, ft1v, H, W, img6.sh);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float w0, w1, gx, gy;
+                sample_d(vp(img6, b, c, 0), t0, w0, gx, gy);
+                sample_d(vp(img6, b, 3 + c, 0), t1, w1, gx, gy);
+                swrp += fabsf(w0 - tg[c]) + fabsf(w1 - tg[c]);
+            }
+        }
+        if (s1terms) {
+            const TapsD a = make_taps_d(x, y, vp(flow4, b, 0, y)[x], vp(flow4, b, 1, y)[x], H, W, img6.sh);
+            const TapsD bq = make_taps_d(x, y, vp(flow4, b, 2, y)[x], vp(flow4, b, 3, y)[x], H, W, img6.sh);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float va, vb, gx, gy;
+                sample_d(vp(img6, b, 3 + c, 0), a, va, gx, gy);           // g(I1, F01) vs I0
+                sample_d(vp(img6, b, c, 0), bq, vb, gx, gy);              // g(I0, F10) vs I1
+                swrp += fabsf(va - i0[c]) + fabsf(vb - i1[c]);
+            }
+        }
+    }
+    red[0][threadIdx.x] = srec;
+    red[1][threadIdx.x] = swrp;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[(b * SQD_CHUNKS + chunk) * 2] = red[0][0];
+        partial[(b * SQD_CHUNKS + chunk) * 2 + 1] = red[1][0];
+    }
+}
+
+__global__ void loss_terms_finish_kernel(const float *__restrict__ partial, float *__restrict__ out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (sample, term)
+    if (i >= 2 * B) return;
+    const int b = i >> 1, term = i & 1;
+    float s = 0.f;
+    for (int k = 0; k < SQD_CHUNKS; ++k) s += partial[(b * SQD_CHUNKS + k) * 2 + term];
+    out[b * 2 + term] = s;
+}
+
 }  // namespace
 
 #define SSM_CHECK_DIMS(name)                                                                         \
@@ -1161,6 +1233,17 @@ extern "C" int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_vi
     SSM_REQUIRE((long long)B * cgroups <= 65535, "sqdiff_grad: B*C too large for one launch");
     hipLaunchKernelGGL(sqdiff_grad_kernel, pix_grid(B * cgroups, H, W), dim3(64, 4), 0, (hipStream_t)stream, a, b, coef, out, C, H, W, cgroups);
     return ssm::check_launch("ssm_sqdiff_grad");
+}
+
+extern "C" int ssm_train_loss_sums(ssm_view img6, ssm_view flow4, ssm_view est4, ssm_view out5, ssm_view pred, ssm_view target, float *scratch,
+                                   float *out, int B, int H, int W, int stage1_terms, int stage2_terms, void *stream) {
+    SSM_CHECK_DIMS("train_loss_sums");
+    SSM_REQUIRE(img6.ptr && flow4.ptr && est4.ptr && out5.ptr && pred.ptr && target.ptr && scratch && out, "train_loss_sums: null pointer");
+    SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "train_loss_sums: plane too large");
+    hipLaunchKernelGGL(loss_terms_partial_kernel, dim3(SQD_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, img6, flow4, est4, out5, pred, target,
+                       scratch, H, W, stage1_terms, stage2_terms);
+    hipLaunchKernelGGL(loss_terms_finish_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, out, B);
+    return ssm::check_launch("ssm_train_loss_sums");
 }
 
 extern "C" int ssm_sqdiff_mean(ssm_view a, ssm_view b, float *scratch, float *out, int B, int C, int H, int W, void *stream) {

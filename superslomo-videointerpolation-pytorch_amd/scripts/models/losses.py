@@ -113,6 +113,31 @@ class SSMLosses(nn.Module):
             per = torch.zeros_like(rec)
         return torch.stack([rec + wrp + per, rec, wrp, per], dim=1)          # [B,4] (losses.py:236-249)
 
+    def planned_losses(self, eng, interpolated_image, target_image):
+        """The same [B,4] tensor for the planned training step (ssm_amd.engine.PairEngine `eng` holds the window's tensors): the L1 terms by
+        ssm_train_loss_sums - two launches instead of ~25 small strided torch kernels between the forward and the backward - and the
+        perceptual term by its own kernels.  Values only: the step supplies the gradients itself (ssm_amd.backward)."""
+        from ssm_amd import hipbind as hb
+        lambda_r, lambda_p, lambda_w = self.loss_weights
+        Bn, _, Hn, Wn = interpolated_image.shape
+        dev = interpolated_image.device
+        key = (Bn, str(dev))
+        if self.__dict__.get("_l1_buf", (None,))[0] != key:
+            self.__dict__["_l1_buf"] = (key, torch.empty(128 * Bn, dtype=torch.float32, device=dev))
+        sums = torch.empty(Bn, 2, dtype=torch.float32, device=dev)
+        in16, out5, flow4 = eng.s2.t["in"], eng.s2.t["out"], eng.s1.t["out"]
+        est = hb.view_of(eng.est) if eng.hl8 else in16.view(6)
+        pred, tgt = interpolated_image.contiguous(), target_image.contiguous()
+        hb.check(hb.load().ssm_train_loss_sums(hb.view_of(eng.img6), flow4.view(), est, out5.view(), hb.view_of(pred), hb.view_of(tgt),
+                                               self._l1_buf[1].data_ptr(), sums.data_ptr(), Bn, Hn, Wn,
+                                               0 if self.cfg.getboolean("STAGE1", "FREEZE") else 1,
+                                               0 if self.cfg.getboolean("STAGE2", "FREEZE") else 1, hb.stream_ptr()))
+        n = 3.0 * Hn * Wn
+        rec, wrp = sums[:, 0] * (lambda_r / n), sums[:, 1] * (lambda_w / n)
+        pt = self.perceptual_term(Bn, Hn, Wn, dev)
+        per = lambda_p * pt.forward(pred, tgt) if pt is not None else torch.zeros_like(rec)
+        return torch.stack([rec + wrp + per, rec, wrp, per], dim=1)
+
     def forward(self, flowC_input, flowC_output, flowI_input, flowI_output, interpolated_image, target_image):
         """Reference signature (losses.py:196-249): flowI_input is the 16-channel stage-2 input, of which channels
         6:8 / 8:10 (the approximated flows) are used."""

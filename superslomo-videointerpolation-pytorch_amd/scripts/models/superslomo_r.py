@@ -73,8 +73,11 @@ class _TrainStep(torch.autograd.Function):
         if pt is not None and os.environ.get("SSM_VGG_OVERLAP", "1") != "0":
             pt.begin_target(target)      # the target's VGG features do not depend on the forward: second stream, beside the U-Nets
         pred = eng.run(img6, t, want_aux=True, want_out5=True).clone()
-        f01, f10, e1, e0, _, _, _ = eng.intermediates()
-        losses = model.loss.losses_from_parts(img6, torch.cat([f01, f10], 1), e1, e0, eng.s2.t["out"].interior, pred, target)
+        if model.loss.feature_extractor is None and os.environ.get("SSM_FUSED_LOSS", "1") != "0":
+            losses = model.loss.planned_losses(eng, pred, target)          # the L1 terms in two launches (ssm_train_loss_sums)
+        else:
+            f01, f10, e1, e0, _, _, _ = eng.intermediates()
+            losses = model.loss.losses_from_parts(img6, torch.cat([f01, f10], 1), e1, e0, eng.s2.t["out"].interior, pred, target)
         ctx.model, ctx.pg, ctx.sd, ctx.target = model, pg, (sd1, sd2), target
         ctx.mark_non_differentiable(pred)
         return pred, losses

@@ -156,6 +156,7 @@ SIGNATURES = {
     "ssm_maxpool2_bwd": (_c_int, [SsmView, SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_sqdiff_grad": (_c_int, [SsmView, SsmView, _vp, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_sqdiff_mean": (_c_int, [SsmView, SsmView, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_train_loss_sums": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmView, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_flowinterp_inputs_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, SsmView, _c_int, _c_int, _c_int, _c_int,
                                            _vp]),
     "ssm_convlstm_cell_fwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, SsmView, SsmHView, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
