@@ -182,7 +182,7 @@ __global__ void pack32_batch_kernel(const ssm_pack32_job *__restrict__ jobs, int
         if (e + q < j.nbias) j.bp[e + q] = (j.bias && e + q < j.Cout) ? j.bias[e + q] : 0.f;
 }
 
-// ---- F(2x2,3x3) filters by TILES (r5): the jobs that carry most of a U-Net's bytes -------------------------------------------------
+// ---- F(2x2,3x3) and direct-form 3x3 filters by TILES (r5): the jobs that carry most of a U-Net's bytes -------------------------------------------------
 // pack32_batch_kernel gives neighbouring threads neighbouring couts: their nine weights sit Cin x 36 bytes apart, every thread fetches its
 // own 36 bytes (0.9 TB/s; 1.15 ms of a 15 ms training step for the four repacks).  Here a workgroup owns a tile of BN couts x 16 input
 // channels: it reads the tile as rows of 144 (transposed: BN x 9) CONTIGUOUS floats into LDS and writes the 16 x 4 x BN quads of the tile,
@@ -210,6 +210,21 @@ __global__ __launch_bounds__(256) void pack32_wino_tiles_kernel(const ssm_pack32
         wl[idx] = src[c];
     }
     __syncthreads();
+    if (j.algo == SSM_PACK_DIRECT) {          // direct form [nb][cin][tap][n]: the tile is the run of 16 x 9 x BN floats of (nb, cin0 .. cin0 + 15)
+        float *outd = j.wp + ((long long)nb * j.Cin + cin0) * 9 * BN;
+        const int nq = BN / 4;
+        for (int qd = tid; qd < 16 * 9 * nq; qd += 256) {
+            const int n4 = (qd % nq) * 4, tap = (qd / nq) % 9, cl = qd / (9 * nq);
+            const int tp = j.transposed ? 8 - tap : tap;
+            pk_f4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (j.transposed ? wl + (cl * BN + n4 + q) * 9 : wl + ((n4 + q) * 16 + cl) * 9)[tp];
+            *reinterpret_cast<pk_f4 *>(outd + ((long long)(cl * 9 + tap) * BN + n4)) = v;
+        }
+        if (tl == 0)
+            for (int i = tid; i < j.nbias; i += 256) j.bp[i] = (j.bias && i < j.Cout) ? j.bias[i] : 0.f;
+        return;
+    }
     float *out = j.wp + ((long long)nb * j.Cin + cin0) * 4 * BN * 4;
     for (int qd = tid; qd < 64 * BN; qd += 256) {
         const int n = qd % BN, q = (qd / BN) & 3, cl = qd / (4 * BN);

@@ -847,7 +847,7 @@ class PackBatch32:
                 assert tuple(w.shape) == ((pk.cin, pk.cout, 3, 3) if transposed else (pk.cout, pk.cin, 3, 3))
                 j.w, j.bias, j.wp, j.bp = w.data_ptr(), (b.data_ptr() if b is not None else None), pk.w.data_ptr(), pk.b.data_ptr()
                 j.Cout, j.Cin, j.CinP, j.k, j.BN = pk.cout, pk.cin, pk.cin_p, 3, pk.bn
-                j.algo, j.transposed, j.nbias = self.ALGO["wino"], 1 if transposed else 0, pk.b.numel()
+                j.algo, j.transposed, j.nbias = self.ALGO[pk.algo], 1 if transposed else 0, pk.b.numel()
                 j.first, j.total = toff, (pk.cout // pk.bn) * (pk.cin // 16)
                 toff += j.total
             self.tiles = (torch.frombuffer(bytearray(bytes(tj)), dtype=torch.uint8).to(device), len(tiled), toff, max(e[0].bn for e in tiled))
@@ -872,8 +872,9 @@ class PackBatch32:
 
     @staticmethod
     def _tiled(pk):
-        return (pk.algo == "wino" and pk.k == 3 and pk.bn in (32, 64) and pk.cout % pk.bn == 0 and pk.cin % 16 == 0 and pk.cin_p == pk.cin
-                and pk.w.numel() == (pk.cout // pk.bn) * pk.cin * 16 * pk.bn)
+        per = {"wino": 16, "direct": 9}.get(getattr(pk, "algo", "direct"))          # packed floats per (cout, cin)
+        return (per is not None and pk.k == 3 and pk.bn in (32, 64) and pk.cout % pk.bn == 0 and pk.cin % 16 == 0 and pk.cin_p == pk.cin
+                and pk.w.numel() == (pk.cout // pk.bn) * pk.cin * per * pk.bn)
 
     def run(self):
         lib, st = load(), stream_ptr()

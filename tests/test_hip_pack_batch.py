@@ -21,7 +21,9 @@ def test_batched_fp32_pack_matches_per_layer_packs(dev):
     B, H, W = 2, 64, 96
     cases = [(hb.PackedConv, 7, 6, 32), (hb.PackedConv, 5, 32, 64), (hb.PackedConv, 3, 64, 40), (hb.PackedConv, 3, 32, 5),
              (hb.PackedWino, 3, 16, 64), (hb.PackedWino, 3, 64, 32), (hb.PackedWino1d, 7, 6, 32), (hb.PackedWino1d, 7, 32, 32),
-             (hb.PackedWino1d, 5, 32, 64), (hb.PackedWino4, 3, 8, 32), (hb.PackedWino4, 3, 64, 96)]
+             (hb.PackedWino1d, 5, 32, 64), (hb.PackedWino4, 3, 8, 32), (hb.PackedWino4, 3, 64, 96),
+             # whole tiles of BN couts x 16 input channels: the tiled kernel (ssm_pack32_wino_tiles_batch), forward and transposed
+             (hb.PackedConv, 3, 64, 64), (hb.PackedConv, 3, 128, 32), (hb.PackedWino, 3, 128, 128), (hb.PackedWino, 3, 48, 96)]
     entries, want = [], []
     for cls, k, cin, cout in cases:
         w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
@@ -43,7 +45,9 @@ def test_batched_fp32_pack_matches_per_layer_packs(dev):
             tgtt.b.fill_(7.0)
             entries.append((tgtt, w, None, True))
             want.append((reft, tgtt, "%s k%d %d->%d transposed" % (cls.__name__, k, cin, cout)))
-    hb.PackBatch32(entries, dev).run()
+    batch = hb.PackBatch32(entries, dev)
+    assert batch.tiles is not None and batch.tiles[1] >= 6 and batch.n >= 10, "the cases of this test no longer cover both pack kernels"
+    batch.run()
     torch.cuda.synchronize()
     for ref, tgt, tag in want:
         assert torch.equal(ref.w, tgt.w), "%s: packed filter differs (max %.3e)" % (tag, float((ref.w - tgt.w).abs().max()))
