@@ -7,8 +7,16 @@
  * Conventions
  *  - all tensors are fp32 device memory owned by the caller; the library never
  *    allocates, frees or keeps a pointer past return;
- *  - every call is asynchronous on `stream` (a hipStream_t passed as void*),
- *    re-entrant, and takes the device from the pointers it is given;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*) and
+ *    re-entrant.  It launches on the CALLING THREAD's current device
+ *    (hipGetDevice), which must own `stream` and every pointer passed; the
+ *    library never calls hipSetDevice and keeps no "current device" of its
+ *    own.  One process may drive several GPUs from several host threads (the
+ *    reference's torch.nn.DataParallel replica threads, scripts/main.py:74-76:
+ *    each thread has set its device): per-device state - the opt-in of a
+ *    kernel to more than 64 KiB of dynamic LDS - is keyed on (kernel, device)
+ *    and taken on a thread's first launch there (csrc/ssm_common.h
+ *    reserve_lds; tests/test_build_fences_cpu.py fences process-wide guards);
  *  - return value 0 = ok, negative = SSM_E_* ; ssm_last_error_string() holds a
  *    message for the calling thread.  Nothing throws or exits.  The Python side
  *    turns non-zero codes into RuntimeError, mirroring the reference's

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 
 #include "../../include/ssm_hip.h"
@@ -20,6 +22,22 @@ inline int check_launch(const char *what) {
         return SSM_E_LAUNCH;
     }
     return SSM_OK;
+}
+
+// Opt a kernel into more than 64 KiB of dynamic LDS.  The attribute belongs to the (kernel, DEVICE) pair, so the guard is a bit per
+// device of the calling thread's current device, kept by the call site (one `static std::atomic<uint64_t>` per kernel instantiation):
+// a process that drives several GPUs from several threads - torch.nn.DataParallel's replica threads, scripts/main.py:74-76 of the
+// reference - opts every device in on its first launch there.  Two threads racing on one device both set the (idempotent) attribute.
+inline hipError_t reserve_lds(std::atomic<uint64_t> &done, const void *kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev > 63) return hipErrorInvalidDevice;
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 #define SSM_REQUIRE(cond, ...)          \

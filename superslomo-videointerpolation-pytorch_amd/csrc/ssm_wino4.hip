@@ -1081,9 +1081,8 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
     if (const char *e = getenv("SSM_WINO4_SOLO"))          // diagnostics: one workgroup per CU (the LDS request leaves no room for a second)
         if (atoi(e) && lds_bytes < 100 * 1024) lds_bytes = 100 * 1024;
 #endif
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    static std::atomic<uint64_t> lds_reserved{0};          // one bit per device: the attribute is per (kernel, device)
+    const hipError_t attr_rc = ssm::reserve_lds(lds_reserved, (const void *)kern, lds_bytes);
     if (attr_rc != hipSuccess) {
         ssm::set_error("wino4 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;

@@ -933,9 +933,8 @@ int w5launch(W5Params &p, int B, hipStream_t st) {
     void (*kern)(const W5Params) = wino5_kernel<C>;
     constexpr int lds_bytes = C::BYTES, threads = 256;
 #endif
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    static std::atomic<uint64_t> lds_reserved{0};          // one bit per device: the attribute is per (kernel, device)
+    const hipError_t attr_rc = ssm::reserve_lds(lds_reserved, (const void *)kern, lds_bytes);
     if (attr_rc != hipSuccess) {
         ssm::set_error("wino5 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;

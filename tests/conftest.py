@@ -19,7 +19,7 @@ def pytest_configure(config):
 # Collection order (the driver runs `pytest -x`): kernel-level suites that hold every forced tile configuration of a kernel family to the
 # oracle run first, model-level suites at small sizes next, end-to-end cases at a BASELINE workload size (720p / 4K / config 3-5) last -
 # a marginal big-shape assertion must never hide a kernel suite.  Module-scoped fixtures stay grouped: the key is (tier, suite rank inside the kernel tier, original index).
-_KERNEL_SUITES = ("test_hip_wino7", "test_hip_wino5", "test_hip_wino4", "test_hip_wino1d", "test_hip_wino", "test_hip_overshoot", "test_hip_conv_f32", "test_hip_ops", "test_hip_pack_batch",
+_KERNEL_SUITES = ("test_hip_wino7", "test_hip_wino5", "test_hip_wino4", "test_hip_wino1d", "test_hip_wino", "test_hip_overshoot", "test_hip_conv_f32", "test_hip_ops", "test_hip_pack_batch", "test_hip_threads",
                   "test_frames_eval", "test_hip_rccl_world1", "test_hip_conv16", "test_hip_conv16_q8")   # the headline's kernels first
 _BIG_SHAPE = ("720p", "4k", "config3", "config4", "config5")
 

@@ -49,3 +49,48 @@ def test_scan_stops_at_an_unconditional_branch_but_crosses_a_conditional_one():
             "\tglobal_store_dword v1, v2, s[4:5]                          // 8: DC708000 00040201\n")
     assert run(base % "\ts_cbranch_scc0 12                                           // 4: BF84000C\n").returncode == 1
     assert run(base % "\ts_branch 12                                                 // 4: BF82000C\n").returncode == 0
+
+
+def _strip_comments(src):
+    import re
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def test_no_process_wide_guard_on_a_per_device_attribute():
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (kernel, device) pair.  A std::call_once / function-static
+    flag around it opts in the FIRST device only, and a second GPU driven from the same process (the reference's DataParallel
+    replica threads, scripts/main.py:74-76) is refused at launch.  The one sanctioned caller is
+    ssm::reserve_lds (ssm_common.h, bit per device) and conv16's (kernel, device) set."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp")))
+    assert len(files) >= 12
+    callers = {}
+    for f in files:
+        src = _strip_comments(open(f).read())
+        for m in re.finditer(r"hipFuncSetAttribute\s*\(", src):
+            callers.setdefault(os.path.basename(f), []).append(src[max(0, m.start() - 600):m.start()])
+        # a call_once whose body (up to the closing "});") touches a per-device HIP call
+        for m in re.finditer(r"call_once\s*\(", src):
+            body = src[m.start():src.find("});", m.start()) + 3]
+            assert not re.search(r"hipFuncSet|hipDeviceSet|hipSetDevice|hipFuncGetAttributes", body), (f, body[:200])
+    assert sorted(callers) == ["ssm_common.h", "ssm_conv16.hip"], sorted(callers)
+    for name, ctxs in callers.items():
+        for ctx in ctxs:
+            assert "hipGetDevice" in ctx, "%s: hipFuncSetAttribute without a device key in front of it" % name
+    # every > 64 KiB launcher goes through the per-device helper with its own per-kernel mask
+    for name in ("ssm_wino.hip", "ssm_wino1d.hip", "ssm_wino4.hip", "ssm_wino5.hip", "ssm_wino7.hip"):
+        src = _strip_comments(open(os.path.join(csrc, name)).read())
+        assert "ssm::reserve_lds(lds_reserved" in src and "static std::atomic<uint64_t> lds_reserved" in src, name
+
+
+def test_header_states_the_device_contract_the_code_implements():
+    hdr = open(os.path.join(ROOT, "include", "ssm_hip.h")).read()
+    assert "takes the device from the pointers" not in hdr
+    assert "CALLING THREAD's current device" in hdr and "keyed on (kernel, device)" in hdr
+    csrc = os.path.join(ROOT, "superslomo-videointerpolation-pytorch_amd", "csrc")
+    import glob
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")):
+        assert "hipSetDevice" not in _strip_comments(open(f).read()), f
