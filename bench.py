@@ -408,6 +408,7 @@ def train_bench(args):
     sync()
     trainer.allreduce.exposed_seconds()          # (drop the warm-up's brackets)
     elapsed = sdist.timed_steps(step, args.steps, 0, sync)
+    ar_brackets = len(trainer.allreduce._exposed_events)          # GPU + RCCL: one event bracket per timed step (a dead measurement shows as 0)
     ar_ms = 1e3 * trainer.allreduce.exposed_seconds() / args.steps
     timer = KernelTimer()
     UNetPlan.timer = timer
@@ -428,6 +429,7 @@ def train_bench(args):
                                                                                   "VGG16 conv4_3 perceptual term (synthetic VGG weights)"),
                       "global_batch": B * world},
            "allreduce": {"bytes": trainer.allreduce.bytes, "ms_per_step": round(ar_ms, 3), "buckets_per_step": trainer.allreduce.last_buckets,
+                         "brackets": ar_brackets,
                          "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                          "note": "ms_per_step = time the compute stream waited for the bucketed exchange (event brackets; the exchange overlaps the backward and never blocks the host)"},
            "host_enqueue_ms_per_step": round(1e3 * sdist.timed_steps.last_enqueue_s / args.steps, 3)}

@@ -189,10 +189,14 @@ int ssm_wino_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const f
 int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view pool, ssm_view add, int add_div, int B, int C, int H, int W,
                           float slope, int flags, void *stream);
 /* The direct-form twin (csrc/ssm_conv.hip) for the maps no Winograd form takes (odd widths: config 3's 11x11 bottleneck): the same
- * convolution as ssm_conv2d_fwd - one or two sources, no fused pool - with KS workgroups per output tile; `part` and the finishing
+ * convolution as ssm_conv2d_fwd - ONE source when KS > 1 (C2 must be 0: the kernel offsets its first source by the split's channel
+ * range; two sources are accepted with KS = 1 only), no fused pool - with KS workgroups per output tile; `part` and the finishing
  * launch as above (ssm_splitk_finish_fwd takes odd widths too).  ssm_conv_splitk_plan: KS for the tile configuration the filter was
  * packed for (1: do not split; $SSM_CONV_SPLITK=0: always 1).                                                                    */
 int ssm_conv_splitk_plan(int k, int Cin, int Cout, int B, int H, int W, int *KS);
+/* Run-time twin of $SSM_WINO_SPLITK / $SSM_CONV_SPLITK for the two plan functions: 1 = on, 0 = off, -1 = leave.  Returns the previous
+ * state as (wino | conv << 1).  A split reorders a layer's fp32 sum over the input channels: tests A/B it in one process.            */
+int ssm_splitk_enable(int wino, int conv);
 int ssm_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view part,
                           int KS, int B, int H, int W, int Cout, int k, void *stream);
 /* ... with the pre-activation addend of ssm_conv2d_add_fwd (8-byte aligned view). */
@@ -524,6 +528,28 @@ int ssm_conv2d_wgrad_bias(ssm_view x, ssm_view dz, float *dw_oihw, float *db_acc
  * The weight gradient of the f16f8 training plan; the exact-fp32 plan keeps ssm_conv2d_wgrad.                                 */
 int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, int B, int Cin, int Cout, int H, int W, int k, int cin_total,
                             int ci_offset, int zero_first, void *stream);
+/* Weight gradient of a 3x3 layer in the Winograd domain, F(2x2,3x3), fp32 throughout (csrc/ssm_wgradw.hip) - the same quantity as
+ * ssm_conv2d_wgrad(k = 3) (autograd of nn.Conv2d.weight, scripts/models/layers.py:21-33 under scripts/main.py:138-197) for 16 instead of
+ * 36 multiplies per 2x2 output tile, in two launches:
+ *   ssm_conv2d_wgrad_wino   du[16][Cout][cin_total] (+ ci_offset) += sum_tiles (A dZ A^T) (.) (B^T x B)     fp32 atomics; du must be
+ *                           zero before a step's first launch (ssm_wgrad_wino_scratch_floats floats; the finishing launch re-zeroes
+ *                           it); db_acc (may be NULL): += sum dz, as ssm_conv2d_wgrad_bias; two-source layers call it once per source
+ *   ssm_wgrad_wino_finish   for each job: dw_oihw[co][ci][3][3] += scale * G^T du[.][co][ci] G, du := 0.  `jobs` is a DEVICE array of
+ *                           n_jobs ssm_wgradw_finish_job records (one per layer: a training step finishes a gradient bucket's layers
+ *                           in one launch); max_n = the largest n among them
+ * ssm_wgrad_wino_supported: 3x3, Cin and Cout >= 32, maps of 40+ pixels (below that K = tiles is too short against the 16 x Cout x
+ * Cin partial sums every workgroup adds; those layers keep ssm_conv2d_wgrad).                                                      */
+typedef struct ssm_wgradw_finish_job {
+    float *du;       /* [16][Cout][cin_total] scratch of the layer                 */
+    float *dw;       /* [Cout][cin_total][3][3] gradient, accumulated into         */
+    int n;           /* Cout * cin_total                                           */
+    int pad_;
+} ssm_wgradw_finish_job;
+int ssm_wgrad_wino_supported(int Cin, int Cout, int H, int W, int k);
+long long ssm_wgrad_wino_scratch_floats(int Cout, int cin_total);
+int ssm_conv2d_wgrad_wino(ssm_view x, ssm_view dz, float *du, float *db_acc, int B, int Cin, int Cout, int H, int W, int cin_total,
+                          int ci_offset, void *stream);
+int ssm_wgrad_wino_finish(const void *jobs_dev, int n_jobs, int max_n, float scale, void *stream);
 int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int h, int w, int acc_a, int acc_b,
                            void *stream);
 int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,

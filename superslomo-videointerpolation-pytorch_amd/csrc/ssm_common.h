@@ -40,6 +40,10 @@ inline hipError_t reserve_lds(std::atomic<uint64_t> &done, const void *kernel, i
     return e;
 }
 
+// split-K switches of the two plan functions (ssm_wino_splitk_plan, ssm_conv_splitk_plan): initialised from $SSM_WINO_SPLITK / $SSM_CONV_SPLITK
+// on first use, settable at run time through ssm_splitk_enable (tests A/B the reordered sums in one process)
+std::atomic<int> &splitk_switch(int which);          // 0: Winograd form, 1: direct form; value -1 = not initialised yet
+
 #define SSM_REQUIRE(cond, ...)          \
     do {                                \
         if (!(cond)) {                  \

@@ -796,10 +796,7 @@ extern "C" int ssm_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2, cons
 extern "C" int ssm_conv_splitk_plan(int k, int Cin, int Cout, int B, int H, int W, int *KS) {
     SSM_REQUIRE(KS, "conv splitk_plan: null pointer");
     *KS = 1;
-    static const int enabled = [] {
-        const char *e = getenv("SSM_CONV_SPLITK");
-        return e ? atoi(e) : 1;
-    }();
+    const int enabled = ssm::splitk_switch(1).load(std::memory_order_relaxed);          // ($SSM_CONV_SPLITK, ssm_splitk_enable)
     if (!enabled || Cin < 128) return SSM_OK;
     const int kd = pick_kind(k, Cin, Cout, B, H, W, 0, 0);
     if (kd != K3N32T) return SSM_OK;          // (the one configuration with a split-K instantiation, see conv_split_ok)

@@ -1179,10 +1179,7 @@ int pick_wkind_split(int CinPart, int Cout, int B, int H, int W, int ups, int BN
 extern "C" int ssm_wino_splitk_plan(int Cin, int Cout, int B, int H, int W, int ups, int BN, int *KS) {
     SSM_REQUIRE(KS, "wino splitk_plan: null pointer");
     *KS = 1;
-    static const int enabled = [] {
-        const char *e = getenv("SSM_WINO_SPLITK");
-        return e ? atoi(e) : 1;
-    }();
+    const int enabled = ssm::splitk_switch(0).load(std::memory_order_relaxed);          // ($SSM_WINO_SPLITK, ssm_splitk_enable)
     if (!enabled || W % 2 || BN % 32 || Cin < 128) return SSM_OK;
     const int kd = pick_wkind_split(Cin, Cout, B, H, W, ups, BN);
     if (kd < 0) return SSM_OK;

@@ -125,6 +125,8 @@ class SSMLosses(nn.Module):
         if self.__dict__.get("_l1_buf", (None,))[0] != key:
             self.__dict__["_l1_buf"] = (key, torch.empty(128 * Bn, dtype=torch.float32, device=dev))
         sums = torch.empty(Bn, 2, dtype=torch.float32, device=dev)
+        # the kernel indexes the stage-1 flows and the pair by the stage-2 batch entry: one interpolation time per sample (training plan)
+        assert eng.G == 1 and eng.B1 == Bn, "planned_losses needs one interpolation time per pair (stage-2 batch %d, pairs %d)" % (eng.B2, eng.B1)
         in16, out5, flow4 = eng.s2.t["in"], eng.s2.t["out"], eng.s1.t["out"]
         est = hb.view_of(eng.est) if eng.hl8 else in16.view(6)
         pred, tgt = interpolated_image.contiguous(), target_image.contiguous()

@@ -20,6 +20,9 @@ from . import hipbind as hb
 
 DGRAD_BLOCKED = os.environ.get("SSM_TRAIN_DGRAD_BLOCKED", "1") != "0"
 DGRAD_WINO4 = os.environ.get("SSM_TRAIN_DGRAD_WINO4", "1") != "0"          # 3x3 data gradients as F(4x4,3x3) where the cost model prefers it
+# r6: weight gradients of the 3x3 layers of an f32w plan in the Winograd domain (csrc/ssm_wgradw.hip: 16 instead of 36 multiplies per 2x2
+# tile, like that plan's forward and data gradients) on the maps hb.wgrad_wino_supported accepts; $SSM_WGRAD_WINO=0: the direct kernel
+WGRAD_WINO = os.environ.get("SSM_WGRAD_WINO", "1") != "0"
 
 
 def transposed_filter(w):
@@ -146,6 +149,27 @@ class UNetGrad:
         if cur:
             self.buckets.append(cur)
         self._pending = []
+        # Winograd-domain weight gradients: per layer a [16, Cout, Cin] scratch of partial sums (one zeroed arena per U-Net; the finishing
+        # launch of a bucket - G^T dU G added into the flat gradient buffer - leaves it zeroed for the next step)
+        self.ww, self._ww_finish = {}, [None] * len(self.buckets)
+        if WGRAD_WINO and getattr(plan, "wino", False) and not self.hl8:
+            chosen = []
+            for name, (ci, co, k) in plan.layers.items():
+                s = layer_scale(name)
+                srcs = self.io[name][0]
+                cmin = min(plan.t[sn].C for sn in srcs) if all(sn in plan.t for sn in srcs) else ci
+                if hb.wgrad_wino_supported(cmin, co, plan.H // s, plan.W // s, k):
+                    chosen.append((name, 16 * co * ci))
+            arena = torch.zeros(sum(n for _, n in chosen), dtype=torch.float32, device=self.dev)
+            off = 0
+            for name, n in chosen:
+                ci, co, _ = plan.layers[name]
+                self.ww[name] = arena[off:off + n].view(16, co, ci)
+                off += n
+            for i, bucket in enumerate(self.buckets):
+                ent = [(self.ww[n], self.grads[param_key(n, "weight")]) for n in bucket if n in self.ww]
+                if ent:
+                    self._ww_finish[i] = hb.WgradWinoFinish(ent, self.dev)
 
     N_BUCKETS = int(os.environ.get("SSM_GRAD_BUCKETS", "4"))
 
@@ -162,6 +186,8 @@ class UNetGrad:
             if name in pend:
                 pend.discard(name)
                 if not pend:
+                    if self._ww_finish[i] is not None:      # the bucket's Winograd-domain partial sums -> dW (same stream, behind them)
+                        self._ww_finish[i].run()
                     a = self._span_of(self.buckets[i][0])[0]
                     b = self._span_of(self.buckets[i][-1])[1]
                     view = self.flat[a:b]
@@ -254,18 +280,19 @@ class UNetGrad:
                 if (use_w and (getattr(self.plan, "wino4", False) or DGRAD_WINO4) and hb.wino4_supported(co, ci, self.plan.H // s, self.plan.W // s, k)
                         and hb.wino4_preferred(co, ci, self.B, self.plan.H // s, self.plan.W // s, False)):
                     cls = hb.PackedWino4
-                from .engine import wino1d_enabled
+                from .engine import WINO5, WINO7, WINO_SKIP, wino1d_enabled
                 if getattr(self.plan, "wino1d", False) and wino1d_enabled(k) and hb.wino1d_supported(co, ci, self.plan.H // s, self.plan.W // s, k):
-                    cls = hb.PackedWino1d          # data gradient of a 7x7 / 5x5 layer: the same convolution on the transposed filter
+                    cls = hb.PackedWino1d          # (inference-style plans only: a training plan never sets wino1d)
                 # r5: the data gradient of a 7x7 / 5x5 layer in the blocked two-dimensional forms of the inference plans (csrc/ssm_wino7.hip,
-                # ssm_wino5.hip) where the transposed layer has whole 32-channel output blocks (conv1b, conv2a, conv2b).  The forward of a
-                # training plan stays in the direct form - a coarser forward rounding moves pre-activations across the loss's kinks
-                # (engine.UNetPlan) - but a data gradient is linear in dZ and the masks come from that forward: nothing moves, the
-                # gradient carries the form's own 3e-5 and the bars of tests/test_hip_backward.py hold.  $SSM_TRAIN_DGRAD_BLOCKED=0: off
-                if getattr(self.plan, "wino", False) and DGRAD_BLOCKED:
-                    if hb.wino7_supported(co, ci, self.plan.H // s, self.plan.W // s, k) or (k == 7 and 8 <= ci < 32):
+                # ssm_wino5.hip) where the transposed layer has whole 32-channel output blocks (conv1b, conv2a, conv2b).  A data gradient is
+                # linear in dZ and the masks come from the forward: the gradient carries the form's own 3e-5 and the bars of
+                # tests/test_hip_backward.py hold.  $SSM_TRAIN_DGRAD_BLOCKED=0: off; the plan-wide switches $SSM_WINO7=0 / $SSM_WINO5=0 /
+                # $SSM_WINO_SKIP=<layer> restore the direct form here as they do in the forward
+                skip = name in WINO_SKIP or "all" in WINO_SKIP
+                if getattr(self.plan, "wino", False) and DGRAD_BLOCKED and not skip:
+                    if WINO7 not in ("0", "") and (hb.wino7_supported(co, ci, self.plan.H // s, self.plan.W // s, k) or (k == 7 and 8 <= ci < 32)):
                         cls = hb.PackedWino7          # (stage 2's conv1a, 16 inputs: the transposed layer padded to one 32-channel block, see backward())
-                    elif hb.wino5_supported(co, ci, self.plan.H // s, self.plan.W // s, k) and co % 4 == 0:
+                    elif WINO5 not in ("0", "") and hb.wino5_supported(co, ci, self.plan.H // s, self.plan.W // s, k) and co % 4 == 0:
                         cls = hb.PackedWino5
                 self.pk_t[name] = cls(transposed_filter(w), torch.zeros(ci, device=self.dev), self.B, self.plan.H // s, self.plan.W // s)
                 if getattr(self.plan, "wino", False) and cls is hb.PackedConv:
@@ -305,12 +332,17 @@ class UNetGrad:
                 ev.record()                      # dZ of this layer is complete on the caller's stream
                 self.side.wait_event(ev)
             with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
+                du = self.ww.get(name)
                 if tm is not None:
-                    e0, e1 = tm.span("wgrad", "s%d.%s" % (plan.stage, name), flops)
+                    e0, e1 = tm.span("wgrad", "s%d.%s" % (plan.stage, name), flops, issued=flops * (16.0 / 36.0 if du is not None else 1.0))
                     e0.record()
                 off = 0
                 for sname in srcs:
                     X = self.act(sname)
+                    if du is not None:          # Winograd domain: partial sums into the layer's scratch, dW at the bucket's finishing launch
+                        hb.wgrad_wino(X.view(), dz.view(), du, self.grads[bk] if off == 0 else None, self.B, X.C, co, Y.H, Y.W, ci, off)
+                        off += X.C
+                        continue
                     # fp32 path: the bias gradient rides in the first source's GEMM as one more column (no pass of its own over dZ)
                     wgrad(X, dz, self.grads[wk], k, ci_offset=off, zero_first=False, split=self.split_wgrad,
                           bias_acc=self.grads[bk] if off == 0 and not self.split_wgrad else None)

@@ -152,7 +152,9 @@ class GradientAllReduce:
             self._exposed_events.append((e0, e1))
             if len(self._exposed_events) > 4096:          # a long run that never reads the figure
                 del self._exposed_events[:2048]
-        el = 0.0 if cuda else time.perf_counter() - t0
+        # RCCL's Work.wait() only orders streams; every other backend (gloo, also on device tensors) blocks the caller inside wait()
+        host_blocked = not (cuda and dist.get_backend() == "nccl")
+        el = time.perf_counter() - t0 if host_blocked else 0.0
         self._exposed_host_s += el
         self.last_buckets, self._works = len(self._works), []
         covered, self._bucket_bytes = self._bucket_bytes, 0
@@ -210,6 +212,7 @@ class GradientAllReduce:
             if cuda:
                 torch.cuda.synchronize(self.flat.device)
             el = time.perf_counter() - t0
+            self._exposed_host_s += el          # (the non-bucketed paths block the host: their wait is all exposed)
             for r in runs:
                 r.div_(dist.get_world_size())
             return el
@@ -225,6 +228,7 @@ class GradientAllReduce:
         if cuda:
             torch.cuda.synchronize(self.flat.device)
         el = time.perf_counter() - t0
+        self._exposed_host_s += el
         self.flat.div_(dist.get_world_size())
         off = 0
         for p in self.params:

@@ -108,7 +108,7 @@ TRAIN_FWD_BLOCKED = os.environ.get("SSM_TRAIN_FWD_BLOCKED", "1")
 
 # fused-upsample 3x3 layers of an f32w INFERENCE plan in the sub-pixel form (interior: a plain F(4x4,3x3) convolution of the low-res sources with 4 Cout
 # effective channels in the 64-cout kernel form; border ring: the fused-upsample kernel; hb.PackedSubpixelWino4): conv11a, the one 32-cout
-# fused-upsample layer (1.67 -> ms at batch 7, profiles/r11l_*); $SSM_WINO4_SUBPIXEL=0 keeps the fused-upsample kernel everywhere
+# fused-upsample layer (1.68 -> 1.36 ms at batch 7, profiles/r11l_subpixel_conv11a.txt); $SSM_WINO4_SUBPIXEL=0 keeps the fused-upsample kernel everywhere
 WINO4_SUBPIXEL = tuple(n for n in os.environ.get("SSM_WINO4_SUBPIXEL", "conv11a").split(",") if n not in ("", "0"))
 
 
@@ -121,16 +121,20 @@ def wino1d_enabled(k):
     return k in (5, 7) and str(k) in WINO1D
 
 
-def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d, wino4=None):
+def choose_algo(name, ci, co, k, nb, h, w, ups, wino, wino1d, wino4=None, blocked2d=None):
     """Algorithm of one convolution of an fp32 plan: "direct" (csrc/ssm_conv.hip), "wino" = F(2x2,3x3) (ssm_wino.hip), "wino4" =
     F(4x4,3x3) (ssm_wino4.hip), "wino1d" = F(2,7) / F(4,5) along x (ssm_wino1d.hip), "wino7" = the 7x7 layers as 2x2 blocks of F(4x4,4x4) (ssm_wino7.hip).  wino: the plan is mode f32w; wino1d: it is an
     inference plan (the 8-frequency forms stay out of the training plans).  Pure function of the problem: bench.py uses it to count the
     multiply-adds the matrix cores issue."""
     skip = name in WINO_SKIP or "all" in WINO_SKIP or name == "final_conv"
     wino4 = wino1d if wino4 is None else wino4
-    if wino1d and not skip and k == 7 and WINO7 not in ("0", "") and hb.wino7_supported(ci, co, h, w, k):
+    # blocked2d: the plan may run the 7x7 / 5x5 layers in the two-dimensional blocked forms; wino1d: ... and, where those do not apply or
+    # are switched off, in the 1-D forms (inference plans only: a training plan takes wino7 / wino5 or else the direct form - the 1-D
+    # forms miss its gradient bar, TRAIN_FWD_BLOCKED above)
+    blocked2d = wino1d if blocked2d is None else blocked2d
+    if blocked2d and not skip and k == 7 and WINO7 not in ("0", "") and hb.wino7_supported(ci, co, h, w, k):
         return "wino7"
-    if wino1d and not skip and k == 5 and WINO5 not in ("0", "") and ci % 4 == 0 and hb.wino5_supported(ci, co, h, w, k):
+    if blocked2d and not skip and k == 5 and WINO5 not in ("0", "") and ci % 4 == 0 and hb.wino5_supported(ci, co, h, w, k):
         return "wino5"
     if wino1d and not skip and wino1d_enabled(k) and hb.wino1d_supported(ci, co, h, w, k):
         return "wino1d"
@@ -220,7 +224,8 @@ class UNetPlan:
         # 7x7 / 5x5 layers in a Winograd form (choose_algo: the blocked 2-D forms, else the 1-D ones): inference plans, and since r5 the
         # training plans too (TRAIN_FWD_BLOCKED above: the gradient bars hold with the 2-D forms)
         infer_plan = self.fuse_up and not twins
-        self.wino1d = self.wino and (infer_plan or TRAIN_FWD_BLOCKED == "1")
+        self.wino1d = self.wino and infer_plan                                      # the 1-D forms: inference plans only
+        self.blocked2d = self.wino and (infer_plan or TRAIN_FWD_BLOCKED == "1")     # wino7 / wino5
         self.wino4 = self.wino and (infer_plan or TRAIN_WINO4 == "1")          # F(4x4,3x3) for the 3x3 layers
         # hoist = (B1, G): stage-2 inference plan whose batch holds G interpolation times for each of B1 pairs (entry p*G + i).  The
         # parts of two convolutions' inputs that do not depend on t - the image channels 0:3 / 13:16 of conv1a's 16-channel input
@@ -335,7 +340,7 @@ class UNetPlan:
             else:
                 nb = self.Bd if name in self.DECODER else self.B
                 ups = self.fuse_up and name in self.UPS
-                cls = _ALGO_CLASS[choose_algo(name, ci, co, k, nb, self.H // s, self.W // s, ups, self.wino, self.wino1d, self.wino4)]()
+                cls = _ALGO_CLASS[choose_algo(name, ci, co, k, nb, self.H // s, self.W // s, ups, self.wino, self.wino1d, self.wino4, self.blocked2d)]()
                 if self.hoist and name == "conv1a":
                     # per-t part: channels 3:13 (warped frames + estimated flows); per-pair part: the frames themselves in stage 1's
                     # input order (I0 = channels 13:16, I1 = channels 0:3), no bias, no activation

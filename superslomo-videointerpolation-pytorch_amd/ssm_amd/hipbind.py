@@ -149,6 +149,11 @@ SIGNATURES = {
     "ssm_bias_grad_acc": (_c_int, [SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_wgrad_bf16x3": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_splitk_enable": (_c_int, [_c_int, _c_int]),
+    "ssm_wgrad_wino_supported": (_c_int, [_c_int] * 5),
+    "ssm_wgrad_wino_scratch_floats": (ctypes.c_longlong, [_c_int, _c_int]),
+    "ssm_conv2d_wgrad_wino": (_c_int, [SsmView, SsmView, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_wgrad_wino_finish": (_c_int, [_vp, _c_int, _c_int, _c_float, _vp]),
     "ssm_upsample2x_cat_bwd": (_c_int, [SsmView, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_synthesize_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int,
                                     _c_int, _c_int, _vp]),
@@ -335,7 +340,8 @@ def conv2d(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None
         "filter was packed for another tile configuration (batch/size/pool changed)"
     # launches that leave most of the chip idle run split over the input channels (see wino_splitk) - only where the plan allows it
     # (pk.split_ok: mode f32w; mode f32 and torch.ops.ssm.conv2d keep the reference's one fmaf chain per output)
-    if pool is None and getattr(pk, "split_ok", False):
+    # (the split kernel offsets its FIRST source by the split's channel range: two-source launches fall through to the plain kernel)
+    if pool is None and x2 is None and c2 == 0 and getattr(pk, "split_ok", False):
         key = (B, H, W)
         cache = pk.__dict__.setdefault("_splitk", {})
         if key not in cache:
@@ -882,6 +888,43 @@ class PackBatch32:
             check(lib.ssm_pack32_weights_batch(self.table.data_ptr(), self.n, self.total, st))
         if self.tiles is not None:
             check(lib.ssm_pack32_wino_tiles_batch(self.tiles[0].data_ptr(), self.tiles[1], self.tiles[2], self.tiles[3], st))
+
+
+class SsmWgradwFinishJob(ctypes.Structure):
+    """ssm_wgradw_finish_job (include/ssm_hip.h)."""
+    _fields_ = [("du", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("n", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+def wgrad_wino_supported(cin, cout, H, W, k):
+    return bool(load().ssm_wgrad_wino_supported(cin, cout, H, W, k))
+
+
+def wgrad_wino(x_view, dz_view, du, bias_acc, B, cin, cout, H, W, cin_total, ci_offset):
+    """du [16, cout, cin_total] (fp32, zero before a step's first launch) += the Winograd-domain partial sums of one source."""
+    assert du.is_contiguous() and du.dtype == torch.float32 and du.numel() == 16 * cout * cin_total
+    check(load().ssm_conv2d_wgrad_wino(x_view, dz_view, du.data_ptr(), bias_acc.data_ptr() if bias_acc is not None else None, B, cin, cout,
+                                       H, W, cin_total, ci_offset, stream_ptr()))
+
+
+class WgradWinoFinish:
+    """One finishing launch for several layers: dw += scale * G^T du G, du := 0 (ssm_wgrad_wino_finish).  entries: (du [16,Cout,Cin]
+    scratch, dw [Cout,Cin,3,3] gradient slice) - raw pointers, static for the life of the training plan."""
+
+    def __init__(self, entries, device):
+        jobs = (SsmWgradwFinishJob * len(entries))()
+        self.keep = list(entries)
+        self.max_n = 0
+        for j, (du, dw) in zip(jobs, entries):
+            assert dw.is_contiguous() and du.is_contiguous() and dw.dim() == 4 and tuple(dw.shape[2:]) == (3, 3)
+            n = dw.shape[0] * dw.shape[1]
+            assert du.numel() == 16 * n
+            j.du, j.dw, j.n = du.data_ptr(), dw.data_ptr(), n
+            self.max_n = max(self.max_n, n)
+        self.n = len(entries)
+        self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
+
+    def run(self, scale=1.0):
+        check(load().ssm_wgrad_wino_finish(self.table.data_ptr(), self.n, self.max_n, float(scale), stream_ptr()))
 
 
 def conv2d_hl8(x1, c1, x2, c2, pk, y_hl8, y_f32, pool, B, H, W, lrelu=True, slope=0.1, fast=False):

@@ -165,6 +165,19 @@ def test_full_model_recurrent_vs_oracle(dev, kind, precision):
     # (two launch plans of the same arithmetic: the loss path decodes every window, so its batch - and with it tile configurations and
     # the split-K factors of the bottleneck layers, i.e. the order of the fp32 sums - differs from the inference plan's)
     assert float((img2 - img).abs().max()) < 5e-5 and tuple(losses.shape) == (2, 4) and bool(torch.isfinite(losses).all())
+    if precision in ("f32", "f32w"):
+        # A/B of the split itself: with split-K OFF in both plan functions the two plans meet the old 1e-5 bar, and the frame
+        # moves by less than 3e-5 when the split is switched back on - the wider bar above is the split's reordering and nothing else
+        from ssm_amd import hipbind as hb
+        prev = hb.load().ssm_splitk_enable(0, 0)
+        try:
+            m0 = _model(kind, dev, precision)
+            img_off, _ = m0(x.to(dev), t.to(dev), inference_mode=True)
+            img2_off, _ = m0(x.to(dev), t.to(dev), target_images=tgt, inference_mode=False)
+        finally:
+            hb.load().ssm_splitk_enable(prev & 1, prev >> 1)
+        assert float((img2_off - img_off).abs().max()) < 1e-5, "split-K off: the two plans differ by %.2e" % float((img2_off - img_off).abs().max())
+        assert float((img_off - img).abs().max()) < 3e-5, "switching split-K on moves the frame by %.2e" % float((img_off - img).abs().max())
 
 
 def test_interpolate_windows_hoisted(dev):
