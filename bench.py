@@ -103,7 +103,12 @@ def spawn_ranks(n):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # a rank that dies before the rendezvous would leave the others waiting for it until the store times out: poll, and end the launch
     # as soon as any rank has failed
-    out = b""
+    # rank 0's pipe is drained by a thread WHILE the ranks are polled: a line longer than the 64 KB pipe buffer (today's is ~20 KB) would
+    # otherwise block rank 0 in write() forever while this loop waits for it to exit
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     while True:
         rcs = [p.poll() for p in procs]
         if any(rc not in (None, 0) for rc in rcs) or all(rc == 0 for rc in rcs):
@@ -113,8 +118,9 @@ def spawn_ranks(n):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    out = procs[0].stdout.read() if procs[0].stdout else b""
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=30)
+    out = b"".join(chunks)
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
@@ -205,9 +211,34 @@ def setup_ranks(args):
         sdist.init("gloo")
         return rank, local_rank, world, torch.device("cpu")
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    # one process per GPU: the device is the LOCAL rank (the driver starts N ranks on ONE node; a global rank would index past the node)
+    ndev = torch.cuda.device_count()
+    assert 0 <= local_rank < ndev, "LOCAL_RANK %d but %d visible GPU(s): one rank per GPU of the node" % (local_rank, ndev)
     torch.cuda.set_device(local_rank)
+    assert torch.cuda.current_device() == local_rank
+    free_b, total_b = torch.cuda.mem_get_info(local_rank)
+    need = hbm_needed_bytes(args)
+    assert free_b >= need, ("rank %d: %.0f GB of HBM free on cuda:%d, this configuration's plans need ~%.0f GB (activations are planned, "
+                            "nothing aliased: DESIGN 2)" % (rank, free_b / 1e9, local_rank, need / 1e9))
+    args.hbm = {"device_total_gb": round(total_b / 1e9, 1), "free_at_start_gb": round(free_b / 1e9, 1), "planned_need_gb": round(need / 1e9, 1)}
     sdist.init("nccl")
     return rank, local_rank, world, torch.device("cuda", local_rank)
+
+
+def hbm_needed_bytes(args):
+    """Conservative per-RANK HBM need of a configuration (one process per GPU, so per GPU): a UNetPlan keeps ~45 activations of a
+    U-Net resident, 2.2 GB per batch entry at 736x1280, scaled by the pixels; a pass holds pairs_per_batch stage-1 entries +
+    7 x that many stage-2 entries, `streams` passes in flight.  Training (2 x 352x352, forward activations + gradient planes +
+    materialised upsample tensors + VGG16 + Adam state): 14 GB measured.  The parity / side-mode legs of a default line reuse the
+    same memory after the timed plans are dropped."""
+    if args.mode == "train":
+        return int(20e9)
+    px = (2176 * 3840) if args.size == "4k" else (736 * 1280)
+    per_entry = 2.2e9 * px / (736 * 1280) / 2.0          # (2.2 GB covers a stage-1 + a stage-2 entry)
+    if args.mode == "recurrent":
+        return int(3 * 2 * per_entry * 2 + 8e9)
+    entries = args.streams * args.pairs_per_batch * (1 + N_T)
+    return int(entries * per_entry + 8e9)
 
 
 def conv_flops_per_pair(h, w, n_t, issued_for=None, batch=2):
@@ -595,6 +626,77 @@ def stub_bench(args):
         torch.distributed.destroy_process_group()
 
 
+def stub_train_bench(args):
+    """--mode train --stub: the TRAINING launcher path at world N on CPU / gloo (the real one needs N GPUs: only RCCL at world 1 runs
+    in `pytest -m gpu`).  Everything of the exchange is real - the two U-Nets' flat gradient buffers in their true layout
+    (ssm_amd.backward.grad_layout: 38,848,553 floats = 155.4 MB, 4 buckets each, handed over tail first as the backward completes
+    them), GradientAllReduce.reduce / __call__, the 1/world pre-scale, barrier-bracketed timing, max over ranks - only the gradients are
+    synthetic: rank r contributes (r + 1) x a fixed pattern, so every rank can check the average it receives."""
+    import torch.nn as nn
+    from ssm_amd import dist as sdist
+    from ssm_amd.backward import UNetGrad, grad_layout
+    from ssm_amd.weights import unet_layers
+    rank, local_rank, world, dev = setup_ranks(args)
+    os.environ["SSM_FORCE_ALLREDUCE"] = "1"
+    flats, buckets, params = [], [], []
+    for stage in (1, 2):
+        layers = {n: (ci, co, k) for n, ci, co, k in unet_layers(stage, True)}
+        sizes, span, bk = grad_layout(layers, UNetGrad.N_BUCKETS)
+        flat = torch.empty(sum(int(torch.Size(sh).numel()) for _, sh in sizes))
+        off = 0
+        for key, sh in sizes:
+            n = int(torch.Size(sh).numel())
+            prm = nn.Parameter(torch.empty(0))
+            prm.data = torch.zeros(sh)
+            prm.grad = flat[off:off + n].view(sh)
+            params.append(prm)
+            off += n
+        flats.append(flat)
+        buckets.append([(span[param_key_layer(b[0])][0], span[param_key_layer(b[-1])][1]) for b in bk])
+    ar = sdist.GradientAllReduce(params)
+
+    class _PG:          # what GradientAllReduce.attach configures on a PairGrad
+        sync, sync_scale = None, 1.0
+    pg = _PG()
+    ar.attach(pg)
+    assert pg.sync is ar and abs(pg.sync_scale - 1.0 / world) < 1e-12
+    pattern = [torch.linspace(0.5, 1.5, f.numel()) for f in flats]
+    checks = []
+
+    def step():
+        for u in (1, 0):                                   # the backward runs stage 2 first, then stage 1; buckets complete tail first
+            flats[u].copy_(pattern[u] * float(rank + 1))
+            for a, b in reversed(buckets[u]):
+                view = flats[u][a:b]
+                view.mul_(pg.sync_scale)
+                pg.sync.reduce(view)
+        ar()
+        want = (world + 1) / 2.0                           # mean over ranks of (r + 1)
+        checks.append(max(float((flats[u][::4097] - want * pattern[u][::4097]).abs().max()) for u in (0, 1)))
+
+    elapsed = sdist.timed_steps(step, args.steps, args.warmup, lambda: None)
+    assert max(checks) < 1e-5, "averaged gradients are off by %.3e" % max(checks)
+    B = 2
+    if rank == 0:
+        print(json.dumps({"metric": "training samples/sec (352x352 crops, forward+backward+Adam)", "value": round(B * world * args.steps / elapsed, 3),
+                          "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub (no GPU work: launcher / gradient-exchange test only)",
+                          "config": {"workload": "stub of superslomo_original.ini training: the real gradient layout and exchange, synthetic gradients",
+                                     "global_batch": B * world},
+                          "allreduce": {"bytes": ar.bytes, "buckets_per_step": ar.last_buckets, "backend": torch.distributed.get_backend(),
+                                        "ms_per_step": round(1e3 * ar.exposed_seconds() / max(args.steps + args.warmup, 1), 3),
+                                        "max_abs_err_of_the_average": max(checks)},
+                          "host": {"usable_cpus": usable_cpus(), "cpus_of_this_rank": args.rank_cpus}}))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def param_key_layer(name):
+    from ssm_amd.weights import param_key
+    return param_key(name, "weight")[:-len(".weight")]
+
+
 def start_clock_probe(dev, seconds):
     """Diagnostic (optional: needs tools/libclockprobe.so, built by __graft_entry__.build()): one wave on a side stream spins
     for `seconds` and records shader-clock ticks against the 100 MHz reference."""
@@ -760,6 +862,48 @@ def io_legs(dev, h, w, reps=10):
     return {"h2d_ms": round(acc[0] / reps, 4), "h2d_bytes": u8.numel(), "ingest_kernel_ms": round(acc[1] / reps, 4),
             "d2h_ms": round(acc[3] / reps, 4), "d2h_bytes": host_out.numel(),
             "note": "per pair: 2 uint8 frames in, 7 uint8 frames out, pinned memory; not part of `value` (inputs resident in HBM)"}
+
+
+def streamed_with_io(pipe, dev, h, w, P, PB, t_dev, steps, sdist, sync, cfg=None):
+    """The evaluator's loop END TO END (scripts/evaluate_interpolation_results.py:246-278: `.cuda().float()` in, `.cpu().numpy()` out per
+    batch), streamed: uint8 pairs in PINNED host memory -> H2D -> ssm_frames_from_u8_fwd (normalise + pad) -> the timed pipeline ->
+    ssm_frames_to_u8_fwd (crop + denormalise + uint8) -> D2H into pinned memory.  Every leg of a pass is queued on that pass's HIP stream:
+    with `streams` passes in flight the copy engines move one pass's frames while the other passes' convolutions run, and nothing
+    synchronises the host inside the loop.  Same pairs per step and passes in flight as the headline region; never part of `value`."""
+    from ssm_amd.frames import frames_from_u8, frames_to_u8
+    from ssm_amd.weights import synthetic_frames_u8
+    nb = P // PB
+    host_in = [torch.cat([synthetic_frames_u8(2, h, w, seed=42 + b * PB + j).permute(0, 2, 3, 1) for j in range(PB)], 0).contiguous().pin_memory()
+               for b in range(nb)]                                                       # [2 PB, h, w, 3] uint8 per pass
+    dev_in = [torch.empty(2 * PB, h, w, 3, dtype=torch.uint8, device=dev) for _ in range(pipe.n)]
+    host_out = [torch.empty(PB * N_T, h, w, 3, dtype=torch.uint8).pin_memory() for _ in range(pipe.n)]
+    state = {"i": 0}
+
+    def step():
+        for b in range(nb):
+            k = state["i"] % pipe.n
+            state["i"] += 1
+            with torch.cuda.stream(pipe.streams[k]):
+                dev_in[k].copy_(host_in[b], non_blocking=True)
+                x = frames_from_u8(dev_in[k], cfg)                                      # [2 PB, 3, Hp, Wp]
+                frames = pipe.engines[k].run(x.view(PB, 6, x.shape[2], x.shape[3]), t_dev, False)
+                host_out[k].copy_(frames_to_u8(frames, h, w, cfg), non_blocking=True)
+
+    for _ in range(2):
+        step()
+    sync()
+    elapsed = sdist.timed_steps(step, steps, 0, sync)
+    # the streamed frames are the frames of the resident-input path: the last pass of the last step against a direct evaluation
+    k = (state["i"] - 1) % pipe.n
+    x = frames_from_u8(host_in[nb - 1].to(dev), cfg)
+    want = frames_to_u8(pipe.engines[k].run(x.view(PB, 6, x.shape[2], x.shape[3]), t_dev, False), h, w, cfg).cpu()
+    sync()
+    return {"value_with_io": round(N_T * P * steps / elapsed, 3), "unit": "frames/s", "ms_per_pair": round(1e3 * elapsed / steps / P, 3),
+            "pairs": P * steps, "bitwise_equal_to_resident_path": bool(torch.equal(host_out[k], want)),
+            "bytes_per_pair": {"h2d": 2 * h * w * 3, "d2h": N_T * h * w * 3},
+            "note": "uint8 frames in pinned host memory -> H2D -> normalise + pad kernel -> the same pipeline (same passes in flight) -> crop + "
+                    "denormalise + uint8 kernel -> D2H to pinned memory, all on the pass's stream, timed like `value` over the same number of "
+                    "steps; `value` itself has its inputs resident in HBM (SURVEY 8d)"}
 
 
 def infer_bench(args):
@@ -937,8 +1081,13 @@ def infer_bench(args):
     out["host_enqueue_ms_per_step"] = round(he, 3)
     out["host"] = {"enqueue_ms_per_step": round(he, 3), "enqueue_share_of_step": round(he / main_res["ms_per_step"], 3),
                    "usable_cpus": usable_cpus(), "cpus_of_this_rank": args.rank_cpus,
+                   "hbm": dict(getattr(args, "hbm", {}), peak_allocated_gb=round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)),
                    "note": "one host thread per rank issues the launches; at N ranks per host the ranks need N x this share of a core each "
                            "(DESIGN 6): the step is GPU-bound as long as the share stays below 1"}
+    if rank == 0 and world == 1 and not args.no_io and args.size == "720p":
+        wio = streamed_with_io(main_res["_pipe"], dev, h_in, w_in, P, PB, t_dev, args.steps, sdist, sync, cfg)
+        wio["vs_value"] = round(wio["value_with_io"] / out["value"], 4)
+        out["with_io"] = wio
     if torch.distributed.is_initialized():          # rendezvous, timing barrier and max-over-ranks reduction ran on this backend
         out["dist"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size()}
 
@@ -990,7 +1139,17 @@ def infer_bench(args):
                 first = (fw, ff) == ("uniform", "texture")
                 fams.append(family_parity(cfg, dev, fw, ff, ("f32w", "f32"), want32=want[3] if first else None, x=xs[0] if first else None))
         low = [f["modes"][headline]["max_abs_vs_oracle"] for f in fams if f["frames"] == "texture" and headline in f["modes"]]
-        out["parity"] = {"max_abs_vs_oracle": max([par[headline]["max_abs_vs_oracle"]] + low), "per_t": par[headline]["per_t"], "tolerance": 1e-3,
+        allf = [f["modes"][headline]["max_abs_vs_oracle"] for f in fams if headline in f["modes"]]
+        in_d = [f["modes"][headline]["vs_oracle_in_units_of_d"] for f in fams if headline in f["modes"]]
+        # One line, the whole truth: max_abs_vs_oracle = the TIMED pair over its 7 t; the low-gradient families
+        # (the imagery the 1e-3 contract is about) and ALL families incl. the hard-edge ones (where the oracle's own fp32 rounding d is
+        # itself > 1e-3) side by side, the worst family also in units of d.
+        out["parity"] = {"max_abs_vs_oracle": par[headline]["max_abs_vs_oracle"], "per_t": par[headline]["per_t"], "tolerance": 1e-3,
+                         "max_abs_low_gradient_families": max([par[headline]["max_abs_vs_oracle"]] + low),
+                         "max_abs_all_families": max([par[headline]["max_abs_vs_oracle"]] + allf),
+                         "worst_in_units_of_d": max(in_d) if in_d else None,
+                         "tolerance_note": "1e-3 on low-gradient imagery; 2 d on hard edges, d = max|oracle fp32 - oracle fp64| on the same input "
+                                           "(1.2-1.7e-3 there: the reference's own CPU fp32 path is that far from its float64 evaluation)",
                          "frames": N_T, "size": "%dx%d" % (Hp, Wp), "mode": headline, "families": fams,
                          "families_note": "weights: uniform = index-hash He-uniform (the fixtures' and the timed family), smooth = He-normal, "
                                           "Gaussian-windowed 7x7 / 5x5 filters, decoder gain 1.25; frames: texture = low-pass texture, 3-px motion, "
@@ -1064,7 +1223,7 @@ def main():
     if (args.gpus == 1 and "RANK" not in os.environ and args.mode == "infer" and args.size == "720p" and not args.stub and not args.no_configs):
         args.configs = collect_configs()          # children first: this process has not initialised the GPU yet
     if args.stub:
-        return stub_bench(args)
+        return stub_train_bench(args) if args.mode == "train" else stub_bench(args)
     if args.mode == "recurrent":
         return recurrent_bench(args)
     if args.mode == "train":

@@ -23,6 +23,7 @@ DGRAD_WINO4 = os.environ.get("SSM_TRAIN_DGRAD_WINO4", "1") != "0"          # 3x3
 # r6: weight gradients of the 3x3 layers of an f32w plan in the Winograd domain (csrc/ssm_wgradw.hip: 16 instead of 36 multiplies per 2x2
 # tile, like that plan's forward and data gradients) on the maps hb.wgrad_wino_supported accepts; $SSM_WGRAD_WINO=0: the direct kernel
 WGRAD_WINO = os.environ.get("SSM_WGRAD_WINO", "1") != "0"
+WGRAD_WINO_ALL = os.environ.get("SSM_WGRAD_WINO", "1") == "all"
 
 
 def transposed_filter(w):
@@ -91,6 +92,38 @@ _POOL_OF = {"conv1b": "p2", "conv2b": "p3", "conv3b": "p4", "conv4b": "p5", "con
 _UP_SOURCES = {"u7": ("c6", None), "u8": ("c7", "c5"), "u9": ("c8", "c4"), "u10": ("c9", "c3"), "u11": ("c10", "c2")}
 
 
+def grad_layout(layers, n_buckets):
+    """Layout of a U-Net's parameter gradients in ONE flat fp32 buffer, a pure function of the layer table {name: (cin, cout, k)} in
+    state-dict order: ([(state-dict key, shape)], {layer: [a, b) of its weight + bias}, buckets).  The backward walks the layers in
+    reverse state-dict order, so the buffer completes from its tail: a bucket = a run of consecutive layers of roughly 1 / n_buckets
+    of the floats.  Shared by UNetGrad and by `bench.py --mode train --stub` (the gloo rehearsal of the exchange at world 8)."""
+    sizes = []
+    for name, (ci, co, k) in layers.items():
+        sizes += [(param_key(name, "weight"), (co, ci, k, k)), (param_key(name, "bias"), (co,))]
+    off, span = 0, {}
+    for key, sh in sizes:
+        n = 1
+        for d in sh:
+            n *= int(d)
+        lname = key[:-len(".weight")] if key.endswith(".weight") else key[:-len(".bias")]
+        a, _ = span.get(lname, (off, off))
+        span[lname] = (a, off + n)
+        off += n
+    total = off
+    target = total / float(n_buckets)
+    buckets, cur, size = [], [], 0
+    for name in layers:
+        a, b = span[param_key(name, "weight")[:-len(".weight")]]
+        cur.append(name)
+        size += b - a
+        if size >= target and len(buckets) < n_buckets - 1:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    return sizes, span, buckets
+
+
 class UNetGrad:
     """Two forward plans are supported: the fp32 plan with materialised upsample tensors (every activation is an fp32 plane),
     and the Q8 plan (mode f16f8, fused upsample) with fp32 twins: there the data gradients run on the fp16 + fp8 convolution
@@ -116,38 +149,19 @@ class UNetGrad:
         self.split_wgrad = self.hl8 and os.environ.get("SSM_WGRAD", "bf16x3") != "f32"
         # every parameter gradient of the U-Net lives in ONE flat buffer (state-dict order), zeroed by one launch per backward; the
         # weight / bias gradient kernels accumulate into their slices (they add partial sums with atomics anyway)
-        sizes = []
-        for name, (ci, co, k) in plan.layers.items():
-            sizes += [(param_key(name, "weight"), (co, ci, k, k)), (param_key(name, "bias"), (co,))]
+        sizes, span, self.buckets = grad_layout(plan.layers, self.N_BUCKETS)
         self.flat = torch.empty(sum(int(torch.Size(sh).numel()) for _, sh in sizes), dtype=torch.float32, device=self.dev)
         off = 0
-        span = {}
         for key, sh in sizes:
             n = int(torch.Size(sh).numel())
             self.grads[key] = self.flat[off:off + n].view(sh)
-            lname = key[:-len(".weight")] if key.endswith(".weight") else key[:-len(".bias")]
-            a, _ = span.get(lname, (off, off))
-            span[lname] = (a, off + n)
             off += n
-        # Buckets of the flat buffer ("bucketed and overlapped with backward").  The backward walks the layers in
-        # reverse state-dict order, so the buffer completes from its tail: a bucket = a run of consecutive layers of roughly
-        # 1/N_BUCKETS of the bytes; when the weight-gradient kernels of its last layer have been queued (side stream), the bucket
-        # is post-scaled (loss scale of the f16f8 plan, 1/world) and handed to `sync.reduce` - the RCCL all-reduce of the
-        # decoder's gradients then runs while the encoder's (and the other U-Net's) backward is still computing.
+        # Buckets of the flat buffer ("bucketed and overlapped with backward"; the partition itself: grad_layout).  When the
+        # weight-gradient kernels of a bucket's last layer have been queued (side stream), the bucket is post-scaled (loss scale of the
+        # f16f8 plan, 1/world) and handed to `sync.reduce` - the RCCL all-reduce of the decoder's gradients then runs while the
+        # encoder's (and the other U-Net's) backward is still computing.
         self.sync, self.post_scale = None, 1.0
-        self.layer_span = {param_layer: se for param_layer, se in span.items()}
-        names = list(plan.layers)
-        target = self.flat.numel() / float(self.N_BUCKETS)
-        self.buckets, cur, size = [], [], 0
-        for name in names:
-            a, b = self._span_of(name)
-            cur.append(name)
-            size += b - a
-            if size >= target and len(self.buckets) < self.N_BUCKETS - 1:
-                self.buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(cur)
+        self.layer_span = span
         self._pending = []
         # Winograd-domain weight gradients: per layer a [16, Cout, Cin] scratch of partial sums (one zeroed arena per U-Net; the finishing
         # launch of a bucket - G^T dU G added into the flat gradient buffer - leaves it zeroed for the next step)
@@ -158,7 +172,12 @@ class UNetGrad:
                 s = layer_scale(name)
                 srcs = self.io[name][0]
                 cmin = min(plan.t[sn].C for sn in srcs) if all(sn in plan.t for sn in srcs) else ci
-                if hb.wgrad_wino_supported(cmin, co, plan.H // s, plan.W // s, k):
+                # where it pays (profiles/r17d_wgradw_layers.txt, r17f_train_ab.txt): every workgroup adds 16 x its couts x cins partial sums
+                # whatever its share of K, so the form wins on the layers with many tiles per (cout, cin) pair - the decoder's "a" layers
+                # (Cin >= 2 Cout) and the 176 / 352-pixel maps - and ties or loses on the square 44 / 88-pixel layers, which keep the
+                # direct kernel ($SSM_WGRAD_WINO=all: every supported layer)
+                pays = WGRAD_WINO_ALL or ci >= 2 * co or plan.W // s >= 176
+                if pays and hb.wgrad_wino_supported(cmin, co, plan.H // s, plan.W // s, k):
                     chosen.append((name, 16 * co * ci))
             arena = torch.zeros(sum(n for _, n in chosen), dtype=torch.float32, device=self.dev)
             off = 0

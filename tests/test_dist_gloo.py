@@ -158,6 +158,41 @@ def test_bench_eight_ranks_stub_launch():
     assert abs(out["value"] - 7 * 8 * 8 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]
 
 
+def test_bench_eight_ranks_training_stub_exchanges_every_gradient_bucket():
+    """`python bench.py --gpus 8 --mode train --stub`: the TRAINING launcher path at world 8 over gloo - the two
+    U-Nets' flat gradient buffers in their true layout (155.4 MB), 4 buckets each handed to GradientAllReduce tail first, 1/world
+    pre-scale, every rank checking the average it receives - with synthetic gradients (the real backward needs the GPUs)."""
+    import json
+    r = _run_bench("--gpus", "8", "--mode", "train", "--stub", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["unit"] == "samples/s" and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+    ar = out["allreduce"]
+    assert ar["bytes"] == 4 * 38848553 and ar["buckets_per_step"] == 8 and ar["backend"] == "gloo"
+    assert ar["max_abs_err_of_the_average"] < 1e-5 and ar["ms_per_step"] > 0.0          # (gloo blocks the host in wait(): exposed, and booked)
+
+
+def test_gradient_layout_is_a_pure_function_of_the_layer_table():
+    """ssm_amd.backward.grad_layout (shared by the GPU backward and the stub above): both U-Nets' keys in state-dict order, spans that
+    tile the flat buffer, 4 buckets of consecutive layers that cover it."""
+    from ssm_amd.backward import grad_layout
+    from ssm_amd.weights import synthetic_state_dict, unet_layers
+    total = 0
+    for stage in (1, 2):
+        layers = {n: (ci, co, k) for n, ci, co, k in unet_layers(stage, True)}
+        sizes, span, buckets = grad_layout(layers, 4)
+        sd = synthetic_state_dict(stage)
+        assert [k for k, _ in sizes] == list(sd.keys()) and all(tuple(sd[k].shape) == tuple(sh) for k, sh in sizes)
+        n = sum(sd[k].numel() for k in sd)
+        ends = sorted(span.values())
+        assert ends[0][0] == 0 and ends[-1][1] == n and all(a[1] == b[0] for a, b in zip(ends, ends[1:]))
+        assert len(buckets) == 4 and [x for b in buckets for x in b] == list(layers)
+        total += n
+    assert total == 38848553
+
+
 def test_bench_eight_ranks_one_failing_rank_fails_the_launch():
     """A rank that exits with an error (here before the rendezvous) ends the launch promptly: non-zero exit, no JSON line."""
     import time as _t
