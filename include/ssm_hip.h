@@ -472,6 +472,31 @@ int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, const float 
 int ssm_final_conv_fwd(ssm_view x, const float *w_oihw, const float *bias, int NC, ssm_view out, ssm_view img6, ssm_view in16,
                        const float *t, ssm_view y3, ssm_view aux, int B, int H, int W, void *stream);
 
+/* ---- launch programs (csrc/ssm_program.cpp) ------------------------------------------------------------------------
+ * The reference's training loop (scripts/main.py:116-145,188-197) issues its step op by op through the framework; here a step is ~900
+ * launches of this library with the SAME pointers, grids and arguments every time (the plans own every activation, gradient and packed
+ * filter), so the host side of a step can be recorded once and replayed with a handful of calls (HIP graphs were measured slower than
+ * eager issue on ROCm 7.2).
+ *   ssm_program_create / destroy   a program handle
+ *   ssm_program_begin   start recording with the pass's streams as slots 0..n-1 (n <= 8): from now on EVERY launch of the library in
+ *                       this process is executed as usual AND appended to the program (one recording at a time; meant for one
+ *                       single-threaded warm-up pass).  A launch on a stream that is no slot makes ssm_program_end fail.
+ *   ssm_program_mark    number of nodes recorded so far: a cut point for host-side work (framework kernels, collectives) that must run
+ *                       between two ranges of nodes at replay
+ *   ssm_program_end     stop recording; *n_nodes = nodes recorded
+ *   ssm_program_run     issue nodes [first, last) again on `streams` (same count as at begin; normally the same handles); buffers
+ *                       the recorded arguments point to must still be alive - they are the plans' own
+ *   ssm_stream_wait     dst_stream waits for everything queued on src_stream so far (event record + wait).  The cross-stream ordering
+ *                       of a pass (side stream of the weight gradients, VGG stream) must go through this call to be part of a program;
+ *                       outside a recording it is a plain pair of HIP calls.                                                       */
+int ssm_program_create(void **handle);
+int ssm_program_destroy(void *handle);
+int ssm_program_begin(void *handle, void *const *streams, int n_streams);
+int ssm_program_mark(void *handle, int *n_nodes);
+int ssm_program_end(void *handle, int *n_nodes);
+int ssm_program_run(void *handle, int first, int last, void *const *streams, int n_streams);
+int ssm_stream_wait(void *src_stream, void *dst_stream);
+
 /* ---- frame formats either side of the path (uint8 HWC RGB on the device) ----------------
  * ssm_frames_from_u8_fwd: [N,H,W,3] uint8 -> normalised fp32 [N,3,Hp,Wp], image at (top,left),
  *   fusing ToTensor + Normalize + EvalPad (scripts/utils/dataloaders/augmentations.py:141-200;

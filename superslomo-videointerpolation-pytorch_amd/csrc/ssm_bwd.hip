@@ -1004,8 +1004,8 @@ extern "C" int ssm_lrelu_bwd(ssm_view dy, ssm_view dpool, ssm_view y, ssm_view d
     const long long total = (long long)B * C * H * (vec ? W / 4 : W);
     SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "lrelu_bwd: problem too large for one launch");
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (vec) hipLaunchKernelGGL(lrelu_bwd_flat_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act, total);
-    else hipLaunchKernelGGL(lrelu_bwd_flat_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act, total);
+    if (vec) SSM_LAUNCH(lrelu_bwd_flat_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act, total);
+    else SSM_LAUNCH(lrelu_bwd_flat_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, dpool, y, dz, C, H, W, slope, has_act, total);
     return ssm::check_launch("ssm_lrelu_bwd");
 }
 
@@ -1016,7 +1016,7 @@ extern "C" int ssm_lrelu_bwd_q8(ssm_view dy, ssm_view dpool, ssm_view y, ssm_vie
     SSM_REQUIRE(ssm::aligned16(dz_q8.ptr), "lrelu_bwd_q8: the Q8 view must be 16-byte aligned");
     const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "lrelu_bwd_q8: B*C too large for one launch");
-    hipLaunchKernelGGL(lrelu_bwd_q8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y,
+    SSM_LAUNCH(lrelu_bwd_q8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, dy, dpool, y,
                        dz, dz_q8, C, H, W, slope, has_act, cgroups);
     return ssm::check_launch("ssm_lrelu_bwd_q8");
 }
@@ -1024,7 +1024,7 @@ extern "C" int ssm_lrelu_bwd_q8(ssm_view dy, ssm_view dpool, ssm_view y, ssm_vie
 static int bias_grad_launch(ssm_view dz, float *db, int B, int C, int H, int W, int zero_first, void *stream) {
     SSM_REQUIRE(dz.ptr && db && B > 0 && C > 0 && H > 0 && W > 0, "bias_grad: bad arguments");
     if (zero_first) {
-        hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, (hipStream_t)stream);
+        hipError_t e = ssm::memset_async(db, 0, sizeof(float) * (size_t)C, (hipStream_t)stream);
         if (e != hipSuccess) {
             ssm::set_error("bias_grad: memset failed: %s", hipGetErrorString(e));
             return SSM_E_LAUNCH;
@@ -1033,7 +1033,7 @@ static int bias_grad_launch(ssm_view dz, float *db, int B, int C, int H, int W, 
     int chunks = (B * H + 63) / 64;          // ~16 rows per wave
     if (chunks < 1) chunks = 1;
     if (chunks > 1024) chunks = 1024;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, db, B, H, W);
+    SSM_LAUNCH(bias_grad_kernel, dim3(C, chunks), dim3(256), 0, (hipStream_t)stream, dz, db, B, H, W);
     return ssm::check_launch("ssm_bias_grad");
 }
 
@@ -1056,7 +1056,7 @@ static int wgrad_launch(ssm_view x, ssm_view dz, float *dw_oihw, float *db, int 
                 "wgrad: views must be 16-byte aligned with strides that are multiples of 4 floats");
     hipStream_t st = (hipStream_t)stream;
     if (zero_first) {
-        hipError_t e = hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)Cout * cin_total * k * k, st);
+        hipError_t e = ssm::memset_async(dw_oihw, 0, sizeof(float) * (size_t)Cout * cin_total * k * k, st);
         if (e != hipSuccess) {
             ssm::set_error("wgrad: memset failed: %s", hipGetErrorString(e));
             return SSM_E_LAUNCH;
@@ -1082,7 +1082,7 @@ static int wgrad_launch(ssm_view x, ssm_view dz, float *dw_oihw, float *db, int 
     if (split > 65535) split = 65535;
     const dim3 grid(gx, gy, split);
 #define SSM_WGRAD_L(KS_, XC_, NTC_, SEG_, RR_)                                                                                       \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<KS_, XC_, NTC_, SEG_, RR_>), grid, dim3(256), 0, st, x, dz, dw_oihw, db, B, Cin, Cout, H, W, \
+    SSM_LAUNCH((wgrad_mfma_kernel<KS_, XC_, NTC_, SEG_, RR_>), grid, dim3(256), 0, st, x, dz, dw_oihw, db, B, Cin, Cout, H, W, \
                        cin_total, ci_offset)
 #define SSM_WGRAD_S(KS_, XC_, NTC_)                              \
     if (seg == 64) SSM_WGRAD_L(KS_, XC_, NTC_, 64, 2);           \
@@ -1125,7 +1125,7 @@ extern "C" int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, 
                 "wgrad_bf16x3: views must be 16-byte aligned with strides that are multiples of 4 floats");
     hipStream_t st = (hipStream_t)stream;
     if (zero_first) {
-        hipError_t e = hipMemsetAsync(dw_oihw, 0, sizeof(float) * (size_t)Cout * cin_total * k * k, st);
+        hipError_t e = ssm::memset_async(dw_oihw, 0, sizeof(float) * (size_t)Cout * cin_total * k * k, st);
         if (e != hipSuccess) {
             ssm::set_error("wgrad_bf16x3: memset failed: %s", hipGetErrorString(e));
             return SSM_E_LAUNCH;
@@ -1146,7 +1146,7 @@ extern "C" int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, 
         if (nsl > 65535) nsl = 65535;                                                                                             \
         const int sps = (total + nsl - 1) / nsl;                                                                                  \
         nsl = (total + sps - 1) / sps;                                                                                            \
-        hipLaunchKernelGGL((wgrad_bf16x3_kernel<KS_, TY_, SEG_, WAN_, WBN_>), dim3(gx, gy, nsl), dim3(256), 0, st, x, dz, dw_oihw, B, \
+        SSM_LAUNCH((wgrad_bf16x3_kernel<KS_, TY_, SEG_, WAN_, WBN_>), dim3(gx, gy, nsl), dim3(256), 0, st, x, dz, dw_oihw, B, \
                            Cin, Cout, H, W, cin_total, ci_offset, sps);                                                           \
     }
     switch (k) {
@@ -1177,13 +1177,13 @@ extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view
     if (W % 2 == 0 && al16(du) && al8(da) && (Cb == 0 || al8(db))) {
         const long long total = (long long)B * (Ca + Cb) * H * (W / 2);
         SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "upsample2x_cat_bwd: problem too large for one launch");
-        hipLaunchKernelGGL(upsample_cat_bwd2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, du, da, Ca,
+        SSM_LAUNCH(upsample_cat_bwd2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, du, da, Ca,
                            Cb ? db : da, Cb, H, W, acc_a, acc_b, total);
         return ssm::check_launch("ssm_upsample2x_cat_bwd");
     }
     const int cgroups = (Ca + Cb + BWD_CPT - 1) / BWD_CPT;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "upsample2x_cat_bwd: B*C too large for one launch");
-    hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, du, da,
+    SSM_LAUNCH(upsample_cat_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, du, da,
                        Ca, Cb ? db : da, Cb, H, W, acc_a, acc_b, cgroups);
     return ssm::check_launch("ssm_upsample2x_cat_bwd");
 }
@@ -1193,7 +1193,7 @@ extern "C" int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, s
                                   int stage2_terms, void *stream) {
     SSM_CHECK_DIMS("synthesize_bwd");
     SSM_REQUIRE(img6.ptr && est4.ptr && out5.ptr && target.ptr && t && c_rec && c_warp && dout5.ptr && dest4.ptr, "synthesize_bwd: null pointer");
-    hipLaunchKernelGGL(synth_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, est4, out5, target, t, c_rec,
+    SSM_LAUNCH(synth_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, est4, out5, target, t, c_rec,
                        c_warp, dy_extra, dout5, dest4, H, W, stage2_terms);
     return ssm::check_launch("ssm_synthesize_bwd");
 }
@@ -1202,7 +1202,7 @@ extern "C" int ssm_flowinterp_inputs_bwd(ssm_view img6, ssm_view flow4, ssm_view
                                          ssm_view dflow4, int B, int H, int W, int stage1_terms, void *stream) {
     SSM_CHECK_DIMS("flowinterp_inputs_bwd");
     SSM_REQUIRE(img6.ptr && flow4.ptr && din16.ptr && dest4.ptr && t && c_warp && dflow4.ptr, "flowinterp_inputs_bwd: null pointer");
-    hipLaunchKernelGGL(inputs_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, din16, dest4, t, c_warp,
+    SSM_LAUNCH(inputs_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, din16, dest4, t, c_warp,
                        dflow4, H, W, stage1_terms);
     return ssm::check_launch("ssm_flowinterp_inputs_bwd");
 }
@@ -1212,7 +1212,7 @@ extern "C" int ssm_maxpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int
     SSM_REQUIRE(x.ptr && y.ptr && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2: null pointer / odd size");
     const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "maxpool2: B*C too large for one launch");
-    hipLaunchKernelGGL(maxpool2_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, y, C, H / 2, W / 2, cgroups);
+    SSM_LAUNCH(maxpool2_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, y, C, H / 2, W / 2, cgroups);
     return ssm::check_launch("ssm_maxpool2_fwd");
 }
 
@@ -1221,7 +1221,7 @@ extern "C" int ssm_maxpool2_bwd(ssm_view x, ssm_view dy, ssm_view dx, int B, int
     SSM_REQUIRE(x.ptr && dy.ptr && dx.ptr && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2_bwd: null pointer / odd size");
     const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "maxpool2_bwd: B*C too large for one launch");
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, dy, dx, C, H / 2, W / 2,
+    SSM_LAUNCH(maxpool2_bwd_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, dy, dx, C, H / 2, W / 2,
                        cgroups);
     return ssm::check_launch("ssm_maxpool2_bwd");
 }
@@ -1231,7 +1231,7 @@ extern "C" int ssm_sqdiff_grad(ssm_view a, ssm_view b, const float *coef, ssm_vi
     SSM_REQUIRE(a.ptr && b.ptr && coef && out.ptr && C > 0, "sqdiff_grad: null pointer");
     const int cgroups = (C + BWD_CPT - 1) / BWD_CPT;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "sqdiff_grad: B*C too large for one launch");
-    hipLaunchKernelGGL(sqdiff_grad_kernel, pix_grid(B * cgroups, H, W), dim3(64, 4), 0, (hipStream_t)stream, a, b, coef, out, C, H, W, cgroups);
+    SSM_LAUNCH(sqdiff_grad_kernel, pix_grid(B * cgroups, H, W), dim3(64, 4), 0, (hipStream_t)stream, a, b, coef, out, C, H, W, cgroups);
     return ssm::check_launch("ssm_sqdiff_grad");
 }
 
@@ -1240,17 +1240,17 @@ extern "C" int ssm_train_loss_sums(ssm_view img6, ssm_view flow4, ssm_view est4,
     SSM_CHECK_DIMS("train_loss_sums");
     SSM_REQUIRE(img6.ptr && flow4.ptr && est4.ptr && out5.ptr && pred.ptr && target.ptr && scratch && out, "train_loss_sums: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "train_loss_sums: plane too large");
-    hipLaunchKernelGGL(loss_terms_partial_kernel, dim3(SQD_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, img6, flow4, est4, out5, pred, target,
+    SSM_LAUNCH(loss_terms_partial_kernel, dim3(SQD_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, img6, flow4, est4, out5, pred, target,
                        scratch, H, W, stage1_terms, stage2_terms);
-    hipLaunchKernelGGL(loss_terms_finish_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, out, B);
+    SSM_LAUNCH(loss_terms_finish_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, out, B);
     return ssm::check_launch("ssm_train_loss_sums");
 }
 
 extern "C" int ssm_sqdiff_mean(ssm_view a, ssm_view b, float *scratch, float *out, int B, int C, int H, int W, void *stream) {
     SSM_CHECK_DIMS("sqdiff_mean");
     SSM_REQUIRE(a.ptr && b.ptr && scratch && out && C > 0, "sqdiff_mean: null pointer");
-    hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(SQD_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, a, b, scratch, C, H, W);
-    hipLaunchKernelGGL(sqdiff_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, out, B,
+    SSM_LAUNCH(sqdiff_partial_kernel, dim3(SQD_CHUNKS, B), dim3(256), 0, (hipStream_t)stream, a, b, scratch, C, H, W);
+    SSM_LAUNCH(sqdiff_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, out, B,
                        1.0f / ((float)C * (float)H * (float)W));
     return ssm::check_launch("ssm_sqdiff_mean");
 }
@@ -1261,6 +1261,6 @@ extern "C" int ssm_warp_bilinear_bwd(ssm_view img, ssm_view flow, ssm_view dy, s
     SSM_REQUIRE(img.ptr && flow.ptr && dy.ptr && C > 0 && (dflow.ptr || dimg.ptr), "warp_bwd: null pointer / C");
     SSM_REQUIRE(!dimg.ptr || dimg.sh == img.sh, "warp_bwd: dimg must have the image's row stride");
     SSM_REQUIRE((long long)H * img.sh < 0x7fffffffLL, "warp_bwd: plane too large");
-    hipLaunchKernelGGL(warp_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img, flow, dy, dflow, dimg, C, H, W);
+    SSM_LAUNCH(warp_bwd_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img, flow, dy, dflow, dimg, C, H, W);
     return ssm::check_launch("ssm_warp_bilinear_bwd");
 }

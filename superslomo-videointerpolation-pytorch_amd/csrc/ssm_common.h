@@ -4,8 +4,12 @@
 
 #include <atomic>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/ssm_hip.h"
 
@@ -43,6 +47,39 @@ inline hipError_t reserve_lds(std::atomic<uint64_t> &done, const void *kernel, i
 // split-K switches of the two plan functions (ssm_wino_splitk_plan, ssm_conv_splitk_plan): initialised from $SSM_WINO_SPLITK / $SSM_CONV_SPLITK
 // on first use, settable at run time through ssm_splitk_enable (tests A/B the reordered sums in one process)
 std::atomic<int> &splitk_switch(int which);          // 0: Winograd form, 1: direct form; value -1 = not initialised yet
+
+// ---- launch programs (ssm_program.cpp; include/ssm_hip.h "launch programs") --------------------------------------------------------
+// Every kernel launch of the library goes through ssm::launch (SSM_LAUNCH): the kernel's arguments are converted to its parameter types,
+// launched with hipLaunchKernel - what hipLaunchKernelGGL does - and, while a program records, appended to it as a node (host function,
+// grid, block, dynamic LDS, stream slot, a copy of the argument values).  ssm_program_run replays the nodes with the same call.
+struct Recorder;
+extern std::atomic<Recorder *> g_recorder;          // process-wide: a program records one single-threaded warm-up pass
+void record_kernel(Recorder *r, const void *fn, dim3 grid, dim3 block, unsigned lds, hipStream_t st, void *const *args, const size_t *sizes,
+                   const size_t *aligns, int n);
+void record_memset(Recorder *r, void *dst, int value, size_t bytes, hipStream_t st);
+
+template <class... KArgs, class... Args, size_t... I>
+inline void launch_impl(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t st, std::index_sequence<I...>, Args &&...args) {
+    std::tuple<std::decay_t<KArgs>...> vals{static_cast<std::decay_t<KArgs>>(std::forward<Args>(args))...};
+    void *ptrs[sizeof...(KArgs) + 1] = {static_cast<void *>(&std::get<I>(vals))..., nullptr};
+    (void)hipLaunchKernel(reinterpret_cast<const void *>(kern), grid, block, ptrs, lds, st);          // (errors: hipGetLastError in check_launch)
+    if (Recorder *r = g_recorder.load(std::memory_order_acquire)) {
+        static const size_t sizes[sizeof...(KArgs) + 1] = {sizeof(std::decay_t<KArgs>)..., 0};
+        static const size_t aligns[sizeof...(KArgs) + 1] = {alignof(std::decay_t<KArgs>)..., 0};
+        record_kernel(r, reinterpret_cast<const void *>(kern), grid, block, lds, st, ptrs, sizes, aligns, (int)sizeof...(KArgs));
+    }
+}
+template <class... KArgs, class... Args>
+inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t st, Args &&...args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    launch_impl(kern, grid, block, lds, st, std::index_sequence_for<KArgs...>{}, std::forward<Args>(args)...);
+}
+inline hipError_t memset_async(void *dst, int value, size_t bytes, hipStream_t st) {
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, st);
+    if (Recorder *r = g_recorder.load(std::memory_order_acquire)) record_memset(r, dst, value, bytes, st);
+    return e;
+}
+#define SSM_LAUNCH(...) ssm::launch(__VA_ARGS__)
 
 #define SSM_REQUIRE(cond, ...)          \
     do {                                \

@@ -612,7 +612,7 @@ int launch(ConvParams &p, int B, hipStream_t st) {
         constexpr int lds_bytes = Lds<C, UPS>::BYTES;
         if (p.NSPLIT > 1) {
             if constexpr (!UPS && conv_split_ok<C>()) {
-                hipLaunchKernelGGL((conv_mfma_kernel<C, false, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+                SSM_LAUNCH((conv_mfma_kernel<C, false, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
                 return ssm::check_launch("ssm_conv2d_splitk_fwd");
             } else {
                 ssm::set_error("conv_splitk: this tile configuration has no split-K form");
@@ -620,7 +620,7 @@ int launch(ConvParams &p, int B, hipStream_t st) {
             }
         }
         auto kern = conv_mfma_kernel<C, UPS>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+        SSM_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
         return ssm::check_launch(UPS ? "ssm_conv2d_ups_fwd" : "ssm_conv2d_fwd");
     }
 }
@@ -746,7 +746,7 @@ extern "C" int ssm_pack_weights(const float *w, const float *bias, float *wp, fl
     const long long total = (long long)ssm_packed_weight_floats(Cout, CinP, k, BN);
     const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
     const long long n = total > nbias ? total : nbias;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+    SSM_LAUNCH(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                        bias, wp, bp, Cout, Cin, CinP, k * k, BN, total, nbias);
     return ssm::check_launch("ssm_pack_weights");
 }

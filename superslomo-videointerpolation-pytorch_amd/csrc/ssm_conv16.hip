@@ -925,7 +925,7 @@ int launch16(Conv16Params &p, int B, hipStream_t st) {
         return SSM_E_ARG;
     }
     if (!reserve_lds((const void *)conv16_kernel<C>, C::LDS_BYTES)) return SSM_E_LAUNCH;
-    hipLaunchKernelGGL(conv16_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS_ALL), C::LDS_BYTES, st, p);
+    SSM_LAUNCH(conv16_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS_ALL), C::LDS_BYTES, st, p);
     return ssm::check_launch("ssm_conv2d_hl8_fwd");
 }
 
@@ -940,7 +940,7 @@ int launch16_ups(Conv16Params &p, int B, hipStream_t st) {
         return SSM_E_ARG;
     }
     if (!reserve_lds((const void *)conv16_ups_kernel<C>, C::LDS_BYTES)) return SSM_E_LAUNCH;
-    hipLaunchKernelGGL(conv16_ups_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+    SSM_LAUNCH(conv16_ups_kernel<C>, dim3((unsigned)blocks), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
     return ssm::check_launch("ssm_conv2d_ups_hl8_fwd");
 }
 
@@ -1196,7 +1196,7 @@ extern "C" int ssm_pack16_weights(const float *w, const float *bias, void *wp, f
     const long long total = (long long)ssm_packed16_weight_halves(Cout, CinP, k, BN);
     const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
     const long long n = total > nbias ? total : nbias;
-    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias,
+    SSM_LAUNCH(pack16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias,
                        (_Float16 *)wp, bp, Cout, Cin, CinP, k, KYS, BN, scale, total, nbias);
     return ssm::check_launch("ssm_pack16_weights");
 }
@@ -1204,14 +1204,14 @@ extern "C" int ssm_pack16_weights(const float *w, const float *bias, void *wp, f
 extern "C" int ssm_hl8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream) {
     SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && H > 0 && W > 0, "hl8_from_f32: bad arguments");
     SSM_REQUIRE((long long)B * G <= 65535, "hl8_from_f32: B*G too large");
-    hipLaunchKernelGGL(to_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    SSM_LAUNCH(to_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
     return ssm::check_launch("ssm_hl8_from_f32");
 }
 
 extern "C" int ssm_hl8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream) {
     SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && H > 0 && W > 0, "hl8_to_f32: bad arguments");
     SSM_REQUIRE((long long)B * G <= 65535, "hl8_to_f32: B*G too large");
-    hipLaunchKernelGGL(from_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    SSM_LAUNCH(from_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
     return ssm::check_launch("ssm_hl8_to_f32");
 }
 
@@ -1251,13 +1251,13 @@ extern "C" int ssm_pack16q_weights(const float *w, const float *bias, void *wp, 
     const dim3 grid((unsigned)((total + 63) / 64));
     (void)stages;
     switch (k) {
-        case 3: hipLaunchKernelGGL(pack16q_kernel<3>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
-        case 5: hipLaunchKernelGGL(pack16q_kernel<5>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
-        case 7: hipLaunchKernelGGL(pack16q_kernel<7>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
+        case 3: SSM_LAUNCH(pack16q_kernel<3>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
+        case 5: SSM_LAUNCH(pack16q_kernel<5>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
+        case 7: SSM_LAUNCH(pack16q_kernel<7>, grid, dim3(64), 0, (hipStream_t)stream, w, (char *)wp, Cout, Cin, CinP, KYS, BN, scale, sb, qbase, total); break;
         default: ssm::set_error("pack16q: kernel size %d unsupported", k); return SSM_E_UNSUPPORTED;
     }
     const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
-    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)((nbias + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, (_Float16 *)nullptr, bp,
+    SSM_LAUNCH(pack16_kernel, dim3((unsigned)((nbias + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, (_Float16 *)nullptr, bp,
                        Cout, Cin, CinP, k, KYS, BN, scale, 0LL, nbias);
     return ssm::check_launch("ssm_pack16q_weights");
 }
@@ -1272,21 +1272,21 @@ extern "C" int ssm_pack16q_job_blocks(int Cout, int CinP, int k, int BN, int *ro
 
 extern "C" int ssm_pack16q_weights_batch(const ssm_pack16q_job *jobs_device, int n_jobs, int total_blocks, void *stream) {
     SSM_REQUIRE(jobs_device && n_jobs > 0 && total_blocks > 0, "pack16q_batch: bad arguments");
-    hipLaunchKernelGGL(pack16q_batch_kernel, dim3((unsigned)total_blocks), dim3(64), 0, (hipStream_t)stream, jobs_device, n_jobs);
+    SSM_LAUNCH(pack16q_batch_kernel, dim3((unsigned)total_blocks), dim3(64), 0, (hipStream_t)stream, jobs_device, n_jobs);
     return ssm::check_launch("ssm_pack16q_weights_batch");
 }
 
 extern "C" int ssm_hq8_from_f32(ssm_view src, ssm_hview dst, int B, int C, int G, int H, int W, void *stream) {
     SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && G % 2 == 0 && H > 0 && W > 0, "hq8_from_f32: bad arguments (Q8 tensors hold an even number of channel groups)");
     SSM_REQUIRE((long long)B * G <= 65535, "hq8_from_f32: B*G too large");
-    hipLaunchKernelGGL(to_hq8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    SSM_LAUNCH(to_hq8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
     return ssm::check_launch("ssm_hq8_from_f32");
 }
 
 extern "C" int ssm_hq8_to_f32(ssm_hview src, ssm_view dst, int B, int C, int G, int H, int W, void *stream) {
     SSM_REQUIRE(src.ptr && dst.ptr && B > 0 && C > 0 && G * 8 >= C && G % 2 == 0 && H > 0 && W > 0, "hq8_to_f32: bad arguments (Q8 tensors hold an even number of channel groups)");
     SSM_REQUIRE((long long)B * G <= 65535, "hq8_to_f32: B*G too large");
-    hipLaunchKernelGGL(from_hq8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
+    SSM_LAUNCH(from_hq8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * G), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, G, H, W);
     return ssm::check_launch("ssm_hq8_to_f32");
 }
 
@@ -1398,7 +1398,7 @@ static int fill_problem(Conv16Params &p, int B, long long &blocks) {
 template <class C>
 static int launch16_multi(const Conv16Multi &m, hipStream_t st) {
     if (!reserve_lds((const void *)conv16_multi_kernel<C>, C::LDS_BYTES)) return SSM_E_LAUNCH;
-    hipLaunchKernelGGL(conv16_multi_kernel<C>, dim3((unsigned)m.start[m.n]), dim3(C::NTHREADS_ALL), C::LDS_BYTES, st, m);
+    SSM_LAUNCH(conv16_multi_kernel<C>, dim3((unsigned)m.start[m.n]), dim3(C::NTHREADS_ALL), C::LDS_BYTES, st, m);
     return ssm::check_launch("ssm_conv16_subpixel_run");
 }
 
@@ -1500,7 +1500,7 @@ extern "C" int ssm_hl8_gather_cols(ssm_hview a, int Ga, ssm_hview b, int Gb, ssm
     SSM_REQUIRE(a.ptr && dst.ptr && Ga > 0 && Gb >= 0 && (Gb == 0 || b.ptr) && B > 0 && H > 0 && ncols > 0 && col0 >= 0, "gather_cols: bad arguments");
     SSM_REQUIRE((long long)B * (Ga + Gb) <= 65535 && ncols <= 1024, "gather_cols: grid too large");
     const int rows = col1 >= 0 ? 2 * ncols + 1 : ncols;
-    hipLaunchKernelGGL(gather_cols_kernel, dim3((H + 255) / 256, rows, B * (Ga + Gb)), dim3(256), 0, (hipStream_t)stream, a, Ga, b, Gb, dst, H,
+    SSM_LAUNCH(gather_cols_kernel, dim3((H + 255) / 256, rows, B * (Ga + Gb)), dim3(256), 0, (hipStream_t)stream, a, Ga, b, Gb, dst, H,
                        col0, ncols, col1);
     return ssm::check_launch("ssm_hl8_gather_cols");
 }

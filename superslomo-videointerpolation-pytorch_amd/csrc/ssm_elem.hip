@@ -722,7 +722,7 @@ inline bool even_view(const ssm_view &v) { return ((reinterpret_cast<size_t>(v.p
 extern "C" int ssm_copy_view(ssm_view src, ssm_view dst, int B, int C, int H, int W, void *stream) {
     SSM_CHECK_DIMS("copy_view");
     SSM_REQUIRE(src.ptr && dst.ptr && C > 0, "copy_view: null pointer / C");
-    hipLaunchKernelGGL(copy_view_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, H, W);
+    SSM_LAUNCH(copy_view_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, src, dst, C, H, W);
     return ssm::check_launch("ssm_copy_view");
 }
 
@@ -733,7 +733,7 @@ extern "C" int ssm_avgpool2_fwd(ssm_view x, ssm_view y, int B, int C, int H, int
     SSM_REQUIRE(even_view(x), "avgpool2: input view must be 8-byte aligned with even strides");
     const int cgroups = (C + 3) / 4;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "avgpool2: B*C too large for one launch");
-    hipLaunchKernelGGL(avgpool2_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, y, C, H / 2, W / 2, cgroups);
+    SSM_LAUNCH(avgpool2_kernel, pix_grid(B * cgroups, H / 2, W / 2), dim3(64, 4), 0, (hipStream_t)stream, x, y, C, H / 2, W / 2, cgroups);
     return ssm::check_launch("ssm_avgpool2_fwd");
 }
 
@@ -746,7 +746,7 @@ extern "C" int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view
         SSM_REQUIRE(!add.ptr || (add_div >= 1 && B % add_div == 0), "splitk_finish: addend divisor");
         const long long tot1 = (long long)B * C * H * W;
         SSM_REQUIRE(tot1 <= 0x7fffffffLL * 256LL, "splitk_finish: problem too large for one launch");
-        hipLaunchKernelGGL(splitk_finish1_kernel, dim3((unsigned)((tot1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, add,
+        SSM_LAUNCH(splitk_finish1_kernel, dim3((unsigned)((tot1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, add,
                            add_div < 1 ? 1 : add_div, B, C, H, W, (flags & SSM_FLAG_LRELU) ? slope : 1.f, tot1);
         return ssm::check_launch("ssm_splitk_finish_fwd");
     }
@@ -756,7 +756,7 @@ extern "C" int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view
     const long long total = (long long)B * C * ((H + 1) / 2) * (W / 2);
     SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "splitk_finish: problem too large for one launch");
     const float sl = (flags & SSM_FLAG_LRELU) ? slope : 1.f;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, pool, add,
+    SSM_LAUNCH(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, pool, add,
                        add_div < 1 ? 1 : add_div, B, C, H, W, sl, total);
     return ssm::check_launch("ssm_splitk_finish_fwd");
 }
@@ -769,9 +769,9 @@ extern "C" int ssm_upsample2x_cat_fwd(ssm_view a, int Ca, ssm_view b, int Cb, ss
     SSM_REQUIRE((long long)B * cgroups <= 65535, "upsample2x_cat: B*C too large for one launch");
     const dim3 grid(((W + 1) / 2 + 31) / 32, (H + 7) / 8, B * cgroups);
     if (vec4)
-        hipLaunchKernelGGL(upsample2x_cat_kernel<true>, grid, dim3(32, 8), 0, (hipStream_t)stream, a, Ca, Cb ? b : a, Cb, y, H, W, cgroups);
+        SSM_LAUNCH(upsample2x_cat_kernel<true>, grid, dim3(32, 8), 0, (hipStream_t)stream, a, Ca, Cb ? b : a, Cb, y, H, W, cgroups);
     else
-        hipLaunchKernelGGL(upsample2x_cat_kernel<false>, grid, dim3(32, 8), 0, (hipStream_t)stream, a, Ca, Cb ? b : a, Cb, y, H, W, cgroups);
+        SSM_LAUNCH(upsample2x_cat_kernel<false>, grid, dim3(32, 8), 0, (hipStream_t)stream, a, Ca, Cb ? b : a, Cb, y, H, W, cgroups);
     return ssm::check_launch("ssm_upsample2x_cat_fwd");
 }
 
@@ -779,7 +779,7 @@ extern "C" int ssm_warp_bilinear_fwd(ssm_view img, ssm_view flow, ssm_view out, 
     SSM_CHECK_DIMS("warp");
     SSM_REQUIRE(img.ptr && flow.ptr && out.ptr && C > 0, "warp: null pointer / C");
     SSM_REQUIRE((long long)H * img.sh < 0x7fffffffLL, "warp: plane too large");
-    hipLaunchKernelGGL(warp_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img, flow, out, C, H, W);
+    SSM_LAUNCH(warp_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img, flow, out, C, H, W);
     return ssm::check_launch("ssm_warp_bilinear_fwd");
 }
 
@@ -787,7 +787,7 @@ extern "C" int ssm_flowinterp_inputs_fwd(ssm_view img6, ssm_view flow4, const fl
     SSM_CHECK_DIMS("flowinterp_inputs");
     SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && t, "flowinterp_inputs: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs: plane too large");
-    hipLaunchKernelGGL(flowinterp_inputs_kernel<true>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, H, W);
+    SSM_LAUNCH(flowinterp_inputs_kernel<true>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, H, W);
     return ssm::check_launch("ssm_flowinterp_inputs_fwd");
 }
 
@@ -795,7 +795,7 @@ extern "C" int ssm_flowinterp_inputs_t_fwd(ssm_view img6, ssm_view flow4, const 
     SSM_CHECK_DIMS("flowinterp_inputs_t");
     SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && t, "flowinterp_inputs_t: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_t: plane too large");
-    hipLaunchKernelGGL(flowinterp_inputs_kernel<false>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, H, W);
+    SSM_LAUNCH(flowinterp_inputs_kernel<false>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, H, W);
     return ssm::check_launch("ssm_flowinterp_inputs_t_fwd");
 }
 
@@ -803,7 +803,7 @@ extern "C" int ssm_synthesize_fwd(ssm_view img6, ssm_view in16, ssm_view out5, c
     SSM_CHECK_DIMS("synthesize");
     SSM_REQUIRE(img6.ptr && in16.ptr && out5.ptr && y3.ptr && t, "synthesize: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "synthesize: plane too large");
-    hipLaunchKernelGGL(synthesize_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, in16, out5, t, y3, aux, H, W);
+    SSM_LAUNCH(synthesize_kernel, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, in16, out5, t, y3, aux, H, W);
     return ssm::check_launch("ssm_synthesize_fwd");
 }
 
@@ -834,12 +834,12 @@ extern "C" int ssm_final_conv_fwd(ssm_view x, const float *w_oihw, const float *
     const dim3 grid((unsigned)blocks), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (use_valu) {
-        if (synth) hipLaunchKernelGGL((final_conv_valu_kernel<5, true, 2>), grid, blk, 0, st, p);
-        else if (NC == 4) hipLaunchKernelGGL((final_conv_valu_kernel<4, false, 2>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((final_conv_valu_kernel<5, false, 2>), grid, blk, 0, st, p);
-    } else if (synth) hipLaunchKernelGGL((final_conv_kernel<2, true>), grid, blk, 0, st, p);
-    else if (NC <= 4) hipLaunchKernelGGL((final_conv_kernel<1, false>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((final_conv_kernel<2, false>), grid, blk, 0, st, p);
+        if (synth) SSM_LAUNCH((final_conv_valu_kernel<5, true, 2>), grid, blk, 0, st, p);
+        else if (NC == 4) SSM_LAUNCH((final_conv_valu_kernel<4, false, 2>), grid, blk, 0, st, p);
+        else SSM_LAUNCH((final_conv_valu_kernel<5, false, 2>), grid, blk, 0, st, p);
+    } else if (synth) SSM_LAUNCH((final_conv_kernel<2, true>), grid, blk, 0, st, p);
+    else if (NC <= 4) SSM_LAUNCH((final_conv_kernel<1, false>), grid, blk, 0, st, p);
+    else SSM_LAUNCH((final_conv_kernel<2, false>), grid, blk, 0, st, p);
     return ssm::check_launch("ssm_final_conv_fwd");
 }
 
@@ -847,7 +847,7 @@ extern "C" int ssm_upsample2x_cat_hl8_fwd(ssm_hview a, int Ga, ssm_hview b, int 
     SSM_CHECK_DIMS("upsample2x_cat_hl8");
     SSM_REQUIRE(a.ptr && y.ptr && Ga > 0 && Gb >= 0 && (Gb == 0 || b.ptr), "upsample2x_cat_hl8: null pointer / groups");
     SSM_REQUIRE((long long)B * (Ga + Gb) <= 65535, "upsample2x_cat_hl8: B*G too large for one launch");
-    hipLaunchKernelGGL(upsample2x_cat_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * (Ga + Gb)), dim3(64, 4), 0,
+    SSM_LAUNCH(upsample2x_cat_hl8_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * (Ga + Gb)), dim3(64, 4), 0,
                        (hipStream_t)stream, a, Ga, Gb ? b : a, Gb, y, H, W);
     return ssm::check_launch("ssm_upsample2x_cat_hl8_fwd");
 }
@@ -856,7 +856,7 @@ extern "C" int ssm_flowinterp_inputs_hl8_fwd(ssm_view img6, ssm_view flow4, cons
     SSM_CHECK_DIMS("flowinterp_inputs_hl8");
     SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && flows.ptr && t, "flowinterp_inputs_hl8: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_hl8: plane too large");
-    hipLaunchKernelGGL(flowinterp_inputs_hl8_kernel<false>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
+    SSM_LAUNCH(flowinterp_inputs_hl8_kernel<false>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
     return ssm::check_launch("ssm_flowinterp_inputs_hl8_fwd");
 }
 
@@ -865,7 +865,7 @@ extern "C" int ssm_flowinterp_inputs_hq8_fwd(ssm_view img6, ssm_view flow4, cons
     SSM_CHECK_DIMS("flowinterp_inputs_hq8");
     SSM_REQUIRE(img6.ptr && flow4.ptr && out16.ptr && flows.ptr && t, "flowinterp_inputs_hq8: null pointer");
     SSM_REQUIRE((long long)H * img6.sh < 0x7fffffffLL, "flowinterp_inputs_hq8: plane too large");
-    hipLaunchKernelGGL(flowinterp_inputs_hl8_kernel<true>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
+    SSM_LAUNCH(flowinterp_inputs_hl8_kernel<true>, pix_grid(B, H, W), dim3(64, 4), 0, (hipStream_t)stream, img6, flow4, t, out16, flows, H, W);
     return ssm::check_launch("ssm_flowinterp_inputs_hq8_fwd");
 }
 
@@ -874,7 +874,7 @@ extern "C" int ssm_frames_from_u8_fwd(const unsigned char *frames_hwc, ssm_view 
     SSM_REQUIRE(frames_hwc && out.ptr && mean3 && std3, "frames_from_u8: null pointer");
     SSM_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0 && Hp >= H + top && Wp >= W + left && top >= 0 && left >= 0,
                 "frames_from_u8: bad geometry %dx%d -> %dx%d at (%d,%d)", H, W, Hp, Wp, top, left);
-    hipLaunchKernelGGL(frames_from_u8_kernel, pix_grid(N, Hp, Wp), dim3(64, 4), 0, (hipStream_t)stream, frames_hwc, out, H, W, Hp,
+    SSM_LAUNCH(frames_from_u8_kernel, pix_grid(N, Hp, Wp), dim3(64, 4), 0, (hipStream_t)stream, frames_hwc, out, H, W, Hp,
                        Wp, top, left, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], pad_before_norm);
     return ssm::check_launch("ssm_frames_from_u8_fwd");
 }
@@ -883,7 +883,7 @@ extern "C" int ssm_frames_to_u8_fwd(ssm_view in, unsigned char *frames_hwc, int 
                                     const float *mean3, const float *std3, int mode, void *stream) {
     SSM_REQUIRE(frames_hwc && in.ptr && mean3 && std3, "frames_to_u8: null pointer");
     SSM_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0 && top >= 0 && left >= 0 && (mode == 0 || mode == 1), "frames_to_u8: bad arguments");
-    hipLaunchKernelGGL(frames_to_u8_kernel, pix_grid(N, H, W), dim3(64, 4), 0, (hipStream_t)stream, in, frames_hwc, H, W, top, left,
+    SSM_LAUNCH(frames_to_u8_kernel, pix_grid(N, H, W), dim3(64, 4), 0, (hipStream_t)stream, in, frames_hwc, H, W, top, left,
                        mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], mode);
     return ssm::check_launch("ssm_frames_to_u8_fwd");
 }

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void pack32_wino_tiles_kernel(const ssm_pack32
 extern "C" int ssm_pack32_wino_tiles_batch(const ssm_pack32_job *jobs_device, int n_jobs, long long total_tiles, int max_bn, void *stream) {
     SSM_REQUIRE(jobs_device && n_jobs > 0 && total_tiles > 0 && total_tiles <= 0x7fffffffLL, "pack32 wino tiles: empty / oversized job table");
     SSM_REQUIRE(max_bn == 32 || max_bn == 64, "pack32 wino tiles: cout blocks of 32 or 64 (got %d)", max_bn);
-    hipLaunchKernelGGL(pack32_wino_tiles_kernel, dim3((unsigned)total_tiles), dim3(256), (size_t)max_bn * 144 * sizeof(float), (hipStream_t)stream,
+    SSM_LAUNCH(pack32_wino_tiles_kernel, dim3((unsigned)total_tiles), dim3(256), (size_t)max_bn * 144 * sizeof(float), (hipStream_t)stream,
                        jobs_device, n_jobs, total_tiles);
     return ssm::check_launch("ssm_pack32_wino_tiles_batch");
 }
@@ -256,6 +256,6 @@ extern "C" int ssm_pack32_weights_batch(const ssm_pack32_job *jobs_device, int n
     // (every job's `first`, `total` and BN are multiples of 4 and its packed buffer is 16-byte aligned: a thread stores 4 elements)
     const long long blocks = ((total_elements + 3) / 4 + 255) / 256;
     SSM_REQUIRE(blocks <= 0x7fffffffLL, "pack32 batch: %lld elements out of range", total_elements);
-    hipLaunchKernelGGL(pack32_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs, total_elements);
+    SSM_LAUNCH(pack32_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, n_jobs, total_elements);
     return ssm::check_launch("ssm_pack32_weights_batch");
 }

@@ -189,7 +189,7 @@ extern "C" int ssm_convlstm_cell_fwd(ssm_view gates_x, ssm_view gates_h, ssm_vie
     SSM_CELL_DIMS("convlstm_cell");
     SSM_REQUIRE(gates_x.ptr && c_next.ptr && (h_f32.ptr || h_hl8.ptr), "convlstm_cell: null pointer");
     SSM_REQUIRE(!h_hl8.ptr || ssm::aligned16(h_hl8.ptr), "convlstm_cell: HL8 output must be 16-byte aligned");
-    hipLaunchKernelGGL(convlstm_cell_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, c_prev,
+    SSM_LAUNCH(convlstm_cell_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, c_prev,
                        c_next, h_f32, h_hl8, Hc, H, W, q8);
     return ssm::check_launch("ssm_convlstm_cell_fwd");
 }
@@ -201,7 +201,7 @@ extern "C" int ssm_convgru_reset_fwd(ssm_view gates_x, ssm_view gates_h, ssm_vie
     SSM_CELL_DIMS("convgru_reset");
     SSM_REQUIRE(gates_x.ptr && gates_h.ptr && h_prev.ptr && (rh_f32.ptr || rh_hl8.ptr), "convgru_reset: null pointer");
     SSM_REQUIRE(!rh_hl8.ptr || ssm::aligned16(rh_hl8.ptr), "convgru_reset: HL8 output must be 16-byte aligned");
-    hipLaunchKernelGGL(convgru_reset_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, h_prev,
+    SSM_LAUNCH(convgru_reset_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, h_prev,
                        rh_f32, rh_hl8, Hc, H, W, q8);
     return ssm::check_launch("ssm_convgru_reset_fwd");
 }
@@ -215,7 +215,7 @@ extern "C" int ssm_convgru_update_fwd(ssm_view gates_x, ssm_view gates_h, ssm_vi
     SSM_REQUIRE((gates_h.ptr != nullptr) == (h_prev.ptr != nullptr) && (cand_h.ptr != nullptr) == (h_prev.ptr != nullptr),
                 "convgru_update: hidden-state inputs must be all present or all absent (first step)");
     SSM_REQUIRE(!h_hl8.ptr || ssm::aligned16(h_hl8.ptr), "convgru_update: HL8 output must be 16-byte aligned");
-    hipLaunchKernelGGL(convgru_update_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, cand_x,
+    SSM_LAUNCH(convgru_update_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, cand_x,
                        cand_h, h_prev, h_f32, h_hl8, Hc, H, W, q8);
     return ssm::check_launch("ssm_convgru_update_fwd");
 }
@@ -224,7 +224,7 @@ extern "C" int ssm_convlstm_cell_bwd(ssm_view gates_x, ssm_view gates_h, ssm_vie
                                      ssm_view dc_prev, int B, int Hc, int H, int W, void *stream) {
     SSM_CELL_DIMS("convlstm_cell_bwd");
     SSM_REQUIRE(gates_x.ptr && dh.ptr && dgates.ptr && dc_prev.ptr, "convlstm_cell_bwd: null pointer");
-    hipLaunchKernelGGL(convlstm_cell_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, c_prev, dh,
+    SSM_LAUNCH(convlstm_cell_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates_x, gates_h, c_prev, dh,
                        dc_next, dgates, dc_prev, Hc, H, W);
     return ssm::check_launch("ssm_convlstm_cell_bwd");
 }
@@ -233,7 +233,7 @@ extern "C" int ssm_convgru_reset_bwd(ssm_view gates, ssm_view h_prev, ssm_view d
                                      int W, void *stream) {
     SSM_CELL_DIMS("convgru_reset_bwd");
     SSM_REQUIRE(gates.ptr && h_prev.ptr && drh.ptr && dgates.ptr && dh_prev.ptr, "convgru_reset_bwd: null pointer");
-    hipLaunchKernelGGL(convgru_reset_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates, h_prev, drh, dgates,
+    SSM_LAUNCH(convgru_reset_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates, h_prev, drh, dgates,
                        dh_prev, Hc, H, W);
     return ssm::check_launch("ssm_convgru_reset_bwd");
 }
@@ -243,7 +243,7 @@ extern "C" int ssm_convgru_update_bwd(ssm_view gates, ssm_view cand, ssm_view h_
     SSM_CELL_DIMS("convgru_update_bwd");
     SSM_REQUIRE(gates.ptr && cand.ptr && dh_next.ptr && dgates.ptr && dcand.ptr, "convgru_update_bwd: null pointer");
     SSM_REQUIRE((h_prev.ptr != nullptr) == (dh_prev.ptr != nullptr), "convgru_update_bwd: h_prev and dh_prev go together");
-    hipLaunchKernelGGL(convgru_update_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates, cand, h_prev, dh_next,
+    SSM_LAUNCH(convgru_update_bwd_kernel, cell_grid(B, Hc, H, W), dim3(64, 4), 0, (hipStream_t)stream, gates, cand, h_prev, dh_next,
                        dgates, dcand, dh_prev, Hc, H, W);
     return ssm::check_launch("ssm_convgru_update_bwd");
 }

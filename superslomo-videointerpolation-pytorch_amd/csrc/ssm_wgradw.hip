@@ -371,7 +371,7 @@ int ww_launch(const WwParams &p, int target, hipStream_t st) {
         ssm::set_error("wgrad_wino: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(wgradw_kernel<C>, dim3(gx, gy, split), dim3(256), lds_bytes, st, p);
+    SSM_LAUNCH(wgradw_kernel<C>, dim3(gx, gy, split), dim3(256), lds_bytes, st, p);
     return ssm::check_launch("ssm_conv2d_wgrad_wino");
 }
 
@@ -427,7 +427,7 @@ extern "C" int ssm_conv2d_wgrad_wino(ssm_view x, ssm_view dz, float *du, float *
 // jobs: DEVICE array of n_jobs {du, dw, n, pad} records (struct layout of ssm_wgradw_finish_job in ssm_hip.h); max_n = the largest n.
 extern "C" int ssm_wgrad_wino_finish(const void *jobs_dev, int n_jobs, int max_n, float scale, void *stream) {
     SSM_REQUIRE(jobs_dev && n_jobs > 0 && n_jobs <= 65535 && max_n > 0, "wgrad_wino_finish: bad arguments");
-    hipLaunchKernelGGL(wgradw_finish_kernel, dim3((max_n + 255) / 256, n_jobs), dim3(256), 0, (hipStream_t)stream,
+    SSM_LAUNCH(wgradw_finish_kernel, dim3((max_n + 255) / 256, n_jobs), dim3(256), 0, (hipStream_t)stream,
                        (const WwFinishJob *)jobs_dev, scale);
     return ssm::check_launch("ssm_wgrad_wino_finish");
 }

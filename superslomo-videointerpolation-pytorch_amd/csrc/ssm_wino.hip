@@ -978,7 +978,7 @@ int wlaunch(WinoParams &p, int B, hipStream_t st) {
         ssm::set_error("wino conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+    SSM_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
     return ssm::check_launch(UPS ? "ssm_wino_conv2d_ups_fwd" : "ssm_wino_conv2d_fwd");
 }
 
@@ -1126,7 +1126,7 @@ extern "C" int ssm_wino_pack_weights(const float *w, const float *bias, float *w
     const long long total = (long long)ssm_wino_packed_weight_floats(Cout, Cin, BN);
     const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
     const long long n = total > nbias ? total : nbias;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
+    SSM_LAUNCH(wino_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
                        BN, total, nbias);
     return ssm::check_launch("ssm_wino_pack_weights");
 }

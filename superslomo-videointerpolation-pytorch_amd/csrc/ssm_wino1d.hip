@@ -497,7 +497,7 @@ int w1launch(W1Params &p, int B, hipStream_t st) {
         ssm::set_error("wino1d conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
+    SSM_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, p);
     return ssm::check_launch("ssm_wino1d_conv2d_fwd");
 }
 
@@ -582,7 +582,7 @@ extern "C" int ssm_wino1d_pack_weights(const float *w, const float *bias, float 
     const long long total = (long long)ssm_wino1d_packed_weight_floats(Cout, CinP, k, BN);
     const int nbias = (int)ssm_packed_bias_floats(Cout, BN);
     const long long n = total > nbias ? total : nbias;
-    hipLaunchKernelGGL(wino1d_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
+    SSM_LAUNCH(wino1d_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
                        CinP, k, BN, total, nbias);
     return ssm::check_launch("ssm_wino1d_pack_weights");
 }

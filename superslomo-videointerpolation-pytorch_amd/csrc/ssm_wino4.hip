@@ -1087,7 +1087,7 @@ int w4launch(W4Params &p, int B, hipStream_t st) {
         ssm::set_error("wino4 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds_bytes, st, p);
+    SSM_LAUNCH(kern, dim3((unsigned)blocks), dim3(threads), lds_bytes, st, p);
     return ssm::check_launch(UPS ? "ssm_wino4_conv2d_ups_fwd" : "ssm_wino4_conv2d_fwd");
 }
 
@@ -1282,7 +1282,7 @@ extern "C" int ssm_wino4_pack_weights(const float *w, const float *bias, float *
     const long long total = (long long)ssm_wino4_packed_weight_floats(Cout, Cin);
     const int nbias = Cout;
     const long long n = total > nbias ? total : nbias;
-    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
+    SSM_LAUNCH(wino4_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin,
                        total, nbias);
     return ssm::check_launch("ssm_wino4_pack_weights");
 }

@@ -939,7 +939,7 @@ int w5launch(W5Params &p, int B, hipStream_t st) {
         ssm::set_error("wino5 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds_bytes, st, p);
+    SSM_LAUNCH(kern, dim3((unsigned)blocks), dim3(threads), lds_bytes, st, p);
     return ssm::check_launch("ssm_wino5_conv2d_add_fwd");
 }
 
@@ -1002,7 +1002,7 @@ extern "C" int ssm_wino5_pack_weights(const float *w, const float *bias, float *
     const long long total = (long long)ssm_wino5_packed_weight_floats(Cout, CinP);
     const int nbias = Cout;
     const long long n = (total > nbias ? total : nbias) / 4 + 1;
-    hipLaunchKernelGGL(wino5_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin, CinP,
+    SSM_LAUNCH(wino5_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin, CinP,
                        total, nbias);
     return ssm::check_launch("ssm_wino5_pack_weights");
 }

@@ -1065,7 +1065,7 @@ int w7launch(W7Params &p, int B, hipStream_t st) {
         ssm::set_error("wino7 conv: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(attr_rc));
         return SSM_E_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SPLIT ? 512 : 256), lds_bytes, st, p);
+    SSM_LAUNCH(kern, dim3((unsigned)blocks), dim3(SPLIT ? 512 : 256), lds_bytes, st, p);
     return ssm::check_launch("ssm_wino7_conv2d_add_fwd");
 }
 
@@ -1129,7 +1129,7 @@ extern "C" int ssm_wino7_pack_weights(const float *w, const float *bias, float *
     const long long total = (long long)ssm_wino7_packed_weight_floats(Cout, Cin);
     const int nbias = (Cout + 31) / 32 * 32;          // (bias_packed holds whole blocks too)
     const long long n = (total > nbias ? total : nbias) / 4 + 1;
-    hipLaunchKernelGGL(wino7_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin, total,
+    SSM_LAUNCH(wino7_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, bias, wp, bp, Cout, Cin, total,
                        nbias);
     return ssm::check_launch("ssm_wino7_pack_weights");
 }

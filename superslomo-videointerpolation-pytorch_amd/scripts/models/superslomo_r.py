@@ -72,7 +72,17 @@ class _TrainStep(torch.autograd.Function):
         pt = model.loss.perceptual_term(B, H, W, img6.device)
         if pt is not None and os.environ.get("SSM_VGG_OVERLAP", "1") != "0":
             pt.begin_target(target)      # the target's VGG features do not depend on the forward: second stream, beside the U-Nets
-        pred = eng.run(img6, t, want_aux=True, want_out5=True).clone()
+        pred = eng.run(img6, t, want_aux=True, want_out5=True)
+        if hb._recorder is not None:      # a recorded step (ssm_amd.training.Trainer programs): the frame lives in a buffer of the plan's life
+            keep = model.__dict__.setdefault("_pred_static", {})
+            stat = keep.get(tuple(pred.shape))
+            if stat is None or stat.device != pred.device:
+                stat = keep[tuple(pred.shape)] = torch.empty_like(pred)
+            src = pred
+            hb.host_op(lambda: stat.copy_(src))
+            pred = stat
+        else:
+            pred = pred.clone()
         if model.loss.feature_extractor is None and os.environ.get("SSM_FUSED_LOSS", "1") != "0":
             losses = model.loss.planned_losses(eng, pred, target)          # the L1 terms in two launches (ssm_train_loss_sums)
         else:

@@ -211,15 +211,17 @@ class UNetGrad:
                     b = self._span_of(self.buckets[i][-1])[1]
                     view = self.flat[a:b]
                     if self.post_scale != 1.0:
-                        view.mul_(self.post_scale)
+                        scale = self.post_scale
+                        hb.host_op(lambda: view.mul_(scale))
                     if self.sync is not None:
-                        self.sync.reduce(view)
+                        sync = self.sync
+                        hb.host_op(lambda: sync.reduce(view))
                 return
 
     def join(self):
         """The caller's stream waits for the parameter gradients queued on the side stream."""
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            hb.stream_wait(self.side, torch.cuda.current_stream())
 
     def act(self, name):
         """fp32 planes of a forward activation."""
@@ -345,11 +347,7 @@ class UNetGrad:
         if need_wgrad:
             wk, bk = param_key(name, "weight"), param_key(name, "bias")
             if self.side is not None:
-                ev = self._ev.get(name)
-                if ev is None:
-                    ev = self._ev[name] = torch.cuda.Event()
-                ev.record()                      # dZ of this layer is complete on the caller's stream
-                self.side.wait_event(ev)
+                hb.stream_wait(torch.cuda.current_stream(), self.side)      # dZ of this layer is complete on the caller's stream
             with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
                 du = self.ww.get(name)
                 if tm is not None:
@@ -394,9 +392,9 @@ class UNetGrad:
         plan = self.plan
         if need_wgrad:
             if self.side is not None:
-                self.side.wait_stream(torch.cuda.current_stream())       # last step's consumers of the gradients are done
+                hb.stream_wait(torch.cuda.current_stream(), self.side)       # last step's consumers of the gradients are done
             with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
-                self.flat.zero_()
+                hb.host_op(self.flat.zero_)
             self._arm()
         L("final_conv", d_out, None, G("tf"), need_wgrad, act=False)
         cat = G("cat_fuse", like="tf", C=plan.t["c11"].C + plan.t["c1"].C)
@@ -490,8 +488,8 @@ class PairGrad:
         B, H, W = e.B2, e.H, e.W
         n = 3.0 * H * W * n_windows
         S = self.loss_scale(max(lambda_r, lambda_w, lambda_p), n_windows)
-        self.cr.copy_((g_losses[:, 0] + g_losses[:, 1]) * (S * lambda_r / n))
-        self.cw.copy_((g_losses[:, 0] + g_losses[:, 2]) * (S * lambda_w / n))
+        hb.host_op(lambda: (self.cr.copy_((g_losses[:, 0] + g_losses[:, 1]) * (S * lambda_r / n)),
+                            self.cw.copy_((g_losses[:, 0] + g_losses[:, 2]) * (S * lambda_w / n))))
         target = target.contiguous()
         img6 = hb.view_of(e.img6)
         in16, out5, flow4 = e.s2.t["in"], e.s2.t["out"], e.s1.t["out"]

@@ -815,9 +815,9 @@ class PairEngine:
         st = hb.stream_ptr()
         t = t.reshape(-1)
         if t.numel() == self.G and self.B1 > 1:
-            self.t_dev.view(self.B1, self.G).copy_(t.view(1, self.G).expand(self.B1, self.G), non_blocking=True)
+            hb.host_op(lambda: self.t_dev.view(self.B1, self.G).copy_(t.view(1, self.G).expand(self.B1, self.G), non_blocking=True))
         else:
-            self.t_dev.copy_(t, non_blocking=True)
+            hb.host_op(lambda: self.t_dev.copy_(t, non_blocking=True))
         flow4 = self.s1.t["out"]
         in16 = self.s2.t["in"]
         tm = UNetPlan.timer

@@ -150,6 +150,13 @@ SIGNATURES = {
     "ssm_conv2d_wgrad": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_conv2d_wgrad_bf16x3": (_c_int, [SsmView, SsmView, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_splitk_enable": (_c_int, [_c_int, _c_int]),
+    "ssm_program_create": (_c_int, [ctypes.POINTER(_vp)]),
+    "ssm_program_destroy": (_c_int, [_vp]),
+    "ssm_program_begin": (_c_int, [_vp, ctypes.POINTER(_vp), _c_int]),
+    "ssm_program_mark": (_c_int, [_vp, ctypes.POINTER(_c_int)]),
+    "ssm_program_end": (_c_int, [_vp, ctypes.POINTER(_c_int)]),
+    "ssm_program_run": (_c_int, [_vp, _c_int, _c_int, ctypes.POINTER(_vp), _c_int]),
+    "ssm_stream_wait": (_c_int, [_vp, _vp]),
     "ssm_wgrad_wino_supported": (_c_int, [_c_int] * 5),
     "ssm_wgrad_wino_scratch_floats": (ctypes.c_longlong, [_c_int, _c_int]),
     "ssm_conv2d_wgrad_wino": (_c_int, [SsmView, SsmView, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -216,6 +223,114 @@ def stream_ptr():
     if _raw_stream is not None:
         return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- launch programs (csrc/ssm_program.cpp): record one pass through the C ABI, replay it without the interpreter ----------------------
+_recorder = None          # the LaunchProgram that is recording (process-wide, like the C side), or None
+
+
+def host_op(fn):
+    """Run `fn()` - framework-side GPU work inside a pass that may be recorded: a torch kernel on the plan's static tensors, an RCCL
+    bucket.  Outside a recording it is just the call.  While a program records, the call also becomes an item of the program between two
+    ranges of C-ABI nodes and is called again, on the stream that was current here, at every replay: `fn` must read and write STATIC
+    tensors only (anything it allocates is gone by the next step) and return nothing."""
+    if _recorder is None:
+        fn()
+    else:
+        _recorder._host_op(fn)
+
+
+def stream_wait(src, dst):
+    """`dst` (torch.cuda.Stream) waits for everything queued on `src` so far - torch's dst.wait_stream(src), through the C ABI so that
+    the ordering is part of a recorded program (ssm_stream_wait)."""
+    check(load().ssm_stream_wait(ctypes.c_void_p(src.cuda_stream), ctypes.c_void_p(dst.cuda_stream)))
+
+
+class LaunchProgram:
+    """One recorded pass: ranges of C-ABI nodes (replayed by ssm_program_run) interleaved with the framework-side calls of `host_op`.
+
+        prog = LaunchProgram([main, side, ...])          # torch.cuda.Stream objects = the program's stream slots
+        with prog.recording():
+            step_body()                                   # launches run as usual and are recorded
+        prog.replay()                                     # the same launches, ~2 us of host time each
+
+    The body must be a pass whose pointers do not change from step to step (plans, static input buffers), warmed up before it is recorded
+    (lazily built buffers, packed filters), and must route its torch-side GPU work through hb.host_op and its cross-stream ordering
+    through hb.stream_wait."""
+
+    def __init__(self, streams):
+        assert 1 <= len(streams) <= 8
+        self.streams = list(streams)
+        self._raw = (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+        h = ctypes.c_void_p()
+        check(load().ssm_program_create(ctypes.byref(h)))
+        self._h = h
+        self.items = []          # ("c", first, last) | ("py", fn, stream or None)
+        self._cut = 0
+        self.n_nodes = 0
+        self.ready = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                load().ssm_program_destroy(self._h)
+                self._h = None
+        except Exception:          # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def _mark(self):
+        n = ctypes.c_int(0)
+        check(load().ssm_program_mark(self._h, ctypes.byref(n)))
+        if n.value > self._cut:
+            self.items.append(("c", self._cut, n.value))
+            self._cut = n.value
+
+    def _host_op(self, fn):
+        self._mark()
+        fn()
+        cur = torch.cuda.current_stream()
+        self.items.append(("py", fn, None if cur.cuda_stream == self.streams[0].cuda_stream else cur))
+
+    def recording(self):
+        prog = self
+
+        class _Ctx:
+            def __enter__(self):
+                global _recorder
+                assert _recorder is None, "another program is recording"
+                check(load().ssm_program_begin(prog._h, prog._raw, len(prog.streams)))
+                _recorder = prog
+                return prog
+
+            def __exit__(self, et, ev, tb):
+                global _recorder
+                _recorder = None
+                if et is None:
+                    prog._mark()
+                n = ctypes.c_int(0)
+                rc = load().ssm_program_end(prog._h, ctypes.byref(n))
+                if et is None:
+                    check(rc)
+                    prog.n_nodes = n.value
+                    prog.ready = True
+                return False
+        return _Ctx()
+
+    def replay(self):
+        """Issue the recorded pass again.  The caller's current stream must be slot 0's."""
+        assert self.ready, "nothing recorded"
+        lib, h, raw, n = load(), self._h, self._raw, len(self.streams)
+        run = lib.ssm_program_run
+        for it in self.items:
+            if it[0] == "c":
+                rc = run(h, it[1], it[2], raw, n)
+                if rc:
+                    check(rc)
+            elif it[2] is None:
+                it[1]()
+            else:
+                with torch.cuda.stream(it[2]):
+                    it[1]()
 
 
 def require_device(t, what="tensor"):

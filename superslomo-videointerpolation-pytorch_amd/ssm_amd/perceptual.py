@@ -208,6 +208,7 @@ class PerceptualTerm:
         self.both = torch.empty(2 * B, 3, H, W, dtype=torch.float32, device=device)
         self._side, self._pending = None, None
         self._sq_scratch = torch.empty(64 * B, dtype=torch.float32, device=device)          # slice sums of ssm_sqdiff_mean
+        self._mse = torch.empty(B, dtype=torch.float32, device=device)
 
     def begin_target(self, target):
         """Start the target's half of the VGG pass on a second stream (the training step calls this before the U-Net forward: the
@@ -215,7 +216,7 @@ class PerceptualTerm:
         predicted frames only and joins."""
         if self._side is None:
             self._side = torch.cuda.Stream(device=target.device)
-        self._side.wait_stream(torch.cuda.current_stream())      # the last step's readers of these buffers are queued before this
+        hb.stream_wait(torch.cuda.current_stream(), self._side)      # the last step's readers of these buffers are queued before this
         with torch.cuda.stream(self._side):
             self.vgg.forward(target, b0=self.B)
         self._pending = target
@@ -225,14 +226,13 @@ class PerceptualTerm:
         B = self.B
         if self._pending is not None and self._pending is target:
             self.vgg.forward(pred, b0=0)
-            torch.cuda.current_stream().wait_stream(self._side)
+            hb.stream_wait(self._side, torch.cuda.current_stream())
         else:
-            self.both[:B].copy_(pred)
-            self.both[B:].copy_(target)
+            hb.host_op(lambda: (self.both[:B].copy_(pred), self.both[B:].copy_(target)))
             self.vgg.forward(self.both)
         self._pending = None
         phi = self.vgg.t[self.vgg.out]
-        out = torch.empty(B, dtype=torch.float32, device=phi.full.device)
+        out = self._mse          # (a buffer of the term: the launch below may be part of a recorded program)
         hb.check(hb.load().ssm_sqdiff_mean(phi.view(), phi.view(b0=B), self._sq_scratch.data_ptr(), out.data_ptr(), B, phi.C, phi.H, phi.W,
                                            hb.stream_ptr()))
         return out
@@ -242,7 +242,7 @@ class PerceptualTerm:
         d(loss)/d(pred)."""
         B, phi = self.B, self.vgg.t[self.vgg.out]
         n = float(phi.C * phi.H * phi.W)
-        self.coef.copy_(weight * (2.0 / n))
+        hb.host_op(lambda: self.coef.copy_(weight * (2.0 / n)))
         dphi = self.vgg._G(self.vgg.out)
         hb.check(hb.load().ssm_sqdiff_grad(phi.view(), phi.view(b0=B), self.coef.data_ptr(), dphi.view(), B, phi.C, phi.H, phi.W,
                                            hb.stream_ptr()))

@@ -20,10 +20,16 @@ class Trainer:
     ROCm 7.2 the replay of the ~900-node graph costs the host as much as issuing the launches (17.8 ms vs 15.6 ms per step
     measured), so the step got slower (20.3 vs 18.0 ms); the eager step's launch count is what was cut instead."""
 
-    def __init__(self, model, cfg, graphs=None):
+    def __init__(self, model, cfg, graphs=None, programs=None):
         self.model, self.cfg = model, cfg
         self.graphs = (os.environ.get("SSM_TRAIN_GRAPH", "0") != "0") if graphs is None else bool(graphs)
         self._graph = None
+        # programs (default on; $SSM_TRAIN_PROGRAM=0: off): the planned step's ~900 C-ABI launches are recorded once into a launch program
+        # (csrc/ssm_program.cpp, hipbind.LaunchProgram) and replayed by a handful of host calls - the step then costs the host ~2 us per
+        # launch instead of the interpreter + ctypes price of each (11 of 15 ms).  Unlike the HIP graph above the gradient exchange stays
+        # INSIDE the step (its buckets are host-side items of the program, overlapped with the backward as in the eager step).
+        self.programs = (os.environ.get("SSM_TRAIN_PROGRAM", "1") != "0") if programs is None else bool(programs)
+        self._prog, self._prog_seen = None, {}
         self.learning_rate = cfg.getfloat("TRAIN", "LEARNING_RATE")
         self.lr_period = cfg.getint("TRAIN", "LR_PERIOD")
         self.lr_decay = cfg.getfloat("TRAIN", "LR_DECAY")
@@ -79,6 +85,11 @@ class Trainer:
             assert bool(in_range), "Interpolation values out of bounds."
         if self.graphs and input_images.is_cuda and not self._timers_on():
             losses = self._replay(input_images, target_images, t_interp, iteration)
+        elif self.programs and self._program_ok(input_images):
+            losses = self._program_step(input_images, target_images, t_interp, iteration)
+            self.last_allreduce_s = self.allreduce()
+            self.optimizer.step()
+            return losses.detach().clone()          # (the program writes its loss vector in place every step)
         else:
             self.optimizer.zero_grad()
             losses = self._forward_backward(input_images, target_images, t_interp, iteration)
@@ -91,6 +102,85 @@ class Trainer:
         losses = losses.mean(dim=0)
         losses[0].backward()
         return losses
+
+    # ---- launch programs ---------------------------------------------------------------------------------------------------------
+    PROGRAM_WARMUP = 2          # eager steps of a shape before its program is recorded (plans, packed filters, lazily built buffers)
+
+    def _program_ok(self, input_images):
+        """The planned one-window step (models.superslomo_r._TrainStep) on the GPU, fp32 plans, no event timers."""
+        m = self.model
+        if not (input_images.is_cuda and input_images.shape[1] == 2 and not m.recurrent and not self._timers_on()):
+            return False
+        mode = m.train_precision or os.environ.get("SSM_TRAIN_PRECISION", "f32")
+        if mode not in ("f32", "f32w") or (m.loss.feature_extractor is not None) or os.environ.get("SSM_FUSED_LOSS", "1") == "0":
+            return False
+        return all(p.requires_grad for p in m.stage1_model.parameters()) or all(p.requires_grad for p in m.stage2_model.parameters())
+
+    def _program_step(self, input_images, target_images, t_interp, iteration):
+        key = (tuple(input_images.shape), str(input_images.device))
+        pr = self._prog
+        if pr is not None and (pr["key"] != key or pr["train"] is not getattr(self.model, "_train", None)):
+            pr = self._prog = None          # another shape, or the plans were dropped (load_state_dict): record again
+        if pr is None:
+            seen = self._prog_seen.get(key, 0)
+            if seen < self.PROGRAM_WARMUP:
+                self._prog_seen[key] = seen + 1
+                self.optimizer.zero_grad()
+                return self._forward_backward(input_images, target_images, t_interp, iteration)
+            pr = self._record_program(key, input_images, target_images, t_interp)
+        else:
+            self._load_inputs(pr, input_images, target_images, t_interp)
+            for p, g in pr["grads"]:          # (an eager step in between drops the references: the program writes these tensors)
+                p.grad = g
+            pr["program"].replay()
+        return pr["losses"]
+
+    @staticmethod
+    def _load_inputs(pr, input_images, target_images, t_interp):
+        pr["img6"][:, 0:3].copy_(input_images[:, 0])
+        pr["img6"][:, 3:6].copy_(input_images[:, 1])
+        pr["target"].copy_(target_images[:, 0])
+        pr["t"].copy_(t_interp.reshape(-1))
+
+    def _record_program(self, key, input_images, target_images, t_interp):
+        """Run one step through the planned forward and the hand-written backward DIRECTLY (models.superslomo_r._TrainStep's two halves,
+        no autograd graph: the upstream gradient of `losses.mean(0)[0]` is the constant 1/B in column 0) while a LaunchProgram records,
+        from static input buffers."""
+        import types
+
+        from models.superslomo_r import _TrainStep
+
+        from . import hipbind as hb
+        model = self.model
+        B, _, _, H, W = input_images.shape
+        dev = input_images.device
+        pr = {"key": key, "img6": torch.empty(B, 6, H, W, dtype=torch.float32, device=dev),
+              "target": torch.empty(B, 3, H, W, dtype=torch.float32, device=dev), "t": torch.empty(B, dtype=torch.float32, device=dev),
+              "losses": torch.empty(4, dtype=torch.float32, device=dev)}
+        self._load_inputs(pr, input_images, target_images, t_interp)
+        eng, pg = model._train_engine(B, H, W, dev)
+        pr["train"] = model._train
+        streams = [torch.cuda.current_stream()]
+        for st in (pg.u1.side, getattr(model.loss.perceptual_term(B, H, W, dev), "_side", None)):
+            if st is not None and all(st.cuda_stream != x.cuda_stream for x in streams):
+                streams.append(st)
+        d_losses = torch.zeros(B, 4, dtype=torch.float32, device=dev)
+        d_losses[:, 0] = 1.0 / B
+        params = list(model.stage1_model.parameters()) + list(model.stage2_model.parameters())
+        self.optimizer.zero_grad(set_to_none=True)          # the recorded backward then ASSIGNS .grad: slices of the plan's flat buffers
+        ctx = types.SimpleNamespace(mark_non_differentiable=lambda *a: None)
+        prog = hb.LaunchProgram(streams)
+        with torch.no_grad(), prog.recording():
+            _, losses = _TrainStep.forward(ctx, model, pr["img6"], pr["t"], pr["target"], *params)
+            out = pr["losses"]
+            hb.host_op(lambda: out.copy_(losses.mean(dim=0)))
+            _TrainStep.backward(ctx, None, d_losses)
+        pr["grads"] = [(p, p.grad) for p in params if p.requires_grad and p.grad is not None]
+        pr["program"] = prog
+        self._prog = pr
+        log.info("training step recorded into a launch program: %d C-ABI nodes, %d items, %d stream(s), input %s", prog.n_nodes,
+                 len(prog.items), len(streams), key[0])
+        return pr
 
     @staticmethod
     def _timers_on():

@@ -452,6 +452,78 @@ def test_trainer_graph_replay_matches_eager_steps(dev):
         assert float((a - b).abs().mean()) <= 0.05 * tr.learning_rate
 
 
+@pytest.mark.parametrize("train_precision,perceptual", [("f32w", True), ("f32", False)])
+def test_trainer_launch_program_replay_matches_eager_steps(dev, train_precision, perceptual):
+    """Trainer(programs=True) - after two eager warm-up steps the step's C-ABI launches are recorded into a launch program
+    (csrc/ssm_program.cpp) and replayed, the torch-side pieces (loss assembly, gradient buckets, zeroing) as host items between the node
+    ranges - follows the eager trainer over 6 steps on changing batches: same losses, same parameters up to the atomics' summation
+    order; the program really ran (hundreds of nodes, three recorded-then-replayed steps) and on every stream it was recorded on."""
+    from ssm_amd.perceptual import synthetic_vgg_state_dict
+    from ssm_amd.training import Trainer
+    from ssm_amd.weights import synthetic_frames
+    batches = []
+    for i in range(6):
+        clips = torch.cat([synthetic_frames(3, 64, 64, seed=100 + 2 * i), synthetic_frames(3, 64, 64, seed=101 + 2 * i)], 0).to(dev)
+        batches.append((clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous(),
+                        torch.tensor([0.5, 0.125 * (i + 1)], device=dev).view(2, 1, 1, 1, 1)))
+    hist, finals = {}, {}
+    for programs in (False, True):
+        m, cfg = _train_model(dev)
+        if perceptual:
+            m.loss.load_vgg16(synthetic_vgg_state_dict())
+        m.train_precision = train_precision
+        tr = Trainer(m, cfg, programs=programs)
+        hist[programs] = [tr.train_step(x, y, t).cpu() for x, y, t in batches]
+        finals[programs] = [p.detach().clone() for p in m.parameters()]
+        assert (tr._prog is not None) == programs
+        if programs:
+            prog = tr._prog["program"]
+            assert prog.ready and prog.n_nodes > 300 and len(prog.streams) == (3 if perceptual else 2), (prog.n_nodes, len(prog.streams))
+            assert sum(1 for it in prog.items if it[0] == "py") >= 5
+    for a, b in zip(hist[False], hist[True]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+    for a, b in zip(finals[False], finals[True]):       # Adam normalises: a ~0 gradient whose sign flips with the atomics' order moves a weight by lr per step
+        assert float((a - b).abs().max()) <= 6 * 2 * tr.learning_rate + 1e-7
+        assert float((a - b).abs().mean()) <= 0.05 * tr.learning_rate
+
+
+def test_launch_program_records_and_replays_plain_launches(dev):
+    """The C side alone: two streams, kernels + a cross-stream wait recorded once and replayed twice give the eager result; a launch on a
+    stream that is no slot of the program fails the recording."""
+    from ssm_amd import hipbind as hb
+    main, side, other = torch.cuda.current_stream(), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    x = hb.Planes(2, 8, 16, 32, dev).load(torch.randn(2, 8, 16, 32, device=dev))
+    y, z = hb.Planes(2, 8, 8, 16, dev), hb.Planes(2, 8, 8, 16, dev)
+    lib = hb.load()
+
+    def body():
+        hb.check(lib.ssm_avgpool2_fwd(x.view(), y.view(), 2, 8, 16, 32, hb.stream_ptr()))
+        hb.stream_wait(main, side)
+        with torch.cuda.stream(side):
+            hb.check(lib.ssm_copy_view(y.view(), z.view(), 2, 8, 8, 16, hb.stream_ptr()))
+        hb.stream_wait(side, main)
+        hb.host_op(lambda: z.full.mul_(2.0))          # torch-side work on the main stream, behind the side stream's copy
+        hb.check(lib.ssm_copy_view(z.view(), y.view(), 2, 8, 8, 16, hb.stream_ptr()))
+
+    prog = hb.LaunchProgram([main, side])
+    with prog.recording():
+        body()
+    torch.cuda.synchronize()
+    assert prog.n_nodes == 5 and [(it[0], it[1:3] if it[0] == "c" else None) for it in prog.items] == [("c", (0, 4)), ("py", None), ("c", (4, 5))]
+    want = 2.0 * torch.nn.functional.avg_pool2d(x.interior, 2)
+    assert torch.equal(y.interior, want) and torch.equal(z.interior, want)          # the recording pass itself executed
+    for _ in range(2):
+        y.full.zero_(), z.full.zero_()
+        prog.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y.interior, want) and torch.equal(z.interior, want)
+    bad = hb.LaunchProgram([main])
+    with pytest.raises(RuntimeError, match="not one of the program"):
+        with bad.recording():
+            with torch.cuda.stream(other):
+                hb.check(lib.ssm_copy_view(y.view(), z.view(), 2, 8, 8, 16, hb.stream_ptr()))
+
+
 def test_main_entry_point_trains_and_checkpoints(dev, tmp_path):
     """scripts/main.py (reference CLI flags): two epochs on synthetic batches, a checkpoint in the reference's layout
     that loads back through models.unetflow.get_model (strict)."""
