@@ -135,7 +135,7 @@ CONFIG_RUNS = (
     ("config3_train", 2, ["--mode", "train", "--precision", "f32w", "--steps", "20", "--warmup", "3", "--force-allreduce"], True),
     ("config4_recurrent", 3, ["--mode", "recurrent", "--precision", "f32w", "--steps", "10", "--warmup", "2"], False),
     ("config5_4k", 4, ["--size", "4k", "--precision", "f32w", "--streams", "1", "--pairs-per-batch", "1", "--pairs-per-step", "1", "--steps", "4",
-                       "--warmup", "1", "--no-kernel-timers", "--no-clock-probes", "--parity-4k"], False),
+                       "--warmup", "1", "--no-kernel-timers", "--no-clock-probes", "--parity-4k", "--modes-4k", "f16"], False),
 )
 
 
@@ -147,7 +147,7 @@ def under_profiler():
             or "rocprof" in env.get("LD_PRELOAD", "").lower())
 
 
-def collect_configs(timeout_s=240):
+def collect_configs(timeout_s=300):
     """BASELINE configs[2..4] beside the headline: short runs of `--mode train` (with the RCCL gradient buckets
     forced at world 1), `--mode recurrent` and `--size 4k`, each a fresh child process of THIS script, one after the other, started
     before this process has touched the GPU (no exec from a process that holds the device).  Returns {key: summary}."""
@@ -182,6 +182,10 @@ def collect_configs(timeout_s=240):
         for k in ("allreduce", "host_enqueue_ms_per_step"):
             if k in d:
                 rec[k] = d[k]
+        if d.get("modes"):          # config 5: the fp16 MFMA path named by BASELINE.json beside the f32w answer
+            rec["modes"] = {m: {"value": v.get("value"), "unit": v.get("unit"), "dtype": v.get("dtype"), "parity": v.get("parity"),
+                                "roofline": {k: v.get("roofline", {}).get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}}
+                            for m, v in d["modes"].items()}
         out[key] = rec
     return out
 
@@ -1092,7 +1096,10 @@ def infer_bench(args):
         out["dist"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size()}
 
     results = {headline: main_res}
-    side = [m for m in args.modes.split(",") if m and m != headline] if (world == 1 and args.size == "720p") else []
+    # side modes: the 720p line reports the opt-in modes beside the headline; at 4K only what --modes-4k names (BASELINE config 5 as
+    # worded - "fp16 MFMA conv path" - beside the f32w answer)
+    side = ([m for m in args.modes.split(",") if m and m != headline] if args.size == "720p" else
+            [m for m in args.modes_4k.split(",") if m and m != headline]) if world == 1 else []
     for m in side:
         main_res.pop("_pipe", None)     # free the previous mode's activations
         torch.cuda.empty_cache()
@@ -1175,6 +1182,18 @@ def infer_bench(args):
         got4 = model.interpolate(xs[0].to(dev), [0.5]).cpu()
         out["parity"] = {"max_abs_vs_oracle": float((got4 - want4).abs().max()), "tolerance": 1e-3, "frames": 1, "t": 0.5,
                          "size": "%dx%d" % (Hp, Wp), "mode": headline}
+
+        def psnr(got):          # PSNR of the frame in [0, 1] pixel units (denormalised with the ImageNet std) against the fp32 CPU oracle
+            from ssm_amd.weights import IMAGENET_STD
+            e = (got - want4) * torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+            return float(10.0 * torch.log10(1.0 / (e.double() ** 2).mean()))
+        out["parity"]["psnr_db_vs_oracle"] = round(psnr(got4), 2)
+        for m in side:          # the narrower modes: PSNR is their parity statement
+            model.precision = m
+            gm = model.interpolate(xs[0].to(dev), [0.5]).cpu()
+            out["modes"][m]["parity"] = {"psnr_db_vs_oracle": round(psnr(gm), 2), "max_abs_vs_oracle": float((gm - want4).abs().max()),
+                                         "note": "vs the fp32 CPU oracle, one pair, t = 0.5; this mode is narrower than fp32: PSNR, not the 1e-3 bar"}
+        model.precision = headline
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():
@@ -1199,6 +1218,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "f32w", "f16x3", "f16", "f16f8"],
                     help="headline conv arithmetic (default f32 = the reference's arithmetic)")
     ap.add_argument("--modes", default="f32,f16x3,f16f8", help="comma list of further modes reported under `modes` (N=1, 720p only); '' = none")
+    ap.add_argument("--modes-4k", default="", help="--size 4k: comma list of further modes run after the headline one (e.g. f16: BASELINE config 5 as worded)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "recurrent"],
                     help="infer = the headline (BASELINE configs[1]); train = configs[2]: training step on 352x352 crops, "
                          "2 samples per GPU, gradient all-reduce over RCCL; recurrent = configs[3]: superslomo_recurrent.ini "

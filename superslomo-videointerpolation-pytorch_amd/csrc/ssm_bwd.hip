@@ -367,8 +367,10 @@ __device__ __forceinline__ void wg_split4(const float4 &v, wg_i2 &hi, wg_i2 &lo)
 
 constexpr int wg_odd16(int bytes) { return (((bytes + 15) / 16) | 1) * 16; }      // LDS row pitch: an odd number of 16-byte units
 
+// (launch bounds: two workgroups per CU except the 7-tap / 128-pixel instantiation, whose 7 windows x 3 products per lane need more than
+// the 128 registers two co-resident workgroups leave a wave - at (256, 2) it spilled 4 registers to scratch; check_isa.sh fences that)
 template <int KS, int TY, int SEG, int WAN, int WBN>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
+__global__ __launch_bounds__(256, (KS == 7 && SEG == 128) ? 1 : 2) void wgrad_bf16x3_kernel(ssm_view x, ssm_view dz, float *__restrict__ dw, int B, int Cin, int Cout,
                                                               int H, int W, int cin_total, int ci_offset, int steps_per_slice) {
     constexpr int P = (KS - 1) / 2, WKN = 4 / (WAN * WBN), NK = SEG / 16, NKY = KS / TY;
     static_assert(WAN * WBN * WKN == 4 && NK % WKN == 0 && NKY * TY == KS && P <= 3, "tile configuration");

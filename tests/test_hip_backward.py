@@ -456,35 +456,52 @@ def test_trainer_graph_replay_matches_eager_steps(dev):
 def test_trainer_launch_program_replay_matches_eager_steps(dev, train_precision, perceptual):
     """Trainer(programs=True) - after two eager warm-up steps the step's C-ABI launches are recorded into a launch program
     (csrc/ssm_program.cpp) and replayed, the torch-side pieces (loss assembly, gradient buckets, zeroing) as host items between the node
-    ranges - follows the eager trainer over 6 steps on changing batches: same losses, same parameters up to the atomics' summation
-    order; the program really ran (hundreds of nodes, three recorded-then-replayed steps) and on every stream it was recorded on."""
+    ranges - beside an eager trainer IN LOCKSTEP on changing batches.
+      (1) learning rate 0 (frozen parameters: the only way to compare step by step - under Adam a gradient of ~0 whose sign flips with the
+          atomics' summation order moves a weight by 2 lr, and two EAGER runs drift apart by 1e-4 in the loss within four steps,
+          profiles/r17h_program_vs_eager.txt): eager, recorded and replayed steps give the same losses to 1e-6 and every parameter gradient
+          to 5e-6 of the largest one (measured: 0 and 4e-7, profiles/r17j_lockstep_lr0.txt);
+      (2) learning rate on: the program trainer's trajectory stays inside that drift (losses within 2e-3, decreasing like the eager one).
+    The program really ran: hundreds of nodes, host items in between, every stream it was recorded on."""
     from ssm_amd.perceptual import synthetic_vgg_state_dict
     from ssm_amd.training import Trainer
     from ssm_amd.weights import synthetic_frames
     batches = []
-    for i in range(6):
+    for i in range(5):
         clips = torch.cat([synthetic_frames(3, 64, 64, seed=100 + 2 * i), synthetic_frames(3, 64, 64, seed=101 + 2 * i)], 0).to(dev)
         batches.append((clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous(),
                         torch.tensor([0.5, 0.125 * (i + 1)], device=dev).view(2, 1, 1, 1, 1)))
-    hist, finals = {}, {}
-    for programs in (False, True):
+
+    def make(programs, lr0):
         m, cfg = _train_model(dev)
         if perceptual:
             m.loss.load_vgg16(synthetic_vgg_state_dict())
         m.train_precision = train_precision
         tr = Trainer(m, cfg, programs=programs)
+        if lr0:
+            for g in tr.optimizer.param_groups:
+                g["lr"] = 0.0
+        return m, tr
+
+    (mE, tE), (mP, tP) = make(False, True), make(True, True)
+    for i, (x, y, t) in enumerate(batches):
+        lE, lP = tE.train_step(x, y, t), tP.train_step(x, y, t)
+        assert float((lE - lP).abs().max()) <= 1e-6 * float(lE.abs().max()), "step %d: losses %s vs %s" % (i, lE.tolist(), lP.tolist())
+        gmax = max(float(p.grad.abs().max()) for p in mE.parameters())
+        worst = max(float((a.grad - b.grad).abs().max()) for a, b in zip(mE.parameters(), mP.parameters()))
+        assert worst <= 5e-6 * gmax, "step %d: a parameter gradient differs by %.2e of the largest gradient" % (i, worst / gmax)
+    prog = tP._prog["program"]
+    assert tE._prog is None and prog.ready and prog.n_nodes > 300 and len(prog.streams) == (3 if perceptual else 2), (prog.n_nodes, len(prog.streams))
+    assert sum(1 for it in prog.items if it[0] == "py") >= 5
+    del mE, tE, mP, tP
+    hist = {}
+    for programs in (False, True):
+        m, tr = make(programs, False)
         hist[programs] = [tr.train_step(x, y, t).cpu() for x, y, t in batches]
-        finals[programs] = [p.detach().clone() for p in m.parameters()]
         assert (tr._prog is not None) == programs
-        if programs:
-            prog = tr._prog["program"]
-            assert prog.ready and prog.n_nodes > 300 and len(prog.streams) == (3 if perceptual else 2), (prog.n_nodes, len(prog.streams))
-            assert sum(1 for it in prog.items if it[0] == "py") >= 5
     for a, b in zip(hist[False], hist[True]):
-        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
-    for a, b in zip(finals[False], finals[True]):       # Adam normalises: a ~0 gradient whose sign flips with the atomics' order moves a weight by lr per step
-        assert float((a - b).abs().max()) <= 6 * 2 * tr.learning_rate + 1e-7
-        assert float((a - b).abs().mean()) <= 0.05 * tr.learning_rate
+        assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
+    assert float(hist[True][-1][0]) < 0.8 * float(hist[True][0][0])
 
 
 def test_launch_program_records_and_replays_plain_launches(dev):
