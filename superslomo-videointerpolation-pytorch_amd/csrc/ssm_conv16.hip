@@ -86,13 +86,19 @@ struct Cfg16 {
     static constexpr int PBUFS = PBUFS_;      // 2: patch double-buffered in the workgroup (1 workgroup / CU);
                                               // 1: single patch buffer, latency hidden by a 2nd workgroup on the CU
     static constexpr bool SPLIT3 = MODE_ == 1, Q8 = MODE_ == 2;
+    // FAST (plain fp16, BASELINE config 5): only the hi planes exist for this mode - the patch holds the two channel groups' hi planes,
+    // the epilogue stores hi only (the lo planes of a plan's tensors stay at their initial zeros: no convolution of the mode reads them,
+    // and hi + 0 is what the other readers - the fused-upsample expander, to_nchw - then see).  Half the HBM and LDS-DMA bytes of a
+    // launch: the 32-channel full-resolution 3x3 layers are HBM-bound at fp16 (ridge 312 FLOP/B; profiles/r17l_layers16_4k_fast.txt).
+    static constexpr bool FAST = MODE_ == 0;
+    static constexpr int NPL = FAST ? 2 : 4;     // planes of a 16-channel chunk in the patch: group x (hi | second plane)
     static constexpr int NQ = (KS + 3) / 4;      // K=64 correction steps per filter row (4 taps x 16 channels each)
     static constexpr int PAD = (KS - 1) / 2;
     static constexpr int NW = WN * WY * WX, NTHREADS = 64 * NW;
     static constexpr int BN = 32 * NT * WN, TH = MTY * WY, TW = 32 * MTX * WX, MT = MTY * MTX;
     static constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
     static constexpr int NIT = KS / KYS;                          // iterations (filter-row stages) per chunk
-    static constexpr int PATCH_PIECES = 4 * PH * PW;              // 16-byte pieces
+    static constexpr int PATCH_PIECES = NPL * PH * PW;            // 16-byte pieces
     static constexpr int PNI = (PATCH_PIECES + 63) / 64;          // 1-KiB DMA instructions per patch
     static constexpr int PATCH_BYTES = PNI * 1024;
     // filter stage: [tap][h][part][BN] x 16 B;  Q8: [tap][h][BN] (fp16 hi) then [row][quad][operand][piece][half][BN] (fp8)
@@ -117,6 +123,12 @@ struct Cfg16 {
 #define SSM_GLDS16B(gp, lp)                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp),       \
                                      (__attribute__((address_space(3))) void *)(lp), 16, 0, 0)
+
+__device__ __forceinline__ void hi_store(char *plane_hi, float v0, float v1, float v2, float v3) {          // mode FAST: the hi plane only
+    h4 hi;
+    hi[0] = (_Float16)v0; hi[1] = (_Float16)v1; hi[2] = (_Float16)v2; hi[3] = (_Float16)v3;
+    *reinterpret_cast<h4 *>(plane_hi) = hi;
+}
 
 __device__ __forceinline__ void split_store(char *plane_hi, long long sp_bytes, float v0, float v1, float v2, float v3) {
     h4 hi, lo;
@@ -394,6 +406,8 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
                                 char *d = p.dh + (((long long)b * p.dhsb + (long long)(cr >> 3) * p.dhsg + (long long)Y * p.dhsh + X) * 16);
                                 if constexpr (C::Q8)
                                     split_store_q8(d, p.dhsp * 16, p.dhsg * 16, cr >> 3, half, v[m][0], v[m][1], v[m][2], v[m][3]);
+                                else if constexpr (C::FAST)
+                                    hi_store(d + half * 8, v[m][0], v[m][1], v[m][2], v[m][3]);
                                 else
                                     split_store(d + half * 8, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
                             }
@@ -403,6 +417,8 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
                             char *d = p.dh + (((long long)b * p.dhsb + (long long)(co0 >> 3) * p.dhsg + (long long)y * p.dhsh + x) * 16);
                             if constexpr (C::Q8)
                                 split_store_q8(d, p.dhsp * 16, p.dhsg * 16, co0 >> 3, half, v[m][0], v[m][1], v[m][2], v[m][3]);
+                            else if constexpr (C::FAST)
+                                hi_store(d + half * 8, v[m][0], v[m][1], v[m][2], v[m][3]);
                             else
                                 split_store(d + half * 8, p.dhsp * 16, v[m][0], v[m][1], v[m][2], v[m][3]);
                         }
@@ -431,6 +447,8 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Params &p, f32x16 (&
                                 char *d = p.ph + (((long long)b * p.phsb + (long long)(co0 >> 3) * p.phsg + (long long)(y >> 1) * p.phsh + (x >> 1)) * 16);
                                 if constexpr (C::Q8)
                                     split_store_q8(d, p.phsp * 16, p.phsg * 16, co0 >> 3, half, s[0], s[1], s[2], s[3]);
+                                else if constexpr (C::FAST)
+                                    hi_store(d + half * 8, s[0], s[1], s[2], s[3]);
                                 else
                                     split_store(d + half * 8, p.phsp * 16, s[0], s[1], s[2], s[3]);
                             }
@@ -483,7 +501,8 @@ __device__ __forceinline__ void conv16_body(const Conv16Params &p, const int blk
             const int rem = q - pl * (PH * PW);
             const int r = rem / PW;
             const int c = rem - r * PW;
-            poff[m] = (int)(((long long)(pl >> 1) * p.sg + (long long)(pl & 1) * p.sp + (long long)r * p.sh + c) * 16);
+            const int grp = C::FAST ? pl : pl >> 1, part = C::FAST ? 0 : pl & 1;
+            poff[m] = (int)(((long long)grp * p.sg + (long long)part * p.sp + (long long)r * p.sh + c) * 16);
         }
     }
     const int woff = (lw * 64 + lane) * 16;
@@ -551,7 +570,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params &p, const int blk
             for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
     // per-lane operand byte offsets inside a patch buffer / filter stage
-    const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
+    const int bOff = ((half * (C::NPL / 2) * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
     const int aOff = C::Q8 ? (half * BN + wn * (NT * 32) + l31) * 16 : (half * 2 * BN + wn * (NT * 32) + l31) * 16;
     const int bqOff = ((PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;      // q plane of group 0 (Q8 mode)
 
@@ -594,7 +613,7 @@ __device__ __forceinline__ void conv16_body(const Conv16Params &p, const int blk
 template <int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int NWE_, int MODE_>
 struct CfgUps {
     static constexpr int KS = 3, KYS = KYS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_;
-    static constexpr bool SPLIT3 = MODE_ == 1, Q8 = MODE_ == 2;
+    static constexpr bool SPLIT3 = MODE_ == 1, Q8 = MODE_ == 2, FAST = MODE_ == 0;
     static constexpr int NQ = 1;
     static constexpr int PAD = 1;
     static constexpr int NWM = WN * WY * WX, NWE = NWE_, NTHREADS = 64 * (NWM + NWE);

@@ -496,6 +496,9 @@ class PairGrad:
         need_s1 = train_s1
         for u in (self.u1, self.u2):          # every bucket of the flat gradient buffers is multiplied by this when it completes
             u.post_scale, u.sync = self.sync_scale / S, self.sync
+        # (r6, measured and not kept: repacking the data-gradient filters on the side stream while the forward runs - 14.46 -> 16.2 ms per
+        # step, profiles/r17n_train_ab2.txt: the side stream's launches at the head of the step delay the forward more than the 0.3 ms of
+        # repack they take off the backward's chain)
         self.u2.refresh(sd2, need_input_grad=need_s1)
         self.u2.prepare(cross=e.s1.f32.get("c6") if e.hl8 else None)
         d_out5 = self.u2._G("out", C=self.u2.pk_t["final_conv"].cin_p)
