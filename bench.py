@@ -179,7 +179,7 @@ def collect_configs(timeout_s=300):
                "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "workload": d["config"].get("workload"),
                "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac") if k in rf},
                "parity": d.get("parity"), "argv": " ".join(argv), "child_wall_s": round(time.perf_counter() - t0, 1)}
-        for k in ("allreduce", "host_enqueue_ms_per_step"):
+        for k in ("allreduce", "host_enqueue_ms_per_step", "host"):
             if k in d:
                 rec[k] = d[k]
         if d.get("modes"):          # config 5: the fp16 MFMA path named by BASELINE.json beside the f32w answer

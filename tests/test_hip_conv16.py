@@ -56,7 +56,14 @@ def test_conv16_vs_oracle(dev, k, cin, cout, B, H, W, fast):
     assert err < tol, "conv16 k%d %d->%d %dx%dx%d fast=%s: max err %.3e" % (k, cin, cout, B, H, W, fast, err)
     if dst is not None:
         got2 = dst.to_nchw().cpu()
-        assert float((got2 - got).abs().max()) < 1e-5, "HL8 output differs from fp32 output"
+        if fast:
+            # mode FAST (r6) stores the hi plane only - no convolution of the mode reads a lo plane, and half the HBM bytes of the launch
+            # go away: the HL8 output is the fp32 output rounded to fp16 (2^-11 relative), its lo plane keeps the zeros it was allocated with
+            assert float((got2 - got).abs().max()) <= 2.0 ** -10 * float(got.abs().max()), "HL8 output is not fp16(fp32 output)"
+            planes = dst.buf[:B * dst.G * 2 * dst.Hp * dst.Wp * 8].view(B, dst.G, 2, dst.Hp, dst.Wp, 8)
+            assert float(planes[:, :, 1].abs().max()) == 0.0, "mode FAST wrote a lo plane"
+        else:
+            assert float((got2 - got).abs().max()) < 1e-5, "HL8 output differs from fp32 output"
 
 
 def test_conv16_fused_pool_and_cat(dev):
