@@ -812,6 +812,8 @@ def cpu_baseline(sd1, sd2, pair):
         want1 = O.interpolate_pair(sd1, sd2, pair1, [0.5], hoist=False)
         c1_s = time.perf_counter() - t0
     out = {"value": round(len(sample_ts) / recompute_s, 4), "unit": "frames/s", "cores": best, "kind": "port",
+           "cores_note": "%d threads = the best of a sweep over a 736x1280 stage-1 pass; %d physical cores (%d logical CPUs usable) are present - "
+                         "torch's batch-1 CPU convolutions do not scale beyond that" % (best, phys, logical),
            "sample": "reference-style loop (stage 1 + stage 2 per t) over 3 of the 7 t of one 736x1280 pair, torch CPU fp32 oracle, warm, "
                      "%d threads (best of a sweep over a 736x1280 stage-1 pass): %.1f s" % (best, recompute_s),
            "hoisted": {"value": round(N_T / hoisted_s, 4), "seconds": round(hoisted_s, 2), "sample": "1 pair x 7 t, stage 1 once"},
