@@ -67,6 +67,12 @@ extern "C" {
 #define SSM_FLAG_LRELU 1    /* apply LeakyReLU(slope) after bias             */
 #define SSM_FLAG_FP16_FAST 2 /* HL8 conv: hi*hi product only (plain fp16 inputs) */
 #define SSM_FLAG_Q8 4        /* HL8 conv on Q8 operands: 1 fp16 MFMA + 2 block-scaled fp8 MFMAs per product */
+#define SSM_FLAG_MASK 8      /* the `add` view of an *_add_fwd entry point (ssm_wino_conv2d_add_fwd, ssm_wino4_conv2d_add_fwd,
+                              * ssm_splitk_finish_fwd) is a MASK source m instead of a pre-activation addend: out = conv(x) * (m > 0 ? 1 :
+                              * slope), no activation (SSM_FLAG_LRELU must be clear).  The training step's data gradients use it: the
+                              * gradient wrt a layer's input leaves the convolution as dZ of the layer that produced that input -
+                              * dX * LeakyReLU'(its output) - and the separate ssm_lrelu_bwd pass over it disappears (autograd of
+                              * layers.conv's LeakyReLU(0.1), scripts/models/layers.py:21-33)                                              */
 
 typedef struct ssm_view {
     float *ptr;
@@ -577,6 +583,10 @@ int ssm_conv2d_wgrad_wino(ssm_view x, ssm_view dz, float *du, float *db_acc, int
 int ssm_wgrad_wino_finish(const void *jobs_dev, int n_jobs, int max_n, float scale, void *stream);
 int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int h, int w, int acc_a, int acc_b,
                            void *stream);
+/* ... with the LeakyReLU' of the layer that produced `a` applied to da (after the optional accumulation): da = dZ of that layer, ya = its
+ * output [B, Ca, h, w] - the a-source of a decoder level has no other consumer (scripts/models/flow_computation.py:244-247).               */
+int ssm_upsample2x_cat_bwd_mask(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, ssm_view ya, float slope, int B, int h, int w,
+                                int acc_a, int acc_b, void *stream);
 int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,
                        const float *c_warp, ssm_view dy_extra, ssm_view dout5, ssm_view dest4, int B, int H, int W, int stage2_terms,
                        void *stream);

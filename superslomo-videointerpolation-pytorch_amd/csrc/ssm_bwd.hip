@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, (KS == 7 && SEG == 128) ? 1 : 2) void wgrad_bf
 // gathers its 4x4 hi-res neighbourhood.  1-D weights of x[i] in U(Y): Y=2i: .75 (1 at i=0); Y=2i+1: .75 (1 at
 // i=h-1); Y=2i+2: .25 if i+1<h; Y=2i-1: .25 if i>0.
 __global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(ssm_view du, ssm_view da, int Ca, ssm_view dbv, int Cb, int H, int W,
-                                                               int acc_a, int acc_b, int cgroups) {
+                                                               int acc_a, int acc_b, int cgroups, ssm_view ya, float msl) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;      // H, W = LOW-res dims
     const int b = blockIdx.z / cgroups, cg = blockIdx.z - b * cgroups;
     if (x >= W || y >= H) return;
@@ -614,7 +614,9 @@ __global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(ssm_view du, ssm_
         }
         if (c < Ca) {
             float *d = vp(da, b, c, y) + x;
-            *d = acc_a ? *d + s : s;
+            float o = acc_a ? *d + s : s;
+            if (ya.ptr) o *= vp(ya, b, c, y)[x] > 0.f ? 1.f : msl;          // dZ of the layer that produced `a`: x LeakyReLU'(its output)
+            *d = o;
         } else {
             float *d = vp(dbv, b, c - Ca, y) + x;
             *d = acc_b ? *d + s : s;
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(ssm_view du, ssm_
 // hi-res columns 2x-1 .. 2x+4 of a row arrive as one 16-byte piece + two scalars (12 loads for two outputs instead of 32) - over one flat
 // index (the maps are 22-176 pixels wide: a grid shaped after the map leaves lanes idle).
 __global__ __launch_bounds__(256) void upsample_cat_bwd2_kernel(ssm_view du, ssm_view da, int Ca, ssm_view dbv, int Cb, int H, int W, int acc_a,
-                                                                int acc_b, long long total) {
+                                                                int acc_b, long long total, ssm_view ya, float msl) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int C = Ca + Cb, wp = W / 2;
@@ -666,6 +668,11 @@ __global__ __launch_bounds__(256) void upsample_cat_bwd2_kernel(ssm_view du, ssm
         const float2 p = *d;
         o.x += p.x;
         o.y += p.y;
+    }
+    if (ya.ptr && c < Ca) {
+        const float2 m = *reinterpret_cast<const float2 *>(vp(ya, b, c, y) + x);
+        o.x *= m.x > 0.f ? 1.f : msl;
+        o.y *= m.y > 0.f ? 1.f : msl;
     }
     *d = o;
 }
@@ -1170,24 +1177,35 @@ extern "C" int ssm_conv2d_wgrad_bf16x3(ssm_view x, ssm_view dz, float *dw_oihw, 
     return ssm::check_launch("ssm_conv2d_wgrad_bf16x3");
 }
 
-extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int H, int W, int acc_a, int acc_b,
-                                      void *stream) {
+static int upsample_cat_bwd_launch(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, ssm_view ya, float msl, int B, int H, int W, int acc_a,
+                                   int acc_b, void *stream) {
     SSM_CHECK_DIMS("upsample2x_cat_bwd");
     SSM_REQUIRE(du.ptr && da.ptr && Ca > 0 && Cb >= 0 && (Cb == 0 || db.ptr), "upsample2x_cat_bwd: null pointer / channels");
     auto al16 = [](const ssm_view &v) { return ssm::aligned16(v.ptr) && v.sh % 4 == 0 && v.sc % 4 == 0 && v.sb % 4 == 0; };
     auto al8 = [](const ssm_view &v) { return (reinterpret_cast<size_t>(v.ptr) & 7) == 0 && v.sh % 2 == 0 && v.sc % 2 == 0 && v.sb % 2 == 0; };
-    if (W % 2 == 0 && al16(du) && al8(da) && (Cb == 0 || al8(db))) {
+    if (W % 2 == 0 && al16(du) && al8(da) && (Cb == 0 || al8(db)) && (!ya.ptr || al8(ya))) {
         const long long total = (long long)B * (Ca + Cb) * H * (W / 2);
         SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "upsample2x_cat_bwd: problem too large for one launch");
         SSM_LAUNCH(upsample_cat_bwd2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, du, da, Ca,
-                           Cb ? db : da, Cb, H, W, acc_a, acc_b, total);
+                           Cb ? db : da, Cb, H, W, acc_a, acc_b, total, ya, msl);
         return ssm::check_launch("ssm_upsample2x_cat_bwd");
     }
     const int cgroups = (Ca + Cb + BWD_CPT - 1) / BWD_CPT;
     SSM_REQUIRE((long long)B * cgroups <= 65535, "upsample2x_cat_bwd: B*C too large for one launch");
     SSM_LAUNCH(upsample_cat_bwd_kernel, dim3((W + 63) / 64, (H + 3) / 4, B * cgroups), dim3(64, 4), 0, (hipStream_t)stream, du, da,
-                       Ca, Cb ? db : da, Cb, H, W, acc_a, acc_b, cgroups);
+                       Ca, Cb ? db : da, Cb, H, W, acc_a, acc_b, cgroups, ya, msl);
     return ssm::check_launch("ssm_upsample2x_cat_bwd");
+}
+
+extern "C" int ssm_upsample2x_cat_bwd(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, int B, int H, int W, int acc_a, int acc_b,
+                                      void *stream) {
+    return upsample_cat_bwd_launch(du, da, Ca, db, Cb, ssm_view{nullptr, 0, 0, 0}, 1.f, B, H, W, acc_a, acc_b, stream);
+}
+
+extern "C" int ssm_upsample2x_cat_bwd_mask(ssm_view du, ssm_view da, int Ca, ssm_view db, int Cb, ssm_view ya, float slope, int B, int H, int W,
+                                           int acc_a, int acc_b, void *stream) {
+    SSM_REQUIRE(ya.ptr, "upsample2x_cat_bwd_mask: null mask source");
+    return upsample_cat_bwd_launch(du, da, Ca, db, Cb, ya, slope, B, H, W, acc_a, acc_b, stream);
 }
 
 extern "C" int ssm_synthesize_bwd(ssm_view img6, ssm_view est4, ssm_view out5, ssm_view target, const float *t, const float *c_rec,

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(ssm_view xin, ssm_view yo
 // kernels' epilogues).  One thread = a 2x2 block of one channel (W even, H any), the blocks of the whole batch in one flat index: the
 // maps this runs on are 22-46 pixels wide - a grid shaped after the map would leave most lanes of a wave without a block.
 __global__ __launch_bounds__(256) void splitk_finish_kernel(ssm_view part, int KS, ssm_view yout, ssm_view pool, ssm_view add, int adiv, int B,
-                                                            int C, int H, int W, float sl, long long total) {
+                                                            int C, int H, int W, float sl, float msl, long long total) {          // msl > 0: the addend is a mask source (SSM_FLAG_MASK), slope msl
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int bw = W / 2, bh = (H + 1) / 2;
@@ -430,12 +430,22 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ssm_view part, int K
     }
     if (add.ptr) {
         const float2 z0 = *reinterpret_cast<const float2 *>(vp(add, b / adiv, c, 2 * y) + 2 * x);
-        r0.x += z0.x;
-        r0.y += z0.y;
+        if (msl > 0.f) {
+            r0.x *= z0.x > 0.f ? 1.f : msl;
+            r0.y *= z0.y > 0.f ? 1.f : msl;
+        } else {
+            r0.x += z0.x;
+            r0.y += z0.y;
+        }
         if (two) {
             const float2 z1 = *reinterpret_cast<const float2 *>(vp(add, b / adiv, c, 2 * y + 1) + 2 * x);
-            r1.x += z1.x;
-            r1.y += z1.y;
+            if (msl > 0.f) {
+                r1.x *= z1.x > 0.f ? 1.f : msl;
+                r1.y *= z1.y > 0.f ? 1.f : msl;
+            } else {
+                r1.x += z1.x;
+                r1.y += z1.y;
+            }
         }
     }
     r0.x = fmaxf(r0.x, r0.x * sl);
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ssm_view part, int K
 
 // the same for odd map widths (the 11x11 bottleneck maps of config 3: direct-form split-K, no fused mean): one thread = one pixel
 __global__ __launch_bounds__(256) void splitk_finish1_kernel(ssm_view part, int KS, ssm_view yout, ssm_view add, int adiv, int B, int C, int H,
-                                                             int W, float sl, long long total) {
+                                                             int W, float sl, float msl, long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int x = (int)(idx % W);
@@ -459,7 +469,11 @@ __global__ __launch_bounds__(256) void splitk_finish1_kernel(ssm_view part, int 
     const int c = (int)(r % C), b = (int)(r / C);
     float v = 0.f;
     for (int k = 0; k < KS; ++k) v += vp(part, k * B + b, c, y)[x];
-    if (add.ptr) v += vp(add, b / adiv, c, y)[x];
+    if (add.ptr) {
+        const float z = vp(add, b / adiv, c, y)[x];
+        if (msl > 0.f) v *= z > 0.f ? 1.f : msl;
+        else v += z;
+    }
     vp(yout, b, c, y)[x] = fmaxf(v, v * sl);
 }
 
@@ -747,7 +761,7 @@ extern "C" int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view
         const long long tot1 = (long long)B * C * H * W;
         SSM_REQUIRE(tot1 <= 0x7fffffffLL * 256LL, "splitk_finish: problem too large for one launch");
         SSM_LAUNCH(splitk_finish1_kernel, dim3((unsigned)((tot1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, add,
-                           add_div < 1 ? 1 : add_div, B, C, H, W, (flags & SSM_FLAG_LRELU) ? slope : 1.f, tot1);
+                           add_div < 1 ? 1 : add_div, B, C, H, W, (flags & SSM_FLAG_LRELU) ? slope : 1.f, (flags & SSM_FLAG_MASK) ? slope : 0.f, tot1);
         return ssm::check_launch("ssm_splitk_finish_fwd");
     }
     SSM_REQUIRE(even_view(part) && even_view(y), "splitk_finish: partial sums and output must be 8-byte aligned views with even strides");
@@ -757,7 +771,7 @@ extern "C" int ssm_splitk_finish_fwd(ssm_view part, int KS, ssm_view y, ssm_view
     SSM_REQUIRE(total <= 0x7fffffffLL * 256LL, "splitk_finish: problem too large for one launch");
     const float sl = (flags & SSM_FLAG_LRELU) ? slope : 1.f;
     SSM_LAUNCH(splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, KS, y, pool, add,
-                       add_div < 1 ? 1 : add_div, B, C, H, W, sl, total);
+                       add_div < 1 ? 1 : add_div, B, C, H, W, sl, (flags & SSM_FLAG_MASK) ? slope : 0.f, total);
     return ssm::check_launch("ssm_splitk_finish_fwd");
 }
 

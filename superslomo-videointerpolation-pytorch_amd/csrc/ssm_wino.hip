@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef SSM_WINO_ABLATE
     if ((p.abl & 2) && acc[0][0] != 12345.678f) return;
 #endif
-    const float sl = p.lrelu ? p.slope : 1.f;
+    const float sl = (p.lrelu & 1) ? p.slope : 1.f;
+    const bool amask = (p.lrelu & 2) != 0;          // SSM_FLAG_MASK: the addend view is a mask source (see ssm_hip.h)
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
     const int cu0 = nb * BN + wn * 32;
@@ -450,8 +451,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 s0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
                 s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
             }
-            float y00 = s0[0] + s0[1] + s0[2] + ad0[0], y01 = s0[1] - s0[2] - s0[3] + ad0[1];
-            float y10 = s1[0] + s1[1] + s1[2] + ad1[0], y11 = s1[1] - s1[2] - s1[3] + ad1[1];
+            float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
+            float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+            if (amask) {          // y * LeakyReLU'(m): the data gradient of a layer leaves as dZ of the layer below (training step)
+                y00 *= ad0[0] > 0.f ? 1.f : p.slope;
+                y01 *= ad0[1] > 0.f ? 1.f : p.slope;
+                y10 *= ad1[0] > 0.f ? 1.f : p.slope;
+                y11 *= ad1[1] > 0.f ? 1.f : p.slope;
+            } else {
+                y00 += ad0[0];
+                y01 += ad0[1];
+                y10 += ad1[0];
+                y11 += ad1[1];
+            }
             y00 = fmaxf(y00, y00 * sl);
             y01 = fmaxf(y01, y01 * sl);
             y10 = fmaxf(y10, y10 * sl);
@@ -813,7 +825,8 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
     __syncthreads();
     {
         const int px = x0 + (wtx * C::GTW + txl) * 2, py = y0 + (wty * C::GTH + tyl) * 2;
-        const float sl = p.lrelu ? p.slope : 1.f;
+        const float sl = (p.lrelu & 1) ? p.slope : 1.f;
+        const bool amask = (p.lrelu & 2) != 0;          // SSM_FLAG_MASK: the addend view is a mask source (see ssm_hip.h)
         float *dstb = p.dst + (long long)(b + ks * p.ksB) * p.dsb;
         float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
         const int cu0 = nb * BN + wn * 32;
@@ -842,8 +855,19 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                 }
                 const f32x4 q = xb4[r * 64];
                 const f32x4 m = share(r);
-                float y00 = m[0] + q[0] + ad0[0], y01 = m[1] + q[1] + ad0[1];
-                float y10 = m[2] + q[2] + ad1[0], y11 = m[3] + q[3] + ad1[1];
+                float y00 = m[0] + q[0], y01 = m[1] + q[1];
+                float y10 = m[2] + q[2], y11 = m[3] + q[3];
+                if (amask) {
+                    y00 *= ad0[0] > 0.f ? 1.f : p.slope;
+                    y01 *= ad0[1] > 0.f ? 1.f : p.slope;
+                    y10 *= ad1[0] > 0.f ? 1.f : p.slope;
+                    y11 *= ad1[1] > 0.f ? 1.f : p.slope;
+                } else {
+                    y00 += ad0[0];
+                    y01 += ad0[1];
+                    y10 += ad1[0];
+                    y11 += ad1[1];
+                }
                 y00 = fmaxf(y00, y00 * sl);
                 y01 = fmaxf(y01, y01 * sl);
                 y10 = fmaxf(y10, y10 * sl);
@@ -1064,7 +1088,7 @@ int wfill(WinoParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *
     p.ws = W / 2;
     p.Cout = Cout;
     p.slope = slope;
-    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.lrelu = ((flags & SSM_FLAG_LRELU) ? 1 : 0) | ((flags & SSM_FLAG_MASK) ? 2 : 0);
     p.abl = 0;
     p.add = nullptr;
     p.asb = p.asc = 0;

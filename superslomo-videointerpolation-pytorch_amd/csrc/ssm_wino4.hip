@@ -247,7 +247,8 @@ template <bool SHUF>
 __device__ __forceinline__ void w4_epilogue_shuffle(const W4Params &p, const f32x4 (&acc)[36], const float (&bv)[4], int b, int cu0, int q, int px, int py);
 
 __device__ __forceinline__ void w4_epilogue(const W4Params &p, const f32x4 (&acc)[36], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
-        const float sl = p.lrelu ? p.slope : 1.f;
+        const float sl = (p.lrelu & 1) ? p.slope : 1.f;
+        const bool amask = (p.lrelu & 2) != 0;          // SSM_FLAG_MASK: the addend view is a mask source (see ssm_hip.h)
         float *dstb = p.dst + (long long)b * p.dsb;
         float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
                 const unsigned pb = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
@@ -292,14 +293,23 @@ __device__ __forceinline__ void w4_epilogue(const W4Params &p, const f32x4 (&acc
                 for (int i = 0; i < 4; ++i) {
                     if (vok) {
                         const f32x4 z = *(const f32x4 *)(ap + (long long)i * p.ash);
-                        y[i][0] += z[0];
-                        y[i][1] += z[1];
-                        y[i][2] += z[2];
-                        y[i][3] += z[3];
+                        if (amask) {          // y * LeakyReLU'(m): the data gradient of a layer leaves as dZ of the layer below (training step)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[i][e] *= z[e] > 0.f ? 1.f : p.slope;
+                        } else {
+                            y[i][0] += z[0];
+                            y[i][1] += z[1];
+                            y[i][2] += z[2];
+                            y[i][3] += z[3];
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (py + i < p.H && px + e < p.W) y[i][e] += ap[(long long)i * p.ash + e];
+                            if (py + i < p.H && px + e < p.W) {
+                                const float z = ap[(long long)i * p.ash + e];
+                                if (amask) y[i][e] *= z > 0.f ? 1.f : p.slope;
+                                else y[i][e] += z;
+                            }
                     }
                 }
             }
@@ -366,7 +376,7 @@ __device__ __forceinline__ void w4_output_tile(const f32x4 (&acc)[36], int r, fl
 
 template <>
 __device__ __forceinline__ void w4_epilogue_shuffle<true>(const W4Params &p, const f32x4 (&acc)[36], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
-    const float sl = p.lrelu ? p.slope : 1.f;
+    const float sl = (p.lrelu & 1) ? p.slope : 1.f;
     float *dstb = p.dst + (long long)b * p.dsb + (long long)(cu0 >> 2) * p.dsc;          // real channel cu0 / 4 (+ q per lane)
     const unsigned pb = 4u * ((unsigned)q * (unsigned)p.dsc + (unsigned)(2 * py) * (unsigned)p.dsh + (unsigned)(2 * px));
     const bool vok = py + 4 <= p.H && px + 4 <= p.W && p.vec;          // whole low-res tile inside the region, output rows as aligned 16-byte pieces
@@ -1191,7 +1201,7 @@ int w4fill(W4Params &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w
     p.ws = W / 2;
     p.Cout = Cout;
     p.slope = slope;
-    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.lrelu = ((flags & SSM_FLAG_LRELU) ? 1 : 0) | ((flags & SSM_FLAG_MASK) ? 2 : 0);
     p.abl = 0;
     p.border = 0;
     p.add = nullptr;

@@ -24,6 +24,10 @@ DGRAD_WINO4 = os.environ.get("SSM_TRAIN_DGRAD_WINO4", "1") != "0"          # 3x3
 # tile, like that plan's forward and data gradients) on the maps hb.wgrad_wino_supported accepts; $SSM_WGRAD_WINO=0: the direct kernel
 WGRAD_WINO = os.environ.get("SSM_WGRAD_WINO", "1") != "0"
 WGRAD_WINO_ALL = os.environ.get("SSM_WGRAD_WINO", "1") == "all"
+# r6: LeakyReLU' of the layer BELOW fused into the kernel that produces its upstream gradient - the F(2x2) / F(4x4) data-gradient launch of
+# the layer above (SSM_FLAG_MASK) or the upsample adjoint - where that gradient has one source; $SSM_LRELU_FUSE=0: a separate ssm_lrelu_bwd
+# launch per layer as before
+LRELU_FUSE = os.environ.get("SSM_LRELU_FUSE", "1") != "0"
 
 
 def transposed_filter(w):
@@ -65,7 +69,13 @@ def wgrad(x, dz, out, k, ci_offset=0, zero_first=True, split=False, bias_acc=Non
     return out
 
 
-def upsample_cat_bwd(du, da, db=None, acc_a=False, acc_b=False):
+def upsample_cat_bwd(du, da, db=None, acc_a=False, acc_b=False, mask_a=None, slope=0.1):
+    """mask_a (Planes: the output of the layer that produced the a-source): da receives dZ of that layer, the adjoint x LeakyReLU'(mask_a)."""
+    if mask_a is not None:
+        hb.check(hb.load().ssm_upsample2x_cat_bwd_mask(du.view(), da.view(), da.C, db.view() if db is not None else hb.NULL_VIEW,
+                                                       db.C if db is not None else 0, mask_a.view(), slope, da.B, da.H, da.W,
+                                                       1 if acc_a else 0, 1 if acc_b else 0, hb.stream_ptr()))
+        return
     hb.check(hb.load().ssm_upsample2x_cat_bwd(du.view(), da.view(), da.C, db.view() if db is not None else hb.NULL_VIEW,
                                               db.C if db is not None else 0, da.B, da.H, da.W, 1 if acc_a else 0,
                                               1 if acc_b else 0, hb.stream_ptr()))
@@ -321,19 +331,33 @@ class UNetGrad:
         if batch32:
             self._pack32 = (key32, hb.PackBatch32([(self.pk_t[n], w, None, True) for n, w in zip(names, ws)], self.dev))
 
-    def _layer(self, name, dy, dpool, dx, need_wgrad, act=True):
-        """One convolution: dZ, parameter gradients, data gradient into `dx` (None: not needed)."""
+    def _dzbuf(self, name):
+        """dZ planes of a layer (channels padded to its data-gradient filter's chunk), built on first use."""
+        if name not in self.dz:
+            _, dst = self.io[name]
+            co = self.plan.layers[name][1]
+            Y = self.act(dst) if dst != "out" else self.plan.t["out"]
+            pk = self.pk_t.get(name)
+            self.dz[name] = hb.Planes(self.B, pk.cin_p if pk is not None else co, Y.H, Y.W, self.dev)
+        return self.dz[name]
+
+    def _layer(self, name, dy, dpool, dx, need_wgrad, act=True, dz_ready=False, fuse_next=None):
+        """One convolution: dZ, parameter gradients, data gradient into `dx` (None: not needed).
+        dz_ready: this layer's dZ was already written by the kernel that produced its upstream gradient (no ssm_lrelu_bwd launch).
+        fuse_next: the layer whose OUTPUT is this layer's only input - its dZ is this layer's data gradient x LeakyReLU'(that output), and
+        where the data-gradient kernel has the mask epilogue (F(2x2) / F(4x4), SSM_FLAG_MASK) it is written directly (`dx` stays
+        untouched).  Returns True if it was: the caller passes dz_ready=True to that layer."""
         plan = self.plan
         srcs, dst = self.io[name]
         ci, co, k = plan.layers[name]
         Y = self.act(dst) if dst != "out" else plan.t["out"]
         pk = self.pk_t.get(name)
         cpad = pk.cin_p if pk is not None else co
-        if name not in self.dz:
-            self.dz[name] = hb.Planes(self.B, cpad, Y.H, Y.W, self.dev)
-        dzp = self.dz[name]
+        dzp = self._dzbuf(name)
         dz = dzp.slice(0, co)
-        if self.hl8 and dx is not None:          # dZ also in the Q8 form: operand of the data-gradient convolution
+        if dz_ready:
+            pass          # (written by the data-gradient launch of the layer above / the upsample adjoint)
+        elif self.hl8 and dx is not None:          # dZ also in the Q8 form: operand of the data-gradient convolution
             if name not in self.dzq:
                 self.dzq[name] = hb.HPlanes(self.B, cpad, Y.H, Y.W, self.dev, q8=True)
             hb.check(hb.load().ssm_lrelu_bwd_q8(dy.view() if dy is not None else hb.NULL_VIEW,
@@ -375,13 +399,22 @@ class UNetGrad:
                 from .engine import issued_factor
                 e0, e1 = tm.span("dgrad", "s%d.%s" % (plan.stage, name), flops, issued=flops * (1.0 if self.hl8 else issued_factor(pk)))
                 e0.record()
+            fused = False
             if self.hl8:
                 hb.conv2d_hl8(self.dzq[name].view(), cpad, None, 0, pk, None, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             else:
                 from .engine import conv_fn
-                conv_fn(pk)(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
+                if fuse_next is not None and LRELU_FUSE and pk.algo in ("wino", "wino4") and plan.layers[fuse_next][1] == ci:
+                    below = self.act(self.io[fuse_next][1])          # the output of the layer below = this layer's input
+                    conv_fn(pk)(dzp.view(), cpad, None, 0, pk, self._dzbuf(fuse_next).slice(0, ci).view(), None, self.B, Y.H, Y.W, lrelu=False,
+                                add=below.view(), mask=True)
+                    fused = True
+                else:
+                    conv_fn(pk)(dzp.view(), cpad, None, 0, pk, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             if tm is not None:
                 e1.record()
+            return fused
+        return False
 
     def backward(self, d_out, need_wgrad=True, need_input_grad=False, cross_grad_out=None, c6_grad_init=None):
         """d_out: Planes with the gradient of final_conv's output (channels padded to the data-gradient chunk).
@@ -396,45 +429,57 @@ class UNetGrad:
             with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
                 hb.host_op(self.flat.zero_)
             self._arm()
+        fuse = LRELU_FUSE and not self.hl8
+
+        def up(du, a_name, b_planes, conv_below, **kw):
+            """Adjoint of cat + upsample; with the fusion on, the a-source's gradient leaves as dZ of `conv_below` (its only consumer).
+            Returns dz_ready for that layer."""
+            if fuse and not kw.get("acc_a"):
+                upsample_cat_bwd(du, self._dzbuf(conv_below).slice(0, plan.layers[conv_below][1]), b_planes, mask_a=self.act(a_name), **kw)
+                return True
+            upsample_cat_bwd(du, G(a_name), b_planes, **kw)
+            return False
+
         L("final_conv", d_out, None, G("tf"), need_wgrad, act=False)
         cat = G("cat_fuse", like="tf", C=plan.t["c11"].C + plan.t["c1"].C)
         L("fuse_conv", G("tf"), None, cat, need_wgrad)
         d_c11, d_c1 = cat.slice(0, plan.t["c11"].C), cat.slice(plan.t["c11"].C, plan.t["c1"].C)
-        L("conv11b", d_c11, None, G("t11a"), need_wgrad)
-        L("conv11a", G("t11a"), None, G("u11"), need_wgrad)
-        upsample_cat_bwd(G("u11"), G("c10"), G("c2"))
-        L("conv10b", G("c10"), None, G("t10a"), need_wgrad)
-        L("conv10a", G("t10a"), None, G("u10"), need_wgrad)
-        upsample_cat_bwd(G("u10"), G("c9"), G("c3"))
-        L("conv9b", G("c9"), None, G("t9a"), need_wgrad)
-        L("conv9a", G("t9a"), None, G("u9"), need_wgrad)
-        upsample_cat_bwd(G("u9"), G("c8"), G("c4"))
-        L("conv8b", G("c8"), None, G("t8a"), need_wgrad)
-        L("conv8a", G("t8a"), None, G("u8"), need_wgrad)
-        upsample_cat_bwd(G("u8"), G("c7"), G("c5"))
-        L("conv7b", G("c7"), None, G("t7a"), need_wgrad)
-        L("conv7a", G("t7a"), None, G("u7"), need_wgrad)
+        f = L("conv11b", d_c11, None, G("t11a"), need_wgrad, fuse_next="conv11a")
+        L("conv11a", G("t11a"), None, G("u11"), need_wgrad, dz_ready=f)
+        r = up(G("u11"), "c10", G("c2"), "conv10b")
+        f = L("conv10b", G("c10"), None, G("t10a"), need_wgrad, dz_ready=r, fuse_next="conv10a")
+        L("conv10a", G("t10a"), None, G("u10"), need_wgrad, dz_ready=f)
+        r = up(G("u10"), "c9", G("c3"), "conv9b")
+        f = L("conv9b", G("c9"), None, G("t9a"), need_wgrad, dz_ready=r, fuse_next="conv9a")
+        L("conv9a", G("t9a"), None, G("u9"), need_wgrad, dz_ready=f)
+        r = up(G("u9"), "c8", G("c4"), "conv8b")
+        f = L("conv8b", G("c8"), None, G("t8a"), need_wgrad, dz_ready=r, fuse_next="conv8a")
+        L("conv8a", G("t8a"), None, G("u8"), need_wgrad, dz_ready=f)
+        r = up(G("u8"), "c7", G("c5"), "conv7b")
+        f = L("conv7b", G("c7"), None, G("t7a"), need_wgrad, dz_ready=r, fuse_next="conv7a")
+        L("conv7a", G("t7a"), None, G("u7"), need_wgrad, dz_ready=f)
         if c6_grad_init is not None:            # stage 1 with a cross-skip: add to the gradient stage 2 left there
             self.g["c6"] = c6_grad_init
             upsample_cat_bwd(G("u7"), self.g["c6"], None, acc_a=True)
+            r = False
         elif plan.cross:                        # stage 2: second source of u7 = stage 1's bottleneck
-            upsample_cat_bwd(G("u7"), G("c6"), cross_grad_out)
+            r = up(G("u7"), "c6", cross_grad_out, "conv6.1")
         else:
-            upsample_cat_bwd(G("u7"), G("c6"), None)
-        L("conv6.1", G("c6"), None, G("t6a"), need_wgrad)
-        L("conv6.0", G("t6a"), None, G("p6"), need_wgrad)
-        L("conv5b", G("c5"), G("p6"), G("t5a"), need_wgrad)
-        L("conv5a", G("t5a"), None, G("p5"), need_wgrad)
-        L("conv4b", G("c4"), G("p5"), G("t4a"), need_wgrad)
-        L("conv4a", G("t4a"), None, G("p4"), need_wgrad)
-        L("conv3b", G("c3"), G("p4"), G("t3a"), need_wgrad)
-        L("conv3a", G("t3a"), None, G("p3"), need_wgrad)
-        L("conv2b", G("c2"), G("p3"), G("t2a"), need_wgrad)
-        L("conv2a", G("t2a"), None, G("p2"), need_wgrad)
-        L("conv1b", d_c1, G("p2"), G("t1a"), need_wgrad)
+            r = up(G("u7"), "c6", None, "conv6.1")
+        f = L("conv6.1", G("c6"), None, G("t6a"), need_wgrad, dz_ready=r, fuse_next="conv6.0")
+        L("conv6.0", G("t6a"), None, G("p6"), need_wgrad, dz_ready=f)
+        f = L("conv5b", G("c5"), G("p6"), G("t5a"), need_wgrad, fuse_next="conv5a")
+        L("conv5a", G("t5a"), None, G("p5"), need_wgrad, dz_ready=f)
+        f = L("conv4b", G("c4"), G("p5"), G("t4a"), need_wgrad, fuse_next="conv4a")
+        L("conv4a", G("t4a"), None, G("p4"), need_wgrad, dz_ready=f)
+        f = L("conv3b", G("c3"), G("p4"), G("t3a"), need_wgrad, fuse_next="conv3a")
+        L("conv3a", G("t3a"), None, G("p3"), need_wgrad, dz_ready=f)
+        f = L("conv2b", G("c2"), G("p3"), G("t2a"), need_wgrad, fuse_next="conv2a")
+        L("conv2a", G("t2a"), None, G("p2"), need_wgrad, dz_ready=f)
+        f = L("conv1b", d_c1, G("p2"), G("t1a"), need_wgrad, fuse_next="conv1a")
         # (a data gradient in the blocked 7x7 form writes whole 32-channel blocks: zeros beyond the layer's inputs)
         d_in = G("in", C=getattr(self.pk_t.get("conv1a"), "cout_p", None)) if need_input_grad else None
-        L("conv1a", G("t1a"), None, d_in, need_wgrad)
+        L("conv1a", G("t1a"), None, d_in, need_wgrad, dz_ready=f)
         return d_in
 
 

@@ -16,6 +16,7 @@ SSM_PADX = 4
 SSM_PADY = 3
 SSM_TAIL_SLACK_FLOATS = 1 << 16
 SSM_FLAG_LRELU = 1
+SSM_FLAG_MASK = 8      # the `add` view is a mask source: out = conv(x) * (add > 0 ? 1 : slope) (include/ssm_hip.h)
 
 
 class SsmView(ctypes.Structure):
@@ -162,6 +163,7 @@ SIGNATURES = {
     "ssm_conv2d_wgrad_wino": (_c_int, [SsmView, SsmView, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_wgrad_wino_finish": (_c_int, [_vp, _c_int, _c_int, _c_float, _vp]),
     "ssm_upsample2x_cat_bwd": (_c_int, [SsmView, SsmView, _c_int, SsmView, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ssm_upsample2x_cat_bwd_mask": (_c_int, [SsmView, SsmView, _c_int, SsmView, _c_int, SsmView, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ssm_synthesize_bwd": (_c_int, [SsmView, SsmView, SsmView, SsmView, _vp, _vp, _vp, SsmView, SsmView, SsmView, _c_int, _c_int,
                                     _c_int, _c_int, _vp]),
     "ssm_maxpool2_fwd": (_c_int, [SsmView, SsmView, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -544,7 +546,14 @@ def wino_splitk(pk, B, H, W, ups=False):
     return cache[key]
 
 
-def _splitk_launch(x1, c1, x2, c2, pk, y, pool, add, add_div, ks, ups, B, H, W, lrelu, slope):
+def _flags(lrelu, mask, add):
+    if mask:
+        assert add is not None and not lrelu, "mask epilogue: a mask source and no activation"
+        return SSM_FLAG_MASK
+    return SSM_FLAG_LRELU if lrelu else 0
+
+
+def _splitk_launch(x1, c1, x2, c2, pk, y, pool, add, add_div, ks, ups, B, H, W, lrelu, slope, mask=False):
     lib, st = load(), stream_ptr()
     scratch = pk.__dict__.setdefault("_splitk_part", {})          # the partial sums: one tensor per (stream, problem) - plans on other streams run beside this one
     key = (getattr(st, "value", st), ks, B, H, W)
@@ -554,19 +563,20 @@ def _splitk_launch(x1, c1, x2, c2, pk, y, pool, add, add_div, ks, ups, B, H, W, 
     check(lib.ssm_wino_conv2d_splitk_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), part.view(), ks,
                                          1 if ups else 0, B, H, W, pk.cout, pk.bn, st))
     check(lib.ssm_splitk_finish_fwd(part.view(), ks, y, pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div,
-                                    B, pk.cout, H, W, slope, SSM_FLAG_LRELU if lrelu else 0, st))
+                                    B, pk.cout, H, W, slope, _flags(lrelu, mask, add), st))
 
 
-def conv2d_wino(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+def conv2d_wino(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1, mask=False):
+    """mask: `add` is a mask source - the output is conv(x) * LeakyReLU'(add) (SSM_FLAG_MASK; the training step's data gradients)."""
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
     assert (pk.bn, pk.ck) == wino_plan(c1 + c2, pk.cout, B, H, W, False)[1:], "filter was packed for another tile configuration"
     ks = wino_splitk(pk, B, H, W, False)
     if ks > 1:
-        return _splitk_launch(x1, c1, x2, c2, pk, y, pool, add, add_div, ks, False, B, H, W, lrelu, slope)
+        return _splitk_launch(x1, c1, x2, c2, pk, y, pool, add, add_div, ks, False, B, H, W, lrelu, slope, mask)
     check(lib.ssm_wino_conv2d_add_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                       pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, H, W,
-                                      pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+                                      pk.cout, slope, _flags(lrelu, mask, add), stream_ptr()))
 
 
 def conv2d_ups_wino(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
@@ -621,12 +631,12 @@ class PackedWino4:
         check(lib.ssm_wino4_pack_weights(wc.data_ptr(), bc.data_ptr(), self.w.data_ptr(), self.b.data_ptr(), self.cout, self.cin, stream_ptr()))
 
 
-def conv2d_wino4(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
+def conv2d_wino4(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1, mask=False):
     lib = load()
     assert pk.cin == c1 + c2, "packed filter expects %d input channels, got %d" % (pk.cin, c1 + c2)
     check(lib.ssm_wino4_conv2d_add_fwd(x1, c1, x2 if x2 is not None else NULL_VIEW, c2, pk.w.data_ptr(), pk.b.data_ptr(), y,
                                        pool if pool is not None else NULL_VIEW, add if add is not None else NULL_VIEW, add_div, B, H, W,
-                                       pk.cout, slope, SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+                                       pk.cout, slope, _flags(lrelu, mask, add), stream_ptr()))
 
 
 def conv2d_ups_wino4(a, c1, b, c2, pk, y, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):

@@ -90,6 +90,53 @@ def test_wgrad_bf16x3(dev, k, cin, cout, B, H, W, gscale):
     assert rel_err(dw.cpu(), w.grad) < 2e-4
 
 
+@pytest.mark.parametrize("algo,cin,cout,B,H,W", [("wino", 64, 32, 2, 44, 46), ("wino", 512, 512, 2, 22, 22), ("wino4", 64, 64, 2, 48, 80),
+                                                  ("wino4", 32, 32, 1, 37, 70)])
+def test_mask_epilogue_is_lrelu_bwd_of_the_layer_below(dev, algo, cin, cout, B, H, W):
+    """SSM_FLAG_MASK (r6): a data-gradient convolution that writes dZ of the layer below - conv(dz) * LeakyReLU'(that layer's output) -
+    gives the bits of the two launches it replaces (the convolution into dX, then ssm_lrelu_bwd), in the F(2x2) form (incl. its split-K
+    path: 512 channels on a 22x22 map) and the F(4x4) form, whole and ragged tiles."""
+    from ssm_amd import backward as Bk
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(cin + cout + H)
+    cls, fn = (hb.PackedWino, hb.conv2d_wino) if algo == "wino" else (hb.PackedWino4, hb.conv2d_wino4)
+    if algo == "wino4" and not hb.wino4_supported(cin, cout, H, W, 3):
+        pytest.skip("F(4x4) does not take this shape")
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dev)
+    pk = cls(w, torch.zeros(cout, device=dev), B, H, W)
+    dz = hb.Planes(B, cin, H, W, dev).load(torch.randn(B, cin, H, W, generator=g).to(dev))
+    below = hb.Planes(B, cout, H, W, dev).load(torch.randn(B, cout, H, W, generator=g).to(dev))
+    dx, ref, fused = hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, H, W, dev), hb.Planes(B, cout, H, W, dev)
+    fn(dz.view(), cin, None, 0, pk, dx.view(), None, B, H, W, lrelu=False)
+    Bk.lrelu_bwd(dx, None, below, ref)
+    fn(dz.view(), cin, None, 0, pk, fused.view(), None, B, H, W, lrelu=False, add=below.view(), mask=True)
+    assert float(ref.full.abs().max()) > 0.0 and torch.equal(fused.full, ref.full)
+    with pytest.raises(AssertionError):
+        fn(dz.view(), cin, None, 0, pk, fused.view(), None, B, H, W, lrelu=True, add=below.view(), mask=True)
+
+
+def test_upsample_adjoint_with_the_mask_of_the_a_source(dev):
+    """ssm_upsample2x_cat_bwd_mask: the a-source's gradient leaves as dZ of the layer that produced it (x LeakyReLU'(its output)), with and
+    without accumulation, even and odd widths - the bits of ssm_upsample2x_cat_bwd followed by ssm_lrelu_bwd."""
+    from ssm_amd import backward as Bk
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(3)
+    for B, Ca, Cb, h, w in ((2, 8, 4, 11, 22), (1, 6, 0, 9, 13)):
+        du = hb.Planes(B, Ca + Cb, 2 * h, 2 * w, dev).load(torch.randn(B, Ca + Cb, 2 * h, 2 * w, generator=g).to(dev))
+        ya = hb.Planes(B, Ca, h, w, dev).load(torch.randn(B, Ca, h, w, generator=g).to(dev))
+        init = torch.randn(B, Ca, h, w, generator=g).to(dev)
+        for acc in (False, True):
+            da, db = hb.Planes(B, Ca, h, w, dev).load(init), (hb.Planes(B, Cb, h, w, dev) if Cb else None)
+            Bk.upsample_cat_bwd(du, da, db, acc_a=acc)
+            ref = hb.Planes(B, Ca, h, w, dev)
+            Bk.lrelu_bwd(da, None, ya, ref)
+            fa, fb = hb.Planes(B, Ca, h, w, dev).load(init), (hb.Planes(B, Cb, h, w, dev) if Cb else None)
+            Bk.upsample_cat_bwd(du, fa, fb, acc_a=acc, mask_a=ya)
+            assert torch.equal(fa.full, ref.full), (B, Ca, h, w, acc)
+            if Cb:
+                assert torch.equal(fb.full, db.full)
+
+
 def test_pool_adjoint_fused_in_lrelu_bwd(dev):
     from oracle import ssm_oracle as O
     from ssm_amd import backward as Bk
