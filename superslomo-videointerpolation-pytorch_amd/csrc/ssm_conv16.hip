@@ -614,6 +614,7 @@ template <int KYS_, int NT_, int WN_, int MTY_, int MTX_, int WY_, int WX_, int 
 struct CfgUps {
     static constexpr int KS = 3, KYS = KYS_, NT = NT_, WN = WN_, MTY = MTY_, MTX = MTX_, WY = WY_, WX = WX_;
     static constexpr bool SPLIT3 = MODE_ == 1, Q8 = MODE_ == 2, FAST = MODE_ == 0;
+    static constexpr int NPL = FAST ? 2 : 4;          // planes of a 16-channel chunk (mode FAST: the two groups' hi planes only, see Cfg16)
     static constexpr int NQ = 1;
     static constexpr int PAD = 1;
     static constexpr int NWM = WN * WY * WX, NWE = NWE_, NTHREADS = 64 * (NWM + NWE);
@@ -621,8 +622,8 @@ struct CfgUps {
     static constexpr int PH = TH + 2, PW = TW + 2;                 // hi-res patch
     static constexpr int RH = TH / 2 + 2, RW = TW / 2 + 2;         // low-res raw patch
     static constexpr int NIT = KS / KYS;
-    static constexpr int PATCH_BYTES = (4 * PH * PW * 16 + 1023) / 1024 * 1024;
-    static constexpr int RAW_PIECES = 4 * RH * RW;
+    static constexpr int PATCH_BYTES = (NPL * PH * PW * 16 + 1023) / 1024 * 1024;
+    static constexpr int RAW_PIECES = NPL * RH * RW;
     static constexpr int RNI = (RAW_PIECES + 63) / 64;
     static constexpr int RAW_BYTES = RNI * 1024;
     static constexpr int WST_PIECES = Q8 ? KYS * KS * 2 * BN + KYS * NQ * 8 * BN : KYS * KS * 4 * BN;
@@ -697,7 +698,8 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
         const int rem = q - pl * (RH * RW);
         const int r = rem / RW;
         const int c = rem - r * RW;
-        roff[m] = (int)(((long long)(pl >> 1) * p.sg + (long long)(pl & 1) * p.sp + (long long)r * p.sh + c) * 16);
+        const int grp = C::FAST ? pl : pl >> 1, part = C::FAST ? 0 : pl & 1;
+        roff[m] = (int)(((long long)grp * p.sg + (long long)part * p.sp + (long long)r * p.sh + c) * 16);
     }
     auto issue_raw = [&](int ch) {
         const int c0 = ch * 16;
@@ -741,13 +743,16 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
             const int i = ly0 + by, jx = lx0 + bx;
             const int r0 = min(max(i, 0), lh - 1) - ly0, r1 = min(max(i + 1, 0), lh - 1) - ly0;
             const int c0 = min(max(jx, 0), lw - 1) - lx0, c1 = min(max(jx + 1, 0), lw - 1) - lx0;
-            const char *rg = rb + (g * 2 * RH * RW) * 16 + hs * 8;
+            const char *rg = rb + (g * (C::NPL / 2) * RH * RW) * 16 + hs * 8;
             auto ld = [&](int rr, int cc, float (&o)[4]) {
                 const h4 hi = *reinterpret_cast<const h4 *>(rg + (rr * RW + cc) * 16);
                 if constexpr (C::Q8) {      // lo bytes of both groups sit in the odd group's second plane (raw plane 3)
                     const int w = *reinterpret_cast<const int *>(rb + (3 * RH * RW + rr * RW + cc) * 16 + g * 8 + hs * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (float)hi[e] + fp8_byte(w, e) * (1.0f / 2048.0f);
+                } else if constexpr (C::FAST) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (float)hi[e];
                 } else {
                     const h4 lo = *reinterpret_cast<const h4 *>(rg + (rr * RW + cc) * 16 + R_LO);
 #pragma unroll
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
             const int Y = 2 * i + 1, X = 2 * jx + 1;
             const bool zy0 = Y < 0 || Y >= p.H, zy1 = Y + 1 < 0 || Y + 1 >= p.H;
             const bool zx0 = X < 0 || X >= p.W, zx1 = X + 1 < 0 || X + 1 >= p.W;
-            char *pg = pb + (g * 2 * PH * PW) * 16 + ((2 * by) * PW + 2 * bx) * 16 + hs * 8;
+            char *pg = pb + (g * (C::NPL / 2) * PH * PW) * 16 + ((2 * by) * PW + 2 * bx) * 16 + hs * 8;
             auto st = [&](char *d, float wa, float wb, const float (&ta)[4], const float (&ua)[4], bool zero) {
                 h4 hi, lo;
                 float x[4];
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
                     *reinterpret_cast<int *>(q) = pack4_fp8(x[0], x[1], x[2], x[3]);
                     *reinterpret_cast<int *>(q + 2 * P_LO) = pack4_fp8((x[0] - (float)hi[0]) * 2048.0f, (x[1] - (float)hi[1]) * 2048.0f,
                                                                       (x[2] - (float)hi[2]) * 2048.0f, (x[3] - (float)hi[3]) * 2048.0f);
-                } else {
+                } else if constexpr (!C::FAST) {
                     *reinterpret_cast<h4 *>(d + P_LO) = lo;
                 }
             };
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(C::NTHREADS, 1) void conv16_ups_kernel(const Conv16
     };
 
     // ---- matrix-side operand bases ---------------------------------------------------------------------
-    const int bOff = ((half * 2 * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
+    const int bOff = ((half * (C::NPL / 2) * PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
     const int aOff = C::Q8 ? (half * BN + wn * (NT * 32) + l31) * 16 : (half * 2 * BN + wn * (NT * 32) + l31) * 16;
     const int bqOff = ((PH + wy * C::MTY) * PW + wx * (C::MTX * 32) + l31) * 16;
 
