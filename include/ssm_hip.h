@@ -6,7 +6,11 @@
  *
  * Conventions
  *  - all tensors are fp32 device memory owned by the caller; the library never
- *    allocates, frees or keeps a pointer past return;
+ *    allocates or frees device memory and keeps no pointer past return - with
+ *    ONE exception the caller opts into: a launch program (ssm_program_*)
+ *    keeps a copy of the argument values, pointers included, of every launch
+ *    it recorded until ssm_program_destroy; the buffers they point to must
+ *    outlive the program's last ssm_program_run;
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*) and
  *    re-entrant.  It launches on the CALLING THREAD's current device
  *    (hipGetDevice), which must own `stream` and every pointer passed; the
