@@ -72,7 +72,7 @@ ALGO_NOTE = {"f32w": "fp32 throughout; 3x3 convolutions as Winograd F(4x4,3x3) (
                      "(csrc/ssm_elem.hip); the t-independent input channels of stage 2's conv1a / conv7a convolved once per pair",
              "f32": "fp32 throughout; every convolution in the direct form (an fmaf chain per output; the t-independent input channels of "
                     "stage 2's conv1a / conv7a summed once per pair and added - SSM_HOIST=0 keeps one chain)"}
-PMC_FILES = {"f32w": ("r18_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7s_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_valu_kernel", "final_conv_kernel"))}
+PMC_FILES = {"f32w": ("r20_pmc_traffic_f32w_summary.json", ("wino4_kernel", "wino7s_kernel", "wino7_kernel", "wino5s_kernel", "wino5_kernel", "wino1d_kernel", "wino2_kernel", "wino_kernel", "conv_mfma_kernel", "final_conv_valu_kernel", "final_conv_kernel"))}
 # (the side modes report no `traffic`: their counter passes date from rounds 1-2 - profiles/r2_pmc_traffic_f32_summary.json, r1k / r1q - and the
 # kernels have changed since; only the headline mode's summary is regenerated every round by tools/final_profiles.sh)
 
