@@ -117,7 +117,8 @@ class Trainer:
         return all(p.requires_grad for p in m.stage1_model.parameters()) or all(p.requires_grad for p in m.stage2_model.parameters())
 
     def _program_step(self, input_images, target_images, t_interp, iteration):
-        key = (tuple(input_images.shape), str(input_images.device))
+        # (the caller's current stream is slot 0 of the program: a step issued under another stream context records its own)
+        key = (tuple(input_images.shape), str(input_images.device), torch.cuda.current_stream().cuda_stream)
         pr = self._prog
         if pr is not None and (pr["key"] != key or pr["train"] is not getattr(self.model, "_train", None)):
             pr = self._prog = None          # another shape, or the plans were dropped (load_state_dict): record again

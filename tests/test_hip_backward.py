@@ -551,6 +551,42 @@ def test_trainer_launch_program_replay_matches_eager_steps(dev, train_precision,
     assert float(hist[True][-1][0]) < 0.8 * float(hist[True][0][0])
 
 
+def test_trainer_launch_program_with_stage1_frozen(dev):
+    """STAGE1.FREEZE = TRUE (the reference's staged training, configs/*.ini): only stage 2's backward is part of the recorded step; eager
+    and program trainers in lockstep at learning rate 0 agree on the losses to 1e-6 and on every stage-2 gradient to 5e-6 of the largest."""
+    from models.superslomo_r import FullModel
+    from ssm_amd.config import load_config, synthetic_weight_overrides
+    from ssm_amd.training import Trainer
+    from ssm_amd.weights import synthetic_frames, synthetic_state_dict
+
+    def make(programs):
+        ov = synthetic_weight_overrides()
+        ov[("STAGE1", "FREEZE")] = "TRUE"
+        ov[("STAGE2", "FREEZE")] = "FALSE"
+        cfg = load_config("superslomo_original.ini", ov)
+        m = FullModel(cfg)
+        m.stage1_model.load_state_dict(synthetic_state_dict(1))
+        m.stage2_model.load_state_dict(synthetic_state_dict(2))
+        m = m.to(dev).train()
+        m.train_precision = "f32w"
+        tr = Trainer(m, cfg, programs=programs)
+        for g in tr.optimizer.param_groups:
+            g["lr"] = 0.0
+        return m, tr
+
+    (mE, tE), (mP, tP) = make(False), make(True)
+    for i in range(4):
+        clips = torch.cat([synthetic_frames(3, 64, 64, seed=300 + 2 * i), synthetic_frames(3, 64, 64, seed=301 + 2 * i)], 0).to(dev)
+        x, y, t = clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous(), torch.tensor([0.5, 0.25], device=dev).view(2, 1, 1, 1, 1)
+        lE, lP = tE.train_step(x, y, t), tP.train_step(x, y, t)
+        assert float((lE - lP).abs().max()) <= 1e-6 * float(lE.abs().max())
+        grads = [(a.grad, b.grad) for a, b in zip(mE.parameters(), mP.parameters()) if a.grad is not None]
+        assert len(grads) == 48 and all(b is not None for _, b in grads)          # stage 2's 24 layers x (weight, bias)
+        gmax = max(float(a.abs().max()) for a, _ in grads)
+        assert max(float((a - b).abs().max()) for a, b in grads) <= 5e-6 * gmax
+    assert tP._prog is not None and tP._prog["program"].n_nodes > 100 and all(p.grad is None for p in mP.stage1_model.parameters())
+
+
 def test_launch_program_records_and_replays_plain_launches(dev):
     """The C side alone: two streams, kernels + a cross-stream wait recorded once and replayed twice give the eager result; a launch on a
     stream that is no slot of the program fails the recording."""

@@ -17,7 +17,7 @@ from ssm_amd.weights import synthetic_frames, synthetic_state_dict  # noqa: E402
 
 def make(dev, mode, programs, vgg):
     ov = synthetic_weight_overrides()
-    ov[("STAGE1", "FREEZE")] = "FALSE"
+    ov[("STAGE1", "FREEZE")] = "TRUE" if os.environ.get("FREEZE1") else "FALSE"          # FREEZE1=1: only stage 2 trains
     ov[("STAGE2", "FREEZE")] = "FALSE"
     cfg = load_config("superslomo_original.ini", ov)
     m = FullModel(cfg)
@@ -47,9 +47,10 @@ def main():
         lE, lP = tE.train_step(x, y, t), tP.train_step(x, y, t)
         torch.cuda.synchronize()
         gmax, worst, wname = 0.0, 0.0, ""
-        for (n, a), (_, b) in zip(mE.named_parameters(), mP.named_parameters()):
+        pairs = [(n, a, b) for (n, a), (_, b) in zip(mE.named_parameters(), mP.named_parameters()) if a.grad is not None]
+        for n, a, b in pairs:
             gmax = max(gmax, float(a.grad.abs().max()))
-        for (n, a), (_, b) in zip(mE.named_parameters(), mP.named_parameters()):
+        for n, a, b in pairs:
             d = float((a.grad - b.grad).abs().max()) / gmax
             if d > worst:
                 worst, wname = d, n
