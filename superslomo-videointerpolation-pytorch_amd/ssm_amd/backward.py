@@ -155,6 +155,7 @@ class UNetGrad:
         # there, ordered after that layer's dZ by an event, while the data-gradient chain continues on the caller's stream.  Nothing
         # they read (dZ of the layer, forward activations) is rewritten before join(); their outputs are read after it.
         self.side, self._ev = None, {}
+        self.more_sides, self._rr = [], 0          # further side streams the layers' weight gradients are dealt over ($SSM_WGRAD_STREAMS)
         # the f16f8 plan's weight gradients run on the split-bf16 matrix path; the exact plan's on fp32 MFMA
         self.split_wgrad = self.hl8 and os.environ.get("SSM_WGRAD", "bf16x3") != "f32"
         # every parameter gradient of the U-Net lives in ONE flat buffer (state-dict order), zeroed by one launch per backward; the
@@ -210,28 +211,41 @@ class UNetGrad:
         self._pending = [set(b) for b in self.buckets]
 
     def _layer_done(self, name):
-        """Called in the context (stream) that queued the layer's parameter-gradient kernels."""
+        """Called when a layer's parameter-gradient kernels have been queued.  A completed bucket is finished on the FIRST side stream,
+        behind every side stream that may carry one of its layers."""
         for i, pend in enumerate(self._pending):
             if name in pend:
                 pend.discard(name)
                 if not pend:
-                    if self._ww_finish[i] is not None:      # the bucket's Winograd-domain partial sums -> dW (same stream, behind them)
-                        self._ww_finish[i].run()
-                    a = self._span_of(self.buckets[i][0])[0]
-                    b = self._span_of(self.buckets[i][-1])[1]
-                    view = self.flat[a:b]
-                    if self.post_scale != 1.0:
-                        scale = self.post_scale
-                        hb.host_op(lambda: view.mul_(scale))
-                    if self.sync is not None:
-                        sync = self.sync
-                        hb.host_op(lambda: sync.reduce(view))
+                    for sd in self._more():
+                        hb.stream_wait(sd, self.side)
+                    with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
+                        if self._ww_finish[i] is not None:      # the bucket's Winograd-domain partial sums -> dW (behind them)
+                            self._ww_finish[i].run()
+                        a = self._span_of(self.buckets[i][0])[0]
+                        b = self._span_of(self.buckets[i][-1])[1]
+                        view = self.flat[a:b]
+                        if self.post_scale != 1.0:
+                            scale = self.post_scale
+                            hb.host_op(lambda: view.mul_(scale))
+                        if self.sync is not None:
+                            sync = self.sync
+                            hb.host_op(lambda: sync.reduce(view))
                 return
 
     def join(self):
         """The caller's stream waits for the parameter gradients queued on the side stream."""
         if self.side is not None:
             hb.stream_wait(self.side, torch.cuda.current_stream())
+            for sd in self._more():
+                hb.stream_wait(sd, torch.cuda.current_stream())
+
+    def _more(self):
+        """The further side streams - none while a HIP graph is being captured (the opt-in Trainer(graphs=True) path: capture_end of
+        ROCm 7.2 crashed with three forked streams, profiles/r22_backward_tests_3streams.txt; that path keeps the one side stream)."""
+        if self.more_sides and not torch.cuda.is_current_stream_capturing():
+            return self.more_sides
+        return ()
 
     def act(self, name):
         """fp32 planes of a forward activation."""
@@ -370,9 +384,14 @@ class UNetGrad:
         flops = 2.0 * self.B * Y.H * Y.W * co * ci * k * k
         if need_wgrad:
             wk, bk = param_key(name, "weight"), param_key(name, "bias")
-            if self.side is not None:
-                hb.stream_wait(torch.cuda.current_stream(), self.side)      # dZ of this layer is complete on the caller's stream
-            with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
+            sd = self.side
+            if sd is not None and self._more():          # deal the layers over the side streams: their weight gradients are independent
+                allsd = [self.side] + list(self.more_sides)
+                sd = allsd[self._rr % len(allsd)]
+                self._rr += 1
+            if sd is not None:
+                hb.stream_wait(torch.cuda.current_stream(), sd)      # dZ of this layer is complete on the caller's stream
+            with torch.cuda.stream(sd) if sd is not None else contextlib.nullcontext():
                 du = self.ww.get(name)
                 if tm is not None:
                     e0, e1 = tm.span("wgrad", "s%d.%s" % (plan.stage, name), flops, issued=flops * (16.0 / 36.0 if du is not None else 1.0))
@@ -393,7 +412,7 @@ class UNetGrad:
                     bias_grad(dz, self.grads[bk], zero_first=False)
                 if tm is not None:
                     e1.record()
-                self._layer_done(name)
+            self._layer_done(name)
         if dx is not None:
             if tm is not None:
                 from .engine import issued_factor
@@ -428,6 +447,8 @@ class UNetGrad:
                 hb.stream_wait(torch.cuda.current_stream(), self.side)       # last step's consumers of the gradients are done
             with torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext():
                 hb.host_op(self.flat.zero_)
+            for sd in self._more():          # (their first weight gradient must find the zeroed buffer)
+                hb.stream_wait(self.side, sd)
             self._arm()
         fuse = LRELU_FUSE and not self.hl8
 
@@ -494,6 +515,8 @@ class PairGrad:
         self.u1, self.u2 = UNetGrad(engine.s1), UNetGrad(engine.s2)
         if os.environ.get("SSM_WGRAD_STREAM", "1") != "0":
             self.u1.side = self.u2.side = torch.cuda.Stream(device=engine.device)
+            extra = [torch.cuda.Stream(device=engine.device) for _ in range(max(0, int(os.environ.get("SSM_WGRAD_STREAMS", "2")) - 1))]
+            self.u1.more_sides = self.u2.more_sides = extra
         B, H, W, dev = engine.B2, engine.H, engine.W, engine.device
         # gradient exchange (ssm_amd.dist.GradientAllReduce.attach): buckets are scaled by sync_scale (1/world) and reduced as they complete
         self.sync, self.sync_scale = None, 1.0

@@ -162,7 +162,7 @@ class Trainer:
         eng, pg = model._train_engine(B, H, W, dev)
         pr["train"] = model._train
         streams = [torch.cuda.current_stream()]
-        for st in (pg.u1.side, getattr(model.loss.perceptual_term(B, H, W, dev), "_side", None)):
+        for st in [pg.u1.side, getattr(model.loss.perceptual_term(B, H, W, dev), "_side", None)] + list(pg.u1.more_sides):
             if st is not None and all(st.cuda_stream != x.cuda_stream for x in streams):
                 streams.append(st)
         d_losses = torch.zeros(B, 4, dtype=torch.float32, device=dev)

@@ -538,7 +538,8 @@ def test_trainer_launch_program_replay_matches_eager_steps(dev, train_precision,
         worst = max(float((a.grad - b.grad).abs().max()) for a, b in zip(mE.parameters(), mP.parameters()))
         assert worst <= 5e-6 * gmax, "step %d: a parameter gradient differs by %.2e of the largest gradient" % (i, worst / gmax)
     prog = tP._prog["program"]
-    assert tE._prog is None and prog.ready and prog.n_nodes > 200 and len(prog.streams) == (3 if perceptual else 2), (prog.n_nodes, len(prog.streams))
+    n_more = len(mP._train[2].u1.more_sides)          # weight gradients dealt over $SSM_WGRAD_STREAMS side streams (default 2)
+    assert tE._prog is None and prog.ready and prog.n_nodes > 200 and len(prog.streams) == (3 if perceptual else 2) + n_more, (prog.n_nodes, len(prog.streams))
     assert sum(1 for it in prog.items if it[0] == "py") >= 5
     del mE, tE, mP, tP
     hist = {}

@@ -1,0 +1,15 @@
+#!/bin/bash
+# same-box A/B of the training step (BASELINE config 3, RCCL buckets forced at world 1): weight gradients dealt over 1 / 2 / 3 side streams
+OUT=${1:-gpurun_out/r22_wgrad_streams.txt}
+run() { echo "== $*" >> $OUT; env "$@" RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 LOCAL_WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --gpus 1 --no-configs --mode train --precision f32w --steps 20 --warmup 4 --no-cpu-baseline --force-allreduce 2>/dev/null | python -c "
+import json,sys
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d=json.loads(ln); print('samples/s', d['value'], 'ms/step', d['ms_per_step'], 'host enqueue ms', d.get('host_enqueue_ms_per_step'), 'allreduce', d['allreduce']['ms_per_step'], d['allreduce'].get('brackets'))
+" >> $OUT 2>&1; }
+run SSM_WGRAD_STREAMS=1
+run SSM_WGRAD_STREAMS=2
+run SSM_WGRAD_STREAMS=1
+run SSM_WGRAD_STREAMS=2
+run SSM_WGRAD_STREAMS=1
+cat $OUT
