@@ -2,7 +2,7 @@
 """Per-layer A/B of the 3x3 layers at the 736x1280 shapes of SURVEY Appendix A: direct fp32-MFMA kernel (csrc/ssm_conv.hip) vs the
 Winograd F(2x2,3x3) fp32 kernel (csrc/ssm_wino.hip), plain and fused-upsample forms.  TFLOP/s are ALGORITHMIC (direct-form FLOPs).
 usage: python tools/bench_layers_wino.py [B] [H] [W] [wino_kind|-1]      (W4=1: the Winograd column is F(4x4,3x3), csrc/ssm_wino4.hip;
-W4KIND forces its tile configuration)"""
+W4KIND forces its tile configuration; ONLY=a,b: those layers only)"""
 import os
 import sys
 
@@ -46,6 +46,8 @@ def main():
                                                                        "wino ms", "TF/s", "kind", "ratio", "max|diff|"))
     for name, cin, cout, k in unet_layers(2, True):
         if k != 3 or cout < 32:
+            continue
+        if os.environ.get("ONLY") and name not in os.environ["ONLY"].split(","):
             continue
         s = layer_scale(name)
         h, w = H // s, W // s
