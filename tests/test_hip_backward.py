@@ -295,6 +295,33 @@ def test_training_step_at_config3_size_vs_oracle(dev, oracle_352, train_precisio
     assert worst[0][0] < rel_bar, worst[:4]
 
 
+def test_weight_gradients_over_one_and_two_side_streams_agree(dev, monkeypatch):
+    """$SSM_WGRAD_STREAMS (ssm_amd.backward.PairGrad): the layers' parameter-gradient launches dealt over two side streams (default) give
+    the gradients of the one-stream order - same kernels, same arguments; only the atomics of the Winograd-domain sums may land in another
+    order (bar 5e-6 of the largest gradient, the launch-program test's) - for both the bucketed finish and join() ordering: a missing
+    stream wait shows as a stale or half-written bucket."""
+    from ssm_amd.weights import synthetic_frames
+    clips = torch.cat([synthetic_frames(3, 96, 96, seed=310), synthetic_frames(3, 96, 96, seed=311)], 0).to(dev)
+    xin, tgt = clips[:, [0, 2]].contiguous(), clips[:, 1:2].contiguous()
+    t = torch.tensor([0.375, 0.75], device=dev).view(2, 1, 1, 1, 1)
+    grads = {}
+    for n in ("1", "2"):
+        monkeypatch.setenv("SSM_WGRAD_STREAMS", n)
+        m, _, _ = _train_model_p(dev, "f32w")
+        for _ in range(2):          # twice: the second backward starts while the first one's side-stream work may still be queued
+            for p_ in m.parameters():
+                p_.grad = None
+            _, losses = m(xin, t, tgt, None, False)
+            losses.mean(dim=0)[0].backward()
+        torch.cuda.synchronize()
+        assert len(m._train[2].u1.more_sides) == int(n) - 1
+        grads[n] = [p_.grad.clone() for p_ in m.parameters()]
+        del m
+    gmax = max(float(g.abs().max()) for g in grads["1"])
+    worst = max(float((a - b).abs().max()) for a, b in zip(grads["1"], grads["2"]))
+    assert worst <= 5e-6 * gmax, "one vs two side streams: a parameter gradient differs by %.2e of the largest gradient" % (worst / gmax)
+
+
 def test_f16f8_gradients_survive_small_loss_gradients(dev, oracle_352):
     """with the shipped config (batch 32, LAMBDA_R = 60, 224x224 crops) the per-pixel loss gradient is ~1.2e-5,
     below fp16's smallest normal; dZ of the f16f8 plan (fp16 hi + e4m3 lo) would lose its compensation part and deep layers
