@@ -34,6 +34,8 @@ struct Node {
     hipEvent_t ev;            // WAIT
 };
 
+constexpr int kMaxArgs = 64;          // parameters per recorded kernel (the library's widest takes 20)
+
 struct Recorder {
     std::mutex mu;
     std::vector<Node> nodes;
@@ -58,7 +60,7 @@ void record_kernel(Recorder *r, const void *fn, dim3 grid, dim3 block, unsigned 
     std::lock_guard<std::mutex> lock(r->mu);
     if (!r->recording) return;
     const int slot = r->slot_of(st);
-    if (slot < 0) {
+    if (slot < 0 || n > kMaxArgs) {          // (a kernel with more parameters than ssm_program_run's argument table: refused at program_end)
         ++r->bad_stream;
         return;
     }
@@ -174,8 +176,8 @@ extern "C" int ssm_program_end(void *handle, int *n_nodes) {
     std::lock_guard<std::mutex> lock(r->mu);
     r->recording = false;
     if (n_nodes) *n_nodes = (int)r->nodes.size();
-    SSM_REQUIRE(r->bad_stream == 0, "program_end: %d launch(es) of the recorded pass ran on a stream that is not one of the program's %d slots",
-                r->bad_stream, r->n_streams);
+    SSM_REQUIRE(r->bad_stream == 0, "program_end: %d launch(es) of the recorded pass ran on a stream that is not one of the program's %d slots (or took more than %d parameters)",
+                r->bad_stream, r->n_streams, ssm::kMaxArgs);
     return SSM_OK;
 }
 
@@ -186,7 +188,7 @@ extern "C" int ssm_program_run(void *handle, int first, int last, void *const *s
     SSM_REQUIRE(n_streams == r->n_streams, "program_run: %d streams given, the program was recorded with %d", n_streams, r->n_streams);
     SSM_REQUIRE(first >= 0 && first <= last && last <= (int)r->nodes.size(), "program_run: range [%d, %d) outside the program's %d nodes", first, last,
                 (int)r->nodes.size());
-    void *argv[64];
+    void *argv[ssm::kMaxArgs];
     for (int i = first; i < last; ++i) {
         const Node &nd = r->nodes[i];
         hipError_t e = hipSuccess;

@@ -82,6 +82,31 @@ def test_error_convention_bad_arguments():
     assert rc == -1
 
 
+def test_launch_program_state_machine_on_the_host():
+    """ssm_program_* (csrc/ssm_program.cpp) is host logic around recorded launches: its state machine and argument checks answer without a
+    GPU - one recording per process at a time, no run while recording, ranges inside the recorded nodes, the stream count of the recording."""
+    import ctypes
+    from ssm_amd import hipbind as hb
+    lib = hb.load()
+    err = lambda: lib.ssm_last_error_string().decode()  # noqa: E731
+    assert lib.ssm_program_create(None) == -1 and "null" in err()
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.ssm_program_create(ctypes.byref(a)) == 0 and lib.ssm_program_create(ctypes.byref(b)) == 0 and a.value and b.value
+    two = (ctypes.c_void_p * 2)(ctypes.c_void_p(0x10), ctypes.c_void_p(0x20))          # stream handles are only compared while recording
+    nine = (ctypes.c_void_p * 9)(*[ctypes.c_void_p(16 * (i + 1)) for i in range(9)])
+    n = ctypes.c_int(-1)
+    assert lib.ssm_program_begin(a, nine, 9) == -1 and "1..8 streams" in err()
+    assert lib.ssm_program_begin(a, two, 2) == 0
+    assert lib.ssm_program_begin(b, two, 2) == -1 and "another program is recording" in err()
+    assert lib.ssm_program_run(a, 0, 0, two, 2) == -1 and "still recording" in err()
+    assert lib.ssm_program_mark(a, ctypes.byref(n)) == 0 and n.value == 0
+    assert lib.ssm_program_end(a, ctypes.byref(n)) == 0 and n.value == 0
+    assert lib.ssm_program_begin(b, two, 2) == 0 and lib.ssm_program_end(b, None) == 0          # the slot is free again
+    assert lib.ssm_program_run(a, 0, 1, two, 2) == -1 and "outside the program's 0 nodes" in err()
+    assert lib.ssm_program_run(a, 0, 0, two, 1) == -1 and "recorded with 2" in err()
+    assert lib.ssm_program_destroy(a) == 0 and lib.ssm_program_destroy(b) == 0 and lib.ssm_program_destroy(None) == 0
+
+
 def test_cpu_tensors_are_refused_not_emulated():
     from models import layers
     with pytest.raises(RuntimeError, match="no CPU fallback"):
