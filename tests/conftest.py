@@ -14,6 +14,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The CPU oracle (torch fp32 on the host) is what most of the suite's wall time goes to.  A GPU box exposes all 256 logical CPUs of its
+    # host to a job that owns a 16-CPU share of it: torch's default (one thread per core it can see) oversubscribes that share 8x and a
+    # 736x1280 stage-1 pass takes 13 s instead of 2.9 (bench.py's thread sweep, cpu_baseline.thread_sweep_c2_stage1_seconds).  16 threads
+    # at most; fewer where the affinity mask is smaller (8 in the build container).
+    import torch
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
 
 
 # Collection order (the driver runs `pytest -x`): kernel-level suites that hold every forced tile configuration of a kernel family to the
