@@ -1258,6 +1258,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of BASELINE configs 3, 4, 5 reported under `configs` (N = 1, 720p)")
     ap.add_argument("--parity-4k", action="store_true", help="--size 4k: one t of one pair against the CPU oracle (about a minute of host time)")
     args = ap.parse_args()
+    # the CPU-oracle legs (parity, cpu_baseline; world 1 only) run on the host: at most the 16 CPUs a one-GPU job owns on a GPU box - torch's
+    # default of one thread per visible core oversubscribes that share 8x (cpu_baseline() sweeps the count itself and reports what it used)
+    torch.set_num_threads(max(1, min(16, usable_cpus())))
 
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(args.gpus)          # before anything touches the GPU; does not return
