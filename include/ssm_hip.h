@@ -488,9 +488,11 @@ int ssm_final_conv_fwd(ssm_view x, const float *w_oihw, const float *bias, int N
  * filter), so the host side of a step can be recorded once and replayed with a handful of calls (HIP graphs were measured slower than
  * eager issue on ROCm 7.2).
  *   ssm_program_create / destroy   a program handle
- *   ssm_program_begin   start recording with the pass's streams as slots 0..n-1 (n <= 8): from now on EVERY launch of the library in
- *                       this process is executed as usual AND appended to the program (one recording at a time; meant for one
- *                       single-threaded warm-up pass).  A launch on a stream that is no slot makes ssm_program_end fail.
+ *   ssm_program_begin   start recording with the pass's streams as slots 0..n-1 (n <= 8): from now on every launch of the library BY
+ *                       THE CALLING THREAD is executed as usual AND appended to the program; launches of other host threads (the
+ *                       reference's DataParallel replicas, scripts/main.py:74-76) run eagerly and stay out of it.  One recording at a
+ *                       time per process: a second begin is refused (SSM_E_ARG, "another program is recording") - record later.  A
+ *                       launch of the recording thread on a stream that is no slot makes ssm_program_end fail.
  *   ssm_program_mark    number of nodes recorded so far: a cut point for host-side work (framework kernels, collectives) that must run
  *                       between two ranges of nodes at replay
  *   ssm_program_end     stop recording; *n_nodes = nodes recorded

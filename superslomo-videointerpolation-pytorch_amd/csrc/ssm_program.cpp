@@ -10,6 +10,9 @@
 // ssm_program_run issues the nodes [first, last) again with plain hipLaunchKernel calls, ~2 us each, no Python in between.  Work that
 // is not the library's (torch kernels, the RCCL buckets) stays on the Python side between two ranges of nodes (ssm_program_mark).
 //
+// Threads: one program records at a time per process, and only the launches of the thread that called ssm_program_begin belong to it -
+// other host threads (the reference's DataParallel replicas, scripts/main.py:74-76) keep launching eagerly, unrecorded.
+//
 // Streams: a program knows up to 8 stream SLOTS (begin: the handles of the recording pass; run: the handles to replay on - normally
 // the same).  Cross-stream ordering inside a pass is ssm_stream_wait(src, dst) - "dst waits for everything queued on src so far" -
 // executed with an event of the library and recorded as a node with an event of its own.
@@ -18,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace ssm {
@@ -44,6 +48,7 @@ struct Recorder {
     hipStream_t streams[8];
     int n_streams = 0;
     bool recording = false;
+    std::thread::id owner;                      // the thread that called ssm_program_begin: only ITS launches belong to the pass
     int bad_stream = 0;                         // launches seen on a stream that is not one of the slots
 
     int slot_of(hipStream_t st) const {
@@ -58,7 +63,7 @@ std::atomic<Recorder *> g_recorder{nullptr};
 void record_kernel(Recorder *r, const void *fn, dim3 grid, dim3 block, unsigned lds, hipStream_t st, void *const *args, const size_t *sizes,
                    const size_t *aligns, int n) {
     std::lock_guard<std::mutex> lock(r->mu);
-    if (!r->recording) return;
+    if (!r->recording || std::this_thread::get_id() != r->owner) return;          // (other host threads' launches are not part of this pass)
     const int slot = r->slot_of(st);
     if (slot < 0 || n > kMaxArgs) {          // (a kernel with more parameters than ssm_program_run's argument table: refused at program_end)
         ++r->bad_stream;
@@ -83,7 +88,7 @@ void record_kernel(Recorder *r, const void *fn, dim3 grid, dim3 block, unsigned 
 
 void record_memset(Recorder *r, void *dst, int value, size_t bytes, hipStream_t st) {
     std::lock_guard<std::mutex> lock(r->mu);
-    if (!r->recording) return;
+    if (!r->recording || std::this_thread::get_id() != r->owner) return;
     const int slot = r->slot_of(st);
     if (slot < 0) {
         ++r->bad_stream;
@@ -150,6 +155,7 @@ extern "C" int ssm_program_begin(void *handle, void *const *streams, int n_strea
     SSM_REQUIRE(r->nodes.empty() && !r->recording, "program_begin: the program already holds a recording");
     for (int i = 0; i < n_streams; ++i) r->streams[i] = (hipStream_t)streams[i];
     r->n_streams = n_streams;
+    r->owner = std::this_thread::get_id();
     r->recording = true;
     Recorder *expected = nullptr;
     if (!ssm::g_recorder.compare_exchange_strong(expected, r)) {
@@ -216,7 +222,7 @@ extern "C" int ssm_stream_wait(void *src_stream, void *dst_stream) {
     int s0 = -1, s1 = -1;
     if (r) {
         std::lock_guard<std::mutex> lock(r->mu);
-        if (r->recording) {
+        if (r->recording && std::this_thread::get_id() == r->owner) {
             s0 = r->slot_of((hipStream_t)src_stream), s1 = r->slot_of((hipStream_t)dst_stream);
             if (s0 < 0 || s1 < 0) {
                 ++r->bad_stream;

@@ -6,6 +6,7 @@ library is missing or a call fails this raises.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -229,6 +230,11 @@ def stream_ptr():
 
 # ---- launch programs (csrc/ssm_program.cpp): record one pass through the C ABI, replay it without the interpreter ----------------------
 _recorder = None          # the LaunchProgram that is recording (process-wide, like the C side), or None
+_recorder_thread = None   # ... and the thread it records: other threads' host_op calls are plain calls (as their launches are on the C side)
+
+
+class ProgramBusy(RuntimeError):
+    """Another launch program is recording in this process (one at a time): record later."""
 
 
 def host_op(fn):
@@ -236,7 +242,7 @@ def host_op(fn):
     bucket.  Outside a recording it is just the call.  While a program records, the call also becomes an item of the program between two
     ranges of C-ABI nodes and is called again, on the stream that was current here, at every replay: `fn` must read and write STATIC
     tensors only (anything it allocates is gone by the next step) and return nothing."""
-    if _recorder is None:
+    if _recorder is None or threading.get_ident() != _recorder_thread:
         fn()
     else:
         _recorder._host_op(fn)
@@ -298,15 +304,19 @@ class LaunchProgram:
 
         class _Ctx:
             def __enter__(self):
-                global _recorder
-                assert _recorder is None, "another program is recording"
-                check(load().ssm_program_begin(prog._h, prog._raw, len(prog.streams)))
-                _recorder = prog
+                global _recorder, _recorder_thread
+                if _recorder is not None:
+                    raise ProgramBusy("another launch program is recording in this process")
+                rc = load().ssm_program_begin(prog._h, prog._raw, len(prog.streams))
+                if rc and b"another program is recording" in load().ssm_last_error_string():
+                    raise ProgramBusy("another launch program is recording in this process")
+                check(rc)
+                _recorder, _recorder_thread = prog, threading.get_ident()
                 return prog
 
             def __exit__(self, et, ev, tb):
-                global _recorder
-                _recorder = None
+                global _recorder, _recorder_thread
+                _recorder = _recorder_thread = None
                 if et is None:
                     prog._mark()
                 n = ctypes.c_int(0)

@@ -118,6 +118,7 @@ class Trainer:
 
     def _program_step(self, input_images, target_images, t_interp, iteration):
         # (the caller's current stream is slot 0 of the program: a step issued under another stream context records its own)
+        from . import hipbind as hb
         key = (tuple(input_images.shape), str(input_images.device), torch.cuda.current_stream().cuda_stream)
         pr = self._prog
         if pr is not None and (pr["key"] != key or pr["train"] is not getattr(self.model, "_train", None)):
@@ -128,7 +129,11 @@ class Trainer:
                 self._prog_seen[key] = seen + 1
                 self.optimizer.zero_grad()
                 return self._forward_backward(input_images, target_images, t_interp, iteration)
-            pr = self._record_program(key, input_images, target_images, t_interp)
+            try:
+                pr = self._record_program(key, input_images, target_images, t_interp)
+            except hb.ProgramBusy:          # another thread of this process is recording (one at a time): this step eagerly, record later
+                self.optimizer.zero_grad()
+                return self._forward_backward(input_images, target_images, t_interp, iteration)
         else:
             self._load_inputs(pr, input_images, target_images, t_interp)
             for p, g in pr["grads"]:          # (an eager step in between drops the references: the program writes these tensors)

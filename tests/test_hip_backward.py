@@ -652,6 +652,57 @@ def test_launch_program_records_and_replays_plain_launches(dev):
                 hb.check(lib.ssm_copy_view(y.view(), z.view(), 2, 8, 8, 16, hb.stream_ptr()))
 
 
+def test_launch_program_records_its_own_thread_only(dev):
+    """One program records at a time per process, and only the launches of the thread that began it (csrc/ssm_program.cpp): a second host
+    thread - the reference's DataParallel replicas are threads of one process, scripts/main.py:74-76 - keeps launching eagerly on its own
+    stream while the first records: its launches and host_op calls do not enter the program (and do not fail it as foreign-stream launches),
+    and a recording it tries to start meanwhile is refused with ProgramBusy, which ssm_amd.training.Trainer answers with an eager step."""
+    import threading
+    from ssm_amd import hipbind as hb
+    main, other = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+    x = hb.Planes(1, 8, 16, 32, dev).load(torch.randn(1, 8, 16, 32, device=dev))
+    y, y2, z = hb.Planes(1, 8, 8, 16, dev), hb.Planes(1, 8, 8, 16, dev), hb.Planes(1, 8, 16, 32, dev)
+    lib = hb.load()
+    go, done, seen = threading.Event(), threading.Event(), {}
+
+    def second_thread():
+        try:
+            torch.cuda.set_device(dev)
+            go.wait(30)
+            with torch.cuda.stream(other):
+                hb.check(lib.ssm_copy_view(x.view(), z.view(), 1, 8, 16, 32, hb.stream_ptr()))          # eager, on a stream that is no slot
+                hb.host_op(lambda: seen.setdefault("host_op_ran", True))
+                try:
+                    with hb.LaunchProgram([other]).recording():
+                        pass
+                    seen["second_recording"] = "accepted"
+                except hb.ProgramBusy:
+                    seen["second_recording"] = "busy"
+            other.synchronize()
+        except Exception as e:          # noqa: BLE001
+            seen["error"] = repr(e)
+        finally:
+            done.set()
+
+    th = threading.Thread(target=second_thread)
+    th.start()
+    prog = hb.LaunchProgram([main])
+    with prog.recording():
+        hb.check(lib.ssm_avgpool2_fwd(x.view(), y.view(), 1, 8, 16, 32, hb.stream_ptr()))
+        go.set()
+        assert done.wait(60)
+        hb.check(lib.ssm_copy_view(y.view(), y2.view(), 1, 8, 8, 16, hb.stream_ptr()))
+    th.join()
+    torch.cuda.synchronize()
+    assert seen == {"host_op_ran": True, "second_recording": "busy"}, seen
+    assert prog.n_nodes == 2 and [it[0] for it in prog.items] == ["c"]          # the other thread's launch and host_op are not in it
+    assert torch.equal(z.interior, x.interior)
+    y.full.zero_(), y2.full.zero_()
+    prog.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y2.interior, torch.nn.functional.avg_pool2d(x.interior, 2))
+
+
 def test_main_entry_point_trains_and_checkpoints(dev, tmp_path):
     """scripts/main.py (reference CLI flags): two epochs on synthetic batches, a checkpoint in the reference's layout
     that loads back through models.unetflow.get_model (strict)."""
