@@ -29,6 +29,8 @@
 // (further down: 8 frequencies per wave, two workgroups per CU - what the plan picks for most layers; profiles/DESIGN_history_r1-r3.md 3.2d says why).
 #include "ssm_common.h"
 
+#include <cstring>
+
 #include <atomic>
 #include <mutex>
 #include <type_traits>
@@ -1183,17 +1185,28 @@ extern "C" int ssm_wino_conv2d_add_fwd(ssm_view x1, int C1, ssm_view x2, int C2,
 // channels, fill the idle CUs; their raw sums land as KS x B batch entries of a scratch tensor and ssm_splitk_finish_fwd (csrc/ssm_elem.hip)
 // adds them in a fixed order (deterministic), then applies the addend, the activation and the fused 2x2 mean.
 namespace {
-// the two-workgroups-per-CU configuration (wino2_kernel) with BN couts per block that the cost model puts first for Cin / KS channels
+// The two-workgroups-per-CU configuration (wino2_kernel) with BN couts per block for a split launch: the one whose tiles cover the map with
+// the FEWEST workgroups (ties: the cost model).  A split launch is one partial round - as long as one workgroup's channel loop, whatever the
+// tile shape (r6: conv5b of config 3, 512 -> 512 on 22x22 at batch 2, takes 80 us as 384 workgroups of 4x64-pixel tiles AND as 352 of 2x64,
+// profiles/r34_small_maps_forced.txt) - so what shortens it is a deeper split, and the split is capped by co-residency: 8x32-pixel tiles
+// cover a 22x22 map with 3 tiles instead of 6 (4x64: two thirds of every tile row is overshoot), half the workgroups, twice the split.
 int pick_wkind_split(int CinPart, int Cout, int B, int H, int W, int ups, int BN) {
+    static const bool by_cost_only = [] {          // $SSM_WINO_SPLIT_TILES=cost: the r5 rule (cost model alone), for A/B runs
+        const char *e = getenv("SSM_WINO_SPLIT_TILES");
+        return e && !strcmp(e, "cost");
+    }();
     int best = -1;
     double bt = 0.0;
+    long long bw = 0;
     for (int i = 0; i < NWKIND; ++i) {
         const WKindInfo &ki = kWInfo[i];
         if (ki.nblk != 2 || ki.bn != BN || CinPart % ki.ck) continue;
+        const long long nwg = by_cost_only ? 0 : (long long)B * ((W + ki.tw - 1) / ki.tw) * ((H + ki.th - 1) / ki.th) * ((Cout + ki.bn - 1) / ki.bn);
         const double t = estimate_wino(ki, CinPart, Cout, B, H, W, ups);
-        if (best < 0 || t < bt * 0.999) {
+        if (best < 0 || nwg < bw || (nwg == bw && t < bt * 0.999)) {
             best = i;
             bt = t;
+            bw = nwg;
         }
     }
     return best;
