@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned pb0 = 4u * ((unsigned)(4 * half) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
     const unsigned pb1 = pb0 + 4u * (unsigned)p.dsh;
     const unsigned qb = 4u * ((unsigned)(4 * half) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
-    const bool ok0 = py < p.H && px < p.W, ok1 = py + 1 < p.H && px < p.W;
+    const bool ok0 = py < p.H && px < p.W, ok1 = py + 1 < p.H && px < p.W, x1ok = px + 1 < p.W;
     auto st2 = [](const float *base, unsigned off_bytes, f32x2 val) {
         asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
     };
@@ -472,8 +472,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             y11 = fmaxf(y11, y11 * sl);
             float *bp = dstb + (long long)cu * p.dsc;
             f32x2 r0 = {y00, y01}, r1 = {y10, y11};
-            if (ok0 && cok) st2(bp, pb0, r0);
-            if (ok1 && cok) st2(bp, pb1, r1);
+            if (ok0 && cok) {
+                if (x1ok) st2(bp, pb0, r0);
+                else st1(bp, pb0, y00);          // odd map width: the tile's second column is the zero frame - never written
+            }
+            if (ok1 && cok) {
+                if (x1ok) st2(bp, pb1, r1);
+                else st1(bp, pb1, y10);
+            }
             if (poolb) {
                 float *qp = poolb + (long long)cu * p.psc;
                 const float sm = ((y00 + y10) + (y01 + y11)) * 0.25f;
@@ -836,7 +842,7 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
         const unsigned pb0 = 4u * ((unsigned)(4 * half) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
         const unsigned pb1 = pb0 + 4u * (unsigned)p.dsh;
         const unsigned qb = 4u * ((unsigned)(4 * half) * (unsigned)p.psc + (unsigned)(py >> 1) * (unsigned)p.psh + (unsigned)(px >> 1));
-        const bool ok0 = py < p.H && px < p.W, ok1 = py + 1 < p.H && px < p.W;
+        const bool ok0 = py < p.H && px < p.W, ok1 = py + 1 < p.H && px < p.W, x1ok = px + 1 < p.W;
         auto st2 = [](const float *base, unsigned off_bytes, f32x2 val) {
             asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off_bytes), "v"(val), "s"(base) : "memory");
         };
@@ -876,8 +882,14 @@ __device__ __forceinline__ void wino2_body(const WinoParams &p, float *lds) {
                 y11 = fmaxf(y11, y11 * sl);
                 float *bp = dstb + (long long)cu * p.dsc;
                 f32x2 r0 = {y00, y01}, r1 = {y10, y11};
-                if (ok0 && cok) st2(bp, pb0, r0);
-                if (ok1 && cok) st2(bp, pb1, r1);
+                if (ok0 && cok) {
+                    if (x1ok) st2(bp, pb0, r0);
+                    else st1(bp, pb0, y00);          // odd map width: the tile's second column is the zero frame - never written
+                }
+                if (ok1 && cok) {
+                    if (x1ok) st2(bp, pb1, r1);
+                    else st1(bp, pb1, y10);
+                }
                 if (poolb) {
                     float *qp = poolb + (long long)cu * p.psc;
                     const float sm = ((y00 + y10) + (y01 + y11)) * 0.25f;
@@ -1053,7 +1065,6 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, const float *__res
 int wfill(WinoParams &p, ssm_view x1, int C1, ssm_view x2, int C2, const float *w_packed, const float *bias_packed, ssm_view y, int H,
           int W, int Cout, float slope, int flags, int CK, int srcW) {
     SSM_REQUIRE(H > 0 && W > 0 && Cout > 0 && C1 > 0 && C2 >= 0, "wino conv: bad sizes");
-    SSM_REQUIRE(W % 2 == 0, "wino conv: the map width must be even (got %d)", W);
     SSM_REQUIRE(x1.ptr && y.ptr && w_packed && bias_packed, "wino conv: null pointer");
     SSM_REQUIRE(C1 % CK == 0 && C2 % CK == 0, "wino conv: channel counts (%d,%d) must be multiples of %d", C1, C2, CK);
     SSM_REQUIRE(ssm::aligned16(x1.ptr) && x1.sh % 4 == 0 && x1.sc % 4 == 0 && x1.sb % 4 == 0,
@@ -1120,9 +1131,9 @@ int wset_add(WinoParams &p, ssm_view add, int add_div, int B) {
 }  // namespace
 
 extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, int *kind, int *BN, int *CK) {
-    const int kd = (W % 2 == 0) ? pick_wkind(Cin, Cout, B, H, W, ups) : -1;
+    const int kd = pick_wkind(Cin, Cout, B, H, W, ups);          // (odd widths: the epilogue stores the last column alone, r6)
     if (kd < 0) {
-        ssm::set_error("wino conv: no tile configuration for Cin=%d Cout=%d on a %dx%d map (needs even W, Cin a multiple of 8)", Cin, Cout, H, W);
+        ssm::set_error("wino conv: no tile configuration for Cin=%d Cout=%d on a %dx%d map (needs Cin a multiple of 8)", Cin, Cout, H, W);
         return SSM_E_UNSUPPORTED;
     }
     if (kind) *kind = kd;
@@ -1132,7 +1143,7 @@ extern "C" int ssm_wino_plan(int Cin, int Cout, int B, int H, int W, int ups, in
 }
 
 extern "C" double ssm_wino_estimate(int Cin, int Cout, int B, int H, int W, int ups) {
-    const int kd = (W % 2 == 0 && Cin % 8 == 0) ? pick_wkind(Cin, Cout, B, H, W, ups) : -1;
+    const int kd = (Cin % 8 == 0) ? pick_wkind(Cin, Cout, B, H, W, ups) : -1;
     return kd < 0 ? -1.0 : estimate_wino(kWInfo[kd], Cin, Cout, B, H, W, ups);
 }
 
@@ -1217,7 +1228,7 @@ extern "C" int ssm_wino_splitk_plan(int Cin, int Cout, int B, int H, int W, int 
     SSM_REQUIRE(KS, "wino splitk_plan: null pointer");
     *KS = 1;
     const int enabled = ssm::splitk_switch(0).load(std::memory_order_relaxed);          // ($SSM_WINO_SPLITK, ssm_splitk_enable)
-    if (!enabled || W % 2 || BN % 32 || Cin < 128) return SSM_OK;
+    if (!enabled || BN % 32 || Cin < 128) return SSM_OK;
     const int kd = pick_wkind_split(Cin, Cout, B, H, W, ups, BN);
     if (kd < 0) return SSM_OK;
     const WKindInfo &ki = kWInfo[kd];
@@ -1233,7 +1244,7 @@ extern "C" int ssm_wino_conv2d_splitk_fwd(ssm_view x1, int C1, ssm_view x2, int 
                                           int KS, int ups, int B, int H, int W, int Cout, int BN, void *stream) {
     SSM_REQUIRE(B > 0 && KS >= 1 && KS <= 8 && (C1 + C2) % KS == 0, "wino conv_splitk: bad batch / split (KS = %d, Cin = %d)", KS, C1 + C2);
     SSM_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0), "wino conv_splitk: the output of a x2 upsample has even H, W (got %dx%d)", H, W);
-    const int kind = (W % 2 == 0) ? pick_wkind_split((C1 + C2) / KS, Cout, B, H, W, ups, BN) : -1;
+    const int kind = pick_wkind_split((C1 + C2) / KS, Cout, B, H, W, ups, BN);
     if (kind < 0) {
         ssm::set_error("wino conv_splitk: no two-workgroup configuration of %d couts for Cin/KS = %d on a %dx%d map", BN, (C1 + C2) / KS, H, W);
         return SSM_E_UNSUPPORTED;

@@ -514,8 +514,8 @@ def wino_plan(cin, cout, B, H, W, ups=False):
 
 
 def wino_supported(cin, cout, H, W, k=3):
-    """Can this layer run in the Winograd form?  (3x3, even width, whole 8-channel chunks)"""
-    return k == 3 and W % 2 == 0 and cin % 8 == 0
+    """Can this layer run in the Winograd form?  (3x3, whole 8-channel chunks)"""
+    return k == 3 and cin % 8 == 0          # (any map size: odd widths since r6 - the epilogue stores a tile's lone last column by itself)
 
 
 class PackedWino:

@@ -66,6 +66,39 @@ def test_every_wino_configuration_plain_cat_pool(dev, kind):
         assert _err(y.to_nchw().cpu(), O.conv2d(x, w, bias)) < 5e-5
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_every_wino_configuration_odd_widths(dev, kind):
+    """r6: maps of odd WIDTH (config 3's 11x11 bottleneck maps; any crop that is no multiple of 64) - the last 2x2 output tile of a row
+    hangs one column over the map, and that column is the zero frame the next layer reads as padding: it must never be written.  Every
+    tile configuration, plain / two sources / pre-activation addend / LeakyReLU' mask, against the oracle; the frame stays zero."""
+    from oracle import ssm_oracle as O
+    from ssm_amd import hipbind as hb
+    g = torch.Generator().manual_seed(100 + KINDS.index(kind))
+    _force(kind)
+    for B, H, W, c1, c2, cout in ((2, 11, 11, 16, 8, 40), (1, 22, 43, 32, 0, 64), (3, 5, 1, 8, 8, 32), (1, 9, 67, 24, 8, 72)):
+        a = torch.randn(B, c1, H, W, generator=g)
+        b = torch.randn(B, max(c2, 1), H, W, generator=g)
+        w = torch.randn(cout, c1 + c2, 3, 3, generator=g) / ((c1 + c2) * 9) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        add = torch.randn(B, cout, H, W, generator=g)
+        x = torch.cat([a, b], 1) if c2 else a
+        z = O.conv2d(x, w, bias)
+        pa = hb.Planes(B, c1, H, W, dev).load(a.to(dev))
+        pb = hb.Planes(B, c2, H, W, dev).load(b.to(dev)) if c2 else None
+        pz = hb.Planes(B, cout, H, W, dev).load(add.to(dev))
+        pk = hb.PackedWino(w.to(dev), bias.to(dev), B, H, W)
+        for what, kw, want in (("plain", {}, torch.where(z >= 0, z, z * 0.1)),
+                               ("addend", {"add": pz.view()}, torch.where(z + add >= 0, z + add, (z + add) * 0.1)),
+                               ("mask", {"add": pz.view(), "mask": True, "lrelu": False}, z * torch.where(add > 0, torch.ones_like(add), torch.full_like(add, 0.1)))):
+            y = hb.Planes(B, cout, H, W, dev)
+            hb.conv2d_wino(pa.view(), c1, pb.view() if c2 else None, c2, pk, y.view(), None, B, H, W, **kw)
+            got = y.to_nchw().cpu()
+            assert _err(got, want) < 5e-5, "%s %dx%dx%d %s: %.3e" % (kind, B, H, W, what, _err(got, want))
+            full = y.full.cpu().clone()
+            full[:, :, hb.SSM_PADY:hb.SSM_PADY + H, hb.SSM_PADX:hb.SSM_PADX + W] = 0
+            assert float(full.abs().max()) == 0.0, "%s (%s) wrote outside the interior of a %dx%d map" % (kind, what, H, W)
+
+
 UPS_SHAPES = [(1, 23, 40), (2, 5, 7), (1, 8, 48), (2, 11, 11), (1, 1, 1), (1, 3, 34)]     # LOW-res (B, h, w)
 
 
@@ -156,7 +189,9 @@ def test_wino_split_k_bottleneck_layers(dev):
                                                      (2, 256, 128, 512, 22, 22, False, False, True),
                                                      (2, 1024, 512, 512, 22, 22, True, False, False),
                                                      (1, 512, 512, 64, 21, 26, False, False, False),
-                                                     (2, 256, 256, 256, 44, 44, False, True, False)):
+                                                     (2, 256, 256, 256, 44, 44, False, True, False),
+                                                     (2, 512, 512, 512, 11, 11, False, False, False),          # r6: odd width (config 3's 11x11 maps)
+                                                     (2, 512, 256, 512, 11, 11, False, False, True)):
         c2 = cin - c1
         h, wd = (H // 2, W // 2) if ups else (H, W)
         xa, xb = torch.randn(B, c1, h, wd, generator=g), (torch.randn(B, c2, h, wd, generator=g) if c2 else None)
