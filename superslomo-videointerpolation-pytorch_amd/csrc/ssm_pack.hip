@@ -105,6 +105,25 @@ __device__ pk_f4 pack_wino1d_4(const Src &s, const ssm_pack32_job &j, long long 
     return out;
 }
 
+struct W4G {
+    double g[6][3];
+};
+constexpr W4G w4g_table() {
+    W4G t{};
+    const double pt[5] = {0.0, 0.625, -0.625, 1.6, -1.6};
+    for (int f5 = 0; f5 < 5; ++f5) {
+        double nrm = 1.0;
+        for (int o = 0; o < 5; ++o)
+            if (o != f5) nrm *= pt[f5] - pt[o];
+        t.g[f5][0] = 1.0 / nrm;
+        t.g[f5][1] = pt[f5] / nrm;
+        t.g[f5][2] = pt[f5] * pt[f5] / nrm;
+    }
+    t.g[5][0] = t.g[5][1] = 0.0;
+    t.g[5][2] = 1.0;
+    return t;
+}
+
 __device__ pk_f4 pack_wino4_4(const Src &s, const ssm_pack32_job &j, long long idx) {   // as wino4_pack_kernel (points 0, +-5/8, +-8/5, inf); idx: e = 0
     long long r = idx / 4;
     const int n = (int)(r % 32);
@@ -116,18 +135,10 @@ __device__ pk_f4 pack_wino4_4(const Src &s, const ssm_pack32_job &j, long long i
     const int co = nb * 32 + n;
     pk_f4 out = {0.f, 0.f, 0.f, 0.f};
     if (co < j.Cout) {
-        const double pt[5] = {0.0, 0.625, -0.625, 1.6, -1.6};
-        double G[6][3];
-        for (int f5 = 0; f5 < 5; ++f5) {
-            double nrm = 1.0;
-            for (int o = 0; o < 5; ++o)
-                if (o != f5) nrm *= pt[f5] - pt[o];
-            G[f5][0] = 1.0 / nrm;
-            G[f5][1] = pt[f5] / nrm;
-            G[f5][2] = pt[f5] * pt[f5] / nrm;
-        }
-        G[5][0] = G[5][1] = 0.0;
-        G[5][2] = 1.0;
+        // G = [1 p p^2] / prod_{q != p}(p - q) per point, [0 0 1] for the point at infinity: a compile-time table (r6: every thread used to
+        // evaluate it - five fp64 divisions and three more per row - for its four values; the step's repack of the F(4x4) filters took 96 us)
+        constexpr W4G T = w4g_table();
+        const double (&G)[6][3] = T.g;
         double g[3][3];
         for (int a = 0; a < 3; ++a)
             for (int c = 0; c < 3; ++c) g[a][c] = (double)s.at(co, cin, a, c);
@@ -188,6 +199,7 @@ __global__ void pack32_batch_kernel(const ssm_pack32_job *__restrict__ jobs, int
 // channels: it reads the tile as rows of 144 (transposed: BN x 9) CONTIGUOUS floats into LDS and writes the 16 x 4 x BN quads of the tile,
 // which are one contiguous 1024 x BN byte run of the packed filter.  Same expressions as pack_wino_4: bit-identical.
 // jobs: `first` = first tile of the job, `total` = its tiles = (Cout / BN) x (Cin / 16); Cout % BN == 0, Cin % 16 == 0, k == 3, BN <= 64.
+// r6: F(4x4,3x3) jobs too (BN = 32: that form is packed in 32-cout blocks whatever the launch's tile configuration).
 __global__ __launch_bounds__(256) void pack32_wino_tiles_kernel(const ssm_pack32_job *__restrict__ jobs, int njobs, long long total) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const long long t = blockIdx.x;
@@ -220,6 +232,32 @@ __global__ __launch_bounds__(256) void pack32_wino_tiles_kernel(const ssm_pack32
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = (j.transposed ? wl + (cl * BN + n4 + q) * 9 : wl + ((n4 + q) * 16 + cl) * 9)[tp];
             *reinterpret_cast<pk_f4 *>(outd + ((long long)(cl * 9 + tap) * BN + n4)) = v;
+        }
+        if (tl == 0)
+            for (int i = tid; i < j.nbias; i += 256) j.bp[i] = (j.bias && i < j.Cout) ? j.bias[i] : 0.f;
+        return;
+    }
+    if (j.algo == SSM_PACK_WINO4) {          // F(4x4,3x3) [nb][cin][fq][32][4] (BN = 32): the tile is the run of 16 x 9 x 32 quads of (nb, cin0 .. cin0 + 15)
+        constexpr W4G T = w4g_table();          // (r6: these jobs were element-wise - every thread fetched its own 36 bytes, 96 us per U-Net and repack)
+        float *out4 = j.wp + ((long long)nb * j.Cin + cin0) * (9 * 32 * 4);
+        for (int qd = tid; qd < 16 * 9 * 32; qd += 256) {
+            const int n = qd & 31, fq = (qd >> 5) % 9, cl = qd / (9 * 32);
+            const float *gl = j.transposed ? wl + (cl * BN + n) * 9 : wl + (n * 16 + cl) * 9;
+            double g[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[a][c] = (double)(j.transposed ? gl[8 - (3 * a + c)] : gl[3 * a + c]);
+            pk_f4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {          // the expressions of pack_wino4_4 (bit-identical)
+                const int f = 4 * fq + e, fi = (f % 18) / 3, fj = 3 * (f / 18) + f % 3;
+                double val = 0.0;
+                for (int a = 0; a < 3; ++a)
+                    for (int c = 0; c < 3; ++c) val += T.g[fi][a] * g[a][c] * T.g[fj][c];
+                o[e] = (float)val;
+            }
+            *reinterpret_cast<pk_f4 *>(out4 + (long long)qd * 4) = o;
         }
         if (tl == 0)
             for (int i = tid; i < j.nbias; i += 256) j.bp[i] = (j.bias && i < j.Cout) ? j.bias[i] : 0.f;

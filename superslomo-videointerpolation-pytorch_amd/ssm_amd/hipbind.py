@@ -975,7 +975,7 @@ class PackBatch32:
     ALGO = {"direct": 0, "wino": 1, "wino1d": 2, "wino4": 3, "wino7": 4, "wino5": 5}
 
     def __init__(self, entries, device):
-        # F(2x2,3x3) jobs with whole tiles go to the tiled kernel (ssm_pack32_wino_tiles_batch: contiguous reads and writes), the rest to
+        # F(2x2,3x3), direct 3x3 and (r6) F(4x4,3x3) jobs with whole tiles go to the tiled kernel (ssm_pack32_wino_tiles_batch: contiguous reads and writes), the rest to
         # the element-wise one; $SSM_PACK_TILES=0: everything element-wise
         tiled = [e for e in entries if self._tiled(e[0])] if os.environ.get("SSM_PACK_TILES", "1") != "0" else []
         entries = [e for e in entries if not any(e is t for t in tiled)]
@@ -987,11 +987,12 @@ class PackBatch32:
                 assert w.is_contiguous() and w.dtype == torch.float32 and w.device == pk.w.device
                 assert tuple(w.shape) == ((pk.cin, pk.cout, 3, 3) if transposed else (pk.cout, pk.cin, 3, 3))
                 j.w, j.bias, j.wp, j.bp = w.data_ptr(), (b.data_ptr() if b is not None else None), pk.w.data_ptr(), pk.b.data_ptr()
-                j.Cout, j.Cin, j.CinP, j.k, j.BN = pk.cout, pk.cin, pk.cin_p, 3, pk.bn
+                bn = self._tile_bn(pk)
+                j.Cout, j.Cin, j.CinP, j.k, j.BN = pk.cout, pk.cin, pk.cin_p, 3, bn
                 j.algo, j.transposed, j.nbias = self.ALGO[pk.algo], 1 if transposed else 0, pk.b.numel()
-                j.first, j.total = toff, (pk.cout // pk.bn) * (pk.cin // 16)
+                j.first, j.total = toff, (pk.cout // bn) * (pk.cin // 16)
                 toff += j.total
-            self.tiles = (torch.frombuffer(bytearray(bytes(tj)), dtype=torch.uint8).to(device), len(tiled), toff, max(e[0].bn for e in tiled))
+            self.tiles = (torch.frombuffer(bytearray(bytes(tj)), dtype=torch.uint8).to(device), len(tiled), toff, max(self._tile_bn(e[0]) for e in tiled))
             self.keep_tiled = list(tiled)
         jobs = (SsmPack32Job * max(len(entries), 1))()
         off = 0
@@ -1012,10 +1013,18 @@ class PackBatch32:
         self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
 
     @staticmethod
-    def _tiled(pk):
-        per = {"wino": 16, "direct": 9}.get(getattr(pk, "algo", "direct"))          # packed floats per (cout, cin)
-        return (per is not None and pk.k == 3 and pk.bn in (32, 64) and pk.cout % pk.bn == 0 and pk.cin % 16 == 0 and pk.cin_p == pk.cin
-                and pk.w.numel() == (pk.cout // pk.bn) * pk.cin * per * pk.bn)
+    def _tile_bn(pk):
+        """Cout block of a job of the tiled kernel: F(4x4,3x3) filters are packed in 32-cout blocks whatever tile configuration launches them."""
+        return 32 if getattr(pk, "algo", "direct") == "wino4" else pk.bn
+
+    @classmethod
+    def _tiled(cls, pk):
+        per = {"wino": 16, "direct": 9, "wino4": 36}.get(getattr(pk, "algo", "direct"))          # packed floats per (cout, cin)
+        if per is None or type(pk).__name__ == "PackedSubpixelWino4":
+            return False
+        bn = cls._tile_bn(pk)
+        return (pk.k == 3 and bn in (32, 64) and pk.cout % bn == 0 and pk.cin % 16 == 0 and pk.cin_p == pk.cin
+                and pk.w.numel() == (pk.cout // bn) * pk.cin * per * bn)
 
     def run(self):
         lib, st = load(), stream_ptr()

@@ -23,7 +23,8 @@ def test_batched_fp32_pack_matches_per_layer_packs(dev):
              (hb.PackedWino, 3, 16, 64), (hb.PackedWino, 3, 64, 32), (hb.PackedWino1d, 7, 6, 32), (hb.PackedWino1d, 7, 32, 32),
              (hb.PackedWino1d, 5, 32, 64), (hb.PackedWino4, 3, 8, 32), (hb.PackedWino4, 3, 64, 96),
              # whole tiles of BN couts x 16 input channels: the tiled kernel (ssm_pack32_wino_tiles_batch), forward and transposed
-             (hb.PackedConv, 3, 64, 64), (hb.PackedConv, 3, 128, 32), (hb.PackedWino, 3, 128, 128), (hb.PackedWino, 3, 48, 96)]
+             (hb.PackedConv, 3, 64, 64), (hb.PackedConv, 3, 128, 32), (hb.PackedWino, 3, 128, 128), (hb.PackedWino, 3, 48, 96),
+             (hb.PackedWino4, 3, 128, 64), (hb.PackedWino4, 3, 48, 160)]          # r6: F(4x4,3x3) jobs of whole tiles too
     entries, want = [], []
     for cls, k, cin, cout in cases:
         w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
@@ -46,7 +47,8 @@ def test_batched_fp32_pack_matches_per_layer_packs(dev):
             entries.append((tgtt, w, None, True))
             want.append((reft, tgtt, "%s k%d %d->%d transposed" % (cls.__name__, k, cin, cout)))
     batch = hb.PackBatch32(entries, dev)
-    assert batch.tiles is not None and batch.tiles[1] >= 6 and batch.n >= 10, "the cases of this test no longer cover both pack kernels"
+    assert batch.tiles is not None and batch.tiles[1] >= 10 and batch.n >= 8, "the cases of this test no longer cover both pack kernels: %d tiled, %d element-wise" % (batch.tiles[1], batch.n)
+    assert sum(1 for e in batch.keep_tiled if e[0].algo == "wino4") >= 4 and any(e[0].algo == "wino4" for e in [(k[0],) for k in batch.keep])
     batch.run()
     torch.cuda.synchronize()
     for ref, tgt, tag in want:
