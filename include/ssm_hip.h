@@ -71,7 +71,7 @@ extern "C" {
 #define SSM_FLAG_LRELU 1    /* apply LeakyReLU(slope) after bias             */
 #define SSM_FLAG_FP16_FAST 2 /* HL8 conv: hi*hi product only (plain fp16 inputs) */
 #define SSM_FLAG_Q8 4        /* HL8 conv on Q8 operands: 1 fp16 MFMA + 2 block-scaled fp8 MFMAs per product */
-#define SSM_FLAG_MASK 8      /* the `add` view of an *_add_fwd entry point (ssm_wino_conv2d_add_fwd, ssm_wino4_conv2d_add_fwd,
+#define SSM_FLAG_MASK 8      /* the `add` view of an *_add_fwd entry point (ssm_wino_conv2d_add_fwd, ssm_wino4_conv2d_add_fwd, ssm_wino5_conv2d_add_fwd,
                               * ssm_splitk_finish_fwd) is a MASK source m instead of a pre-activation addend: out = conv(x) * (m > 0 ? 1 :
                               * slope), no activation (SSM_FLAG_LRELU must be clear).  The training step's data gradients use it: the
                               * gradient wrt a layer's input leaves the convolution as dZ of the layer that produced that input -

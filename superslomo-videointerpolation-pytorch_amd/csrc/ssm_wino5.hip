@@ -121,7 +121,8 @@ __device__ __forceinline__ void w5_at(float m0, float m1, float m2, float m3, fl
 // path, a branch per element even when no lane takes it, is not compiled in (ssm_wino7.hip: - 2.7 % on a full-resolution layer)
 template <bool FAST>
 __device__ __forceinline__ void w5_epilogue(const W5Params &p, const f32x4 (&acc)[64], const float (&bv)[4], int b, int cu0, int q, int px, int py) {
-    const float sl = p.lrelu ? p.slope : 1.f;
+    const float sl = (p.lrelu & 1) ? p.slope : 1.f;
+    const bool amask = (p.lrelu & 2) != 0;          // SSM_FLAG_MASK: the addend view is a mask source (see ssm_hip.h; r6: the 5x5 data gradients too)
     float *dstb = p.dst + (long long)b * p.dsb;
     float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
     const unsigned pb = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
@@ -174,14 +175,22 @@ __device__ __forceinline__ void w5_epilogue(const W5Params &p, const f32x4 (&acc
             for (int i = 0; i < 4; ++i) {
                 if (vok) {
                     const f32x4 z = zadd[r & 1][i];
-                    y[i][0] += z[0];
-                    y[i][1] += z[1];
-                    y[i][2] += z[2];
-                    y[i][3] += z[3];
+                    if (amask) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[i][e] *= z[e] > 0.f ? 1.f : p.slope;
+                    } else {
+                        y[i][0] += z[0];
+                        y[i][1] += z[1];
+                        y[i][2] += z[2];
+                        y[i][3] += z[3];
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (py + i < p.H && px + e < p.W) y[i][e] += ap[(long long)i * p.ash + e];
+                        if (py + i < p.H && px + e < p.W) {
+                                const float z = ap[(long long)i * p.ash + e];
+                                y[i][e] = amask ? y[i][e] * (z > 0.f ? 1.f : p.slope) : y[i][e] + z;
+                            }
                 }
             }
         }
@@ -801,7 +810,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         const int px = x0 + 4 * Tx, py = y0 + 4 * Ty;
         const int cu0 = nb * 32 + cb * 16;
-        const float sl = p.lrelu ? p.slope : 1.f;
+        const float sl = (p.lrelu & 1) ? p.slope : 1.f;
+    const bool amask = (p.lrelu & 2) != 0;          // SSM_FLAG_MASK: the addend view is a mask source (see ssm_hip.h; r6: the 5x5 data gradients too)
         float *dstb = p.dst + (long long)b * p.dsb;
         float *poolb = p.pool ? p.pool + (long long)b * p.psb : nullptr;
         const unsigned pbo = 4u * ((unsigned)(4 * q) * (unsigned)p.dsc + (unsigned)py * (unsigned)p.dsh + (unsigned)px);
@@ -837,14 +847,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int i = 0; i < 4; ++i) {
                     if (vok) {
                         const f32x4 z = *(const f32x4 *)(ap + (long long)i * p.ash);
-                        y[i][0] += z[0];
-                        y[i][1] += z[1];
-                        y[i][2] += z[2];
-                        y[i][3] += z[3];
+                        if (amask) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[i][e] *= z[e] > 0.f ? 1.f : p.slope;
+                        } else {
+                            y[i][0] += z[0];
+                            y[i][1] += z[1];
+                            y[i][2] += z[2];
+                            y[i][3] += z[3];
+                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (py + i < p.H && px + e < p.W) y[i][e] += ap[(long long)i * p.ash + e];
+                            if (py + i < p.H && px + e < p.W) {
+                                const float z = ap[(long long)i * p.ash + e];
+                                y[i][e] = amask ? y[i][e] * (z > 0.f ? 1.f : p.slope) : y[i][e] + z;
+                            }
                     }
                 }
             }
@@ -1039,7 +1057,7 @@ extern "C" int ssm_wino5_conv2d_add_fwd(ssm_view x, int Cin, const float *w_pack
     p.W = W;
     p.Cout = Cout;
     p.slope = slope;
-    p.lrelu = (flags & SSM_FLAG_LRELU) ? 1 : 0;
+    p.lrelu = ((flags & SSM_FLAG_LRELU) ? 1 : 0) | ((flags & SSM_FLAG_MASK) ? 2 : 0);
     p.add = nullptr;
     p.asb = p.asc = 0;
     p.ash = 0;

@@ -423,7 +423,7 @@ class UNetGrad:
                 hb.conv2d_hl8(self.dzq[name].view(), cpad, None, 0, pk, None, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             else:
                 from .engine import conv_fn
-                if fuse_next is not None and LRELU_FUSE and pk.algo in ("wino", "wino4") and plan.layers[fuse_next][1] == ci:
+                if fuse_next is not None and LRELU_FUSE and pk.algo in ("wino", "wino4", "wino5") and plan.layers[fuse_next][1] == ci:
                     below = self.act(self.io[fuse_next][1])          # the output of the layer below = this layer's input
                     conv_fn(pk)(dzp.view(), cpad, None, 0, pk, self._dzbuf(fuse_next).slice(0, ci).view(), None, self.B, Y.H, Y.W, lrelu=False,
                                 add=below.view(), mask=True)

@@ -780,14 +780,14 @@ class PackedWino5:
                                          stream_ptr()))
 
 
-def conv2d_wino5(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1):
-    """Same call shape as conv2d / conv2d_wino1d; these layers take one source (x2 must be None)."""
+def conv2d_wino5(x1, c1, x2, c2, pk, y, pool, B, H, W, lrelu=True, slope=0.1, add=None, add_div=1, mask=False):
+    """Same call shape as conv2d / conv2d_wino1d; these layers take one source (x2 must be None).  mask: as conv2d_wino (SSM_FLAG_MASK)."""
     lib = load()
     assert x2 is None and c2 == 0, "the 5x5 layers have no concatenated source"
     assert pk.cin_p == c1, "packed filter expects %d input channels, got %d" % (pk.cin_p, c1)
     check(lib.ssm_wino5_conv2d_add_fwd(x1, c1, pk.w.data_ptr(), pk.b.data_ptr(), y, pool if pool is not None else NULL_VIEW,
                                        add if add is not None else NULL_VIEW, add_div, B, H, W, pk.cout, slope,
-                                       SSM_FLAG_LRELU if lrelu else 0, stream_ptr()))
+                                       _flags(lrelu, mask, add), stream_ptr()))
 
 
 # ---- 7x7 convolutions as 2x2 blocks of F(4x4,4x4) Winograd filters in fp32 (csrc/ssm_wino7.hip) ---------------------

@@ -91,18 +91,19 @@ def test_wgrad_bf16x3(dev, k, cin, cout, B, H, W, gscale):
 
 
 @pytest.mark.parametrize("algo,cin,cout,B,H,W", [("wino", 64, 32, 2, 44, 46), ("wino", 512, 512, 2, 22, 22), ("wino4", 64, 64, 2, 48, 80),
-                                                  ("wino4", 32, 32, 1, 37, 70)])
+                                                  ("wino4", 32, 32, 1, 37, 70), ("wino5", 64, 64, 2, 48, 64), ("wino5", 64, 32, 1, 37, 70)])
 def test_mask_epilogue_is_lrelu_bwd_of_the_layer_below(dev, algo, cin, cout, B, H, W):
     """SSM_FLAG_MASK (r6): a data-gradient convolution that writes dZ of the layer below - conv(dz) * LeakyReLU'(that layer's output) -
     gives the bits of the two launches it replaces (the convolution into dX, then ssm_lrelu_bwd), in the F(2x2) form (incl. its split-K
-    path: 512 channels on a 22x22 map) and the F(4x4) form, whole and ragged tiles."""
+    path: 512 channels on a 22x22 map), the F(4x4) form and the 5x5 layers' F(4x4,5x5) form, whole and ragged tiles."""
     from ssm_amd import backward as Bk
     from ssm_amd import hipbind as hb
     g = torch.Generator().manual_seed(cin + cout + H)
-    cls, fn = (hb.PackedWino, hb.conv2d_wino) if algo == "wino" else (hb.PackedWino4, hb.conv2d_wino4)
+    cls, fn = {"wino": (hb.PackedWino, hb.conv2d_wino), "wino4": (hb.PackedWino4, hb.conv2d_wino4), "wino5": (hb.PackedWino5, hb.conv2d_wino5)}[algo]
     if algo == "wino4" and not hb.wino4_supported(cin, cout, H, W, 3):
         pytest.skip("F(4x4) does not take this shape")
-    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dev)
+    k = 5 if algo == "wino5" else 3
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
     pk = cls(w, torch.zeros(cout, device=dev), B, H, W)
     dz = hb.Planes(B, cin, H, W, dev).load(torch.randn(B, cin, H, W, generator=g).to(dev))
     below = hb.Planes(B, cout, H, W, dev).load(torch.randn(B, cout, H, W, generator=g).to(dev))
