@@ -171,7 +171,8 @@ int ssm_conv2d_ups_add_fwd(ssm_view a, int C1, ssm_view b, int C2, const float *
  * scripts/models/layers.py:21-33; decoder step scripts/models/flow_computation.py:244-247), evaluated as
  * Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A per 2x2 output tile: 16 instead of 36 multiplies per (cin, cout, 4 outputs),
  * i.e. 2.25x fewer matrix-core cycles; in fp32 the result differs from the direct form by rounding only (about as much as
- * a different summation order; profiles/DESIGN_history_r1-r3.md 3.2d).  W must be even; Cin and the first cat source multiples of CK.
+ * a different summation order; profiles/DESIGN_history_r1-r3.md 3.2d).  Any H, W (r6: odd widths too - the last tile of a row stores its lone column by itself, the zero frame stays
+ * untouched; the fused pool and the fused upsample need even sizes); Cin and the first cat source multiples of CK.
  * ssm_wino_plan: tile configuration for the problem (ups: the fused-upsample entry point; BN = cout block to pack for, CK =
  * channel chunk); two kernel forms - one workgroup per CU with 16 frequency accumulators per wave, or two per CU with 8.
  * ssm_wino_pack_weights: OIHW fp32 3x3 filter -> U = G g G^T as [Cout/BN][Cin][4][BN][4] (+ bias padded to BN).          */
