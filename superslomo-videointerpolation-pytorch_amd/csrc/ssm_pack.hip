@@ -11,6 +11,8 @@
 // ssm_amd.backward.transposed_filter materialises), read straight from the OIHW tensor; such jobs have no bias (zeros).  Every
 // element is computed by the same arithmetic as the per-layer kernels (tests/test_hip_pack_batch.py holds them bit-identical).
 #include "ssm_common.h"
+
+#include <type_traits>
 #include "ssm_wino5_pack.h"
 #include "ssm_wino7_pack.h"
 
@@ -214,19 +216,28 @@ __global__ __launch_bounds__(256) void pack32_wino_tiles_kernel(const ssm_pack32
     const int tl = (int)(t - j.first), nct = j.Cin / 16, nb = tl / nct, cin0 = (tl - nb * nct) * 16, BN = j.BN;
     const int tid = threadIdx.x;
     // the parameter is [Cout][Cin][3][3], or for a transposed job [Cin][Cout][3][3] (Cout, Cin: the PACKED filter's)
-    const int rowlen = j.transposed ? BN * 9 : 16 * 9, nrows = j.transposed ? 16 : BN;
-    for (int idx = tid; idx < nrows * rowlen; idx += 256) {
-        const int r = idx / rowlen, c = idx - r * rowlen;
-        const float *src = j.transposed ? j.w + ((long long)(cin0 + r) * j.Cout + (long long)nb * BN) * 9
-                                        : j.w + ((long long)(nb * BN + r) * j.Cin + cin0) * 9;
-        wl[idx] = src[c];
-    }
+    // rows of 144 (transposed: BN x 9) contiguous floats, 16-byte aligned (Cin, Cout multiples of 16): moved as 16-byte pieces, the row
+    // length a compile-time constant per case (r6: one float per thread and a run-time division per element made this launch
+    // instruction-bound at 1.9 TB/s)
+    auto stage = [&](auto rowlen4_tag) {
+        constexpr int RL4 = decltype(rowlen4_tag)::value;          // 16-byte pieces per row
+        const int nrows = j.transposed ? 16 : BN;
+        for (int idx = tid; idx < nrows * RL4; idx += 256) {
+            const int r = idx / RL4, c4 = idx - r * RL4;
+            const float *src = j.transposed ? j.w + ((long long)(cin0 + r) * j.Cout + (long long)nb * BN) * 9
+                                            : j.w + ((long long)(nb * BN + r) * j.Cin + cin0) * 9;
+            reinterpret_cast<pk_f4 *>(wl)[idx] = reinterpret_cast<const pk_f4 *>(src)[c4];
+        }
+    };
+    if (!j.transposed) stage(std::integral_constant<int, 36>{});
+    else if (BN == 32) stage(std::integral_constant<int, 72>{});
+    else stage(std::integral_constant<int, 144>{});
     __syncthreads();
     if (j.algo == SSM_PACK_DIRECT) {          // direct form [nb][cin][tap][n]: the tile is the run of 16 x 9 x BN floats of (nb, cin0 .. cin0 + 15)
         float *outd = j.wp + ((long long)nb * j.Cin + cin0) * 9 * BN;
-        const int nq = BN / 4;
+        const int nq = BN / 4, shq = BN == 32 ? 3 : 4;          // (BN is 32 or 64: shifts instead of run-time divisions)
         for (int qd = tid; qd < 16 * 9 * nq; qd += 256) {
-            const int n4 = (qd % nq) * 4, tap = (qd / nq) % 9, cl = qd / (9 * nq);
+            const int n4 = (qd & (nq - 1)) * 4, tap = (qd >> shq) % 9, cl = (qd >> shq) / 9;
             const int tp = j.transposed ? 8 - tap : tap;
             pk_f4 v;
 #pragma unroll
@@ -264,8 +275,9 @@ __global__ __launch_bounds__(256) void pack32_wino_tiles_kernel(const ssm_pack32
         return;
     }
     float *out = j.wp + ((long long)nb * j.Cin + cin0) * 4 * BN * 4;
+    const int shn = BN == 32 ? 5 : 6;
     for (int qd = tid; qd < 64 * BN; qd += 256) {
-        const int n = qd % BN, q = (qd / BN) & 3, cl = qd / (4 * BN);
+        const int n = qd & (BN - 1), q = (qd >> shn) & 3, cl = qd >> (shn + 2);
         const float *g = j.transposed ? wl + (cl * BN + n) * 9 : wl + (n * 16 + cl) * 9;
         float row[3];      // row q of G g
 #pragma unroll
