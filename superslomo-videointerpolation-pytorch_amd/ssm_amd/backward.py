@@ -28,6 +28,11 @@ WGRAD_WINO_ALL = os.environ.get("SSM_WGRAD_WINO", "1") == "all"
 # the layer above (SSM_FLAG_MASK) or the upsample adjoint - where that gradient has one source; $SSM_LRELU_FUSE=0: a separate ssm_lrelu_bwd
 # launch per layer as before
 LRELU_FUSE = os.environ.get("SSM_LRELU_FUSE", "1") != "0"
+# data-gradient forms that write dZ of the layer below through the mask epilogue.  The 5x5 layers' F(4x4,5x5) form has the epilogue too
+# (ssm_wino5_conv2d_add_fwd, bit-identical: tests/test_hip_backward.py) but the step does not use it by default ($SSM_LRELU_FUSE_W5=1: on):
+# its epilogue reads the mask source without the prefetch the 3x3 forms have and the launch grows by what the ssm_lrelu_bwd pass took
+# (wino5s 0.53 -> 0.83 ms per step, lrelu_bwd 0.86 -> 0.56; step 149.2 / 149.3 / 149.2 off, 149.3 / 147.2 / 149.0 on: profiles/r54_w5fuse.txt)
+FUSE_ALGOS = ("wino", "wino4", "wino5") if os.environ.get("SSM_LRELU_FUSE_W5", "0") != "0" else ("wino", "wino4")
 
 
 def transposed_filter(w):
@@ -423,7 +428,7 @@ class UNetGrad:
                 hb.conv2d_hl8(self.dzq[name].view(), cpad, None, 0, pk, None, dx.view(), None, self.B, Y.H, Y.W, lrelu=False)
             else:
                 from .engine import conv_fn
-                if fuse_next is not None and LRELU_FUSE and pk.algo in ("wino", "wino4", "wino5") and plan.layers[fuse_next][1] == ci:
+                if fuse_next is not None and LRELU_FUSE and pk.algo in FUSE_ALGOS and plan.layers[fuse_next][1] == ci:
                     below = self.act(self.io[fuse_next][1])          # the output of the layer below = this layer's input
                     conv_fn(pk)(dzp.view(), cpad, None, 0, pk, self._dzbuf(fuse_next).slice(0, ci).view(), None, self.B, Y.H, Y.W, lrelu=False,
                                 add=below.view(), mask=True)
